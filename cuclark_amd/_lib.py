@@ -1,0 +1,114 @@
+"""ctypes loader for the C-ABI library (cuclark_amd/lib/libmi_clark.so, include/mi_clark.h).
+
+There is no CPU fallback: if the HIP library is missing, or no gfx950 device is present when an engine is
+created, the caller gets an exception — never a silently slower path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmi_clark.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+MIC_RESULT_WORDS = 8
+MIC_FLAG_ROW_OVERFLOW = 1
+MIC_FLAG_DENSE_PATH = 2
+MIC_ROW_INVALID = 0xFFFFFFFF
+
+
+class MicError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmi_clark error {code}: {msg}")
+        self.code = code
+
+
+class MicConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("k", C.c_int32), ("num_targets", C.c_uint32), ("num_batches", C.c_uint32),
+                ("row_words", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class MicDbInfo(C.Structure):
+    _fields_ = [("htsize", C.c_uint64), ("shard_start", C.c_uint64), ("shard_end", C.c_uint64),
+                ("n_elems", C.c_uint64), ("n_elems_file", C.c_uint64), ("n_slots", C.c_uint64),
+                ("n_overflow", C.c_uint64), ("hbm_bytes", C.c_uint64), ("key_bytes", C.c_int32),
+                ("slot_class", C.c_int32), ("max_bucket", C.c_uint32), ("sampling", C.c_uint32)]
+
+
+class MicSynthSpec(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("htsize", C.c_uint64), ("genome_nt", C.c_uint64), ("n_targets", C.c_uint32),
+                ("n_genomes", C.c_uint32), ("k", C.c_int32), ("key_bytes", C.c_int32)]
+
+
+# every symbol include/mi_clark.h declares: (name, restype, argtypes)
+_VP, _SZ, _U32P, _U16P, _U64P = C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p
+SYMBOLS = [
+    ("mic_create", C.c_int, [C.POINTER(MicConfig), C.POINTER(_VP)]),
+    ("mic_destroy", C.c_int, [_VP]),
+    ("mic_last_error", C.c_char_p, []),
+    ("mic_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("mic_db_load_files", C.c_int, [_VP, C.c_char_p, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64]),
+    ("mic_db_load_host", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_int, _VP, C.c_uint32, C.c_uint64, C.c_uint64]),
+    ("mic_db_load_device", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_int, _VP, C.c_uint32, C.c_uint64, C.c_uint64]),
+    ("mic_db_get_info", C.c_int, [_VP, C.POINTER(MicDbInfo)]),
+    ("mic_db_unload", C.c_int, [_VP]),
+    ("mic_batches_alloc", C.c_int, [_VP, _SZ, _SZ, _SZ, _U32P, C.c_int, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP),
+                                    C.POINTER(_VP)]),
+    ("mic_batch_ready", C.c_int, [_VP, _SZ, _SZ, _SZ]),
+    ("mic_batch_query", C.c_int, [_VP, _SZ, C.c_int, C.c_int]),
+    ("mic_batch_wait", C.c_int, [_VP, _SZ]),
+    ("mic_batch_check", C.c_int, [_VP, _SZ, C.POINTER(C.c_int)]),
+    ("mic_sync", C.c_int, [_VP]),
+    ("mic_batches_free", C.c_int, [_VP]),
+    ("mic_query_device", C.c_int, [_VP, _VP, _VP, _SZ, _VP, _VP, _VP]),
+    ("mic_resolve_flagged_device", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_SZ)]),
+    ("mic_merge_rows_device", C.c_int, [_VP, _VP, _VP, _VP, _SZ, _VP]),
+    ("mic_result_from_rows_device", C.c_int, [_VP, _VP, _VP, _SZ, _VP]),
+    ("mic_count_dense_device", C.c_int, [_VP, _VP, _VP, _VP, _SZ, _VP, _VP]),
+    ("mic_last_query_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
+    ("mic_key_bytes_rule", C.c_int, [C.c_uint64, C.c_int]),
+    ("mic_index_reads", C.c_long, [_VP, _SZ, _SZ, _U64P, _U64P, _U64P, _U64P, _U64P]),
+    ("mic_pack_bound", _SZ, [_U64P, _U64P, _SZ, C.c_int]),
+    ("mic_pack_reads", _SZ, [_VP, _U64P, _U64P, _U64P, _SZ, C.c_int, _U32P, _U16P, _SZ]),
+    ("mic_csv_header", C.c_int, [C.c_char_p, _SZ, C.c_int, C.POINTER(C.c_char_p), C.c_uint32]),
+    ("mic_csv_line", C.c_int, [C.c_char_p, _SZ, _VP, _SZ, C.c_uint64, C.c_int, C.c_int, _VP, C.POINTER(C.c_char_p),
+                               C.c_uint32, C.c_int, _VP, _VP]),
+    ("mic_synth_db_device", C.c_int, [C.POINTER(MicSynthSpec), _VP, _VP, _VP, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
+    ("mic_synth_read_pitch", C.c_uint32, [C.c_uint32, C.c_int]),
+    ("mic_synth_reads_device", C.c_int, [C.POINTER(MicSynthSpec), C.c_uint64, _SZ, C.c_uint32, C.c_double, C.c_double,
+                                         C.c_double, _VP, _VP, _SZ, _VP, _VP]),
+]
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libmi_clark.so (and the CLI) for gfx950 with hipcc — works without a GPU."""
+    r = subprocess.run(["make", "-C", CSRC, "all"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libmi_clark.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+def load():
+    """Load the library and bind every declared symbol; raises if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the k-mer query path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MicError(rc, load().mic_last_error().decode(errors="replace"))

@@ -1,0 +1,277 @@
+// mic_build.hip — builds the resident slot table in HBM from the on-disk arrays (.sz/.ky/.lb images).
+//
+// Replaces CuClarkDB::read's host-side u8 -> u32 prefix sums and part copies (CuClarkDB.cu:594-648,
+// 678-782) and swapDbParts' upload (:813-858): the raw images are uploaded once and the table is laid
+// out on the GPU.  One thread per bucket; three light passes over the bucket sizes:
+//   A  per-tile sums of (elements, non-empty buckets)           -> host scan -> tile bases
+//   B  per-tile overflow-slot demand / kept elements / max size -> host scan -> overflow bases
+//   C  slot construction (reachability filter, chain layout)
+#include "mic_internal.h"
+
+#include <stdio.h>
+#include <vector>
+
+#define TILE 256
+
+namespace {
+
+struct TileA { unsigned long long elems; unsigned long long nonzero; };
+struct TileB { unsigned long long ovf_slots; unsigned long long kept; unsigned int max_bucket; unsigned int pad; };
+
+// exclusive scan of (a,b) pairs over a 256-thread block; returns this thread's exclusive prefix and the
+// block totals through tot_a/tot_b.
+__device__ inline void block_scan2(uint32_t a, uint32_t b, uint32_t& ex_a, uint32_t& ex_b, uint32_t& tot_a,
+                                   uint32_t& tot_b) {
+  __shared__ uint32_t sa[TILE], sb[TILE];
+  const int t = threadIdx.x;
+  sa[t] = a; sb[t] = b;
+  __syncthreads();
+  for (int off = 1; off < TILE; off <<= 1) {
+    uint32_t va = 0, vb = 0;
+    if (t >= off) { va = sa[t - off]; vb = sb[t - off]; }
+    __syncthreads();
+    sa[t] += va; sb[t] += vb;
+    __syncthreads();
+  }
+  ex_a = sa[t] - a; ex_b = sb[t] - b;
+  tot_a = sa[TILE - 1]; tot_b = sb[TILE - 1];
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(TILE) tile_a_kernel(const uint8_t* __restrict__ sizes, uint64_t n, TileA* out) {
+  uint64_t i = (uint64_t)blockIdx.x * TILE + threadIdx.x;
+  uint32_t sz = i < n ? sizes[i] : 0;
+  uint32_t ea, eb, ta, tb;
+  block_scan2(sz, sz > 0, ea, eb, ta, tb);
+  if (threadIdx.x == 0) { out[blockIdx.x].elems = ta; out[blockIdx.x].nonzero = tb; }
+}
+
+__device__ inline bool kept_bucket(uint32_t sz, uint64_t rank_incl, uint32_t sampling) {
+  // CuClarkDB.cu:508-519: choice = (all || nbNonZeroBuckets % mod == 0) ? keep : skip, counted over non-empty buckets
+  return sz > 0 && (sampling <= 1 || (rank_incl % sampling) == 0);
+}
+
+template <int CAP>
+__global__ void __launch_bounds__(TILE) tile_b_kernel(const uint8_t* __restrict__ sizes, uint64_t n,
+                                                      const TileA* __restrict__ base, uint32_t sampling,
+                                                      uint64_t rank_base, TileB* out) {
+  uint64_t i = (uint64_t)blockIdx.x * TILE + threadIdx.x;
+  uint32_t sz = i < n ? sizes[i] : 0;
+  uint32_t ea, eb, ta, tb;
+  block_scan2(sz, sz > 0, ea, eb, ta, tb);
+  uint64_t rank_incl = rank_base + base[blockIdx.x].nonzero + eb + (sz > 0);
+  bool keep = kept_bucket(sz, rank_incl, sampling);
+  uint32_t ovf = (keep && sz > CAP) ? (sz - CAP + CAP - 1) / CAP : 0;
+  uint32_t kept = keep ? sz : 0;
+  uint32_t e1, e2, t1, t2;
+  block_scan2(ovf, kept, e1, e2, t1, t2);
+  __shared__ uint32_t smax;
+  if (threadIdx.x == 0) smax = 0;
+  __syncthreads();
+  if (kept) atomicMax(&smax, kept);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[blockIdx.x].ovf_slots = t1; out[blockIdx.x].kept = t2; out[blockIdx.x].max_bucket = smax; out[blockIdx.x].pad = 0;
+  }
+}
+
+template <typename RAW>
+__device__ inline uint64_t raw_key(const void* keys, uint64_t i) { return (uint64_t)((const RAW*)keys)[i]; }
+
+// Emits the chain of one bucket.  Reachable entries are visited twice (count, then emit).
+template <typename RAW, bool KEY64>
+__device__ inline uint32_t build_bucket(const void* __restrict__ keys, const uint16_t* __restrict__ labels,
+                                        uint64_t off, uint32_t n_raw, uint4* __restrict__ slots, uint64_t main_idx,
+                                        uint64_t ovf_idx) {
+  constexpr int CAP = KEY64 ? MIC_CAP64 : MIC_CAP32;
+  // pass 1: count entries the reference scan can reach (CuClarkDB.cu:1291-1307)
+  uint32_t m = 0;
+  uint64_t last = 0;
+  if (n_raw) {
+    last = raw_key<RAW>(keys, off + n_raw - 1);
+    uint64_t run = 0; bool first = true;
+    for (uint32_t i = 0; i < n_raw; ++i) {
+      uint64_t kv = raw_key<RAW>(keys, off + i);
+      if ((first || kv > run) && kv <= last) ++m;
+      if (first || kv > run) { run = kv; first = false; }
+    }
+  }
+  // pass 2: emit slots
+  uint32_t emitted = 0, i = 0;
+  uint64_t run = 0; bool first = true;
+  uint64_t slot = main_idx;
+  uint64_t next = ovf_idx;
+  do {
+    uint64_t kk[CAP]; uint32_t ll[CAP];
+#pragma unroll
+    for (int e = 0; e < CAP; ++e) { kk[e] = ~0ULL; ll[e] = 0; }
+    uint32_t remaining = m - emitted;
+    int pos = 0;
+    while (pos < CAP && i < n_raw) {
+      uint64_t kv = raw_key<RAW>(keys, off + i);
+      bool reach = (first || kv > run) && kv <= last;
+      if (first || kv > run) { run = kv; first = false; }
+      if (reach) {
+        uint32_t lb = labels[off + i];
+#pragma unroll
+        for (int e = 0; e < CAP; ++e) if (pos == e) { kk[e] = kv; ll[e] = lb; }
+        ++pos; ++emitted;
+      }
+      ++i;
+    }
+    uint32_t nmeta = remaining > 255 ? 255 : remaining;
+    uint32_t w0 = nmeta | (uint32_t)((next & 0xFFFFFF) << 8);
+    uint32_t w1 = nmeta | (uint32_t)(((next >> 24) & 0xFFFFFF) << 8);
+    uint4 q[4];
+    if constexpr (KEY64) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = make_uint4((uint32_t)kk[j], (uint32_t)(kk[j] >> 32), ll[j], nmeta);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        q[j] = make_uint4((uint32_t)kk[2 * j], (uint32_t)kk[2 * j + 1], ll[2 * j] | (ll[2 * j + 1] << 16), nmeta);
+    }
+    q[0].w = w0; q[1].w = w1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) slots[slot * 4 + j] = q[j];
+    slot = next; ++next;
+  } while (emitted < m);
+  return m;
+}
+
+template <typename RAW, bool KEY64>
+__global__ void __launch_bounds__(TILE) tile_c_kernel(const uint8_t* __restrict__ sizes, uint64_t n,
+                                                      const void* __restrict__ keys,
+                                                      const uint16_t* __restrict__ labels,
+                                                      const TileA* __restrict__ base_a,
+                                                      const TileB* __restrict__ base_b, uint32_t sampling,
+                                                      uint64_t rank_base, uint4* __restrict__ slots, uint64_t n_main,
+                                                      unsigned long long* __restrict__ kept_elems) {
+  constexpr int CAP = KEY64 ? MIC_CAP64 : MIC_CAP32;
+  uint64_t i = (uint64_t)blockIdx.x * TILE + threadIdx.x;
+  uint32_t sz = i < n ? sizes[i] : 0;
+  uint32_t ea, eb, ta, tb;
+  block_scan2(sz, sz > 0, ea, eb, ta, tb);
+  uint64_t rank_incl = rank_base + base_a[blockIdx.x].nonzero + eb + (sz > 0);
+  bool keep = kept_bucket(sz, rank_incl, sampling);
+  uint32_t ovf = (keep && sz > CAP) ? (sz - CAP + CAP - 1) / CAP : 0;
+  uint32_t e1, e2, t1, t2;
+  block_scan2(ovf, 0, e1, e2, t1, t2);
+  if (i >= n) return;
+  uint64_t off = base_a[blockIdx.x].elems + ea;
+  uint64_t ovf_idx = n_main + base_b[blockIdx.x].ovf_slots + e1;
+  uint32_t m = build_bucket<RAW, KEY64>(keys, labels, off, keep ? sz : 0, slots, i, ovf_idx);
+  if (m) atomicAdd(kept_elems, (unsigned long long)m);
+}
+
+__global__ void reduce_sizes_kernel(const uint8_t* __restrict__ sizes, uint64_t n, unsigned long long* out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long tot = 0, nz = 0;
+  for (; i < n; i += stride) { uint32_t s = sizes[i]; tot += s; nz += s > 0; }
+  for (int off = 32; off > 0; off >>= 1) { tot += __shfl_down(tot, off); nz += __shfl_down(nz, off); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], tot); atomicAdd(&out[1], nz); }
+}
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    snprintf(err, err_cap, "%s failed: %s", #x, hipGetErrorString(e_)); rc = -4; goto done; } } while (0)
+
+}  // namespace
+
+int mic_reduce_sizes(const uint8_t* d_sizes, uint64_t n, uint64_t* total, uint64_t* nonzero, hipStream_t s) {
+  unsigned long long* d = nullptr;
+  if (hipMalloc(&d, 16) != hipSuccess) return -3;
+  unsigned long long h[2] = {0, 0};
+  hipError_t e = hipMemsetAsync(d, 0, 16, s);
+  if (e == hipSuccess && n) {
+    reduce_sizes_kernel<<<2048, 256, 0, s>>>(d_sizes, n, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(d);
+  if (e != hipSuccess) return -4;
+  *total = h[0]; *nonzero = h[1];
+  return 0;
+}
+
+template <int CAP>
+static void launch_b(const uint8_t* sizes, uint64_t n, const TileA* a, uint32_t sampling, uint64_t rank_base, TileB* b,
+                     unsigned n_tiles, hipStream_t s) {
+  tile_b_kernel<CAP><<<n_tiles, TILE, 0, s>>>(sizes, n, a, sampling, rank_base, b);
+}
+
+int mic_build_table(const uint8_t* d_sizes, uint64_t n_buckets, const void* d_keys, int key_bytes,
+                    const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int slot_class, hipStream_t s,
+                    MicBuildOut* out, char* err, size_t err_cap) {
+  int rc = 0;
+  const uint64_t n_tiles64 = (n_buckets + TILE - 1) / TILE;
+  const unsigned n_tiles = (unsigned)n_tiles64;
+  TileA* d_a = nullptr; TileB* d_b = nullptr; unsigned long long* d_kept = nullptr; uint4* slots = nullptr;
+  std::vector<TileA> h_a(n_tiles);
+  std::vector<TileB> h_b(n_tiles);
+  uint64_t tot_elems = 0, tot_nz = 0, tot_ovf = 0, tot_kept = 0; uint32_t maxb = 0;
+  unsigned long long h_kept = 0;
+  if (n_buckets == 0 || n_tiles64 > 0x7fffffffULL) { snprintf(err, err_cap, "bad bucket count"); return -1; }
+  HIPCK(hipMalloc(&d_a, sizeof(TileA) * n_tiles));
+  HIPCK(hipMalloc(&d_b, sizeof(TileB) * n_tiles));
+  HIPCK(hipMalloc(&d_kept, 8));
+  HIPCK(hipMemsetAsync(d_kept, 0, 8, s));
+  // pass A
+  tile_a_kernel<<<n_tiles, TILE, 0, s>>>(d_sizes, n_buckets, d_a);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(h_a.data(), d_a, sizeof(TileA) * n_tiles, hipMemcpyDeviceToHost, s));
+  HIPCK(hipStreamSynchronize(s));
+  for (unsigned t = 0; t < n_tiles; ++t) {
+    uint64_t e = h_a[t].elems, z = h_a[t].nonzero;
+    h_a[t].elems = tot_elems; h_a[t].nonzero = tot_nz;
+    tot_elems += e; tot_nz += z;
+  }
+  HIPCK(hipMemcpyAsync(d_a, h_a.data(), sizeof(TileA) * n_tiles, hipMemcpyHostToDevice, s));
+  // pass B
+  if (slot_class == 64) launch_b<MIC_CAP64>(d_sizes, n_buckets, d_a, sampling, rank_base, d_b, n_tiles, s);
+  else launch_b<MIC_CAP32>(d_sizes, n_buckets, d_a, sampling, rank_base, d_b, n_tiles, s);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(h_b.data(), d_b, sizeof(TileB) * n_tiles, hipMemcpyDeviceToHost, s));
+  HIPCK(hipStreamSynchronize(s));
+  for (unsigned t = 0; t < n_tiles; ++t) {
+    uint64_t o = h_b[t].ovf_slots;
+    h_b[t].ovf_slots = tot_ovf; tot_ovf += o; tot_kept += h_b[t].kept;
+    if (h_b[t].max_bucket > maxb) maxb = h_b[t].max_bucket;
+  }
+  HIPCK(hipMemcpyAsync(d_b, h_b.data(), sizeof(TileB) * n_tiles, hipMemcpyHostToDevice, s));
+  {
+    hipError_t e_ = hipMalloc(&slots, (size_t)(n_buckets + tot_ovf + 1) * MIC_SLOT_BYTES);
+    if (e_ != hipSuccess) {
+      snprintf(err, err_cap, "hipMalloc of %.2f GB for the slot table failed: %s",
+               (double)(n_buckets + tot_ovf + 1) * MIC_SLOT_BYTES / 1e9, hipGetErrorString(e_));
+      rc = -3; goto done;
+    }
+  }
+  // pass C
+#define LAUNCH_C(RAW, K64) tile_c_kernel<RAW, K64><<<n_tiles, TILE, 0, s>>>(d_sizes, n_buckets, d_keys, d_labels, d_a, \
+    d_b, sampling, rank_base, slots, n_buckets, d_kept)
+  if (slot_class == 64) {
+    if (key_bytes == 8) LAUNCH_C(uint64_t, true);
+    else if (key_bytes == 4) LAUNCH_C(uint32_t, true);
+    else LAUNCH_C(uint16_t, true);
+  } else {
+    if (key_bytes == 4) LAUNCH_C(uint32_t, false);
+    else if (key_bytes == 2) LAUNCH_C(uint16_t, false);
+    else { snprintf(err, err_cap, "slot class 32 cannot hold 8-byte keys"); rc = -1; goto done; }
+  }
+#undef LAUNCH_C
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(&h_kept, d_kept, 8, hipMemcpyDeviceToHost, s));
+  HIPCK(hipStreamSynchronize(s));
+  out->slots = slots; slots = nullptr;
+  out->n_main = n_buckets; out->n_overflow = tot_ovf; out->n_elems = h_kept; out->n_elems_file = tot_elems;
+  out->max_bucket = maxb;
+  (void)tot_kept;
+done:
+  if (d_a) hipFree(d_a);
+  if (d_b) hipFree(d_b);
+  if (d_kept) hipFree(d_kept);
+  if (slots) hipFree(slots);
+  return rc;
+}

@@ -1,0 +1,560 @@
+// mic_engine.hip — C-ABI implementation (include/mi_clark.h): engine lifetime, DB load, batch API,
+// device-resident entry points.  Host code over the HIP runtime; kernels live in mic_kernels.hip /
+// mic_build.hip.  Mirrors the public surface of CuClarkDB<HKMERr> (CuClarkDB.cuh:98-150).
+#include "mi_clark.h"
+#include "mic_internal.h"
+
+#include <errno.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return fail(e_ == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+struct Batch {
+  uint32_t* h_rp = nullptr; uint16_t* h_cont = nullptr;
+  uint32_t* d_rp = nullptr; uint16_t* d_cont = nullptr;
+  uint32_t* d_results = nullptr; uint32_t* d_rows = nullptr;
+  uint32_t* d_flagged = nullptr; uint32_t* h_flagged = nullptr;
+  size_t first_read = 0, n_reads = 0, n_cont = 0, max_reads = 0, max_cont = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  bool scheduled = false, resolved = true, extended = false;
+};
+
+}  // namespace
+
+struct mic_engine {
+  mic_config cfg;
+  int device = 0, n_cu = 256;
+  hipStream_t stream = nullptr;
+  // table
+  bool db_loaded = false;
+  uint4* slots = nullptr;
+  MicTable table;
+  int slot_class = 32;
+  mic_db_info info;
+  // batches
+  std::vector<Batch> batches;
+  uint32_t* h_results = nullptr; uint32_t* h_rows = nullptr;
+  size_t num_reads_total = 0;
+  std::mutex submit_mu;
+  // device-API state
+  uint32_t* d_flagged = nullptr; uint32_t flagged_cap = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  size_t last_n_reads = 0;
+};
+
+namespace {
+
+const uint32_t kFlaggedCap = 1u << 16;
+
+int set_device(const mic_engine* e) {
+  HIPTRY(hipSetDevice(e->device));
+  return MIC_OK;
+}
+
+void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s0, uint64_t s1, int key_bytes,
+                uint32_t sampling) {
+  e->slots = b.slots;
+  e->table.slots = b.slots;
+  e->table.n_main = b.n_main;
+  e->table.shard_start = s0;
+  e->table.shard_end = s1;
+  e->table.div = mic_make_div(htsize);
+  e->table.k = e->cfg.k;
+  mic_db_info& i = e->info;
+  i.htsize = htsize; i.shard_start = s0; i.shard_end = s1;
+  i.n_elems = b.n_elems; i.n_elems_file = b.n_elems_file;
+  i.n_slots = b.n_main + b.n_overflow; i.n_overflow = b.n_overflow;
+  i.hbm_bytes = (b.n_main + b.n_overflow + 1) * (uint64_t)MIC_SLOT_BYTES;
+  i.key_bytes = key_bytes; i.slot_class = e->slot_class; i.max_bucket = b.max_bucket; i.sampling = sampling;
+  e->db_loaded = true;
+}
+
+int check_shard(uint64_t htsize, uint64_t& s0, uint64_t& s1) {
+  if (htsize < 2 || htsize > 0xFFFFFFF0ULL) return fail(MIC_E_INVALID, "unsupported table size %llu", (unsigned long long)htsize);
+  if (s1 == 0) s1 = htsize;
+  if (s0 >= s1 || s1 > htsize) return fail(MIC_E_INVALID, "bad shard [%llu,%llu) of %llu", (unsigned long long)s0,
+                                           (unsigned long long)s1, (unsigned long long)htsize);
+  return MIC_OK;
+}
+
+// stream a byte range of a file into device memory through two pinned staging buffers
+int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStream_t s, const char* what) {
+  const size_t CH = 64u << 20;
+  void* stage[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int rc = MIC_OK;
+  if (bytes == 0) return MIC_OK;
+  if (fseeko(f, (off_t)off, SEEK_SET) != 0) return fail(MIC_E_IO, "seek failed in %s", what);
+  for (int i = 0; i < 2 && rc == MIC_OK; ++i) {
+    if (hipHostMalloc(&stage[i], CH, hipHostMallocDefault) != hipSuccess) rc = fail(MIC_E_NOMEM, "pinned staging alloc failed");
+    else if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(MIC_E_HIP, "event create failed");
+  }
+  uint64_t done = 0; int cur = 0; bool used[2] = {false, false};
+  while (rc == MIC_OK && done < bytes) {
+    size_t n = (size_t)((bytes - done) < CH ? (bytes - done) : CH);
+    if (used[cur] && hipEventSynchronize(ev[cur]) != hipSuccess) { rc = fail(MIC_E_HIP, "event sync failed"); break; }
+    if (fread(stage[cur], 1, n, f) != n) { rc = fail(MIC_E_IO, "%s is shorter than the bucket sizes imply", what); break; }
+    if (hipMemcpyAsync((char*)dst + done, stage[cur], n, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipEventRecord(ev[cur], s) != hipSuccess) { rc = fail(MIC_E_HIP, "H2D copy failed"); break; }
+    used[cur] = true; cur ^= 1; done += n;
+  }
+  hipStreamSynchronize(s);
+  for (int i = 0; i < 2; ++i) { if (stage[i]) hipHostFree(stage[i]); if (ev[i]) hipEventDestroy(ev[i]); }
+  return rc;
+}
+
+int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsize, uint64_t s0, uint64_t s1,
+                      const void* d_keys_shard, int key_bytes, const uint16_t* d_labels_shard, uint32_t sampling,
+                      uint64_t rank_base) {
+  e->slot_class = key_bytes == 8 ? 64 : 32;
+  MicBuildOut b;
+  char err[256] = "";
+  int rc = mic_build_table(d_sizes_shard, s1 - s0, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
+                           e->slot_class, e->stream, &b, err, sizeof(err));
+  if (rc != 0) return fail(rc, "table build: %s", err);
+  fill_table(e, b, htsize, s0, s1, key_bytes, sampling);
+  return MIC_OK;
+}
+
+void free_batches(mic_engine* e) {
+  for (Batch& b : e->batches) {
+    if (b.h_rp) hipHostFree(b.h_rp);
+    if (b.h_cont) hipHostFree(b.h_cont);
+    if (b.h_flagged) hipHostFree(b.h_flagged);
+    if (b.d_rp) hipFree(b.d_rp);
+    if (b.d_cont) hipFree(b.d_cont);
+    if (b.d_results) hipFree(b.d_results);
+    if (b.d_rows) hipFree(b.d_rows);
+    if (b.d_flagged) hipFree(b.d_flagged);
+    if (b.done) hipEventDestroy(b.done);
+    if (b.stream) hipStreamDestroy(b.stream);
+  }
+  e->batches.clear();
+  if (e->h_results) { hipHostFree(e->h_results); e->h_results = nullptr; }
+  if (e->h_rows) { hipHostFree(e->h_rows); e->h_rows = nullptr; }
+  e->num_reads_total = 0;
+}
+
+// dense path for a list of read ids held on the device; patches results (and rows)
+int run_dense(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, const uint32_t* d_ids, size_t n_ids,
+              uint32_t* d_results, uint32_t* d_rows, hipStream_t s) {
+  if (!n_ids) return MIC_OK;
+  const uint32_t T = e->cfg.num_targets ? e->cfg.num_targets : 1;
+  // process in slabs of at most ~1 GiB of counters
+  size_t slab = (size_t)((1ull << 30) / ((uint64_t)T * 4));
+  if (slab == 0) slab = 1;
+  if (slab > n_ids) slab = n_ids;
+  uint32_t* d_counts = nullptr;
+  HIPTRY(hipMalloc(&d_counts, slab * (size_t)T * 4));
+  int rc = MIC_OK;
+  for (size_t off = 0; off < n_ids && rc == MIC_OK; off += slab) {
+    size_t n = n_ids - off < slab ? n_ids - off : slab;
+    hipError_t he = mic_launch_dense_count(e->table, e->slot_class, d_rp, d_cont, d_ids + off, n, T, d_counts, s);
+    if (he == hipSuccess) he = mic_launch_dense_finish(d_counts, d_ids + off, n, T, d_results, d_rows, e->cfg.row_words, s);
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    if (he != hipSuccess) rc = fail(MIC_E_HIP, "dense path: %s", hipGetErrorString(he));
+  }
+  hipFree(d_counts);
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mic_last_error(void) { return g_err; }
+
+int mic_device_count(int* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(MIC_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *count = n;
+  return MIC_OK;
+}
+
+int mic_create(const mic_config* cfg, mic_engine** out) {
+  if (!cfg || !out) return fail(MIC_E_INVALID, "null argument");
+  if (cfg->k < 2 || cfg->k > 32) return fail(MIC_E_INVALID, "The k-mer length should be in [2,32].");
+  if (cfg->num_targets > 65535) return fail(MIC_E_INVALID, "too many targets (%u > 65535)", cfg->num_targets);
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(MIC_E_NODEVICE, "no HIP device available: the MI355X engine cannot run (there is no CPU fallback)");
+  int dev = cfg->device;
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+  if (dev >= n) return fail(MIC_E_INVALID, "device %d out of range (%d devices)", dev, n);
+  hipDeviceProp_t prop;
+  HIPTRY(hipSetDevice(dev));
+  HIPTRY(hipGetDeviceProperties(&prop, dev));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MIC_E_NODEVICE, "device %d is %s; this library carries gfx950 (MI355X) code objects only", dev, prop.gcnArchName);
+  mic_engine* e = new (std::nothrow) mic_engine();
+  if (!e) return fail(MIC_E_NOMEM, "out of host memory");
+  e->cfg = *cfg;
+  if (e->cfg.num_batches == 0) e->cfg.num_batches = 1;
+  if (e->cfg.row_words == 0) e->cfg.row_words = 16;
+  if (e->cfg.row_words < 2) e->cfg.row_words = 2;
+  e->device = dev;
+  e->n_cu = prop.multiProcessorCount;
+  memset(&e->info, 0, sizeof(e->info));
+  memset(&e->table, 0, sizeof(e->table));
+  hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev0);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  if (he == hipSuccess) he = hipMalloc(&e->d_flagged, (size_t)(kFlaggedCap + 1) * 4);
+  if (he != hipSuccess) { mic_destroy(e); return fail(MIC_E_HIP, "engine setup: %s", hipGetErrorString(he)); }
+  e->flagged_cap = kFlaggedCap;
+  *out = e;
+  return MIC_OK;
+}
+
+int mic_destroy(mic_engine* e) {
+  if (!e) return MIC_OK;
+  hipSetDevice(e->device);
+  hipDeviceSynchronize();
+  free_batches(e);
+  if (e->slots) hipFree(e->slots);
+  if (e->d_flagged) hipFree(e->d_flagged);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->stream) hipStreamDestroy(e->stream);
+  delete e;
+  return MIC_OK;
+}
+
+int mic_db_unload(mic_engine* e) {
+  if (!e) return fail(MIC_E_INVALID, "null engine");
+  int rc = set_device(e);
+  if (rc) return rc;
+  hipDeviceSynchronize();
+  if (e->slots) hipFree(e->slots);
+  e->slots = nullptr; e->db_loaded = false;
+  memset(&e->info, 0, sizeof(e->info));
+  return MIC_OK;
+}
+
+int mic_db_get_info(const mic_engine* e, mic_db_info* info) {
+  if (!e || !info) return fail(MIC_E_INVALID, "null argument");
+  if (!e->db_loaded) return fail(MIC_E_STATE, "no database loaded");
+  *info = e->info;
+  return MIC_OK;
+}
+
+int mic_db_load_device(mic_engine* e, const uint8_t* d_sizes, uint64_t htsize, const void* d_keys, int key_bytes,
+                       const uint16_t* d_labels, uint32_t sampling, uint64_t s0, uint64_t s1) {
+  if (!e || !d_sizes || !d_keys || !d_labels) return fail(MIC_E_INVALID, "null argument");
+  if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MIC_E_INVALID, "key_bytes must be 2, 4 or 8");
+  int rc = set_device(e);
+  if (rc) return rc;
+  if ((rc = check_shard(htsize, s0, s1))) return rc;
+  if (e->db_loaded) mic_db_unload(e);
+  uint64_t base_elems = 0, base_rank = 0;
+  if (s0 > 0 && mic_reduce_sizes(d_sizes, s0, &base_elems, &base_rank, e->stream) != 0)
+    return fail(MIC_E_HIP, "size reduction failed");
+  return build_from_device(e, d_sizes + s0, htsize, s0, s1, (const char*)d_keys + base_elems * key_bytes, key_bytes,
+                           d_labels + base_elems, sampling, base_rank);
+}
+
+int mic_db_load_host(mic_engine* e, const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes,
+                     const uint16_t* labels, uint32_t sampling, uint64_t s0, uint64_t s1) {
+  if (!e || !sizes || !keys || !labels) return fail(MIC_E_INVALID, "null argument");
+  if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MIC_E_INVALID, "key_bytes must be 2, 4 or 8");
+  int rc = set_device(e);
+  if (rc) return rc;
+  if ((rc = check_shard(htsize, s0, s1))) return rc;
+  if (e->db_loaded) mic_db_unload(e);
+  uint64_t base_elems = 0, base_rank = 0, n_el = 0;
+  for (uint64_t i = 0; i < s0; ++i) { base_elems += sizes[i]; base_rank += sizes[i] > 0; }
+  for (uint64_t i = s0; i < s1; ++i) n_el += sizes[i];
+  uint8_t* d_sz = nullptr; void* d_ky = nullptr; uint16_t* d_lb = nullptr;
+  hipError_t he = hipMalloc(&d_sz, s1 - s0);
+  if (he == hipSuccess) he = hipMalloc(&d_ky, n_el * key_bytes + 16);
+  if (he == hipSuccess) he = hipMalloc(&d_lb, n_el * 2 + 16);
+  if (he == hipSuccess) he = hipMemcpy(d_sz, sizes + s0, s1 - s0, hipMemcpyHostToDevice);
+  if (he == hipSuccess && n_el) he = hipMemcpy(d_ky, (const char*)keys + base_elems * key_bytes, n_el * key_bytes, hipMemcpyHostToDevice);
+  if (he == hipSuccess && n_el) he = hipMemcpy(d_lb, labels + base_elems, n_el * 2, hipMemcpyHostToDevice);
+  if (he != hipSuccess) rc = fail(he == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "upload of DB images: %s", hipGetErrorString(he));
+  else rc = build_from_device(e, d_sz, htsize, s0, s1, d_ky, key_bytes, d_lb, sampling, base_rank);
+  if (d_sz) hipFree(d_sz);
+  if (d_ky) hipFree(d_ky);
+  if (d_lb) hipFree(d_lb);
+  return rc;
+}
+
+int mic_db_load_files(mic_engine* e, const char* prefix, int key_bytes, uint32_t sampling, uint64_t s0, uint64_t s1) {
+  if (!e || !prefix) return fail(MIC_E_INVALID, "null argument");
+  int rc = set_device(e);
+  if (rc) return rc;
+  std::string p(prefix);
+  FILE* fs = fopen((p + ".sz").c_str(), "rb");
+  FILE* fk = fopen((p + ".ky").c_str(), "rb");
+  FILE* fl = fopen((p + ".lb").c_str(), "rb");
+  uint8_t* h_sz = nullptr; uint8_t* d_sz = nullptr; void* d_ky = nullptr; uint16_t* d_lb = nullptr;
+  do {
+    // reference: "Failed to open <file>" and read() returns false (CuClarkDB.cu:490-495)
+    if (!fs) { rc = fail(MIC_E_IO, "Failed to open %s.sz", prefix); break; }
+    if (!fk) { rc = fail(MIC_E_IO, "Failed to open %s.ky", prefix); break; }
+    if (!fl) { rc = fail(MIC_E_IO, "Failed to open %s.lb", prefix); break; }
+    fseeko(fs, 0, SEEK_END);
+    uint64_t htsize = (uint64_t)ftello(fs);
+    fseeko(fs, 0, SEEK_SET);
+    if ((rc = check_shard(htsize, s0, s1))) break;
+    if (key_bytes == 0) key_bytes = mic_key_bytes_rule(htsize, e->cfg.k);
+    if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) { rc = fail(MIC_E_INVALID, "key_bytes must be 2, 4 or 8"); break; }
+    h_sz = (uint8_t*)malloc(htsize);
+    if (!h_sz) { rc = fail(MIC_E_NOMEM, "out of host memory for bucket sizes"); break; }
+    if (fread(h_sz, 1, htsize, fs) != htsize) { rc = fail(MIC_E_IO, "short read on %s.sz", prefix); break; }
+    uint64_t base_elems = 0, base_rank = 0, n_el = 0;
+    for (uint64_t i = 0; i < s0; ++i) { base_elems += h_sz[i]; base_rank += h_sz[i] > 0; }
+    for (uint64_t i = s0; i < s1; ++i) n_el += h_sz[i];
+    if (e->db_loaded) mic_db_unload(e);
+    hipError_t he = hipMalloc(&d_sz, s1 - s0);
+    if (he == hipSuccess) he = hipMalloc(&d_ky, n_el * key_bytes + 16);
+    if (he == hipSuccess) he = hipMalloc(&d_lb, n_el * 2 + 16);
+    if (he == hipSuccess) he = hipMemcpy(d_sz, h_sz + s0, s1 - s0, hipMemcpyHostToDevice);
+    if (he != hipSuccess) { rc = fail(he == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "DB image allocation: %s", hipGetErrorString(he)); break; }
+    if ((rc = upload_file_range(fk, base_elems * key_bytes, n_el * key_bytes, d_ky, e->stream, "the .ky file"))) break;
+    if ((rc = upload_file_range(fl, base_elems * 2, n_el * 2, d_lb, e->stream, "the .lb file"))) break;
+    rc = build_from_device(e, d_sz, htsize, s0, s1, d_ky, key_bytes, d_lb, sampling, base_rank);
+  } while (0);
+  if (fs) fclose(fs);
+  if (fk) fclose(fk);
+  if (fl) fclose(fl);
+  free(h_sz);
+  if (d_sz) hipFree(d_sz);
+  if (d_ky) hipFree(d_ky);
+  if (d_lb) hipFree(d_lb);
+  return rc;
+}
+
+// ---- batch API ---------------------------------------------------------------------------------------
+int mic_batches_alloc(mic_engine* e, size_t num_reads_total, size_t max_reads, size_t max_containers,
+                      const uint32_t* index_batches, int extended, uint32_t** results, uint32_t** rows,
+                      uint32_t** reads_pointer, uint16_t** containers) {
+  if (!e || !index_batches || !results || !reads_pointer || !containers) return fail(MIC_E_INVALID, "null argument");
+  int rc = set_device(e);
+  if (rc) return rc;
+  free_batches(e);
+  const size_t nb = e->cfg.num_batches;
+  const uint32_t rw = e->cfg.row_words;
+  e->num_reads_total = num_reads_total;
+  HIPTRY(hipHostMalloc((void**)&e->h_results, (num_reads_total + 1) * MIC_RESULT_WORDS * 4, hipHostMallocDefault));
+  if (extended) HIPTRY(hipHostMalloc((void**)&e->h_rows, (num_reads_total + 1) * (size_t)rw * 4, hipHostMallocDefault));
+  e->batches.resize(nb);
+  for (size_t b = 0; b < nb; ++b) {
+    Batch& B = e->batches[b];
+    B.first_read = index_batches[b];
+    B.max_reads = max_reads; B.max_cont = max_containers;
+    B.extended = extended != 0;
+    HIPTRY(hipHostMalloc((void**)&B.h_rp, (max_reads + 2) * 4, hipHostMallocDefault));
+    HIPTRY(hipHostMalloc((void**)&B.h_cont, (max_containers + 64) * 2, hipHostMallocDefault));
+    HIPTRY(hipHostMalloc((void**)&B.h_flagged, (size_t)(kFlaggedCap + 1) * 4, hipHostMallocDefault));
+    HIPTRY(hipMalloc(&B.d_rp, (max_reads + 2) * 4));
+    HIPTRY(hipMalloc(&B.d_cont, (max_containers + 64) * 2));
+    HIPTRY(hipMalloc(&B.d_results, (max_reads + 1) * MIC_RESULT_WORDS * 4));
+    if (extended) HIPTRY(hipMalloc(&B.d_rows, (max_reads + 1) * (size_t)rw * 4));
+    HIPTRY(hipMalloc(&B.d_flagged, (size_t)(kFlaggedCap + 1) * 4));
+    HIPTRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+    HIPTRY(hipEventCreateWithFlags(&B.done, hipEventDisableTiming));
+    reads_pointer[b] = B.h_rp;
+    containers[b] = B.h_cont;
+  }
+  *results = e->h_results;
+  if (rows) *rows = e->h_rows;
+  return MIC_OK;
+}
+
+int mic_batch_ready(mic_engine* e, size_t batch, size_t n_reads, size_t n_containers) {
+  if (!e || batch >= e->batches.size()) return fail(MIC_E_INVALID, "bad batch id");
+  Batch& B = e->batches[batch];
+  if (n_reads > B.max_reads || n_containers > B.max_cont)
+    return fail(MIC_E_INVALID, "batch %zu exceeds its allocation (%zu reads, %zu containers)", batch, n_reads, n_containers);
+  B.n_reads = n_reads; B.n_cont = n_containers;
+  return MIC_OK;
+}
+
+int mic_batch_query(mic_engine* e, size_t batch, int extended, int followup) {
+  (void)followup;
+  if (!e || batch >= e->batches.size()) return fail(MIC_E_INVALID, "bad batch id");
+  if (!e->db_loaded) return fail(MIC_E_STATE, "no database loaded");
+  std::lock_guard<std::mutex> lock(e->submit_mu);
+  int rc = set_device(e);
+  if (rc) return rc;
+  Batch& B = e->batches[batch];
+  if (extended && !B.d_rows) return fail(MIC_E_STATE, "batches were not allocated for extended results");
+  hipStream_t s = B.stream;
+  HIPTRY(hipMemcpyAsync(B.d_rp, B.h_rp, (B.n_reads + 1) * 4, hipMemcpyHostToDevice, s));
+  HIPTRY(hipMemcpyAsync(B.d_cont, B.h_cont, (B.n_cont + 16) * 2, hipMemcpyHostToDevice, s));
+  HIPTRY(hipMemsetAsync(B.d_flagged, 0, 4, s));
+  MicQueryArgs a;
+  a.t = e->table; a.reads_ptr = B.d_rp; a.cont = B.d_cont; a.n_reads = (uint32_t)B.n_reads;
+  a.row_words = e->cfg.row_words; a.results = B.d_results; a.rows = extended ? B.d_rows : nullptr;
+  a.flagged = B.d_flagged; a.flagged_cap = kFlaggedCap;
+  HIPTRY(mic_launch_query(a, e->slot_class, e->n_cu, s));
+  HIPTRY(hipMemcpyAsync(e->h_results + B.first_read * MIC_RESULT_WORDS, B.d_results, B.n_reads * MIC_RESULT_WORDS * 4,
+                        hipMemcpyDeviceToHost, s));
+  if (extended)
+    HIPTRY(hipMemcpyAsync(e->h_rows + B.first_read * (size_t)e->cfg.row_words, B.d_rows,
+                          B.n_reads * (size_t)e->cfg.row_words * 4, hipMemcpyDeviceToHost, s));
+  HIPTRY(hipMemcpyAsync(B.h_flagged, B.d_flagged, (size_t)(kFlaggedCap + 1) * 4, hipMemcpyDeviceToHost, s));
+  HIPTRY(hipEventRecord(B.done, s));
+  B.scheduled = true; B.resolved = false; B.extended = extended != 0;
+  return MIC_OK;
+}
+
+int mic_batch_wait(mic_engine* e, size_t batch) {
+  if (!e || batch >= e->batches.size()) return fail(MIC_E_INVALID, "bad batch id");
+  Batch& B = e->batches[batch];
+  if (!B.scheduled) return fail(MIC_E_STATE, "batch %zu was not queried", batch);
+  int rc = set_device(e);
+  if (rc) return rc;
+  HIPTRY(hipEventSynchronize(B.done));
+  if (!B.resolved) {
+    std::lock_guard<std::mutex> lock(e->submit_mu);
+    if (!B.resolved) {
+      uint32_t nf = B.h_flagged[0];
+      if (nf) {
+        // reads whose row overflowed: exact dense recount (ids beyond the list capacity: whole batch)
+        if (nf > kFlaggedCap) {
+          rc = run_dense(e, B.d_rp, B.d_cont, nullptr, B.n_reads, B.d_results, B.extended ? B.d_rows : nullptr, B.stream);
+        } else {
+          rc = run_dense(e, B.d_rp, B.d_cont, B.d_flagged + 1, nf, B.d_results, B.extended ? B.d_rows : nullptr, B.stream);
+        }
+        if (rc) return rc;
+        HIPTRY(hipMemcpy(e->h_results + B.first_read * MIC_RESULT_WORDS, B.d_results, B.n_reads * MIC_RESULT_WORDS * 4,
+                         hipMemcpyDeviceToHost));
+        if (B.extended)
+          HIPTRY(hipMemcpy(e->h_rows + B.first_read * (size_t)e->cfg.row_words, B.d_rows,
+                           B.n_reads * (size_t)e->cfg.row_words * 4, hipMemcpyDeviceToHost));
+      }
+      B.resolved = true;
+    }
+  }
+  return MIC_OK;
+}
+
+int mic_batch_check(mic_engine* e, size_t batch, int* done) {
+  if (!e || batch >= e->batches.size() || !done) return fail(MIC_E_INVALID, "bad argument");
+  Batch& B = e->batches[batch];
+  if (!B.scheduled) { *done = 0; return MIC_OK; }
+  hipError_t he = hipEventQuery(B.done);
+  if (he == hipSuccess) *done = 1;
+  else if (he == hipErrorNotReady) *done = 0;
+  else return fail(MIC_E_HIP, "hipEventQuery: %s", hipGetErrorString(he));
+  return MIC_OK;
+}
+
+int mic_sync(mic_engine* e) {
+  if (!e) return fail(MIC_E_INVALID, "null engine");
+  int rc = set_device(e);
+  if (rc) return rc;
+  HIPTRY(hipDeviceSynchronize());
+  return MIC_OK;
+}
+
+int mic_batches_free(mic_engine* e) {
+  if (!e) return fail(MIC_E_INVALID, "null engine");
+  int rc = set_device(e);
+  if (rc) return rc;
+  hipDeviceSynchronize();
+  free_batches(e);
+  return MIC_OK;
+}
+
+// ---- device-resident entry points ---------------------------------------------------------------------
+int mic_query_device(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, size_t n_reads, uint32_t* d_results,
+                     uint32_t* d_rows, void* stream) {
+  if (!e || !d_rp || !d_cont || !d_results) return fail(MIC_E_INVALID, "null argument");
+  if (!e->db_loaded) return fail(MIC_E_STATE, "no database loaded");
+  if (n_reads > 0xFFFFFFF0ull) return fail(MIC_E_INVALID, "too many reads in one call");
+  int rc = set_device(e);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+  HIPTRY(hipMemsetAsync(e->d_flagged, 0, 4, s));
+  MicQueryArgs a;
+  a.t = e->table; a.reads_ptr = d_rp; a.cont = d_cont; a.n_reads = (uint32_t)n_reads;
+  a.row_words = e->cfg.row_words; a.results = d_results; a.rows = d_rows;
+  a.flagged = e->d_flagged; a.flagged_cap = e->flagged_cap;
+  HIPTRY(hipEventRecord(e->ev0, s));
+  HIPTRY(mic_launch_query(a, e->slot_class, e->n_cu, s));
+  HIPTRY(hipEventRecord(e->ev1, s));
+  e->timed = true;
+  e->last_n_reads = n_reads;
+  return MIC_OK;
+}
+
+int mic_last_query_ms(mic_engine* e, float* ms) {
+  if (!e || !ms) return fail(MIC_E_INVALID, "null argument");
+  if (!e->timed) return fail(MIC_E_STATE, "no query was launched");
+  HIPTRY(hipEventSynchronize(e->ev1));
+  HIPTRY(hipEventElapsedTime(ms, e->ev0, e->ev1));
+  return MIC_OK;
+}
+
+int mic_resolve_flagged_device(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, uint32_t* d_results,
+                               uint32_t* d_rows, void* stream, size_t* n_resolved) {
+  if (!e || !d_rp || !d_cont || !d_results) return fail(MIC_E_INVALID, "null argument");
+  int rc = set_device(e);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+  uint32_t nf = 0;
+  HIPTRY(hipMemcpyAsync(&nf, e->d_flagged, 4, hipMemcpyDeviceToHost, s));
+  HIPTRY(hipStreamSynchronize(s));
+  if (n_resolved) *n_resolved = nf;
+  if (!nf) return MIC_OK;
+  if (nf > e->flagged_cap) {
+    if (n_resolved) *n_resolved = e->last_n_reads;
+    return run_dense(e, d_rp, d_cont, nullptr, e->last_n_reads, d_results, d_rows, s);
+  }
+  return run_dense(e, d_rp, d_cont, e->d_flagged + 1, nf, d_results, d_rows, s);
+}
+
+int mic_merge_rows_device(mic_engine* e, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, void* stream) {
+  if (!e || !a || !b || !out) return fail(MIC_E_INVALID, "null argument");
+  int rc = set_device(e);
+  if (rc) return rc;
+  HIPTRY(mic_launch_merge_rows(a, b, out, e->cfg.row_words, n, nullptr, stream ? (hipStream_t)stream : e->stream));
+  return MIC_OK;
+}
+
+int mic_result_from_rows_device(mic_engine* e, const uint32_t* rows, uint32_t* results, size_t n, void* stream) {
+  if (!e || !rows || !results) return fail(MIC_E_INVALID, "null argument");
+  int rc = set_device(e);
+  if (rc) return rc;
+  HIPTRY(mic_launch_result_from_rows(rows, e->cfg.row_words, results, n, stream ? (hipStream_t)stream : e->stream));
+  return MIC_OK;
+}
+
+int mic_count_dense_device(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, const uint32_t* d_ids,
+                           size_t n_ids, uint32_t* d_counts, void* stream) {
+  if (!e || !d_rp || !d_cont || !d_counts) return fail(MIC_E_INVALID, "null argument");
+  if (!e->db_loaded) return fail(MIC_E_STATE, "no database loaded");
+  int rc = set_device(e);
+  if (rc) return rc;
+  HIPTRY(mic_launch_dense_count(e->table, e->slot_class, d_rp, d_cont, d_ids, n_ids, e->cfg.num_targets ? e->cfg.num_targets : 1,
+                                d_counts, stream ? (hipStream_t)stream : e->stream));
+  return MIC_OK;
+}
+
+}  // extern "C"

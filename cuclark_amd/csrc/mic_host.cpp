@@ -1,0 +1,215 @@
+// mic_host.cpp — host-side pieces of the path: key-width rule, read indexer, read packer, CSV lines,
+// and the division magic.  Pure C++ (no device code); exported through the C ABI of include/mi_clark.h
+// and used by the classifier (classifier.cpp) and the CLI.
+#include "mi_clark.h"
+#include "mic_internal.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+// ---- division magic ---------------------------------------------------------------------------------
+MicDiv mic_make_div(uint64_t d) {
+  MicDiv r;
+  r.d = d; r.magic = 0; r.shift = 0; r.add = 0;
+  if (d == 0) return r;
+  const uint32_t fl = 63 - (uint32_t)__builtin_clzll(d);
+  if ((d & (d - 1)) == 0) { r.shift = fl; return r; }  // power of two
+  const unsigned __int128 num = (unsigned __int128)1 << (64 + fl);
+  uint64_t m = (uint64_t)(num / d);
+  uint64_t rem = (uint64_t)(num % d);
+  const uint64_t e = d - rem;
+  if (e < ((uint64_t)1 << fl)) {
+    r.shift = fl;
+  } else {
+    m += m;
+    const uint64_t twice = rem + rem;
+    if (twice >= d || twice < rem) m += 1;
+    r.shift = fl; r.add = 1;
+  }
+  r.magic = m + 1;
+  return r;
+}
+
+extern "C" {
+
+// main.cc:274-316.  t_b is computed in double exactly as the reference does.
+int mic_key_bytes_rule(uint64_t htsize, int k) {
+  if (htsize < 2 || k < 2 || k > 32) return MIC_E_INVALID;
+  const size_t t_b = (size_t)(log((double)htsize) / log(4.0));
+  if ((size_t)k <= t_b + 8) return 2;
+  if ((size_t)k <= t_b + 16) return 4;
+  return 8;
+}
+
+// ---- read indexer (CuCLARK_hh.hh:1339-1534 for a single batch) -----------------------------------------
+static inline bool name_sep(uint8_t c) { return c == ' ' || c == '\t' || c == '\n'; }  // CuCLARK_hh.hh:300
+
+long mic_index_reads(const uint8_t* map, size_t nb, size_t cap, uint64_t* name_s, uint64_t* name_e, uint64_t* seq_s,
+                     uint64_t* seq_e, uint64_t* length) {
+  if (!map || nb == 0 || (map[0] != '>' && map[0] != '@')) return MIC_E_INVALID;
+  const bool fasta = map[0] == '>';
+  size_t n = 0, i = 1;
+  for (;;) {
+    // name: from the byte after the marker up to the first separator found strictly after it
+    const size_t ns = i;
+    while (i + 1 < nb && !name_sep(map[i + 1])) ++i;
+    ++i;
+    if (i > nb) i = nb;
+    const size_t ne = i;
+    while (i < nb && map[i++] != '\n') {}  // rest of the header line
+    size_t s = i, e = i, len;
+    if (fasta) {
+      size_t lines = 0;
+      while (i < nb && map[i] != '>') {  // sequence lines until the next record
+        while (i < nb && map[i] != '\n') ++i;
+        ++lines;
+        e = i++;
+      }
+      len = (e - s + 1) - lines;  // non-newline bytes (CuCLARK_hh.hh:1385-1389)
+    } else {
+      while (i < nb && map[i] != '\n') ++i;
+      e = i < nb ? i : nb;
+      ++i;
+      len = e - s;
+      while (i < nb && map[i++] != '\n') {}  // '+' line
+      while (i < nb && map[i++] != '\n') {}  // quality line
+    }
+    if (n < cap) { name_s[n] = ns; name_e[n] = ne; seq_s[n] = s; seq_e[n] = e; length[n] = len; }
+    ++n;
+    if (fasta) {
+      if (i >= nb) break;
+      ++i;  // skip '>'
+    } else {
+      if (++i >= nb) break;  // skip '@'
+    }
+  }
+  return (long)n;
+}
+
+// ---- read packer (CuCLARK_hh.hh:1616-1716) --------------------------------------------------------------
+static inline int nt_code(uint8_t c) {
+  switch (c) {  // m_rTable, CuCLARK_hh.hh:291-295
+    case 'A': case 'a': return 3;
+    case 'C': case 'c': return 2;
+    case 'G': case 'g': return 1;
+    case 'T': case 't': case 'U': case 'u': return 0;
+    default: return -1;
+  }
+}
+
+size_t mic_pack_bound(const uint64_t* seq_s, const uint64_t* seq_e, size_t n_reads, int k) {
+  // a part of L nt takes 1 + ceil(L/8) containers; parts need >= k nt and are separated by >= 1 byte;
+  // sub-part splitting adds one header and k-1 nt per MIC_MAX_PART nt.
+  size_t total = 0;
+  for (size_t r = 0; r < n_reads; ++r) {
+    size_t nb = (size_t)(seq_e[r] - seq_s[r]);
+    size_t parts = nb / (size_t)(k + 1) + 1 + nb / (MIC_MAX_PART - 64);
+    total += nb / 8 + 2 * parts + (nb / (MIC_MAX_PART - 64)) * 8 + 2;
+  }
+  return total + 16;
+}
+
+namespace {
+struct Sink {
+  uint16_t* out; size_t cap; size_t n; bool overflow;
+  inline void put(uint16_t v) { if (n < cap) out[n] = v; else overflow = true; ++n; }
+};
+
+// one maximal ACGTU run -> one or more parts [len][containers...]
+void emit_run(Sink& s, const uint8_t* codes, size_t len, int k) {
+  size_t start = 0;
+  for (;;) {
+    size_t plen = len - start;
+    if (plen > MIC_MAX_PART) plen = MIC_MAX_PART;
+    s.put((uint16_t)plen);
+    size_t i = 0;
+    for (; i + 8 <= plen; i += 8) {
+      const uint8_t* c = codes + start + i;
+      s.put((uint16_t)((c[0] << 14) | (c[1] << 12) | (c[2] << 10) | (c[3] << 8) | (c[4] << 6) | (c[5] << 4) | (c[6] << 2) | c[7]));
+    }
+    if (i < plen) {
+      uint16_t v = 0; unsigned cnt = 0;
+      for (; i < plen; ++i, ++cnt) v = (uint16_t)((v << 2) | codes[start + i]);
+      s.put((uint16_t)(v << (2 * (8 - cnt))));
+    }
+    if (start + plen >= len) break;
+    start += plen - (size_t)(k - 1);
+  }
+}
+}  // namespace
+
+size_t mic_pack_reads(const uint8_t* map, const uint64_t* seq_s, const uint64_t* seq_e, const uint64_t* length,
+                      size_t n_reads, int k, uint32_t* reads_pointer, uint16_t* containers, size_t cap) {
+  Sink s{containers, cap, 0, false};
+  std::vector<uint8_t> codes;
+  for (size_t r = 0; r < n_reads; ++r) {
+    reads_pointer[r] = (uint32_t)s.n;
+    if (length[r] < (uint64_t)k) continue;  // reads without a k-mer store nothing (CuCLARK_hh.hh:1633)
+    const uint8_t* p = map + seq_s[r];
+    const size_t nb = (size_t)(seq_e[r] - seq_s[r]);
+    if (codes.size() < nb) codes.resize(nb * 2 + 64);
+    size_t run = 0;
+    for (size_t i = 0; i < nb; ++i) {
+      const int c = nt_code(p[i]);
+      if (c >= 0) { codes[run++] = (uint8_t)c; continue; }
+      if (p[i] == '\n') continue;  // line breaks are transparent (CuCLARK_hh.hh:1674-1678)
+      if (run >= (size_t)k) emit_run(s, codes.data(), run, k);  // any other byte ends the part
+      run = 0;
+    }
+    if (run >= (size_t)k) emit_run(s, codes.data(), run, k);
+  }
+  reads_pointer[n_reads] = (uint32_t)s.n;
+  return s.overflow ? (size_t)-1 : s.n;
+}
+
+// ---- CSV (CuCLARK_hh.hh:1951-2139) ---------------------------------------------------------------------
+int mic_csv_header(char* buf, size_t cap, int extended, const char* const* target_names, uint32_t n_targets) {
+  size_t n = 0;
+  auto app = [&](const char* s) { size_t l = strlen(s); if (n + l < cap) memcpy(buf + n, s, l); n += l; };
+  app("Object_ID");
+  if (extended)
+    for (uint32_t t = 0; t < n_targets; ++t) { app(","); app(target_names[t]); }
+  app(",Length,Gamma,1st_assignment,score1,2nd_assignment,score2,confidence\n");
+  if (n >= cap) return -1;
+  buf[n] = 0;
+  return (int)n;
+}
+
+int mic_csv_line(char* buf, size_t cap, const uint8_t* name, size_t name_len, uint64_t length, int paired, int k,
+                 const uint32_t* res, const char* const* target_names, uint32_t n_targets, int extended,
+                 const uint32_t* row, const uint32_t* dense) {
+  size_t n = 0;
+  if (name_len >= 40) name_len = 39;  // OBJECTNAMEMAX (parameters.hh:46, CuCLARK_hh.hh:2114-2117)
+  if (n + name_len < cap) memcpy(buf, name, name_len);
+  n += name_len;
+  if (extended) {  // dense per-target counts rebuilt from the sparse row (CuCLARK_hh.hh:2014-2031)
+    uint32_t next = 0, nrow = row ? row[0] : 0, e = 0;
+    for (uint32_t t = 0; t < n_targets; ++t) {
+      uint32_t c = 0;
+      if (dense) c = dense[t];
+      else {
+        while (e < nrow && (row[1 + e] & 0xFFFF) < t) ++e;
+        if (e < nrow && (row[1 + e] & 0xFFFF) == t) c = row[1 + e] >> 16;
+      }
+      (void)next;
+      int w = snprintf(buf + (n < cap ? n : cap), n < cap ? cap - n : 0, ",%u", c);
+      n += (size_t)w;
+    }
+  }
+  const uint32_t norm = paired ? (uint32_t)length - 1u : (uint32_t)length;  // ITYPE arithmetic, NBN=1
+  const uint32_t total = res[0], ib = res[1], best = res[2], is = res[3], sbest = res[4];
+  const double gamma = (double)total / (((double)norm - (double)k) + 1.0);
+  double delta = (double)(best + sbest);
+  delta = (delta < 0.001) ? 0 : ((double)best) / delta;
+  const char* n1 = (ib == 0 || ib > n_targets) ? "NA" : target_names[ib - 1];
+  const char* n2 = (is == 0 || is > n_targets) ? "NA" : target_names[is - 1];
+  int w = snprintf(buf + (n < cap ? n : cap), n < cap ? cap - n : 0, ",%u,%g,%s,%u,%s,%u,%g\n", norm, gamma, n1, best, n2,
+                   sbest, delta);
+  n += (size_t)w;
+  return n < cap ? (int)n : -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// mic_internal.h — shared between the HIP kernels and the engine (not part of the public ABI).
+#ifndef MIC_INTERNAL_H
+#define MIC_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+// ---- exact 64-bit division by a runtime-constant divisor (HTSIZE) -------------------------------
+// Granlund–Montgomery "round-up" magic, computed once on the host (mic_make_div):
+//   magic == 0 : divisor is a power of two, q = n >> shift
+//   add == 0   : q = mulhi(magic, n) >> shift
+//   add == 1   : q = (((n - t) >> 1) + t) >> shift,  t = mulhi(magic, n)
+// Replaces the reference's compile-time-constant division `c / HTSIZE` (CuClarkDB.cu:1268-1269):
+// HTSIZE is a runtime value here (= size of .sz), so one binary serves cuCLARK and cuCLARK-l.
+struct MicDiv {
+  uint64_t d;
+  uint64_t magic;
+  uint32_t shift;
+  uint32_t add;
+};
+
+MicDiv mic_make_div(uint64_t d);
+
+static inline __host__ __device__ uint64_t mic_mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+static inline __host__ __device__ uint64_t mic_div(uint64_t n, const MicDiv& dv) {
+  if (dv.magic == 0) return n >> dv.shift;
+  uint64_t t = mic_mulhi64(dv.magic, n);
+  if (dv.add) return (((n - t) >> 1) + t) >> dv.shift;
+  return t >> dv.shift;
+}
+
+// ---- resident table --------------------------------------------------------------------------
+// One 64-byte slot per bucket = 4 quarters of 16 bytes; a quad of 4 lanes loads one slot with a single
+// wave-instruction (global_load_dwordx4), i.e. ONE random 64-byte request per probe.
+//   slot class 32 (quotients < 2^32; u16/u32 keys on disk): quarter j = { key[2j], key[2j+1],
+//        label[2j] | label[2j+1] << 16, meta }        -> 8 entries inline
+//   slot class 64 (u64 keys on disk): quarter j = { key_lo, key_hi, label, meta } -> 4 entries inline
+//   meta: bits 0..7 = n, entries stored from this slot onwards along the chain (saturating at 255);
+//         bits 8..31 of quarters 0 and 1 = low / high 24 bits of the absolute index of the next slot
+//         of the chain (used only when n > capacity).
+// Entries are the bucket's keys that the reference's linear scan can reach (strict prefix maxima
+// that are <= the bucket's last key, CuClarkDB.cu:1291-1307), in ascending order.
+#define MIC_SLOT_BYTES 64
+#define MIC_FLAG_ROW_OVERFLOW_ 1u  /* == MIC_FLAG_ROW_OVERFLOW */
+#define MIC_FLAG_DENSE_PATH_ 2u    /* == MIC_FLAG_DENSE_PATH   */
+#define MIC_ROW_INVALID 0xFFFFFFFFu     /* row[0] of a sparse row that did not fit */
+#define MIC_CAP32 8
+#define MIC_CAP64 4
+
+struct MicTable {
+  const uint4* slots;    // n_main + n_overflow slots
+  uint64_t n_main;       // = shard_end - shard_start
+  uint64_t shard_start;  // first bucket of the shard
+  uint64_t shard_end;
+  MicDiv div;            // division by htsize
+  int k;
+};
+
+struct MicQueryArgs {
+  MicTable t;
+  const uint32_t* reads_ptr;
+  const uint16_t* cont;
+  uint32_t n_reads;
+  uint32_t row_words;   // 0 => no rows
+  uint32_t* results;    // n_reads * 8
+  uint32_t* rows;       // n_reads * row_words or nullptr
+  uint32_t* flagged;    // [0] = count, [1..] = read ids needing the dense path (or nullptr)
+  uint32_t flagged_cap;
+};
+
+// launchers (mic_kernels.hip)
+hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hipStream_t s);
+hipError_t mic_launch_merge_rows(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t row_words, size_t n,
+                                 uint32_t* flags_results, hipStream_t s);
+hipError_t mic_launch_result_from_rows(const uint32_t* rows, uint32_t row_words, uint32_t* results, size_t n,
+                                       hipStream_t s);
+hipError_t mic_launch_dense_count(const MicTable& t, int slot_class, const uint32_t* reads_ptr, const uint16_t* cont,
+                                  const uint32_t* ids, size_t n_ids, uint32_t n_targets, uint32_t* counts,
+                                  hipStream_t s);
+hipError_t mic_launch_dense_finish(const uint32_t* counts, const uint32_t* ids, size_t n_ids, uint32_t n_targets,
+                                   uint32_t* results, uint32_t* rows, uint32_t row_words, hipStream_t s);
+
+// table build (mic_build.hip)
+struct MicBuildOut {
+  uint4* slots;
+  uint64_t n_main, n_overflow, n_elems, n_elems_file;
+  uint32_t max_bucket;
+};
+// d_sizes/d_keys/d_labels point at the first bucket / first element of the shard.
+// rank_base = number of non-empty buckets before the shard (sampling is defined on the whole table).
+int mic_build_table(const uint8_t* d_sizes, uint64_t n_buckets, const void* d_keys, int key_bytes,
+                    const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int slot_class, hipStream_t s,
+                    MicBuildOut* out, char* err, size_t err_cap);
+// sums over d_sizes[0..n): total elements and non-empty buckets
+int mic_reduce_sizes(const uint8_t* d_sizes, uint64_t n, uint64_t* total, uint64_t* nonzero, hipStream_t s);
+
+#endif

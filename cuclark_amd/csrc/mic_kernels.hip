@@ -1,0 +1,474 @@
+// mic_kernels.hip — the fused k-mer query kernel and its companions, hand-written for gfx950 (wave64).
+//
+// Replaces queryKernel + queryElement + resultKernel (CuClarkDB.cu:1045-1314, 1421-1471) and
+// mergeKernel (:1321-1415).  Design:
+//   * one wavefront per read; k-mer t of a 128-k-mer chunk is assembled by lane t%64 in pass t/64 from
+//     the packed containers (10 dwords per chunk held one per lane, fetched with ds_bpermute);
+//   * canonical k-mer, exact division by the runtime HTSIZE (magic multiply), shard filter;
+//   * the probe is transposed so that a QUAD of 4 lanes loads one 64-byte slot (one request per probe);
+//     8 such loads per lane are in flight before the first compare;
+//   * hits are tallied with ballot/popcount on wave-uniform labels into a register-resident sparse row
+//     (one (target,count) entry per lane, 64 entries), best/second are a scalar top-2 over that row;
+//   * reads with more than 64 distinct targets, or whose row does not fit the caller's row pitch, are
+//     listed for the dense fallback kernels below, which are exact for any read.
+#include "mic_internal.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t bperm(int src_lane, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+#define QP_BCAST0 0x00
+#define QP_BCAST1 0x55
+#define QP_BCAST3 0xFF
+#define QP_XOR1 0xB1
+#define QP_XOR2 0x4E
+
+__device__ __forceinline__ uint64_t revcomp_bits(uint64_t x, int k) {
+  // reverse all 64 bits, then swap the two bits of every pair back: 2-bit groups reversed
+  uint64_t r = __builtin_bitreverse64(x);
+  r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+  return (~r) >> (64 - 2 * k);
+}
+
+__device__ __forceinline__ uint64_t canonical(uint64_t kmer, int k) {
+  uint64_t rc = revcomp_bits(kmer, k);
+  return kmer < rc ? kmer : rc;
+}
+
+// k-mer value of nucleotides [nt, nt+k) of a stream whose 32-bit big-endian-in-nt dwords are d0,d1,d2
+// starting at dword nt/16.
+__device__ __forceinline__ uint64_t kmer_from_dwords(uint32_t d0, uint32_t d1, uint32_t d2, int nt_in_dword, int k) {
+  const int s = 2 * nt_in_dword;  // 0..30
+  uint64_t a = ((uint64_t)d0 << 32) | d1;
+  uint64_t x = s ? ((a << s) | (uint64_t)(d2 >> (32 - s))) : a;
+  return x >> (64 - 2 * k);
+}
+
+struct Probe {  // what a pass lane knows about its k-mer
+  uint32_t slot;  // slot index relative to the shard, 0xFFFFFFFF = nothing to probe
+  uint32_t qlo, qhi;
+};
+
+template <bool KEY64>
+__device__ __forceinline__ Probe make_probe(const MicTable& t, uint64_t kmer, bool active) {
+  uint64_t c = canonical(kmer, t.k);
+  uint64_t q = mic_div(c, t.div);
+  uint64_t rem = c - q * t.div.d;
+  Probe p;
+  bool ok = active && rem >= t.shard_start && rem < t.shard_end;  // CuClarkDB.cu:1272-1274
+  // the reference compares the full-width quotient with the stored key (CuClarkDB.cu:1291-1298): a
+  // quotient that does not fit the 32-bit slot class can never be equal to one
+  if (!KEY64) ok = ok && (q >> 32) == 0;
+  p.slot = ok ? (uint32_t)(rem - t.shard_start) : 0xFFFFFFFFu;
+  p.qlo = (uint32_t)q; p.qhi = (uint32_t)(q >> 32);
+  return p;
+}
+
+// Compare one loaded quarter against the quotient.  Returns label+1 in the hitting lane, else 0.
+template <bool KEY64>
+__device__ __forceinline__ uint32_t match_quarter(const uint4& q, uint32_t qlo, uint32_t qhi, int j) {
+  const uint32_t n = q.w & 0xFF;
+  if constexpr (KEY64) {
+    bool hit = (uint32_t)j < n && q.x == qlo && q.y == qhi;
+    return hit ? (q.z & 0xFFFF) + 1 : 0;
+  } else {
+    bool ha = (uint32_t)(2 * j) < n && q.x == qlo;
+    bool hb = (uint32_t)(2 * j + 1) < n && q.y == qlo;
+    uint32_t lab = ha ? (q.z & 0xFFFF) : (q.z >> 16);
+    return (ha | hb) ? lab + 1 : 0;
+  }
+}
+
+// Follow the overflow chain for quads whose bucket holds more than one slot (rare).  `res` is the
+// quad-reduced result so far (label+1 or 0, identical in the 4 lanes).
+template <bool KEY64>
+__device__ __forceinline__ uint32_t chase_chain(const uint4* __restrict__ slots, uint4 q, uint32_t qlo, uint32_t qhi,
+                                                int j, uint32_t res, bool probing) {
+  constexpr uint32_t CAP = KEY64 ? MIC_CAP64 : MIC_CAP32;
+  for (;;) {
+    const uint32_t n = q.w & 0xFF;
+    // largest key of this slot lives in lane 3 of the quad (x,y for 64-bit keys; y for 32-bit keys)
+    uint32_t lk_lo = quad_perm<QP_BCAST3>(KEY64 ? q.x : q.y);
+    uint32_t lk_hi = KEY64 ? quad_perm<QP_BCAST3>(q.y) : 0;
+    uint64_t lastk = ((uint64_t)lk_hi << 32) | lk_lo;
+    uint64_t qq = ((uint64_t)(KEY64 ? qhi : 0) << 32) | qlo;
+    uint32_t w0 = quad_perm<QP_BCAST0>(q.w), w1 = quad_perm<QP_BCAST1>(q.w);
+    uint64_t next = (uint64_t)(w0 >> 8) | ((uint64_t)(w1 >> 8) << 24);
+    bool more = probing && n > CAP && res == 0 && qq > lastk;
+    if (__ballot(more) == 0) break;
+    q = make_uint4(0, 0, 0, 0);
+    if (more) q = slots[next * 4 + j];
+    uint32_t m = more ? match_quarter<KEY64>(q, qlo, qhi, j) : 0;
+    m |= quad_perm<QP_XOR1>(m);
+    m |= quad_perm<QP_XOR2>(m);
+    res |= m;
+    probing = more;
+  }
+  return res;
+}
+
+// Register-resident sparse row of one read: lane i holds entry i.
+struct RowAcc {
+  uint32_t label1;  // label+1, 0 = empty
+  uint32_t count;
+};
+
+__device__ __forceinline__ void row_add(RowAcc& acc, uint32_t& n_ent, uint32_t& overflow, uint32_t l1, uint32_t cnt,
+                                        int lane) {
+  uint64_t f = __ballot(acc.label1 == l1);
+  if (f) {
+    if (acc.label1 == l1) acc.count += cnt;
+  } else if (n_ent < 64) {
+    if ((uint32_t)lane == n_ent) { acc.label1 = l1; acc.count = cnt; }
+    ++n_ent;
+  } else {
+    overflow = 1;
+  }
+}
+
+// Tally the two result registers of a chunk (each lane: label+1 or 0) into the row.
+__device__ __forceinline__ void tally2(uint32_t r0, uint32_t r1, RowAcc& acc, uint32_t& n_ent, uint32_t& overflow,
+                                       uint32_t& total, int lane) {
+  uint64_t m0 = __ballot(r0 != 0), m1 = __ballot(r1 != 0);
+  total += __popcll(m0) + __popcll(m1);
+  while (m0 | m1) {
+    uint32_t l1;
+    if (m0) l1 = __builtin_amdgcn_readlane(r0, __builtin_ctzll(m0));
+    else l1 = __builtin_amdgcn_readlane(r1, __builtin_ctzll(m1));
+    uint64_t e0 = __ballot(r0 == l1), e1 = __ballot(r1 == l1);
+    m0 &= ~e0; m1 &= ~e1;
+    row_add(acc, n_ent, overflow, l1, __popcll(e0) + __popcll(e1), lane);
+  }
+}
+
+// Scalar top-2 over the row under the order (count desc, target asc) — equivalent to resultKernel's
+// ascending scan with strict '>' (CuClarkDB.cu:1440-1459), see DESIGN.md §4.
+__device__ __forceinline__ void finish_read(const RowAcc& acc, uint32_t n_ent, uint32_t total, uint32_t overflow,
+                                            uint32_t r, const MicQueryArgs& a, int lane) {
+  uint64_t best = 0, second = 0;
+  for (uint32_t i = 0; i < n_ent; ++i) {
+    uint32_t l1 = __builtin_amdgcn_readlane(acc.label1, i);
+    uint32_t c = __builtin_amdgcn_readlane(acc.count, i);
+    uint64_t key = ((uint64_t)c << 16) | (uint64_t)(0x10000u - l1);  // 0xFFFF - label
+    if (key > best) { second = best; best = key; }
+    else if (key > second) second = key;
+  }
+  uint32_t flags = 0;
+  if (a.rows) {
+    uint32_t* row = a.rows + (size_t)r * a.row_words;
+    bool fits = n_ent <= a.row_words - 1 && !overflow;
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < n_ent; ++i) {
+      uint32_t li = __builtin_amdgcn_readlane(acc.label1, i);
+      rank += li < acc.label1;
+    }
+    bool big = (uint32_t)lane < n_ent && acc.count > 0xFFFF;
+    if (__ballot(big)) fits = false;
+    if (fits) {
+      if ((uint32_t)lane < n_ent) row[1 + rank] = (acc.count << 16) | (acc.label1 - 1);
+      if (lane == 0) row[0] = n_ent;
+    } else {
+      if (lane == 0) row[0] = MIC_ROW_INVALID;
+      flags |= MIC_FLAG_ROW_OVERFLOW_;
+    }
+  }
+  if (overflow) flags |= MIC_FLAG_ROW_OVERFLOW_;
+  if (lane == 0) {
+    uint4 lo, hi;
+    lo.x = total;
+    lo.y = best ? 0x10000u - (uint32_t)(best & 0xFFFF) : 0;   // label+1
+    lo.z = (uint32_t)(best >> 16);
+    lo.w = second ? 0x10000u - (uint32_t)(second & 0xFFFF) : 0;
+    hi.x = (uint32_t)(second >> 16);
+    hi.y = n_ent; hi.z = flags; hi.w = 0;
+    uint4* out = (uint4*)(a.results + (size_t)r * 8);
+    out[0] = lo; out[1] = hi;
+    if (flags && a.flagged) {
+      uint32_t pos = atomicAdd(&a.flagged[0], 1u);
+      if (pos < a.flagged_cap) a.flagged[1 + pos] = r;
+    }
+  }
+}
+
+template <bool KEY64>
+__global__ void __launch_bounds__(256) query_kernel(const MicQueryArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 3;
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const uint32_t n_waves = gridDim.x * 4;
+  const MicTable& t = a.t;
+  const int k = t.k;
+  const uint4* __restrict__ slots = t.slots;
+  const uint16_t* __restrict__ cont = a.cont;
+
+  for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
+    uint32_t pp = __builtin_amdgcn_readfirstlane(a.reads_ptr[r]);
+    const uint32_t pe = __builtin_amdgcn_readfirstlane(a.reads_ptr[r + 1]);
+    RowAcc acc; acc.label1 = 0; acc.count = 0;
+    uint32_t n_ent = 0, overflow = 0, total = 0;
+
+    while (pp < pe) {  // parts of the read (CuClarkDB.cu:1090-1097)
+      const uint32_t plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
+      if (plen == 0) break;
+      const uint32_t first = pp + 1;
+      pp = first + (plen + 7) / 8;
+      if (plen < (uint32_t)k) continue;
+      const uint32_t nk = plen - k + 1;
+      const uint32_t cend = pp;
+      for (uint32_t base = 0; base < nk; base += 128) {
+        // 10 dwords (160 nt) cover the 128 + k - 1 nucleotides of this chunk; lane i holds dword i
+        uint32_t w = 0;
+        {
+          uint32_t ci = first + base / 8 + 2 * lane;
+          if (lane < 10) {
+            uint32_t hi = ci < cend ? cont[ci] : 0;
+            uint32_t lo = ci + 1 < cend ? cont[ci + 1] : 0;
+            w = (hi << 16) | lo;
+          }
+        }
+        Probe pr[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int idx = 4 * h + (lane >> 4);
+          uint32_t d0 = bperm(idx, w), d1 = bperm(idx + 1, w), d2 = bperm(idx + 2, w);
+          uint64_t kmer = kmer_from_dwords(d0, d1, d2, lane & 15, k);
+          pr[h] = make_probe<KEY64>(t, kmer, base + 64 * h + lane < nk);
+        }
+        // transpose: sub-pass s serves k-mers 16*(s&3) .. +15 of pass s>>2, one quad per k-mer
+        uint4 q[8]; uint32_t qlo[8], qhi[8]; uint32_t sl[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int src = 16 * (s & 3) + (lane >> 2);
+          sl[s] = bperm(src, pr[s >> 2].slot);
+          qlo[s] = bperm(src, pr[s >> 2].qlo);
+          qhi[s] = KEY64 ? bperm(src, pr[s >> 2].qhi) : 0;
+          q[s] = make_uint4(0, 0, 0, 0);
+          if (sl[s] != 0xFFFFFFFFu) q[s] = slots[(uint64_t)sl[s] * 4 + j];
+        }
+        uint32_t res0 = 0, res1 = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          uint32_t m = match_quarter<KEY64>(q[s], qlo[s], qhi[s], j);
+          m |= quad_perm<QP_XOR1>(m);
+          m |= quad_perm<QP_XOR2>(m);
+          constexpr uint32_t CAP = KEY64 ? MIC_CAP64 : MIC_CAP32;
+          if (__ballot((q[s].w & 0xFF) > CAP))
+            m = chase_chain<KEY64>(slots, q[s], qlo[s], qhi[s], j, m, sl[s] != 0xFFFFFFFFu);
+          // lane j of the quad keeps the result of sub-pass with (s&3)==j
+          if (s < 4) res0 = (j == (s & 3)) ? m : res0;
+          else res1 = (j == (s & 3)) ? m : res1;
+        }
+        tally2(res0, res1, acc, n_ent, overflow, total, lane);
+      }
+    }
+    finish_read(acc, n_ent, total, overflow, r, a, lane);
+  }
+}
+
+// ---- merge / result on sparse rows ----------------------------------------------------------------
+// mergeKernel (CuClarkDB.cu:1321-1415): one thread per read, two-pointer merge by ascending target.
+__global__ void merge_rows_kernel(const uint32_t* __restrict__ ra, const uint32_t* __restrict__ rb,
+                                  uint32_t* __restrict__ out, uint32_t row_words, size_t n,
+                                  uint32_t* __restrict__ results) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* a = ra + i * row_words; const uint32_t* b = rb + i * row_words; uint32_t* o = out + i * row_words;
+  uint32_t na = a[0], nb = b[0], ia = 0, ib = 0, no = 0;
+  bool ok = na != MIC_ROW_INVALID && nb != MIC_ROW_INVALID;
+  if (!ok) { na = 0; nb = 0; }
+  while (ia < na || ib < nb) {
+    uint32_t va = ia < na ? a[1 + ia] : 0xFFFFFFFFu, vb = ib < nb ? b[1 + ib] : 0xFFFFFFFFu;
+    uint32_t ta = ia < na ? (va & 0xFFFF) : 0x10000u, tb = ib < nb ? (vb & 0xFFFF) : 0x10000u;
+    uint32_t tgt, cnt;
+    if (ta < tb) { tgt = ta; cnt = va >> 16; ++ia; }
+    else if (tb < ta) { tgt = tb; cnt = vb >> 16; ++ib; }
+    else { tgt = ta; cnt = (va >> 16) + (vb >> 16); ++ia; ++ib; }
+    if (no + 1 < row_words && cnt <= 0xFFFF) o[1 + no] = (cnt << 16) | tgt; else ok = false;
+    ++no;
+  }
+  o[0] = ok ? no : MIC_ROW_INVALID;
+  (void)results;
+}
+
+// resultKernel (CuClarkDB.cu:1421-1471) on a sparse row.
+__global__ void result_rows_kernel(const uint32_t* __restrict__ rows, uint32_t row_words,
+                                   uint32_t* __restrict__ results, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* row = rows + i * row_words;
+  uint32_t cnt = row[0], sum = 0, best = 0, ib = 0, sb = 0, is = 0, flags = 0;
+  if (cnt == MIC_ROW_INVALID) { cnt = 0; flags = MIC_FLAG_ROW_OVERFLOW_; }
+  for (uint32_t e = 0; e < cnt; ++e) {
+    uint32_t v = row[1 + e], tgt = v & 0xFFFF, sc = v >> 16;
+    if (sc > best) { sb = best; is = ib; best = sc; ib = tgt + 1; }
+    else if (sc > sb) { sb = sc; is = tgt + 1; }
+    sum += sc;
+  }
+  uint4* out = (uint4*)(results + i * 8);
+  out[0] = make_uint4(sum, ib, best, is);
+  out[1] = make_uint4(sb, cnt, flags, 0);
+}
+
+// ---- dense fallback: exact for any read (any length, any number of targets) ------------------------
+// One 256-thread block per listed read; every thread walks k-mer positions t, t+256, ... of each part,
+// probes the slot chain sequentially and atomically increments counts[id][label].
+template <bool KEY64>
+__device__ inline uint32_t probe_scalar(const MicTable& t, uint64_t kmer) {
+  constexpr uint32_t CAP = KEY64 ? MIC_CAP64 : MIC_CAP32;
+  uint64_t c = canonical(kmer, t.k);
+  uint64_t q = mic_div(c, t.div);
+  uint64_t rem = c - q * t.div.d;
+  if (rem < t.shard_start || rem >= t.shard_end) return 0;
+  if (!KEY64 && (q >> 32) != 0) return 0;
+  uint64_t slot = rem - t.shard_start;
+  for (;;) {
+    uint4 qq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qq[j] = t.slots[slot * 4 + j];
+    uint32_t n = qq[0].w & 0xFF;
+    uint64_t lastk = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t m = match_quarter<KEY64>(qq[j], (uint32_t)q, (uint32_t)(q >> 32), j);
+      if (m) return m;
+    }
+    lastk = KEY64 ? (((uint64_t)qq[3].y << 32) | qq[3].x) : (uint64_t)qq[3].y;
+    if (n <= CAP || q <= lastk) return 0;
+    slot = (uint64_t)(qq[0].w >> 8) | ((uint64_t)(qq[1].w >> 8) << 24);
+  }
+}
+
+template <bool KEY64>
+__global__ void __launch_bounds__(256) dense_count_kernel(const MicTable t, const uint32_t* __restrict__ reads_ptr,
+                                                          const uint16_t* __restrict__ cont,
+                                                          const uint32_t* __restrict__ ids, uint32_t n_targets,
+                                                          uint32_t* __restrict__ counts) {
+  const uint32_t r = ids ? ids[blockIdx.x] : blockIdx.x;
+  uint32_t* row = counts + (size_t)blockIdx.x * n_targets;
+  uint32_t pp = reads_ptr[r];
+  const uint32_t pe = reads_ptr[r + 1];
+  const int k = t.k;
+  while (pp < pe) {
+    const uint32_t plen = cont[pp];
+    if (plen == 0) break;
+    const uint32_t first = pp + 1;
+    pp = first + (plen + 7) / 8;
+    if (plen < (uint32_t)k) continue;
+    const uint32_t nk = plen - k + 1;
+    for (uint32_t pos = threadIdx.x; pos < nk; pos += blockDim.x) {
+      // nucleotides [pos, pos+k): containers pos/8 .. (pos+k-1)/8, at most 5
+      uint32_t c0 = first + pos / 8;
+      uint64_t hi = 0; uint32_t lo = 0;  // 80-bit window hi(64) : lo(16)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hi = (hi << 16) | (c0 + i < pp ? cont[c0 + i] : 0);
+      lo = c0 + 4 < pp ? cont[c0 + 4] : 0;
+      int s = 2 * (pos & 7);
+      uint64_t x = s ? ((hi << s) | ((uint64_t)lo >> (16 - s))) : hi;
+      uint64_t kmer = x >> (64 - 2 * k);
+      uint32_t m = probe_scalar<KEY64>(t, kmer);
+      if (m && m - 1 < n_targets) atomicAdd(&row[m - 1], 1u);
+    }
+  }
+}
+
+// One block per listed read: scan its dense counts (ascending target) -> result row (+ sparse row if it fits).
+__global__ void __launch_bounds__(256) dense_finish_kernel(const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ ids, uint32_t n_targets,
+                                                           uint32_t* __restrict__ results, uint32_t* __restrict__ rows,
+                                                           uint32_t row_words) {
+  const uint32_t r = ids ? ids[blockIdx.x] : blockIdx.x;
+  const uint32_t* row = counts + (size_t)blockIdx.x * n_targets;
+  __shared__ unsigned long long s_best[256], s_second[256];
+  __shared__ uint32_t s_sum[256], s_n[256];
+  unsigned long long best = 0, second = 0; uint32_t sum = 0, nz = 0;
+  for (uint32_t tg = threadIdx.x; tg < n_targets; tg += blockDim.x) {
+    uint32_t c = row[tg];
+    if (!c) continue;
+    unsigned long long key = ((unsigned long long)c << 16) | (0xFFFFu - tg);
+    if (key > best) { second = best; best = key; } else if (key > second) second = key;
+    sum += c; ++nz;
+  }
+  s_best[threadIdx.x] = best; s_second[threadIdx.x] = second; s_sum[threadIdx.x] = sum; s_n[threadIdx.x] = nz;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    best = 0; second = 0; sum = 0; nz = 0;
+    for (int i = 0; i < 256; ++i) {
+      unsigned long long c2[2] = {s_best[i], s_second[i]};
+      for (int u = 0; u < 2; ++u) {
+        unsigned long long key = c2[u];
+        if (key > best) { second = best; best = key; } else if (key > second) second = key;
+      }
+      sum += s_sum[i]; nz += s_n[i];
+    }
+    uint32_t flags = MIC_FLAG_DENSE_PATH_;
+    if (rows) {
+      uint32_t* orow = rows + (size_t)r * row_words;
+      bool fits = nz <= row_words - 1;
+      if (fits) {
+        uint32_t no = 0;
+        for (uint32_t tg = 0; tg < n_targets && fits; ++tg) {
+          uint32_t c = row[tg];
+          if (!c) continue;
+          if (c > 0xFFFF) { fits = false; break; }
+          orow[1 + no++] = (c << 16) | tg;
+        }
+        if (fits) orow[0] = nz;
+      }
+      if (!fits) { orow[0] = MIC_ROW_INVALID; flags |= MIC_FLAG_ROW_OVERFLOW_; }
+    }
+    uint4* out = (uint4*)(results + (size_t)r * 8);
+    out[0] = make_uint4(sum, best ? 0x10000u - (uint32_t)(best & 0xFFFF) : 0, (uint32_t)(best >> 16),
+                        second ? 0x10000u - (uint32_t)(second & 0xFFFF) : 0);
+    out[1] = make_uint4((uint32_t)(second >> 16), nz, flags, 0);
+  }
+}
+
+}  // namespace
+
+hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hipStream_t s) {
+  if (a.n_reads == 0) return hipSuccess;
+  unsigned blocks = (a.n_reads + 3) / 4;
+  unsigned cap = (unsigned)n_cu * 8;
+  if (blocks > cap) blocks = cap;
+  if (slot_class == 64) query_kernel<true><<<blocks, 256, 0, s>>>(a);
+  else query_kernel<false><<<blocks, 256, 0, s>>>(a);
+  return hipGetLastError();
+}
+
+hipError_t mic_launch_merge_rows(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t row_words, size_t n,
+                                 uint32_t* flags_results, hipStream_t s) {
+  if (!n) return hipSuccess;
+  merge_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a, b, out, row_words, n, flags_results);
+  return hipGetLastError();
+}
+
+hipError_t mic_launch_result_from_rows(const uint32_t* rows, uint32_t row_words, uint32_t* results, size_t n,
+                                       hipStream_t s) {
+  if (!n) return hipSuccess;
+  result_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(rows, row_words, results, n);
+  return hipGetLastError();
+}
+
+hipError_t mic_launch_dense_count(const MicTable& t, int slot_class, const uint32_t* reads_ptr, const uint16_t* cont,
+                                  const uint32_t* ids, size_t n_ids, uint32_t n_targets, uint32_t* counts,
+                                  hipStream_t s) {
+  if (!n_ids) return hipSuccess;
+  hipError_t e = hipMemsetAsync(counts, 0, n_ids * (size_t)n_targets * sizeof(uint32_t), s);
+  if (e != hipSuccess) return e;
+  if (slot_class == 64) dense_count_kernel<true><<<(unsigned)n_ids, 256, 0, s>>>(t, reads_ptr, cont, ids, n_targets, counts);
+  else dense_count_kernel<false><<<(unsigned)n_ids, 256, 0, s>>>(t, reads_ptr, cont, ids, n_targets, counts);
+  return hipGetLastError();
+}
+
+hipError_t mic_launch_dense_finish(const uint32_t* counts, const uint32_t* ids, size_t n_ids, uint32_t n_targets,
+                                   uint32_t* results, uint32_t* rows, uint32_t row_words, hipStream_t s) {
+  if (!n_ids) return hipSuccess;
+  dense_finish_kernel<<<(unsigned)n_ids, 256, 0, s>>>(counts, ids, n_targets, results, rows, row_words);
+  return hipGetLastError();
+}

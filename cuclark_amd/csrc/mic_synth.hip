@@ -1,0 +1,286 @@
+// mic_synth.hip — synthetic workloads generated directly in HBM.
+//
+// Procedural genomes: n_genomes sequences of equal length; nucleotide p of genome g is a pure function
+// of (seed, g, p), so the database builder and the read sampler agree without storing 5.7e9 nucleotides.
+//   DB:    every k-mer of every genome -> canonical -> (rem, quot) -> counting sort by bucket -> per-bucket
+//          sort by (key, label) -> the on-disk arrays (.sz u8 / .ky / .lb images) in device memory.
+//          This is the same transformation the reference's DB build applies on the CPU
+//          (hashTable_hh.hh:221-269 insert, :203-216 sort, :590-663 write) minus the
+//          discriminative-k-mer filter, which is meaningless for random genomes.
+//   reads: sampled from the genomes (either strand, substitutions, N) or uniform random; emitted in the
+//          packed container format of CuCLARK_hh.hh:1616-1716.
+#include "mi_clark.h"
+#include "mic_internal.h"
+
+#include <stdio.h>
+#include <vector>
+
+namespace {
+
+__host__ __device__ inline uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+
+// 32 nucleotides (first one in the top bits) of genome g starting at 32*b
+__host__ __device__ inline uint64_t genome_word(uint64_t seed, uint64_t g, uint64_t b) {
+  return mix64(mix64(seed ^ (g * 0x9E3779B97F4A7C15ULL)) + b * 0xD1B54A32D192ED03ULL);
+}
+
+__host__ __device__ inline uint32_t genome_nt(uint64_t seed, uint64_t g, uint64_t p) {
+  return (uint32_t)(genome_word(seed, g, p >> 5) >> (2 * (31 - (p & 31)))) & 3u;
+}
+
+__device__ inline uint64_t genome_kmer(uint64_t seed, uint64_t g, uint64_t p, int k) {
+  uint64_t w0 = genome_word(seed, g, p >> 5), w1 = genome_word(seed, g, (p >> 5) + 1);
+  int s = 2 * (int)(p & 31);
+  uint64_t x = s ? ((w0 << s) | (w1 >> (64 - s))) : w0;
+  return x >> (64 - 2 * k);
+}
+
+__device__ inline uint64_t revcomp_bits(uint64_t x, int k) {
+  uint64_t r = __builtin_bitreverse64(x);
+  r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+  return (~r) >> (64 - 2 * k);
+}
+
+struct SynthDev {
+  uint64_t seed, genome_len, kmers_per_genome, n_kmers;
+  uint32_t n_genomes, n_targets;
+  int k;
+  MicDiv div;
+};
+
+__device__ inline void kmer_at(const SynthDev& sp, uint64_t idx, uint64_t& rem, uint64_t& quot, uint32_t& label) {
+  uint64_t g = idx / sp.kmers_per_genome, p = idx - g * sp.kmers_per_genome;
+  uint64_t km = genome_kmer(sp.seed, g, p, sp.k);
+  uint64_t rc = revcomp_bits(km, sp.k);
+  uint64_t c = km < rc ? km : rc;
+  quot = mic_div(c, sp.div);
+  rem = c - quot * sp.div.d;
+  label = (uint32_t)(g % sp.n_targets);
+}
+
+__global__ void count_kernel(SynthDev sp, uint32_t* __restrict__ cnt) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < sp.n_kmers; i += stride) {
+    uint64_t rem, quot; uint32_t label;
+    kmer_at(sp, i, rem, quot, label);
+    atomicAdd(&cnt[rem], 1u);
+  }
+}
+
+#define STILE 1024
+__global__ void __launch_bounds__(256) sizes_tile_kernel(const uint32_t* __restrict__ cnt, uint64_t n,
+                                                         uint8_t* __restrict__ sizes,
+                                                         unsigned long long* __restrict__ tile_sum,
+                                                         uint32_t* __restrict__ max_cnt) {
+  __shared__ uint32_t s[256];
+  uint64_t base = (uint64_t)blockIdx.x * STILE + threadIdx.x * 4;
+  uint32_t sum = 0, mx = 0;
+  for (int j = 0; j < 4; ++j) {
+    uint64_t i = base + j;
+    if (i < n) { uint32_t c = cnt[i]; mx = c > mx ? c : mx; sizes[i] = (uint8_t)(c > 255 ? 255 : c); sum += c > 255 ? 255 : c; }
+  }
+  s[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = s[0];
+  if (mx > 255) atomicMax(max_cnt, mx);
+}
+
+__global__ void __launch_bounds__(256) offsets_kernel(const uint8_t* __restrict__ sizes, uint64_t n,
+                                                      const unsigned long long* __restrict__ tile_base,
+                                                      unsigned long long* __restrict__ offsets) {
+  __shared__ uint32_t s[256];
+  uint64_t base = (uint64_t)blockIdx.x * STILE + threadIdx.x * 4;
+  uint32_t v[4], sum = 0;
+  for (int j = 0; j < 4; ++j) { uint64_t i = base + j; v[j] = i < n ? sizes[i] : 0; sum += v[j]; }
+  s[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    uint32_t a = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += a;
+    __syncthreads();
+  }
+  unsigned long long run = tile_base[blockIdx.x] + s[threadIdx.x] - sum;
+  for (int j = 0; j < 4; ++j) { uint64_t i = base + j; if (i < n) offsets[i] = run; run += v[j]; }
+}
+
+template <typename KEY>
+__global__ void scatter_kernel(SynthDev sp, const unsigned long long* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                               KEY* __restrict__ keys, uint16_t* __restrict__ labels) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < sp.n_kmers; i += stride) {
+    uint64_t rem, quot; uint32_t label;
+    kmer_at(sp, i, rem, quot, label);
+    uint32_t pos = atomicAdd(&cursor[rem], 1u);
+    if (pos < 255) { uint64_t d = offsets[rem] + pos; keys[d] = (KEY)quot; labels[d] = (uint16_t)label; }
+  }
+}
+
+template <typename KEY>
+__global__ void bucket_sort_kernel(const uint8_t* __restrict__ sizes, uint64_t n, const unsigned long long* __restrict__ offsets,
+                                   KEY* __restrict__ keys, uint16_t* __restrict__ labels) {
+  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  uint32_t m = sizes[b];
+  if (m < 2) return;
+  KEY* kk = keys + offsets[b]; uint16_t* ll = labels + offsets[b];
+  for (uint32_t i = 1; i < m; ++i) {  // insertion sort by (key, label)
+    KEY kv = kk[i]; uint16_t lv = ll[i];
+    uint32_t j = i;
+    while (j > 0 && (kk[j - 1] > kv || (kk[j - 1] == kv && ll[j - 1] > lv))) { kk[j] = kk[j - 1]; ll[j] = ll[j - 1]; --j; }
+    kk[j] = kv; ll[j] = lv;
+  }
+}
+
+// ---- reads ------------------------------------------------------------------------------------------
+struct ReadGen {
+  uint64_t seed, read_seed, genome_len;
+  uint32_t n_genomes, n_targets, read_len, pitch;
+  int k;
+  uint32_t random_thr, sub_thr, n_thr;  // thresholds on a 32-bit uniform
+};
+
+__global__ void reads_kernel(ReadGen rg, size_t n_reads, uint32_t* __restrict__ rp, uint16_t* __restrict__ cont,
+                             uint32_t* __restrict__ truth) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_reads) return;
+  if (r == n_reads) { rp[r] = (uint32_t)(n_reads * rg.pitch); return; }
+  rp[r] = (uint32_t)(r * rg.pitch);
+  uint16_t* out = cont + r * rg.pitch;
+  const uint64_t h0 = mix64(rg.read_seed * 0x9E3779B97F4A7C15ULL + r);
+  const bool rnd = (uint32_t)h0 < rg.random_thr;
+  const uint64_t h1 = mix64(h0 + 1), h2 = mix64(h0 + 2);
+  const uint64_t g = h1 % rg.n_genomes;
+  const uint64_t p0 = h2 % (rg.genome_len - rg.read_len + 1);
+  const bool rev = (h0 >> 40) & 1;
+  uint32_t w = 0;            // write cursor in containers
+  uint32_t hdr = 0;          // index of the current part's length slot
+  uint32_t run = 0;          // nt in the current part
+  uint32_t clean = 0;        // consecutive unmodified nt (for the expected-hit count)
+  uint32_t expect = 0;
+  uint16_t cur = 0; uint32_t ncur = 0;
+  bool open = false;
+  for (uint32_t i = 0; i <= rg.read_len; ++i) {
+    int code = -1;
+    if (i < rg.read_len) {
+      const uint64_t hb = mix64(h0 ^ (0xABCD0000ULL + i));
+      if (rnd) {
+        code = (int)(hb & 3);
+      } else {
+        uint32_t nt = rev ? 3u - genome_nt(rg.seed, g, p0 + rg.read_len - 1 - i) : genome_nt(rg.seed, g, p0 + i);
+        bool sub = (uint32_t)(hb >> 32) < rg.sub_thr;
+        if (sub) nt = (nt + 1 + (uint32_t)((hb >> 8) % 3)) & 3u;
+        code = (int)nt;
+        clean = sub ? 0 : clean + 1;
+      }
+      if ((uint32_t)(mix64(hb) >> 32) < rg.n_thr) { code = -1; clean = 0; }
+      if (code >= 0 && !rnd && clean >= (uint32_t)rg.k) ++expect;
+    }
+    if (code >= 0) {
+      if (!open) { hdr = w++; open = true; run = 0; cur = 0; ncur = 0; }
+      cur = (uint16_t)((cur << 2) | (uint16_t)code); ++ncur; ++run;
+      if (ncur == 8) { out[w++] = cur; cur = 0; ncur = 0; }
+    } else if (open) {
+      if (ncur) out[w++] = (uint16_t)(cur << (2 * (8 - ncur)));
+      if (run >= (uint32_t)rg.k) out[hdr] = (uint16_t)run; else w = hdr;  // parts shorter than k are dropped
+      open = false;
+    }
+  }
+  if (w < rg.pitch) out[w] = 0;  // terminator
+  if (truth) { truth[2 * r] = rnd ? 0 : (uint32_t)(g % rg.n_targets) + 1; truth[2 * r + 1] = expect; }
+}
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "mic_synth: %s: %s\n", #x, hipGetErrorString(e_)); rc = MIC_E_HIP; goto done; } } while (0)
+
+}  // namespace
+
+extern "C" {
+
+// containers per read used by mic_synth_reads_device: data + 2 per possible part + terminator + room for
+// a short part that is written and then dropped
+uint32_t mic_synth_read_pitch(uint32_t read_len, int k) {
+  return (read_len + 7) / 8 + 2 * (read_len / (uint32_t)(k + 1) + 1) + 1 + 6;
+}
+
+int mic_synth_db_device(const mic_synth_spec* spec, uint8_t* d_sizes, void* d_keys, uint16_t* d_labels,
+                        uint64_t capacity, uint64_t* n_elems, void* stream) {
+  if (!spec || !d_sizes || !d_keys || !d_labels || !n_elems) return MIC_E_INVALID;
+  if (spec->k < 2 || spec->k > 32 || spec->n_genomes == 0 || spec->n_targets == 0 || spec->htsize < 2) return MIC_E_INVALID;
+  if (spec->key_bytes != 4 && spec->key_bytes != 8) return MIC_E_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = MIC_OK;
+  SynthDev sp;
+  sp.seed = spec->seed; sp.genome_len = spec->genome_nt / spec->n_genomes;
+  if (sp.genome_len < (uint64_t)spec->k + 1) return MIC_E_INVALID;
+  sp.kmers_per_genome = sp.genome_len - spec->k + 1;
+  sp.n_kmers = sp.kmers_per_genome * spec->n_genomes;
+  sp.n_genomes = spec->n_genomes; sp.n_targets = spec->n_targets; sp.k = spec->k;
+  sp.div = mic_make_div(spec->htsize);
+  const uint64_t H = spec->htsize;
+  const unsigned n_tiles = (unsigned)((H + STILE - 1) / STILE);
+  uint32_t* d_cnt = nullptr; unsigned long long* d_tile = nullptr; unsigned long long* d_off = nullptr; uint32_t* d_max = nullptr;
+  std::vector<unsigned long long> h_tile(n_tiles);
+  unsigned long long total = 0; uint32_t h_max = 0;
+  HIPCK(hipMalloc(&d_cnt, H * 4));
+  HIPCK(hipMalloc(&d_tile, (size_t)n_tiles * 8));
+  HIPCK(hipMalloc(&d_off, (H + 1) * 8));
+  HIPCK(hipMalloc(&d_max, 4));
+  HIPCK(hipMemsetAsync(d_cnt, 0, H * 4, s));
+  HIPCK(hipMemsetAsync(d_max, 0, 4, s));
+  count_kernel<<<256 * 16, 256, 0, s>>>(sp, d_cnt);
+  HIPCK(hipGetLastError());
+  sizes_tile_kernel<<<n_tiles, 256, 0, s>>>(d_cnt, H, d_sizes, d_tile, d_max);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(h_tile.data(), d_tile, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, s));
+  HIPCK(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
+  HIPCK(hipStreamSynchronize(s));
+  if (h_max > 255) { fprintf(stderr, "mic_synth: a bucket would hold %u > 255 elements; enlarge htsize\n", h_max); rc = MIC_E_INVALID; goto done; }
+  for (unsigned t = 0; t < n_tiles; ++t) { unsigned long long v = h_tile[t]; h_tile[t] = total; total += v; }
+  *n_elems = total;
+  if (total > capacity) { rc = MIC_E_NOMEM; goto done; }
+  HIPCK(hipMemcpyAsync(d_tile, h_tile.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, s));
+  offsets_kernel<<<n_tiles, 256, 0, s>>>(d_sizes, H, d_tile, d_off);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemsetAsync(d_cnt, 0, H * 4, s));
+  if (spec->key_bytes == 4) scatter_kernel<uint32_t><<<256 * 16, 256, 0, s>>>(sp, d_off, d_cnt, (uint32_t*)d_keys, d_labels);
+  else scatter_kernel<uint64_t><<<256 * 16, 256, 0, s>>>(sp, d_off, d_cnt, (uint64_t*)d_keys, d_labels);
+  HIPCK(hipGetLastError());
+  {
+    unsigned blocks = (unsigned)((H + 255) / 256);
+    if (spec->key_bytes == 4) bucket_sort_kernel<uint32_t><<<blocks, 256, 0, s>>>(d_sizes, H, d_off, (uint32_t*)d_keys, d_labels);
+    else bucket_sort_kernel<uint64_t><<<blocks, 256, 0, s>>>(d_sizes, H, d_off, (uint64_t*)d_keys, d_labels);
+    HIPCK(hipGetLastError());
+  }
+  HIPCK(hipStreamSynchronize(s));
+done:
+  if (d_cnt) hipFree(d_cnt);
+  if (d_tile) hipFree(d_tile);
+  if (d_off) hipFree(d_off);
+  if (d_max) hipFree(d_max);
+  return rc;
+}
+
+int mic_synth_reads_device(const mic_synth_spec* spec, uint64_t read_seed, size_t n_reads, uint32_t read_len,
+                           double random_frac, double sub_rate, double n_rate, uint32_t* d_rp, uint16_t* d_cont,
+                           size_t containers_cap, uint32_t* d_truth, void* stream) {
+  if (!spec || !d_rp || !d_cont || read_len == 0) return MIC_E_INVALID;
+  ReadGen rg;
+  rg.seed = spec->seed; rg.read_seed = read_seed;
+  rg.genome_len = spec->genome_nt / spec->n_genomes;
+  if (rg.genome_len < read_len) return MIC_E_INVALID;
+  rg.n_genomes = spec->n_genomes; rg.n_targets = spec->n_targets; rg.read_len = read_len; rg.k = spec->k;
+  rg.pitch = mic_synth_read_pitch(read_len, spec->k);
+  if ((uint64_t)n_reads * rg.pitch > containers_cap || (uint64_t)n_reads * rg.pitch > 0xFFFFFFF0ull) return MIC_E_NOMEM;
+  auto thr = [](double p) { double v = p * 4294967296.0; return v <= 0 ? 0u : (v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v); };
+  rg.random_thr = thr(random_frac); rg.sub_thr = thr(sub_rate); rg.n_thr = thr(n_rate);
+  reads_kernel<<<(unsigned)((n_reads + 1 + 255) / 256), 256, 0, (hipStream_t)stream>>>(rg, n_reads, d_rp, d_cont, d_truth);
+  return hipGetLastError() == hipSuccess ? MIC_OK : MIC_E_HIP;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+"""MiClarkDB — host-side mirror of the reference's CuClarkDB<HKMERr> interface over the C ABI.
+
+Method names and argument meaning follow CuClarkDB.cuh:98-150 (read, malloc, readyBatch, queryBatch,
+swapDbParts, waitForBatch, checkBatch, sync, freeBatchMemory) so that tests read like calls the reference's
+CuCLARK_hh.hh makes.  Differences, all stated in include/mi_clark.h: the key width is a runtime value, results
+are u32 rows of 8 words, the whole table is resident (swapDbParts never has another part), and errors raise
+MicError instead of exit(1).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MicConfig, MicDbInfo, MicError, check, MIC_RESULT_WORDS
+
+
+def _as_np(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+class MiClarkDB:
+    def __init__(self, k, num_targets, num_batches=1, device=-1, row_words=16):
+        self.L = _lib.load()
+        self.k = int(k)
+        self.num_targets = int(num_targets)
+        self.num_batches = int(num_batches)
+        self.row_words = int(row_words)
+        cfg = MicConfig(device, self.k, self.num_targets, self.num_batches, self.row_words, 0)
+        h = C.c_void_p()
+        check(self.L.mic_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self._bufs = None
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mic_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- database (CuClarkDB::read + swapDbParts)
+    def read(self, filename, sampling=1, key_bytes=0, shard=(0, 0)):
+        """Returns False when a DB file cannot be opened (reference: read() returns false, CuClarkDB.cu:490-495)."""
+        rc = self.L.mic_db_load_files(self.h, filename.encode(), int(key_bytes), int(sampling), int(shard[0]), int(shard[1]))
+        if rc == -2:
+            return False
+        check(rc)
+        return True
+
+    def read_arrays(self, sizes, keys, labels, sampling=1, shard=(0, 0)):
+        sizes = np.ascontiguousarray(sizes, np.uint8)
+        keys = np.ascontiguousarray(keys)
+        labels = np.ascontiguousarray(labels, np.uint16)
+        assert keys.dtype.itemsize in (2, 4, 8) and keys.size == labels.size
+        check(self.L.mic_db_load_host(self.h, sizes.ctypes.data, sizes.size, keys.ctypes.data if keys.size else sizes.ctypes.data,
+                                      keys.dtype.itemsize, labels.ctypes.data if labels.size else sizes.ctypes.data,
+                                      int(sampling), int(shard[0]), int(shard[1])))
+
+    def read_device(self, d_sizes, htsize, d_keys, key_bytes, d_labels, sampling=1, shard=(0, 0)):
+        check(self.L.mic_db_load_device(self.h, d_sizes, int(htsize), d_keys, int(key_bytes), d_labels, int(sampling),
+                                        int(shard[0]), int(shard[1])))
+
+    def swapDbParts(self):
+        """The table is fully resident: there is never another part to swap in (CuClarkDB.cu:813-858)."""
+        return False
+
+    def info(self):
+        i = MicDbInfo()
+        check(self.L.mic_db_get_info(self.h, C.byref(i)))
+        return {f: getattr(i, f) for f, _ in MicDbInfo._fields_}
+
+    # -- batch API
+    def malloc(self, num_reads, max_reads, max_containers, index_batches, extended=False):
+        ib = np.ascontiguousarray(index_batches, np.uint32)
+        assert ib.size == self.num_batches + 1
+        res, rows = C.c_void_p(), C.c_void_p()
+        rp = (C.c_void_p * self.num_batches)()
+        ct = (C.c_void_p * self.num_batches)()
+        check(self.L.mic_batches_alloc(self.h, num_reads, max_reads, max_containers, ib.ctypes.data, int(bool(extended)),
+                                       C.byref(res), C.byref(rows), rp, ct))
+        self._bufs = dict(
+            results=_as_np(res.value, (num_reads, MIC_RESULT_WORDS), np.uint32),
+            rows=_as_np(rows.value, (num_reads, self.row_words), np.uint32) if extended else None,
+            reads_pointer=[_as_np(rp[b], (max_reads + 1,), np.uint32) for b in range(self.num_batches)],
+            containers=[_as_np(ct[b], (max_containers,), np.uint16) for b in range(self.num_batches)],
+        )
+        return self._bufs
+
+    def readyBatch(self, batch, num_reads, container_count):
+        check(self.L.mic_batch_ready(self.h, batch, num_reads, container_count))
+        return True
+
+    def queryBatch(self, batch, extended=False, followup=False):
+        check(self.L.mic_batch_query(self.h, batch, int(bool(extended)), int(bool(followup))))
+        return True
+
+    def waitForBatch(self, batch):
+        check(self.L.mic_batch_wait(self.h, batch))
+        return True
+
+    def checkBatch(self, batch):
+        d = C.c_int(0)
+        check(self.L.mic_batch_check(self.h, batch, C.byref(d)))
+        return bool(d.value)
+
+    def sync(self):
+        check(self.L.mic_sync(self.h))
+        return True
+
+    def freeBatchMemory(self):
+        self._bufs = None
+        check(self.L.mic_batches_free(self.h))
+
+    # -- convenience: one batch through the batch API
+    def classify_packed(self, reads_pointer, containers, extended=False):
+        assert self.num_batches == 1
+        rp = np.ascontiguousarray(reads_pointer, np.uint32)
+        ct = np.ascontiguousarray(containers, np.uint16)
+        n = rp.size - 1
+        bufs = self.malloc(n, n, max(ct.size, 1), [0, n], extended)
+        bufs["reads_pointer"][0][: n + 1] = rp
+        bufs["containers"][0][: ct.size] = ct
+        self.readyBatch(0, n, ct.size)
+        self.queryBatch(0, extended)
+        self.waitForBatch(0)
+        res = bufs["results"].copy()
+        rows = bufs["rows"].copy() if extended else None
+        self.freeBatchMemory()
+        return (res, rows) if extended else res
+
+    # -- device-resident entry points (pointers are raw device addresses, e.g. torch.Tensor.data_ptr())
+    def query_device(self, d_reads_pointer, d_containers, n_reads, d_results, d_rows=0, stream=0):
+        check(self.L.mic_query_device(self.h, d_reads_pointer, d_containers, n_reads, d_results, d_rows or None,
+                                      stream or None))
+
+    def resolve_flagged_device(self, d_reads_pointer, d_containers, d_results, d_rows=0, stream=0):
+        n = C.c_size_t(0)
+        check(self.L.mic_resolve_flagged_device(self.h, d_reads_pointer, d_containers, d_results, d_rows or None,
+                                                stream or None, C.byref(n)))
+        return int(n.value)
+
+    def merge_rows_device(self, d_a, d_b, d_out, n_reads, stream=0):
+        check(self.L.mic_merge_rows_device(self.h, d_a, d_b, d_out, n_reads, stream or None))
+
+    def result_from_rows_device(self, d_rows, d_results, n_reads, stream=0):
+        check(self.L.mic_result_from_rows_device(self.h, d_rows, d_results, n_reads, stream or None))
+
+    def count_dense_device(self, d_reads_pointer, d_containers, d_ids, n_ids, d_counts, stream=0):
+        check(self.L.mic_count_dense_device(self.h, d_reads_pointer, d_containers, d_ids or None, n_ids, d_counts,
+                                            stream or None))
+
+    def last_query_ms(self):
+        ms = C.c_float(0)
+        check(self.L.mic_last_query_ms(self.h, C.byref(ms)))
+        return float(ms.value)

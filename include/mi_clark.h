@@ -1,0 +1,198 @@
+/*
+ * mi_clark.h — C ABI of libmi_clark.so: the MI355X (gfx950) k-mer query engine that replaces
+ * CuCLARK's CuClarkDB (device DB + query) behind the same caller contract.
+ *
+ * Plain C types only (pointers, sizes, fixed-width ints): bindable from C, C++, ctypes, cgo, JNI.
+ * Every entry point cites the reference interface it replaces, as file:line under
+ * Funatiq/cuclark src/.  All functions return MIC_OK (0) or a negative MIC_E_* code and never
+ * exit() or print; mic_last_error() returns the message of the last failure on this thread
+ * (reference: CUERR/CUMEMERR print + exit(1), CuClarkDB.cu:45-63).
+ *
+ * Data contract (unchanged from the reference unless stated):
+ *   reads in   : readsPointer u32[nReads+1] + readsInContainers u16[]      CuCLARK_hh.hh:1616-1716
+ *                (per read: parts; per part: 1 length slot + ceil(len/8) containers, 8 nt per u16,
+ *                 first nt in the top bits, A=3 C=2 G=1 T/U=0).  A length slot of 0 ends a read
+ *                 early (lets callers over-allocate per read); the reference never emits one.
+ *   results out: MIC_RESULT_WORDS u32 per read:
+ *                {sum, idxBest, best, idxSecond, second, nTargetsHit, flags, 0}
+ *                words 0..4 are resultKernel's {sumN,indexBest,best,index_sBest,s_best}
+ *                (CuClarkDB.cu:1421-1471) widened from u16 to u32; indices are target+1, 0 = "NA".
+ *   sparse rows: optional, row_words u32 per read: word0 = n, words 1..n = (count<<16 | target) in
+ *                ascending target order (the reference's [n,(t,c)*] u16 rows, CuClarkDB.cu:1178-1243,
+ *                one pair per word).  A row that does not fit (n > row_words-1 or a count > 65535) has
+ *                word0 = MIC_ROW_INVALID and its read carries MIC_FLAG_ROW_OVERFLOW; words 0..4 of its
+ *                result are still exact (dense path), per-target counts come from mic_count_dense_device.
+ */
+#ifndef MI_CLARK_H
+#define MI_CLARK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIC_OK 0
+#define MIC_E_INVALID (-1)  /* bad argument                                   */
+#define MIC_E_IO (-2)       /* file missing / short (reference: read() returns false, CuClarkDB.cu:490-495) */
+#define MIC_E_NOMEM (-3)    /* host or device allocation failed              */
+#define MIC_E_HIP (-4)      /* HIP runtime error                              */
+#define MIC_E_STATE (-5)    /* call out of order (e.g. query before DB load)  */
+#define MIC_E_NODEVICE (-6) /* no usable gfx950 device / kernels not loadable */
+
+#define MIC_RESULT_WORDS 8
+#define MIC_FLAG_ROW_OVERFLOW 1u /* sparse row did not fit; dense path was used */
+#define MIC_FLAG_DENSE_PATH 2u   /* read was (re)processed by the dense fallback */
+
+#define MIC_ROW_INVALID 0xFFFFFFFFu
+#define MIC_MAX_PART 65528u /* parts longer than this are packed as overlapping sub-parts */
+
+typedef struct mic_engine mic_engine;
+
+typedef struct mic_config {
+  int32_t device;       /* HIP device ordinal; -1 = current device                     */
+  int32_t k;            /* k-mer length, 2..32                       main.cc:110-114  */
+  uint32_t num_targets; /* number of labels T (<= 65535)             dataType.hh:48   */
+  uint32_t num_batches; /* batches of the batch API (>=1)            main.cc:220-226  */
+  uint32_t row_words;   /* u32 words per sparse row (0 = default 16 => 15 pairs = MAXHITS, parameters.hh:44) */
+  uint32_t reserved;
+} mic_config;
+
+typedef struct mic_db_info {
+  uint64_t htsize;         /* buckets in the whole table (= size of .sz)               */
+  uint64_t shard_start;    /* first bucket resident on this engine                     */
+  uint64_t shard_end;      /* one past the last resident bucket                        */
+  uint64_t n_elems;        /* elements resident (after sampling / reachability filter) */
+  uint64_t n_elems_file;   /* elements the shard holds on disk                         */
+  uint64_t n_slots;        /* 64-byte slots in HBM (main + overflow chain)             */
+  uint64_t n_overflow;     /* overflow slots                                            */
+  uint64_t hbm_bytes;      /* bytes of HBM held by the table                            */
+  int32_t key_bytes;       /* width of the keys on disk: 2, 4 or 8                      */
+  int32_t slot_class;      /* 32: 8 entries/slot (u32 quotients); 64: 4 entries/slot    */
+  uint32_t max_bucket;     /* largest kept bucket                                       */
+  uint32_t sampling;
+} mic_db_info;
+
+/* ---- engine lifetime: CuClarkDB ctor/dtor (CuClarkDB.cu:85-253) ----------------------------- */
+int mic_create(const mic_config* cfg, mic_engine** out);
+int mic_destroy(mic_engine* e);
+const char* mic_last_error(void);
+/* Number of usable devices (reference: cudaGetDeviceCount loop, CuClarkDB.cu:104-181). */
+int mic_device_count(int* count);
+
+/* ---- database: CuClarkDB::read (CuClarkDB.cu:461-808) + swapDbParts (:813-858) --------------
+ * Loads <prefix>.sz/.ky/.lb and builds the resident table.  key_bytes 0 => rule of main.cc:274-316.
+ * sampling <=1 keeps all buckets, else every sampling-th non-empty bucket (CuClarkDB.cu:497-524).
+ * [shard_start, shard_end) selects the bucket range this engine answers for (the reference's
+ * m_partPointer ranges, CuClarkDB.cu:566-574, 1272-1274); shard_end 0 => htsize. */
+int mic_db_load_files(mic_engine* e, const char* prefix, int key_bytes, uint32_t sampling, uint64_t shard_start,
+                      uint64_t shard_end);
+/* Same from host memory images of the three files (whole table; the shard is cut out here). */
+int mic_db_load_host(mic_engine* e, const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes,
+                     const uint16_t* labels, uint32_t sampling, uint64_t shard_start, uint64_t shard_end);
+/* Same from device memory images (d_keys/d_labels hold the WHOLE table's elements). */
+int mic_db_load_device(mic_engine* e, const uint8_t* d_sizes, uint64_t htsize, const void* d_keys, int key_bytes,
+                       const uint16_t* d_labels, uint32_t sampling, uint64_t shard_start, uint64_t shard_end);
+int mic_db_get_info(const mic_engine* e, mic_db_info* info);
+int mic_db_unload(mic_engine* e);
+
+/* ---- batch API: the calls CuCLARK_hh.hh makes on CuClarkDB ----------------------------------
+ * mic_batches_alloc   = CuClarkDB::malloc        (CuClarkDB.cu:317-419;  caller CuCLARK_hh.hh:1600-1606)
+ *   The engine allocates pinned host buffers and lends them out; the caller fills
+ *   reads_pointer[b] / containers[b] for batch b and reads results after mic_batch_wait.
+ *   index_batches[num_batches+1] = index of the first read of each batch; results/rows are indexed
+ *   by global read index.  rows is NULL unless extended != 0.
+ * mic_batch_ready     = CuClarkDB::readyBatch    (CuClarkDB.cu:864-873;  caller :1735)
+ * mic_batch_query     = CuClarkDB::queryBatch    (CuClarkDB.cu:878-1033; caller :1743,:1772)
+ *   H2D, fused query kernel, result, D2H, event — asynchronous.  `followup` (swap cycles) is accepted
+ *   and ignored: the whole table is resident, there are no cycles.
+ * mic_batch_wait      = CuClarkDB::waitForBatch  (CuClarkDB.cu:440-445;  caller :1997,:2006)
+ * mic_batch_check     = CuClarkDB::checkBatch    (CuClarkDB.cu:450-456)  *done = 1 when finished
+ * mic_sync            = CuClarkDB::sync          (CuClarkDB.cu:424-435)
+ * mic_batches_free    = CuClarkDB::freeBatchMemory (CuClarkDB.cu:279-312)
+ * Threading: distinct batches may be filled concurrently; mic_batch_query is internally serialised;
+ * mic_batch_wait may be called from another thread (reference: CuCLARK_hh.hh:1738-1760). */
+int mic_batches_alloc(mic_engine* e, size_t num_reads_total, size_t max_reads, size_t max_containers,
+                      const uint32_t* index_batches, int extended, uint32_t** results, uint32_t** rows,
+                      uint32_t** reads_pointer /*[num_batches]*/, uint16_t** containers /*[num_batches]*/);
+int mic_batch_ready(mic_engine* e, size_t batch, size_t n_reads, size_t n_containers);
+int mic_batch_query(mic_engine* e, size_t batch, int extended, int followup);
+int mic_batch_wait(mic_engine* e, size_t batch);
+int mic_batch_check(mic_engine* e, size_t batch, int* done);
+int mic_sync(mic_engine* e);
+int mic_batches_free(mic_engine* e);
+
+/* ---- device-resident entry points (kernels only; inputs/outputs already in HBM) --------------
+ * mic_query_device: queryKernel + resultKernel fused (CuClarkDB.cu:1045-1243,1421-1471).
+ *   d_results: n_reads*MIC_RESULT_WORDS u32.  d_rows: n_reads*row_words u32 or NULL.
+ *   Reads whose register row (64 distinct targets) or sparse row overflowed are flagged and listed in an
+ *   engine-owned device list; mic_resolve_flagged_device completes them exactly with the dense path.
+ *   stream: a hipStream_t (NULL = the engine's stream).  Asynchronous. */
+int mic_query_device(mic_engine* e, const uint32_t* d_reads_pointer, const uint16_t* d_containers, size_t n_reads,
+                     uint32_t* d_results, uint32_t* d_rows, void* stream);
+/* Completes the reads flagged by the LAST mic_query_device call (same buffers, same stream): waits for the
+ * stream, runs the dense kernels for the listed reads and patches d_results / d_rows.  *n_resolved
+ * (optional) receives how many reads took the dense path.  Synchronous. */
+int mic_resolve_flagged_device(mic_engine* e, const uint32_t* d_reads_pointer, const uint16_t* d_containers,
+                               uint32_t* d_results, uint32_t* d_rows, void* stream, size_t* n_resolved);
+/* mergeKernel (CuClarkDB.cu:1321-1415): out = a (+) b per read (sum by target); rows as above. */
+int mic_merge_rows_device(mic_engine* e, const uint32_t* d_rows_a, const uint32_t* d_rows_b, uint32_t* d_rows_out,
+                          size_t n_reads, void* stream);
+/* resultKernel (CuClarkDB.cu:1421-1471) on sparse rows. */
+int mic_result_from_rows_device(mic_engine* e, const uint32_t* d_rows, uint32_t* d_results, size_t n_reads,
+                                void* stream);
+/* Dense per-read per-target counts (u32 [n_reads*num_targets]) for the listed reads: the exact
+ * fallback for reads whose rows overflow, and the --extended source of truth. */
+int mic_count_dense_device(mic_engine* e, const uint32_t* d_reads_pointer, const uint16_t* d_containers,
+                           const uint32_t* d_read_ids, size_t n_ids, uint32_t* d_counts, void* stream);
+/* Duration in ms of the last mic_query_device launch on this engine, measured with HIP events on the
+ * stream it ran on (blocks until it finished). */
+int mic_last_query_ms(mic_engine* e, float* ms);
+
+/* ---- host-side pieces of the path (pure CPU, no device needed) -------------------------------- */
+/* Key width rule, main.cc:274-316. */
+int mic_key_bytes_rule(uint64_t htsize, int k);
+/* Read indexer, CuCLARK_hh.hh:1339-1534 (one batch): fills caller arrays of capacity cap; returns the
+ * number of reads (may exceed cap: call again with a larger cap), or MIC_E_INVALID if the first byte
+ * is neither '>' nor '@'. */
+long mic_index_reads(const uint8_t* map, size_t nb, size_t cap, uint64_t* name_s, uint64_t* name_e, uint64_t* seq_s,
+                     uint64_t* seq_e, uint64_t* length);
+/* Upper bound of containers mic_pack_reads can emit for these reads. */
+size_t mic_pack_bound(const uint64_t* seq_s, const uint64_t* seq_e, size_t n_reads, int k);
+/* Read packer, CuCLARK_hh.hh:1616-1716.  Returns containers written or (size_t)-1 if cap is too small. */
+size_t mic_pack_reads(const uint8_t* map, const uint64_t* seq_s, const uint64_t* seq_e, const uint64_t* length,
+                      size_t n_reads, int k, uint32_t* reads_pointer, uint16_t* containers, size_t cap);
+/* CSV, CuCLARK_hh.hh:1951-2139.  Return bytes written or -1 if cap is too small. */
+int mic_csv_header(char* buf, size_t cap, int extended, const char* const* target_names, uint32_t n_targets);
+int mic_csv_line(char* buf, size_t cap, const uint8_t* name, size_t name_len, uint64_t length, int paired, int k,
+                 const uint32_t* result /*MIC_RESULT_WORDS*/, const char* const* target_names, uint32_t n_targets,
+                 int extended, const uint32_t* row /*sparse row or NULL*/, const uint32_t* dense /*or NULL*/);
+
+/* ---- synthetic workload generation in HBM (bench.py / tests) ------------------- */
+typedef struct mic_synth_spec {
+  uint64_t seed;
+  uint64_t htsize;        /* buckets                                                        */
+  uint64_t genome_nt;     /* total nucleotides of the procedural genomes (~ elements)       */
+  uint32_t n_targets;     /* labels; genome g (of equal length) carries label g % n_targets */
+  uint32_t n_genomes;
+  int32_t k;
+  int32_t key_bytes;      /* 4 or 8                                                         */
+} mic_synth_spec;
+/* Builds the on-disk-format arrays of a synthetic database in device memory the caller owns:
+ *   d_sizes u8[htsize], d_keys key_bytes*[capacity], d_labels u16[capacity]; *n_elems out. */
+int mic_synth_db_device(const mic_synth_spec* spec, uint8_t* d_sizes, void* d_keys, uint16_t* d_labels,
+                        uint64_t capacity, uint64_t* n_elems, void* stream);
+/* Builds n_reads packed reads of read_len nt in device memory (reads_pointer u32[n_reads+1],
+ * containers u16[n_reads*mic_synth_read_pitch(read_len,k)]): a fraction `random_frac` are uniform random, the
+ * rest are sampled from the genomes (either strand) with per-base substitution rate `sub_rate` and
+ * N rate `n_rate`.  d_truth (optional, u32[n_reads*2]) receives {label+1 or 0, expected hits lower bound}. */
+uint32_t mic_synth_read_pitch(uint32_t read_len, int k); /* containers reserved per read by the generator */
+int mic_synth_reads_device(const mic_synth_spec* spec, uint64_t read_seed, size_t n_reads, uint32_t read_len,
+                           double random_frac, double sub_rate, double n_rate, uint32_t* d_reads_pointer,
+                           uint16_t* d_containers, size_t containers_cap, uint32_t* d_truth, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+TESTS = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(TESTS)
+for p in (ROOT, TESTS):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import golden_util as gu
+    return gu.oracle()
+
+
+@pytest.fixture(scope="session")
+def lib():
+    """The product library; built on demand (hipcc cross-compiles without a GPU)."""
+    from cuclark_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def db_dir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("golden_db"))

@@ -1,0 +1,404 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the golden
+vectors produced by the reference's own CPU hash table.  Integer work: every comparison is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(k, n_targets, **kw):
+    from cuclark_amd import MiClarkDB
+    return MiClarkDB(k, n_targets, **kw)
+
+
+def _kmer_reads(kmers, k):
+    """One read per k-mer: a single part of k nucleotides."""
+    n = len(kmers)
+    per = 1 + (k + 7) // 8
+    rp = (np.arange(n + 1, dtype=np.uint64) * per).astype(np.uint32)
+    cont = np.zeros(n * per, np.uint16)
+    cont[0::per] = k
+    for j in range((k + 7) // 8):
+        # container j holds nts [8j, 8j+8) of the k-mer, first nt in the top bits
+        hi = 2 * k - 16 * j  # number of k-mer bits at or below this container's top
+        vals = np.array([(int(v) << 16 >> hi) & 0xFFFF if hi >= 16 else (int(v) << (16 - hi)) & 0xFFFF for v in kmers],
+                        dtype=np.uint16)
+        cont[1 + j::per] = vals
+    return rp, cont
+
+
+def _oracle_results(odb, k, rp, cont, T, part=(0, None)):
+    counts, bad = odb.query_batch(k, rp, cont, T, part)
+    assert bad == 0
+    return counts, gu.oracle().result_from_counts(counts)
+
+
+# ------------------------------------------------------------------ golden vectors from the reference
+
+@pytest.mark.parametrize("name", ["light_k27_u32", "light_k31_u64", "light_k20_u16", "light_k32_u64", "full_k31_u32"])
+def test_golden_queries_from_files(name, db_dir):
+    """Per-k-mer answers of the reference's queryElement(), DB loaded from .sz/.ky/.lb files."""
+    prefix, meta = gu.materialize_db(name, db_dir)
+    q = np.load(os.path.join(gu.GOLDEN, f"queries_{name}.npz"))
+    k = meta["k"]
+    T = len(gu.target_names())
+    with _engine(k, T) as e:
+        assert e.read(prefix, key_bytes=0)  # key width from the rule of main.cc:274-316
+        info = e.info()
+        assert info["htsize"] == meta["htsize"] and info["key_bytes"] == meta["key_bytes"]
+        assert info["n_elems"] == meta["ky"].size
+        rp, cont = _kmer_reads(q["kmers"], k)
+        res = e.classify_packed(rp, cont)
+    found = res[:, 0] == 1
+    assert (res[:, 0] <= 1).all()
+    assert (found == (q["found"] == 1)).all()
+    assert (res[found, 1] == q["label"][found].astype(np.uint32) + 1).all()
+    assert (res[found, 2] == 1).all() and (res[~found, 1] == 0).all()
+    os.remove(prefix + ".sz")  # the full-size .sz is 1.6 GB
+
+
+def test_golden_sampling(db_dir):
+    name = "light_k27_u32"
+    prefix, meta = gu.materialize_db(name, db_dir)
+    q = np.load(os.path.join(gu.GOLDEN, f"queries_{name}.npz"))
+    with _engine(27, 6) as e:
+        assert e.read(prefix, sampling=3)
+        rp, cont = _kmer_reads(q["kmers"], 27)
+        res = e.classify_packed(rp, cont)
+    found = res[:, 0] == 1
+    assert (found == (q["found_s3"] == 1)).all()
+    assert (res[found, 1] == q["label_s3"][found].astype(np.uint32) + 1).all()
+
+
+def test_missing_db_files_return_false(db_dir):
+    with _engine(31, 6) as e:
+        assert e.read(os.path.join(db_dir, "does_not_exist")) is False
+        with pytest.raises(Exception):
+            e.classify_packed(np.zeros(2, np.uint32), np.zeros(4, np.uint16))
+
+
+@pytest.mark.parametrize("case", [c[0] for c in gu.expected_csv_cases()])
+def test_golden_csv(case, db_dir):
+    """End to end: index + pack (C++ host) -> HIP query -> CSV, byte-identical to the committed CSV."""
+    from cuclark_amd import host
+    spec = {c[0]: c for c in gu.expected_csv_cases()}[case]
+    _, k, dbname, data, paired, ext = spec
+    names = gu.target_names()
+    db = gu.load_golden_db(dbname)
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    with _engine(k, len(names)) as e:
+        e.read_arrays(gu.golden_sizes(db), db["ky"], db["lb"])
+        out = e.classify_packed(rp, cont, extended=ext)
+    res, rows = out if ext else (out, None)
+    text = host.format_csv(data, idx, res, names, k, paired=paired, extended=ext, rows=rows)
+    expected = open(os.path.join(gu.GOLDEN, f"expected_{case}.csv"), "rb").read()
+    assert text == expected
+
+
+def test_full_htsize_csv_equals_light(db_dir):
+    """Same k-mer set at HTSIZE 1610612741 (u32 keys) and 57777779 (u64 keys): identical classification."""
+    from cuclark_amd import host
+    data = open(os.path.join(gu.GOLDEN, "reads_k31.fa"), "rb").read()
+    names = gu.target_names()
+    db = gu.load_golden_db("full_k31_u32")
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], 31)
+    with _engine(31, len(names)) as e:
+        e.read_arrays(gu.golden_sizes(db), db["ky"], db["lb"])
+        assert e.info()["slot_class"] == 32
+        res = e.classify_packed(rp, cont)
+    text = host.format_csv(data, idx, res, names, 31)
+    assert text == open(os.path.join(gu.GOLDEN, "expected_k31_fa.csv"), "rb").read()
+
+
+# ------------------------------------------------------------------ randomized parity vs the oracle
+
+def _random_reads(rng, canon, k, n_reads, read_len, hit_frac=0.6, n_rate=0.01):
+    """ASCII FASTA with reads stitched from DB k-mers (so they hit) and random sequence."""
+    recs = []
+    for i in range(n_reads):
+        L = int(rng.integers(max(1, read_len // 2), read_len + 1))
+        s = []
+        while sum(len(x) for x in s) < L:
+            if canon.size and rng.random() < hit_frac:
+                km = gu.kmer_to_ascii(canon[int(rng.integers(canon.size))], k)
+                if rng.random() < 0.5:
+                    km = km[::-1].translate(str.maketrans("ACGT", "TGCA"))
+                s.append(km)
+            else:
+                s.append("".join(rng.choice(list("ACGT"), int(rng.integers(1, k + 5)))))
+        seq = list("".join(s)[:L])
+        for p in range(len(seq)):
+            if rng.random() < n_rate:
+                seq[p] = "N"
+        recs.append(f">r{i}\n{''.join(seq)}\n")
+    return "".join(recs).encode()
+
+
+CASES = [
+    # htsize, n_elems, k, key_bytes, n_labels, read_len
+    (1009, 3000, 31, 8, 7, 150),        # tiny prime table, long chains, u64 keys
+    (4096, 9000, 16, 4, 300, 120),      # power-of-two table (shift division), many labels
+    (65537, 40000, 31, 8, 50, 150),
+    (1 << 20, 200000, 25, 4, 4096, 150),
+    (999983, 150000, 12, 2, 12, 100),   # u16 keys
+    (57777779, 50000, 27, 4, 64, 150),  # CuCLARK-l table size
+    (2, 200, 8, 8, 3, 40),              # two buckets
+    (7919, 2000, 2, 2, 5, 30),          # k = 2
+    (104729, 30000, 32, 8, 9, 200),     # k = 32
+]
+
+
+@pytest.mark.parametrize("htsize,n_elems,k,key_bytes,n_labels,read_len", CASES)
+def test_random_db_parity(htsize, n_elems, k, key_bytes, n_labels, read_len):
+    from cuclark_amd import host
+    rng = np.random.default_rng(htsize * 31 + k)
+    n_elems = min(n_elems, (1 << (2 * k)) // 3 if k < 16 else n_elems)
+    sizes, keys, labels, canon = gu.random_db(rng, htsize, n_elems, k, key_bytes, n_labels)
+    o = gu.oracle()
+    odb = o.db_from_arrays(sizes, keys, labels)
+    data = _random_reads(rng, canon, k, 400, read_len)
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    counts, expect = _oracle_results(odb, k, rp, cont, n_labels)
+    with _engine(k, n_labels, row_words=16) as e:
+        e.read_arrays(sizes, keys, labels)
+        res, rows = e.classify_packed(rp, cont, extended=True)
+        info = e.info()
+    assert info["n_elems"] == keys.size
+    assert (res[:, :5] == expect).all()
+    # sparse rows equal the oracle's (ascending targets) whenever they fit
+    for r in range(counts.shape[0]):
+        n, row = o.sparse_row(counts[r], 15)
+        if n <= 15:
+            assert rows[r, 0] == n
+            got = rows[r, 1:1 + n]
+            assert ((got & 0xFFFF) == row[1:1 + 2 * n:2]).all() and ((got >> 16) == row[2:2 + 2 * n:2]).all()
+        else:
+            assert rows[r, 0] == 0xFFFFFFFF and res[r, 6] & 1
+
+
+def test_shards_sum_to_whole():
+    """DB sharded by bucket range (CuClarkDB.cu:566-574,1272): merged shard rows == whole-table rows."""
+    from cuclark_amd import host
+    import torch
+    rng = np.random.default_rng(5)
+    htsize, k, T = 30011, 31, 40
+    sizes, keys, labels, canon = gu.random_db(rng, htsize, 60000, k, 8, T)
+    data = _random_reads(rng, canon, k, 300, 150)
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    n = rp.size - 1
+    o = gu.oracle()
+    odb = o.db_from_arrays(sizes, keys, labels)
+    bounds = [0, 7000, 7001, 20000, htsize]
+    shard_rows = []
+    with _engine(k, T, row_words=32) as whole:
+        whole.read_arrays(sizes, keys, labels)
+        res_whole, rows_whole = whole.classify_packed(rp, cont, extended=True)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        with _engine(k, T, row_words=32) as e:
+            e.read_arrays(sizes, keys, labels, shard=(a, b))
+            res, rows = e.classify_packed(rp, cont, extended=True)
+            counts, expect = _oracle_results(odb, k, rp, cont, T, part=(a, b))
+            assert (res[:, :5] == expect).all()
+            shard_rows.append(rows)
+    # merge on the GPU with the engine's merge kernel, then result kernel
+    with _engine(k, T, row_words=32) as e:
+        dev = torch.device("cuda:0")
+        acc = torch.from_numpy(shard_rows[0].astype(np.int64)).to(dev).to(torch.int32).contiguous()
+        for rows in shard_rows[1:]:
+            nxt = torch.from_numpy(rows.astype(np.int64)).to(dev).to(torch.int32).contiguous()
+            out = torch.empty_like(acc)
+            torch.cuda.synchronize()
+            e.merge_rows_device(acc.data_ptr(), nxt.data_ptr(), out.data_ptr(), n)
+            e.sync()
+            acc = out
+        results = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+        e.result_from_rows_device(acc.data_ptr(), results.data_ptr(), n)
+        e.sync()
+        merged = acc.cpu().numpy().view(np.uint32)
+        results = results.cpu().numpy().view(np.uint32)
+    assert (merged == rows_whole).all()
+    assert (results[:, :5] == res_whole[:, :5]).all()
+
+
+def test_many_targets_dense_path():
+    """Reads hitting more than 64 distinct targets (register row overflow) and more than the row pitch."""
+    rng = np.random.default_rng(11)
+    htsize, k, T = 200003, 21, 500
+    sizes, keys, labels, canon = gu.random_db(rng, htsize, 20000, k, 4, T)
+    o = gu.oracle()
+    odb = o.db_from_arrays(sizes, keys, labels)
+    # read 0: 300 DB k-mers separated by N -> ~250 distinct targets; read 1: 30 k-mers; read 2: nothing
+    picks = rng.choice(canon.size, 300, replace=False)
+    r0 = "N".join(gu.kmer_to_ascii(canon[i], k) for i in picks)
+    r1 = "N".join(gu.kmer_to_ascii(canon[i], k) for i in picks[:30])
+    data = f">many\n{r0}\n>some\n{r1}\n>none\n{'ACGT' * 20}\n".encode()
+    from cuclark_amd import host
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    counts, expect = _oracle_results(odb, k, rp, cont, T)
+    assert (counts[0] > 0).sum() > 64
+    with _engine(k, T, row_words=16) as e:
+        e.read_arrays(sizes, keys, labels)
+        res, rows = e.classify_packed(rp, cont, extended=True)
+        plain = e.classify_packed(rp, cont)
+    assert (res[:, :5] == expect).all() and (plain[:, :5] == expect).all()
+    assert res[0, 6] & 2 and rows[0, 0] == 0xFFFFFFFF      # dense path, row does not fit
+    assert res[0, 5] == (counts[0] > 0).sum()
+    assert res[1, 6] & 1                                    # fits the register row but not 15 pairs
+
+
+def test_long_reads_and_part_splitting():
+    """A 200 kb sequence (parts longer than 65528 nt are split with k-1 overlap) and a multi-chunk read."""
+    from cuclark_amd import host
+    rng = np.random.default_rng(3)
+    htsize, k, T = 1 << 16, 31, 20
+    genome = "".join(rng.choice(list("ACGT"), 200000))
+    o = gu.oracle()
+    # DB = every 3rd k-mer of the genome
+    canon = sorted({o.canonical(int(v), k) for v in
+                    [int("".join(str("TGCA".index(c)) for c in genome[i:i + k]), 4) for i in range(0, 199000, 3)]},
+                   key=lambda c: (c % htsize, c // htsize))
+    sizes = np.zeros(htsize, np.int64)
+    keep = []
+    for c in canon:
+        if sizes[c % htsize] < 255:
+            sizes[c % htsize] += 1
+            keep.append(c)
+    keys = np.array([c // htsize for c in keep], dtype=np.uint64)
+    labels = rng.integers(0, T, len(keep)).astype(np.uint16)
+    odb = o.db_from_arrays(sizes.astype(np.uint8), keys, labels)
+    wrapped = "\n".join(genome[i:i + 70] for i in range(0, len(genome), 70))
+    data = f">genome\n{wrapped}\n>mid\n{genome[5000:5700]}\n>withN\n{genome[100:400]}N{genome[9000:9030]}N{genome[400:900]}\n".encode()
+    idx = host.index_reads(data)
+    assert idx["length"][0] == 200000
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    rp_o, cont_o = o.pack_batch(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    assert (rp == rp_o).all() and (cont == cont_o).all()
+    counts, expect = _oracle_results(odb, k, rp, cont, T)
+    ascii_counts = odb.count_read_ascii(k, data[int(idx["seq_s"][0]):int(idx["seq_e"][0])], 200000, T)
+    assert (ascii_counts == counts[0]).all()
+    with _engine(k, T) as e:
+        e.read_arrays(sizes.astype(np.uint8), keys, labels)
+        res = e.classify_packed(rp, cont)
+    assert (res[:, :5] == expect).all()
+    assert expect[0, 0] > 60000
+
+
+def test_malformed_buckets_follow_reference_scan():
+    """Unsorted buckets / duplicate keys: the table must answer exactly like the reference's linear scan."""
+    rng = np.random.default_rng(9)
+    htsize, k, T = 251, 20, 9
+    sizes = rng.integers(0, 30, htsize).astype(np.uint8)
+    n = int(sizes.sum())
+    keys = rng.integers(0, 60, n).astype(np.uint32)  # small range: many duplicates, unsorted
+    labels = rng.integers(0, T, n).astype(np.uint16)
+    o = gu.oracle()
+    odb = o.db_from_arrays(sizes, keys, labels)
+    kmers = []
+    for r in range(htsize):
+        for qv in range(0, 62):
+            c = qv * htsize + r
+            if o.canonical(c, k) == c:
+                kmers.append(c)
+    kmers = np.array(kmers[:20000], dtype=np.uint64)
+    rp, cont = _kmer_reads(kmers, k)
+    f, l = odb.find_many(kmers, k)
+    with _engine(k, T) as e:
+        e.read_arrays(sizes, keys, labels)
+        res = e.classify_packed(rp, cont)
+    assert ((res[:, 0] == 1) == (f == 1)).all()
+    assert (res[f == 1, 1] == l[f == 1].astype(np.uint32) + 1).all()
+    assert f.sum() > 100
+
+
+def test_batches_concurrent_and_order():
+    """Several batches in flight (CuCLARK_hh.hh:1616-1760 usage): results land at the global read index."""
+    from cuclark_amd import host, MiClarkDB
+    rng = np.random.default_rng(21)
+    htsize, k, T = 10007, 25, 30
+    sizes, keys, labels, canon = gu.random_db(rng, htsize, 20000, k, 8, T)
+    o = gu.oracle()
+    odb = o.db_from_arrays(sizes, keys, labels)
+    data = _random_reads(rng, canon, k, 1000, 120)
+    idx = host.index_reads(data)
+    nb = 4
+    cuts = [0, 200, 500, 501, 1000]
+    packed = [host.pack_reads(data, idx["seq_s"][a:b], idx["seq_e"][a:b], idx["length"][a:b], k) for a, b in zip(cuts[:-1], cuts[1:])]
+    with MiClarkDB(k, T, num_batches=nb) as e:
+        e.read_arrays(sizes, keys, labels)
+        bufs = e.malloc(1000, 499, max(c.size for _, c in packed), cuts)
+        for b, (rp, ct) in enumerate(packed):
+            bufs["reads_pointer"][b][:rp.size] = rp
+            bufs["containers"][b][:ct.size] = ct
+            e.readyBatch(b, rp.size - 1, ct.size)
+        for b in range(nb):
+            e.queryBatch(b)
+        for b in reversed(range(nb)):
+            e.waitForBatch(b)
+            assert e.checkBatch(b)
+        res = bufs["results"].copy()
+        e.freeBatchMemory()
+    rp_all, ct_all = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    _, expect = _oracle_results(odb, k, rp_all, ct_all, T)
+    assert (res[:, :5] == expect).all()
+
+
+def test_synthetic_generator_matches_oracle():
+    """mic_synth_* (bench workload): DB arrays + packed reads made in HBM; GPU results == oracle on them."""
+    import ctypes as C
+    import torch
+    from cuclark_amd import _lib, MiClarkDB
+    L = _lib.load()
+    dev = torch.device("cuda:0")
+    spec = _lib.MicSynthSpec(seed=7, htsize=500009, genome_nt=600000, n_targets=37, n_genomes=60, k=31, key_bytes=8)
+    cap = 700000
+    d_sizes = torch.zeros(spec.htsize, dtype=torch.uint8, device=dev)
+    d_keys = torch.zeros(cap, dtype=torch.int64, device=dev)
+    d_labels = torch.zeros(cap, dtype=torch.int16, device=dev)
+    n_el = C.c_uint64(0)
+    torch.cuda.synchronize()
+    assert L.mic_synth_db_device(C.byref(spec), d_sizes.data_ptr(), d_keys.data_ptr(), d_labels.data_ptr(), cap, C.byref(n_el), None) == 0
+    n_el = n_el.value
+    assert 590000 < n_el <= 600000
+    n_reads, read_len = 5000, 150
+    pitch = L.mic_synth_read_pitch(read_len, 31)
+    d_rp = torch.zeros(n_reads + 1, dtype=torch.int32, device=dev)
+    d_cont = torch.zeros(n_reads * pitch + 64, dtype=torch.int16, device=dev)
+    d_truth = torch.zeros(n_reads * 2, dtype=torch.int32, device=dev)
+    assert L.mic_synth_reads_device(C.byref(spec), 99, n_reads, read_len, 0.2, 0.01, 0.002, d_rp.data_ptr(), d_cont.data_ptr(),
+                                    d_cont.numel(), d_truth.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    sizes = d_sizes.cpu().numpy()
+    keys = d_keys[:n_el].cpu().numpy().view(np.uint64)
+    labels = d_labels[:n_el].cpu().numpy().view(np.uint16)
+    rp = d_rp.cpu().numpy().view(np.uint32)
+    cont = d_cont.cpu().numpy().view(np.uint16)
+    truth = d_truth.cpu().numpy().view(np.uint32).reshape(-1, 2)
+    assert int(sizes.sum()) == n_el
+    o = gu.oracle()
+    odb = o.db_from_arrays(sizes, keys, labels)
+    _, expect = _oracle_results(odb, 31, rp, cont, 37)
+    with MiClarkDB(31, 37) as e:
+        e.read_device(d_sizes.data_ptr(), spec.htsize, d_keys.data_ptr(), 8, d_labels.data_ptr())
+        d_res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr())
+        assert e.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), d_res.data_ptr()) == 0
+        e.sync()
+        assert e.last_query_ms() > 0
+        res = d_res.cpu().numpy().view(np.uint32)
+    assert (res[:, :5] == expect).all()
+    # constructive known answer: genome reads hit their own genome's label for every unmodified window
+    g = truth[:, 0] > 0
+    assert 0.7 < g.mean() < 0.9
+    ok = (res[g, 1] == truth[g, 0]) & (res[g, 2] >= truth[g, 1])
+    assert ok.mean() > 0.99
+    assert (res[~g, 0] == 0).mean() > 0.99

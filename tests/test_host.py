@@ -1,0 +1,109 @@
+"""CPU tests of the product's host side (C ABI, no device needed)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from cuclark_amd import _lib
+    header = open(os.path.join(gu.ROOT, "include", "mi_clark.h")).read()
+    declared = set(re.findall(r"\b(mic_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mic_engine", "mic_config", "mic_db_info", "mic_synth_spec"}
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from cuclark_amd import MiClarkDB, MicError
+    with pytest.raises(MicError) as ei:
+        MiClarkDB(31, 4)
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(gu.ROOT, "cuclark_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "oracle" not in text.replace("no CPU fallback", "").lower() or f == "__init__.py", f
+    init = open(os.path.join(gu.ROOT, "cuclark_amd", "__init__.py")).read()
+    assert "import oracle" not in init and "from oracle" not in init
+
+
+def test_key_bytes_rule(lib, orc):
+    from cuclark_amd import host
+    for h in (1610612741, 57777779, 1009, 1 << 20, 999983):
+        for k in range(2, 33):
+            assert host.key_bytes_rule(h, k) == orc.key_bytes_rule(h, k)
+
+
+@pytest.mark.parametrize("fn", ["reads_k27.fa", "reads_k27.fq", "reads_k31.fa", "reads_k31.fq", "pairs_k31_1.fq"])
+def test_index_and_pack_match_oracle(fn, lib, orc):
+    from cuclark_amd import host
+    data = open(os.path.join(gu.GOLDEN, fn), "rb").read()
+    a, b = host.index_reads(data), orc.index_reads(data)
+    for f in a:
+        assert (a[f] == b[f]).all(), f
+    for k in (12, 27, 31, 32):
+        rp1, c1 = host.pack_reads(data, a["seq_s"], a["seq_e"], a["length"], k)
+        rp2, c2 = orc.pack_batch(data, b["seq_s"], b["seq_e"], b["length"], k)
+        assert (rp1 == rp2).all() and c1.size == c2.size and (c1 == c2).all()
+
+
+def test_index_edge_cases(lib, orc):
+    from cuclark_amd import host
+    cases = [b">a\nACGT", b">a\nACGT\n", b">a b c\nAC\nGT\n\n>b\n\n>c\nA\n", b"@r1\nACGT\n+\nIIII", b"@r1 x\nACGT\n+\nIIII\n\n",
+             b"@r/1\nAC\r\n+\nII\n@r/2\nGG\n+\n@I\n", b">only_header", b">x\n" + b"ACGT" * 1000 + b"\n"]
+    for data in cases:
+        a, b = host.index_reads(data), orc.index_reads(data)
+        assert a is not None and b is not None
+        for f in a:
+            assert (a[f] == b[f]).all(), (data[:20], f)
+    assert host.index_reads(b"ACGT\n") is None and orc.index_reads(b"ACGT\n") is None
+
+
+def test_pack_long_part_split(lib, orc):
+    """Parts longer than 65528 nt become overlapping sub-parts: same k-mers, product == oracle byte for byte."""
+    from cuclark_amd import host
+    rng = np.random.default_rng(4)
+    seq = "".join(rng.choice(list("ACGT"), 150000))
+    data = f">big\n{seq}\n".encode()
+    ix = host.index_reads(data)
+    for k in (5, 31):
+        rp, ct = host.pack_reads(data, ix["seq_s"], ix["seq_e"], ix["length"], k)
+        rp2, ct2 = orc.pack_batch(data, ix["seq_s"], ix["seq_e"], ix["length"], k)
+        assert (rp == rp2).all() and (ct == ct2).all()
+        # walk the parts: lengths sum to n + (parts-1)*(k-1)
+        p, lens = 0, []
+        while p < ct.size:
+            lens.append(int(ct[p]))
+            p += 1 + (lens[-1] + 7) // 8
+        assert len(lens) == 3 and sum(lens) == 150000 + 2 * (k - 1) and max(lens) == 65528
+
+
+@pytest.mark.parametrize("case", [c[0] for c in gu.expected_csv_cases()])
+def test_csv_formatting_matches_golden(case, lib):
+    """C++ CSV writer fed with the oracle's results reproduces the committed CSV byte for byte."""
+    from cuclark_amd import host
+    _, k, dbname, data, paired, ext = {c[0]: c for c in gu.expected_csv_cases()}[case]
+    odb, _ = gu.oracle_db_from_golden(dbname)
+    names = gu.target_names()
+    _, results = odb.classify_file(k, data, names, paired, ext)
+    idx = host.index_reads(data)
+    res8 = np.zeros((results.shape[0], 8), np.uint32)
+    res8[:, :5] = results
+    dense = None
+    if ext:
+        dense = {r: odb.count_read_ascii(k, data[int(idx["seq_s"][r]):int(idx["seq_e"][r])], idx["length"][r], len(names))
+                 for r in range(results.shape[0])}
+    text = host.format_csv(data, idx, res8, names, k, paired=paired, extended=ext, dense=dense)
+    assert text == open(os.path.join(gu.GOLDEN, f"expected_{case}.csv"), "rb").read()
