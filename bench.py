@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py — Mreads/s of the k-mer query hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|light|tiny] [--mode read|db]
+
+A "step" = one pass of the hot path (fused query kernel: canonical k-mer extraction + bucketed probe + per-read
+per-target hit counts + best/second) over one batch of synthetic reads that is already resident in HBM.
+
+Workloads, all synthetic, generated in HBM by libmi_clark.so's generators:
+  full   config 3: 10 M x 150 bp reads (80 % sampled from the genomes with 1 % substitutions and 0.1 % N, 20 % random)
+         vs. a 36 GB-on-disk-equivalent k=31 table: HTSIZE 1610612741, u32 keys, ~5.7e9 k-mers, 4096 targets,
+         resident as 103 GB of 64-byte slots.                                  [default]
+  light  config 2: same reads vs. the CuCLARK-l-scale table: HTSIZE 57777779, k=31 (u64 keys), ~54 M k-mers.
+  tiny   plumbing-size case for quick checks.
+Multi-GPU (one process per GPU, launched with torch.distributed.run):
+  read   reads sharded, table replicated, no collective (config 5 shape)      -> "scaling": "weak"   [default]
+  db     table sharded by bucket range, every rank sees all reads, per-read sparse target-score rows exchanged
+         with all_to_all over RCCL, merged and finalised per read range (config 4) -> "scaling": "strong"
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch / mean kernel time measured with HIP
+events on the kernel's stream; `cpu_baseline` = the CPU oracle (oracle/, a port of the reference's CPU path) timed on
+this box's host cores on a bounded sample, and that sample doubles as a bit-exact parity check of the GPU results.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # htsize, genome_nt, n_genomes, n_targets, k, key_bytes, n_reads, read_len
+    "full": dict(htsize=1610612741, genome_nt=5_730_000_000, n_genomes=8192, n_targets=4096, k=31, key_bytes=4,
+                 n_reads=10_000_000, read_len=150,
+                 name="10M x 150bp synthetic reads vs 36GB-scale k=31 table (HTSIZE 1610612741, u32 keys, ~5.7e9 k-mers, "
+                      "4096 targets) resident in HBM"),
+    "light": dict(htsize=57777779, genome_nt=54_000_000, n_genomes=512, n_targets=512, k=31, key_bytes=8,
+                  n_reads=10_000_000, read_len=150,
+                  name="10M x 150bp synthetic reads vs CuCLARK-l-scale k=31 table (HTSIZE 57777779, u64 keys, ~54M k-mers)"),
+    "tiny": dict(htsize=999983, genome_nt=1_500_000, n_genomes=64, n_targets=50, k=31, key_bytes=4,
+                 n_reads=100_000, read_len=100,
+                 name="100k x 100bp synthetic reads vs 50-target toy table (plumbing)"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+RANDOM_SECTOR_GREQ = 47.5      # measured: random 64-B requests/s this chip sustains (tools/gather_bench.hip)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="full", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="read", choices=["read", "db"])
+    ap.add_argument("--reads", type=int, default=0, help="override the number of reads per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cuclark_amd import MiClarkDB, _lib
+    L = _lib.load()
+    w = dict(WORKLOADS[args.workload])
+    if args.reads:
+        w["n_reads"] = args.reads
+    k, T = w["k"], w["n_targets"]
+    n_reads, read_len = w["n_reads"], w["read_len"]
+    t_setup = time.time()
+
+    # ---- synthetic table in the on-disk layout (.sz/.ky/.lb images), in HBM
+    spec = _lib.MicSynthSpec(seed=4, htsize=w["htsize"], genome_nt=w["genome_nt"], n_targets=T, n_genomes=w["n_genomes"], k=k,
+                             key_bytes=w["key_bytes"])
+    cap = int(w["genome_nt"]) + 1024
+    d_sizes = torch.empty(w["htsize"], dtype=torch.uint8, device=dev)
+    d_keys = torch.empty(cap, dtype=torch.int32 if w["key_bytes"] == 4 else torch.int64, device=dev)
+    d_labels = torch.empty(cap, dtype=torch.int16, device=dev)
+    n_el = C.c_uint64(0)
+    torch.cuda.synchronize()
+    rc = L.mic_synth_db_device(C.byref(spec), d_sizes.data_ptr(), d_keys.data_ptr(), d_labels.data_ptr(), cap, C.byref(n_el), None)
+    assert rc == 0, f"mic_synth_db_device failed ({rc})"
+    n_el = n_el.value
+    t_gen = time.time() - t_setup
+
+    # ---- resident slot table (whole table, or this rank's bucket range in db mode)
+    row_words = 16
+    eng = MiClarkDB(k, T, device=local_rank, row_words=row_words)
+    shard = (0, 0)
+    if args.mode == "db" and world > 1:
+        per = (w["htsize"] + world - 1) // world
+        shard = (rank * per, min(w["htsize"], (rank + 1) * per))
+    t0 = time.time()
+    eng.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr(), shard=shard)
+    info = eng.info()
+    t_build = time.time() - t0
+
+    # ---- reads (packed containers) in HBM; read-sharded ranks draw different reads
+    pitch = L.mic_synth_read_pitch(read_len, k)
+    read_seed = 5 + (rank if args.mode == "read" else 0)
+    d_rp = torch.empty(n_reads + 1, dtype=torch.int32, device=dev)
+    d_cont = torch.zeros(n_reads * pitch + 64, dtype=torch.int16, device=dev)
+    d_truth = torch.empty(n_reads * 2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    rc = L.mic_synth_reads_device(C.byref(spec), read_seed, n_reads, read_len, 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
+                                  d_cont.numel(), d_truth.data_ptr(), None)
+    assert rc == 0, f"mic_synth_reads_device failed ({rc})"
+    torch.cuda.synchronize()
+    d_res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
+    db_mode = args.mode == "db" and world > 1
+    if db_mode:
+        per_r = (n_reads + world - 1) // world
+        n_pad = per_r * world
+        d_rows = torch.zeros((n_pad, row_words), dtype=torch.int32, device=dev)
+        d_recv = torch.zeros((world, per_r, row_words), dtype=torch.int32, device=dev)
+        d_acc = torch.zeros((2, per_r, row_words), dtype=torch.int32, device=dev)
+        d_res_part = torch.zeros((per_r, 8), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sptr = stream.cuda_stream
+
+    def step():
+        if not db_mode:
+            eng.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), 0, sptr)
+            return
+        # table-sharded: local sparse rows -> all_to_all by read range -> merge (sum by target) -> best/second
+        eng.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), d_rows.data_ptr(), sptr)
+        dist.all_to_all_single(d_recv.view(-1), d_rows.view(-1))
+        cur = d_recv[0]
+        for r in range(1, world):
+            out = d_acc[r & 1]
+            eng.merge_rows_device(cur.data_ptr(), d_recv[r].data_ptr(), out.data_ptr(), per_r, sptr)
+            cur = out
+        eng.result_from_rows_device(cur.data_ptr(), d_res_part.data_ptr(), per_r, sptr)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if args.steps <= 64:
+            pass
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # mean duration of the query kernel alone (HIP events recorded around it on its own stream), sampled
+    # outside the timed loop so the event reads do not serialise it
+    for _ in range(min(args.steps, 5)):
+        step()
+        kernel_ms.append(eng.last_query_ms())
+    torch.cuda.synchronize()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    total_reads = n_reads * (world if args.mode == "read" else 1)
+    value = total_reads / (elapsed / args.steps) / 1e6
+
+    # ---- bookkeeping for the roofline: measured k-mers, hit rate, probed-bucket length (product-side kernel)
+    flagged = eng.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), d_res.data_ptr(), d_rows.data_ptr() if db_mode else 0, sptr)
+    st = eng.probe_stats_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads)
+    kern_s = float(np.mean(kernel_ms)) / 1e3
+    h = st["hits"] / max(st["probed"], 1)
+    lam_q = st["bucket_len_sum"] / max(st["probed"], 1)
+    key_b = w["key_bytes"]
+    bytes_per_kmer = 8 + key_b * lam_q + 2 * h                      # bucket begin/end + keys of the bucket + label on hit
+    in_bytes = 2 * (d_cont.numel() - 64) / n_reads + 4              # packed read + pointer as laid out in HBM
+    alg_bytes = st["probed"] * bytes_per_kmer + n_reads * (in_bytes + 32)
+    achieved = alg_bytes / kern_s / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "query_kernel", "kernel_ms": round(kern_s * 1e3, 3),
+                "algorithmic_bytes_per_kmer": round(bytes_per_kmer, 2), "kmers_per_launch": st["kmers"],
+                "probes_per_launch": st["probed"], "hit_rate": round(h, 4), "mean_probed_bucket_len": round(lam_q, 3),
+                "random_sector_requests_per_s_G": round(st["probed"] / kern_s / 1e9, 2),
+                "random_sector_roof_G": RANDOM_SECTOR_GREQ,
+                "frac_of_random_sector_roof": round(st["probed"] / kern_s / 1e9 / RANDOM_SECTOR_GREQ, 4)}
+
+    # ---- constructive known answer at full size: genome reads must hit their genome's label
+    res = d_res.cpu().numpy().view(np.uint32)
+    truth = d_truth.cpu().numpy().view(np.uint32).reshape(-1, 2)
+    gmask = truth[:, 0] > 0
+    if not db_mode:
+        ok = (res[gmask, 1] == truth[gmask, 0]) & (res[gmask, 2] >= truth[gmask, 1])
+        known = {"genome_reads": int(gmask.sum()), "label_and_count_ok": float(ok.mean()) if gmask.any() else 1.0,
+                 "random_reads_no_hit": float((res[~gmask, 0] == 0).mean()) if (~gmask).any() else 1.0,
+                 "tie_rate": float(((res[:, 2] == res[:, 4]) & (res[:, 2] > 0)).mean())}
+    else:
+        known = None
+
+    # ---- CPU baseline (rank 0, N=1): the oracle on this box's host cores, bounded sample; doubles as parity check
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle.binding import Oracle
+        o = Oracle()
+        t0 = time.time()
+        h_sizes = d_sizes.cpu().numpy()
+        h_keys = d_keys[:n_el].cpu().numpy().view(np.uint32 if key_b == 4 else np.uint64)
+        h_labels = d_labels[:n_el].cpu().numpy().view(np.uint16)
+        odb = o.db_wrap_arrays(h_sizes, h_keys, h_labels)
+        t_copy = time.time() - t0
+        ns = min(args.cpu_sample, n_reads)
+        rp = d_rp[: ns + 1].cpu().numpy().view(np.uint32)
+        ct = d_cont[: int(rp[-1]) + 64].cpu().numpy().view(np.uint16)
+        cores = len(os.sched_getaffinity(0))
+        t0 = time.perf_counter()
+        ref = odb.classify_batch(k, rp, ct, T, threads=cores)
+        t_cpu = time.perf_counter() - t0
+        equal = bool((ref == res[:ns, :5]).all())
+        cpu = {"value": round(ns / t_cpu / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
+               "sample": f"first {ns} of the {n_reads} reads of the same workload, same table copied to host RAM "
+                         f"({t_copy:.0f} s copy+prefix sums, not timed); {t_cpu:.2f} s wall",
+               "objects_per_min": int(ns / t_cpu * 60), "parity_with_gpu_on_sample": equal}
+        assert equal, "GPU results differ from the CPU oracle on the sample"
+
+    if rank == 0:
+        out = {
+            "metric": "Mreads/sec (10M x 150bp, k=31)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong" if db_mode else "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": w["name"], "reads_per_gpu": n_reads, "read_len": read_len, "k": k,
+                       "mode": ("table-sharded by bucket range + all_to_all of sparse rows" if db_mode else
+                                ("read-sharded, table replicated" if world > 1 else "single GPU, table resident")),
+                       "table": {"htsize": info["htsize"], "kmers": info["n_elems"], "slot_class": info["slot_class"],
+                                 "hbm_GB": round(info["hbm_bytes"] / 1e9, 2), "overflow_slots": info["n_overflow"],
+                                 "max_bucket": info["max_bucket"], "on_disk_equiv_GB": round((info["htsize"] + n_el * (key_b + 2)) / 1e9, 2)},
+                       "flagged_reads_dense_path": flagged,
+                       "setup_s": {"synth_db": round(t_gen, 1), "table_build": round(t_build, 1)}},
+            "roofline": roofline, "cpu_baseline": cpu, "known_answer": known,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,6 +4,7 @@ There is no CPU fallback: if the HIP library is missing, or no gfx950 device is 
 created, the caller gets an exception — never a silently slower path.
 """
 import ctypes as C
+import importlib.util
 import os
 import subprocess
 
@@ -57,6 +58,7 @@ SYMBOLS = [
     ("mic_batch_ready", C.c_int, [_VP, _SZ, _SZ, _SZ]),
     ("mic_batch_query", C.c_int, [_VP, _SZ, C.c_int, C.c_int]),
     ("mic_batch_wait", C.c_int, [_VP, _SZ]),
+    ("mic_batch_dense_counts", C.c_int, [_VP, _SZ, _SZ, _VP]),
     ("mic_batch_check", C.c_int, [_VP, _SZ, C.POINTER(C.c_int)]),
     ("mic_sync", C.c_int, [_VP]),
     ("mic_batches_free", C.c_int, [_VP]),
@@ -65,6 +67,7 @@ SYMBOLS = [
     ("mic_merge_rows_device", C.c_int, [_VP, _VP, _VP, _VP, _SZ, _VP]),
     ("mic_result_from_rows_device", C.c_int, [_VP, _VP, _VP, _SZ, _VP]),
     ("mic_count_dense_device", C.c_int, [_VP, _VP, _VP, _VP, _SZ, _VP, _VP]),
+    ("mic_probe_stats_device", C.c_int, [_VP, _VP, _VP, _SZ, C.POINTER(C.c_uint64)]),
     ("mic_last_query_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
     ("mic_key_bytes_rule", C.c_int, [C.c_uint64, C.c_int]),
     ("mic_index_reads", C.c_long, [_VP, _SZ, _SZ, _U64P, _U64P, _U64P, _U64P, _U64P]),
@@ -92,11 +95,33 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes in one
+    process cannot both own the GPU, so when torch is installed its copy is loaded first (by full path, RTLD_GLOBAL):
+    libmi_clark.so's DT_NEEDED libamdhip64.so.7 then resolves to it, and a later `import torch` reuses it too.
+    The standalone CLI (exe/cuCLARK) links /opt/rocm's runtime directly."""
+    if os.environ.get("MIC_NO_TORCH_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the library and bind every declared symbol; raises if the HIP extension is not built."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the k-mer query path)")

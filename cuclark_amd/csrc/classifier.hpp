@@ -1,0 +1,61 @@
+// classifier.hpp — C++ host above the C ABI: the equivalent of the reference's CuCLARK<HKMERr> host class
+// (CuCLARK_hh.hh:51-195) for the classification path.  One class, runtime key width and table size.
+#ifndef MIC_CLASSIFIER_HPP
+#define MIC_CLASSIFIER_HPP
+
+#include <stdint.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "mi_clark.h"
+
+namespace mic {
+
+struct Options {
+  size_t k = 31;              // -k
+  uint32_t min_count_t = 0;   // -t
+  size_t threads = 1;         // -n
+  size_t batches = 1;         // -b
+  size_t devices = 0;         // -d (0 = all)
+  uint32_t sampling = 1;      // -s
+  uint64_t gap = 0;           // -g (light only)
+  bool tsk = false;           // --tsk
+  bool extended = false;      // --extended
+  bool light = false;         // cuCLARK-l
+  uint64_t htsize = 1610612741ull;  // parameters.hh:39 / parameters_light_hh:40; --htsize overrides
+  std::string targets, folder, objects, objects2, results;
+};
+
+class Classifier {
+ public:
+  // CuCLARK ctor (CuCLARK_hh.hh:221-310): parses the targets file, locates the database, creates one engine per
+  // device and loads the database into each.  Throws std::runtime_error with the reference's message on failure.
+  explicit Classifier(const Options& opt);
+  ~Classifier();
+
+  // CuCLARK::run single-end (CuCLARK_hh.hh:383-428) and paired-end (:433-506), incl. list-of-files mode.
+  void run(const std::string& objects, const std::string& results);
+  void run_paired(const std::string& f1, const std::string& f2, const std::string& results);
+
+  // CuCLARK::runSimple (:512-574) on an in-memory FASTA/FASTQ image; `shown_name` is what the messages print.
+  void run_buffer(const uint8_t* map, size_t nb, const std::string& results_base, bool paired);
+
+  std::string db_name() const;  // getdbName, CuCLARK_hh.hh:580-591
+  const std::vector<std::string>& target_names() const { return names_; }
+
+ private:
+  void parse_targets();  // getTargetsData, CuCLARK_hh.hh:1795-1906
+  Options opt_;
+  std::vector<std::pair<std::string, std::string>> targets_id_;
+  std::vector<std::string> labels_, labels_c_, names_;
+  std::vector<mic_engine*> engines_;
+  size_t n_objects_ = 0;
+};
+
+// file.cc:205-268: merged FASTA text of two FASTQ mates ("seq1" + 'N' + "seq2").
+std::string merge_paired(const std::string& file1, const std::string& file2);
+
+}  // namespace mic
+#endif

@@ -157,17 +157,27 @@ void free_batches(mic_engine* e) {
   e->num_reads_total = 0;
 }
 
-// dense path for a list of read ids held on the device; patches results (and rows)
+// dense path for a list of read ids held on the device (nullptr = reads 0..n_ids-1); patches results (and rows)
 int run_dense(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, const uint32_t* d_ids, size_t n_ids,
               uint32_t* d_results, uint32_t* d_rows, hipStream_t s) {
   if (!n_ids) return MIC_OK;
   const uint32_t T = e->cfg.num_targets ? e->cfg.num_targets : 1;
+  uint32_t* d_iota = nullptr;
+  if (!d_ids) {
+    std::vector<uint32_t> iota(n_ids);
+    for (size_t i = 0; i < n_ids; ++i) iota[i] = (uint32_t)i;
+    HIPTRY(hipMalloc(&d_iota, n_ids * 4));
+    hipError_t he = hipMemcpy(d_iota, iota.data(), n_ids * 4, hipMemcpyHostToDevice);
+    if (he != hipSuccess) { hipFree(d_iota); return fail(MIC_E_HIP, "dense path: %s", hipGetErrorString(he)); }
+    d_ids = d_iota;
+  }
   // process in slabs of at most ~1 GiB of counters
   size_t slab = (size_t)((1ull << 30) / ((uint64_t)T * 4));
   if (slab == 0) slab = 1;
   if (slab > n_ids) slab = n_ids;
   uint32_t* d_counts = nullptr;
-  HIPTRY(hipMalloc(&d_counts, slab * (size_t)T * 4));
+  hipError_t me = hipMalloc(&d_counts, slab * (size_t)T * 4);
+  if (me != hipSuccess) { if (d_iota) hipFree(d_iota); return fail(MIC_E_NOMEM, "dense path: %s", hipGetErrorString(me)); }
   int rc = MIC_OK;
   for (size_t off = 0; off < n_ids && rc == MIC_OK; off += slab) {
     size_t n = n_ids - off < slab ? n_ids - off : slab;
@@ -177,6 +187,7 @@ int run_dense(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, const
     if (he != hipSuccess) rc = fail(MIC_E_HIP, "dense path: %s", hipGetErrorString(he));
   }
   hipFree(d_counts);
+  if (d_iota) hipFree(d_iota);
   return rc;
 }
 
@@ -454,6 +465,29 @@ int mic_batch_wait(mic_engine* e, size_t batch) {
   return MIC_OK;
 }
 
+int mic_batch_dense_counts(mic_engine* e, size_t batch, size_t read_in_batch, uint32_t* counts) {
+  if (!e || batch >= e->batches.size() || !counts) return fail(MIC_E_INVALID, "bad argument");
+  Batch& B = e->batches[batch];
+  if (!B.scheduled || read_in_batch >= B.n_reads) return fail(MIC_E_INVALID, "bad read index");
+  int rc = set_device(e);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(e->submit_mu);
+  const uint32_t T = e->cfg.num_targets ? e->cfg.num_targets : 1;
+  uint32_t* d_counts = nullptr; uint32_t* d_id = nullptr;
+  uint32_t id = (uint32_t)read_in_batch;
+  HIPTRY(hipEventSynchronize(B.done));
+  HIPTRY(hipMalloc(&d_counts, (size_t)T * 4));
+  hipError_t he = hipMalloc(&d_id, 4);
+  if (he == hipSuccess) he = hipMemcpyAsync(d_id, &id, 4, hipMemcpyHostToDevice, B.stream);
+  if (he == hipSuccess) he = mic_launch_dense_count(e->table, e->slot_class, B.d_rp, B.d_cont, d_id, 1, T, d_counts, B.stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(counts, d_counts, (size_t)T * 4, hipMemcpyDeviceToHost, B.stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(B.stream);
+  hipFree(d_counts);
+  if (d_id) hipFree(d_id);
+  if (he != hipSuccess) return fail(MIC_E_HIP, "dense counts: %s", hipGetErrorString(he));
+  return MIC_OK;
+}
+
 int mic_batch_check(mic_engine* e, size_t batch, int* done) {
   if (!e || batch >= e->batches.size() || !done) return fail(MIC_E_INVALID, "bad argument");
   Batch& B = e->batches[batch];
@@ -543,6 +577,24 @@ int mic_result_from_rows_device(mic_engine* e, const uint32_t* rows, uint32_t* r
   int rc = set_device(e);
   if (rc) return rc;
   HIPTRY(mic_launch_result_from_rows(rows, e->cfg.row_words, results, n, stream ? (hipStream_t)stream : e->stream));
+  return MIC_OK;
+}
+
+int mic_probe_stats_device(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, size_t n_reads, uint64_t out[4]) {
+  if (!e || !d_rp || !d_cont || !out) return fail(MIC_E_INVALID, "null argument");
+  if (!e->db_loaded) return fail(MIC_E_STATE, "no database loaded");
+  int rc = set_device(e);
+  if (rc) return rc;
+  unsigned long long* d = nullptr;
+  unsigned long long h[4] = {0, 0, 0, 0};
+  HIPTRY(hipMalloc(&d, 32));
+  hipError_t he = hipMemsetAsync(d, 0, 32, e->stream);
+  if (he == hipSuccess) he = mic_launch_probe_stats(e->table, e->slot_class, d_rp, d_cont, n_reads, d, e->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(h, d, 32, hipMemcpyDeviceToHost, e->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+  hipFree(d);
+  if (he != hipSuccess) return fail(MIC_E_HIP, "probe stats: %s", hipGetErrorString(he));
+  for (int i = 0; i < 4; ++i) out[i] = h[i];
   return MIC_OK;
 }
 

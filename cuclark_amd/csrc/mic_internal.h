@@ -88,6 +88,9 @@ hipError_t mic_launch_dense_count(const MicTable& t, int slot_class, const uint3
 hipError_t mic_launch_dense_finish(const uint32_t* counts, const uint32_t* ids, size_t n_ids, uint32_t n_targets,
                                    uint32_t* results, uint32_t* rows, uint32_t row_words, hipStream_t s);
 
+hipError_t mic_launch_probe_stats(const MicTable& t, int slot_class, const uint32_t* reads_ptr, const uint16_t* cont,
+                                  size_t n_reads, unsigned long long* d_out, hipStream_t s);
+
 // table build (mic_build.hip)
 struct MicBuildOut {
   uint4* slots;

@@ -429,7 +429,56 @@ __global__ void __launch_bounds__(256) dense_finish_kernel(const uint32_t* __res
   }
 }
 
+// Diagnostics for the roofline bookkeeping (not on the timed path): one thread per read walks its k-mers and
+// accumulates {k-mers, k-mers probed in this shard, hits, sum of the probed buckets' lengths}.
+template <bool KEY64>
+__global__ void __launch_bounds__(256) probe_stats_kernel(const MicTable t, const uint32_t* __restrict__ reads_ptr,
+                                                          const uint16_t* __restrict__ cont, uint32_t n_reads,
+                                                          unsigned long long* __restrict__ out) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long nk = 0, np = 0, nh = 0, nb = 0;
+  if (r < n_reads) {
+    uint32_t pp = reads_ptr[r];
+    const uint32_t pe = reads_ptr[r + 1];
+    const int k = t.k;
+    const uint64_t cutoff = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    while (pp < pe) {
+      const uint32_t plen = cont[pp];
+      if (plen == 0) break;
+      const uint32_t first = pp + 1;
+      pp = first + (plen + 7) / 8;
+      uint64_t kmer = 0;
+      for (uint32_t i = 0; i < plen; ++i) {
+        uint32_t nt = (cont[first + i / 8] >> (14 - 2 * (i % 8))) & 3u;
+        kmer = ((kmer << 2) | nt) & cutoff;
+        if (i + 1 < (uint32_t)k) continue;
+        ++nk;
+        uint64_t c = canonical(kmer, k);
+        uint64_t q = mic_div(c, t.div);
+        uint64_t rem = c - q * t.div.d;
+        if (rem < t.shard_start || rem >= t.shard_end) continue;
+        ++np;
+        nb += t.slots[(rem - t.shard_start) * 4].w & 0xFF;
+        nh += probe_scalar<KEY64>(t, kmer) != 0;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    nk += __shfl_down(nk, off); np += __shfl_down(np, off); nh += __shfl_down(nh, off); nb += __shfl_down(nb, off);
+  }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], nk); atomicAdd(&out[1], np); atomicAdd(&out[2], nh); atomicAdd(&out[3], nb); }
+}
+
 }  // namespace
+
+hipError_t mic_launch_probe_stats(const MicTable& t, int slot_class, const uint32_t* reads_ptr, const uint16_t* cont,
+                                  size_t n_reads, unsigned long long* d_out, hipStream_t s) {
+  if (!n_reads) return hipSuccess;
+  unsigned blocks = (unsigned)((n_reads + 255) / 256);
+  if (slot_class == 64) probe_stats_kernel<true><<<blocks, 256, 0, s>>>(t, reads_ptr, cont, (uint32_t)n_reads, d_out);
+  else probe_stats_kernel<false><<<blocks, 256, 0, s>>>(t, reads_ptr, cont, (uint32_t)n_reads, d_out);
+  return hipGetLastError();
+}
 
 hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hipStream_t s) {
   if (a.n_reads == 0) return hipSuccess;

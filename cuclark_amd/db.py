@@ -164,6 +164,11 @@ class MiClarkDB:
         check(self.L.mic_count_dense_device(self.h, d_reads_pointer, d_containers, d_ids or None, n_ids, d_counts,
                                             stream or None))
 
+    def probe_stats_device(self, d_reads_pointer, d_containers, n_reads):
+        out = (C.c_uint64 * 4)()
+        check(self.L.mic_probe_stats_device(self.h, d_reads_pointer, d_containers, n_reads, out))
+        return dict(kmers=int(out[0]), probed=int(out[1]), hits=int(out[2]), bucket_len_sum=int(out[3]))
+
     def last_query_ms(self):
         ms = C.c_float(0)
         check(self.L.mic_last_query_ms(self.h, C.byref(ms)))

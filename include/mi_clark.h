@@ -119,6 +119,10 @@ int mic_batches_alloc(mic_engine* e, size_t num_reads_total, size_t max_reads, s
 int mic_batch_ready(mic_engine* e, size_t batch, size_t n_reads, size_t n_containers);
 int mic_batch_query(mic_engine* e, size_t batch, int extended, int followup);
 int mic_batch_wait(mic_engine* e, size_t batch);
+/* Dense per-target counts (u32[num_targets]) of read `read_in_batch` of a finished batch whose sparse row did
+ * not fit (row[0] == MIC_ROW_INVALID); the reference has no equivalent — it truncates at MAXHITS and corrupts
+ * the row (CuClarkDB.cu:1200-1211).  Synchronous; valid until the batch is queried again or freed. */
+int mic_batch_dense_counts(mic_engine* e, size_t batch, size_t read_in_batch, uint32_t* counts);
 int mic_batch_check(mic_engine* e, size_t batch, int* done);
 int mic_sync(mic_engine* e);
 int mic_batches_free(mic_engine* e);
@@ -146,6 +150,10 @@ int mic_result_from_rows_device(mic_engine* e, const uint32_t* d_rows, uint32_t*
  * fallback for reads whose rows overflow, and the --extended source of truth. */
 int mic_count_dense_device(mic_engine* e, const uint32_t* d_reads_pointer, const uint16_t* d_containers,
                            const uint32_t* d_read_ids, size_t n_ids, uint32_t* d_counts, void* stream);
+/* Bookkeeping for the roofline figure (not timed): out = {k-mers in the reads, k-mers whose bucket lies in this
+ * engine's shard, hits, sum of the lengths of the probed buckets}.  Synchronous. */
+int mic_probe_stats_device(mic_engine* e, const uint32_t* d_reads_pointer, const uint16_t* d_containers, size_t n_reads,
+                           uint64_t out[4]);
 /* Duration in ms of the last mic_query_device launch on this engine, measured with HIP events on the
  * stream it ran on (blocks until it finished). */
 int mic_last_query_ms(mic_engine* e, float* ms);

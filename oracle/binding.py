@@ -15,7 +15,8 @@ _LIB = os.path.join(_HERE, "liboracle.so")
 
 class _OrcDb(C.Structure):
     _fields_ = [("htsize", C.c_uint64), ("key_bytes", C.c_int), ("n_elems", C.c_uint64),
-                ("bucket_off", C.POINTER(C.c_uint64)), ("keys", C.c_void_p), ("labels", C.POINTER(C.c_uint16))]
+                ("bucket_off", C.POINTER(C.c_uint64)), ("keys", C.c_void_p), ("labels", C.POINTER(C.c_uint16)),
+                ("borrowed", C.c_int)]
 
 
 class _OrcIndex(C.Structure):
@@ -52,6 +53,11 @@ class Oracle:
         L.orc_db_load.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_uint32]
         L.orc_db_from_arrays.restype = C.POINTER(_OrcDb)
         L.orc_db_from_arrays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]
+        L.orc_db_wrap_arrays.restype = C.POINTER(_OrcDb)
+        L.orc_db_wrap_arrays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_classify_batch.restype = C.c_uint64
+        L.orc_classify_batch.argtypes = [C.POINTER(_OrcDb), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
+                                         C.c_void_p, C.c_int]
         L.orc_db_free.argtypes = [C.POINTER(_OrcDb)]
         L.orc_db_find.restype = C.c_int
         L.orc_db_find.argtypes = [C.POINTER(_OrcDb), C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint16)]
@@ -106,6 +112,17 @@ class Oracle:
         if not p:
             raise RuntimeError("orc_db_from_arrays failed")
         return OracleDb(self, p)
+
+    def db_wrap_arrays(self, sizes, keys, labels):
+        """Zero-copy: the numpy arrays must stay alive as long as the returned OracleDb."""
+        assert sizes.dtype == np.uint8 and labels.dtype == np.uint16 and sizes.flags.c_contiguous
+        p = self.L.orc_db_wrap_arrays(sizes.ctypes.data, sizes.size, keys.ctypes.data, keys.dtype.itemsize,
+                                      labels.ctypes.data)
+        if not p:
+            raise RuntimeError("orc_db_wrap_arrays failed")
+        db = OracleDb(self, p)
+        db._keep = (sizes, keys, labels)
+        return db
 
     # -- rows / results
     def sparse_row(self, counts, max_pairs=64):
@@ -214,6 +231,15 @@ class OracleDb:
         bad = self.orc.L.orc_query_batch(self.p, k, rp.ctypes.data, ct.ctypes.data, n, int(part[0]), int(pe), n_targets,
                                          counts.ctypes.data)
         return counts, int(bad)
+
+    def classify_batch(self, k, reads_pointer, containers, n_targets, threads=0):
+        rp = np.ascontiguousarray(reads_pointer, np.uint32)
+        ct = np.ascontiguousarray(containers, np.uint16)
+        n = rp.size - 1
+        res = np.zeros((n, 5), np.uint32)
+        bad = self.orc.L.orc_classify_batch(self.p, k, rp.ctypes.data, ct.ctypes.data, n, n_targets, res.ctypes.data, threads)
+        assert bad == 0
+        return res
 
     def count_read_ascii(self, k, seq, length, n_targets, part=(0, None)):
         buf = np.frombuffer(seq, np.uint8)

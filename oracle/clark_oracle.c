@@ -9,6 +9,9 @@
 #include "clark_oracle.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -146,9 +149,27 @@ orc_db* orc_db_load(const char* prefix, uint64_t htsize, int key_bytes, uint32_t
   return db;
 }
 
+orc_db* orc_db_wrap_arrays(const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes,
+                           const uint16_t* labels) {
+  if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return NULL;
+  orc_db* db = (orc_db*)calloc(1, sizeof(orc_db));
+  if (!db) return NULL;
+  db->htsize = htsize; db->key_bytes = key_bytes; db->borrowed = 1;
+  db->bucket_off = (uint64_t*)malloc((htsize + 1) * sizeof(uint64_t));
+  if (!db->bucket_off) { free(db); return NULL; }
+  uint64_t run = 0;
+  for (uint64_t i = 0; i < htsize; ++i) { db->bucket_off[i] = run; run += sizes[i]; }
+  db->bucket_off[htsize] = run;
+  db->n_elems = run;
+  db->keys = (void*)keys; db->labels = (uint16_t*)labels;
+  return db;
+}
+
 void orc_db_free(orc_db* db) {
   if (!db) return;
-  free(db->bucket_off); free(db->keys); free(db->labels); free(db);
+  free(db->bucket_off);
+  if (!db->borrowed) { free(db->keys); free(db->labels); }
+  free(db);
 }
 
 /* CuClarkDB.cu:1249-1314.  quotient is compared at full width against the stored key
@@ -279,6 +300,41 @@ uint64_t orc_query_batch(const orc_db* db, int k, const uint32_t* reads_pointer,
         if (i + 1 >= (uint32_t)k) bad += tally(db, kmer, k, part_start, part_end, n_targets, row);
       }
     }
+  }
+  return bad;
+}
+
+uint64_t orc_classify_batch(const orc_db* db, int k, const uint32_t* reads_pointer, const uint16_t* containers,
+                            size_t n_reads, uint32_t n_targets, uint32_t* results, int threads) {
+  const uint64_t cutoff = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  uint64_t bad = 0;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#else
+  (void)threads;
+#endif
+#pragma omp parallel reduction(+ : bad)
+  {
+    uint32_t* counts = (uint32_t*)calloc(n_targets ? n_targets : 1, sizeof(uint32_t));
+#pragma omp for schedule(dynamic, 256)
+    for (long r = 0; r < (long)n_reads; ++r) {
+      uint32_t p = reads_pointer[r], end = reads_pointer[r + 1];
+      while (p < end) {
+        uint32_t plen = containers[p];
+        if (plen == 0) break;
+        uint32_t first = p + 1;
+        p = first + (plen - 1) / 8 + 1;
+        uint64_t kmer = 0;
+        for (uint32_t i = 0; i < plen; ++i) {
+          uint32_t nt = (containers[first + i / 8] >> (14 - 2 * (i % 8))) & 3u;
+          kmer = ((kmer << 2) | nt) & cutoff;
+          if (i + 1 >= (uint32_t)k) bad += tally(db, kmer, k, 0, db->htsize, n_targets, counts);
+        }
+      }
+      orc_result_from_counts(counts, n_targets, results + 5 * (size_t)r);
+      memset(counts, 0, (size_t)n_targets * sizeof(uint32_t));
+    }
+    free(counts);
   }
   return bad;
 }

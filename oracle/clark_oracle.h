@@ -52,6 +52,7 @@ typedef struct orc_db {
   uint64_t* bucket_off;  /* [htsize+1] exclusive prefix sum of kept bucket sizes   */
   void* keys;            /* [n_elems] quotients, key_bytes wide                    */
   uint16_t* labels;      /* [n_elems]                                             */
+  int borrowed;          /* keys/labels belong to the caller (orc_db_wrap_arrays) */
 } orc_db;
 
 /* Load <prefix>.sz/.ky/.lb.  htsize==0 => take it from the size of .sz.  sampling<=1 keeps every
@@ -63,6 +64,11 @@ orc_db* orc_db_load(const char* prefix, uint64_t htsize, int key_bytes, uint32_t
 /* Same, from in-memory copies of the three files. */
 orc_db* orc_db_from_arrays(const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes,
                            const uint16_t* labels, uint32_t sampling);
+
+/* Zero-copy variant for sampling <= 1: keys/labels are borrowed (must outlive the db); only the prefix sums
+ * are built.  Used by bench.py's cpu_baseline leg for the 36 GB table. */
+orc_db* orc_db_wrap_arrays(const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes,
+                           const uint16_t* labels);
 
 void orc_db_free(orc_db* db);
 
@@ -95,6 +101,11 @@ size_t orc_pack_batch(const uint8_t* map, const uint64_t* spos, const uint64_t* 
 uint64_t orc_query_batch(const orc_db* db, int k, const uint32_t* reads_pointer, const uint16_t* containers,
                          size_t n_reads, uint64_t part_start, uint64_t part_end, uint32_t n_targets,
                          uint32_t* counts);
+
+/* {sum, idxBest, best, idxSecond, second} for every read of a packed batch (results[n_reads*5]), reads spread
+ * over `threads` OpenMP threads (0 = runtime default).  The CPU baseline timed by bench.py. */
+uint64_t orc_classify_batch(const orc_db* db, int k, const uint32_t* reads_pointer, const uint16_t* containers,
+                            size_t n_reads, uint32_t n_targets, uint32_t* results, int threads);
 
 /* The same counts straight from sequence bytes, using the part rule of SURVEY appendix item 5
  * (maximal ACGTU runs, '\n' transparent, anything else ends a part; parts shorter than k and

@@ -1,0 +1,101 @@
+"""The cuCLARK-compatible command line (exe/cuCLARK, exe/cuCLARK-l): argv contract of main.cc:74-320, .csv output,
+stdout lines scripts parse (CuCLARK_hh.hh:1938-1944)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import golden_util as gu
+
+EXE = os.path.join(gu.ROOT, "exe", "cuCLARK")
+EXE_L = os.path.join(gu.ROOT, "exe", "cuCLARK-l")
+
+
+def _run(args, **kw):
+    return subprocess.run(args, capture_output=True, text=True, timeout=600, **kw)
+
+
+def _targets_file(tmp):
+    p = os.path.join(tmp, "targets.txt")
+    with open(p, "w") as f:
+        for fn, label in gu.target_files_and_labels():
+            f.write(f"{fn} {label}\n")
+    return p
+
+
+def _db_dir(tmp, name, light):
+    """Lay the golden DB out under the reference's file name (CuCLARK_hh.hh:580-591)."""
+    d = os.path.join(tmp, "DB")
+    os.makedirs(d, exist_ok=True)
+    meta = gu.load_golden_db(name)
+    base = f"db_central_k{meta['k']}_t6_s{meta['htsize']}_m0" + ("_light_4" if light else "") + ".tsk"
+    prefix, _ = gu.materialize_db(name, d)
+    for ext in (".sz", ".ky", ".lb"):
+        os.replace(prefix + ext, os.path.join(d, base + ext))
+    return d
+
+
+def test_help_version_and_argument_errors(lib):
+    r = _run([EXE, "--version"])
+    assert r.returncode == 0 and "Version: 1.1" in r.stdout and "CLARK version 1.1.3" in r.stdout
+    r = _run([EXE, "--help"])
+    assert r.returncode == 0 and "-T <fileTargets>" in r.stdout
+    r = _run([EXE, "-k", "31"])
+    assert r.returncode != 0 and "at least four  parameters are necessary" in r.stderr
+    r = _run([EXE, "-k", "40", "-T", "x", "-D", "y", "-O", "z", "-R", "w"])
+    assert r.returncode == 1 and "The k-mer length should be in [2,32]." in r.stderr
+    r = _run([EXE, "-T", "/nonexistent", "-D", "y", "-O", "z", "-R", "w"])
+    assert r.returncode == 1 and "Failed to find/read the file of the targets definition" in r.stderr
+    r = _run([EXE, "-n", "4", "-b", "2", "-T", "x", "-D", "y", "-O", "z"])
+    assert r.returncode == 1 and "number of batches should be higher" in r.stderr
+    r = _run([EXE, "--bogus", "1", "2", "3", "4", "5"])
+    assert r.returncode == 1 and "Failed to recognize option: --bogus" in r.stderr
+
+
+@pytest.mark.gpu
+def test_light_cli_matches_golden(tmp_path):
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "light_k27_u32", light=True)
+    t = _targets_file(tmp)
+    out = os.path.join(tmp, "res")
+    r = _run([EXE_L, "-T", t, "-D", d, "-O", os.path.join(gu.GOLDEN, "reads_k27.fa"), "-R", out, "-n", "2", "-b", "5"])
+    assert r.returncode == 0, r.stderr
+    assert re.search(r"Processing file '.*reads_k27.fa' in 5 batches using 2 CPU thread\(s\)\.", r.stdout)
+    assert re.search(r" - Assignment time: [0-9.e+-]+ s\. Speed: \d+ objects/min\. \(131 objects\)\.", r.stdout)
+    assert f" - Results stored in {out}.csv" in r.stdout
+    assert open(out + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, "expected_k27_fa.csv"), "rb").read()
+    # FASTQ, extended, and paired-end through the same binary
+    for flag, src, exp in (([], ["-O", os.path.join(gu.GOLDEN, "reads_k27.fq")], "expected_k27_fq.csv"),
+                           (["--extended"], ["-O", os.path.join(gu.GOLDEN, "reads_k27.fa")], "expected_k27_fa_ext.csv"),
+                           ([], ["-P", os.path.join(gu.GOLDEN, "pairs_k27_1.fq"), os.path.join(gu.GOLDEN, "pairs_k27_2.fq")],
+                            "expected_k27_pairs.csv")):
+        out2 = os.path.join(tmp, "res_" + exp)
+        r = _run([EXE_L, "-T", t, "-D", d, *src, "-R", out2, *flag])
+        assert r.returncode == 0, r.stderr
+        assert open(out2 + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, exp), "rb").read(), exp
+
+
+@pytest.mark.gpu
+def test_full_cli_matches_golden_and_missing_db(tmp_path):
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "full_k31_u32", light=False)
+    t = _targets_file(tmp)
+    out = os.path.join(tmp, "res")
+    r = _run([EXE, "-k", "31", "-T", t, "-D", d, "-O", os.path.join(gu.GOLDEN, "reads_k31.fa"), "-R", out])
+    assert r.returncode == 0, r.stderr
+    assert open(out + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, "expected_k31_fa.csv"), "rb").read()
+    # list-of-files mode: -O and -R name parallel lists (CuCLARK_hh.hh:413-427)
+    lo, lr = os.path.join(tmp, "objs.txt"), os.path.join(tmp, "ress.txt")
+    open(lo, "w").write(os.path.join(gu.GOLDEN, "reads_k31.fa") + "\n" + os.path.join(gu.GOLDEN, "reads_k31.fq") + "\n")
+    open(lr, "w").write(os.path.join(tmp, "l1") + "\n" + os.path.join(tmp, "l2") + "\n")
+    r = _run([EXE, "-k", "31", "-T", t, "-D", d, "-O", lo, "-R", lr])
+    assert r.returncode == 0, r.stderr
+    assert open(os.path.join(tmp, "l1.csv"), "rb").read() == open(os.path.join(gu.GOLDEN, "expected_k31_fa.csv"), "rb").read()
+    assert open(os.path.join(tmp, "l2.csv"), "rb").read() == open(os.path.join(gu.GOLDEN, "expected_k31_fq.csv"), "rb").read()
+    for ext in (".sz", ".ky", ".lb"):
+        for f in os.listdir(d):
+            if f.endswith(ext):
+                os.remove(os.path.join(d, f))
+    r = _run([EXE, "-k", "31", "-T", t, "-D", d, "-O", os.path.join(gu.GOLDEN, "reads_k31.fa"), "-R", out])
+    assert r.returncode != 0 and "Failed to find the database." in r.stderr
