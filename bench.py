@@ -44,7 +44,7 @@ WORKLOADS = {
     "light": dict(htsize=57777779, genome_nt=54_000_000, n_genomes=512, n_targets=512, k=31, key_bytes=8,
                   n_reads=10_000_000, read_len=150,
                   name="10M x 150bp synthetic reads vs CuCLARK-l-scale k=31 table (HTSIZE 57777779, u64 keys, ~54M k-mers)"),
-    "tiny": dict(htsize=999983, genome_nt=1_500_000, n_genomes=64, n_targets=50, k=31, key_bytes=4,
+    "tiny": dict(htsize=999983, genome_nt=1_500_000, n_genomes=64, n_targets=50, k=31, key_bytes=8,
                  n_reads=100_000, read_len=100,
                  name="100k x 100bp synthetic reads vs 50-target toy table (plumbing)"),
 }
@@ -78,7 +78,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from cuclark_amd import MiClarkDB, _lib
+    from cuclark_amd import MiClarkDB, _lib, multi
     L = _lib.load()
     w = dict(WORKLOADS[args.workload])
     if args.reads:
@@ -106,8 +106,7 @@ def main():
     eng = MiClarkDB(k, T, device=local_rank, row_words=row_words)
     shard = (0, 0)
     if args.mode == "db" and world > 1:
-        per = (w["htsize"] + world - 1) // world
-        shard = (rank * per, min(w["htsize"], (rank + 1) * per))
+        shard = multi.shard_range(w["htsize"], world, rank)
     t0 = time.time()
     eng.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr(), shard=shard)
     info = eng.info()
@@ -127,9 +126,8 @@ def main():
     d_res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
     db_mode = args.mode == "db" and world > 1
     if db_mode:
-        per_r = (n_reads + world - 1) // world
-        n_pad = per_r * world
-        d_rows = torch.zeros((n_pad, row_words), dtype=torch.int32, device=dev)
+        per_r = multi.read_range(n_reads, world, rank)[2]
+        d_rows = multi.padded_rows(n_reads, world, row_words, dev)
         d_recv = torch.zeros((world, per_r, row_words), dtype=torch.int32, device=dev)
         d_acc = torch.zeros((2, per_r, row_words), dtype=torch.int32, device=dev)
         d_res_part = torch.zeros((per_r, 8), dtype=torch.int32, device=dev)
@@ -142,7 +140,7 @@ def main():
             return
         # table-sharded: local sparse rows -> all_to_all by read range -> merge (sum by target) -> best/second
         eng.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), d_rows.data_ptr(), sptr)
-        dist.all_to_all_single(d_recv.view(-1), d_rows.view(-1))
+        multi.exchange_rows(d_rows, world, out=d_recv)
         cur = d_recv[0]
         for r in range(1, world):
             out = d_acc[r & 1]
@@ -192,8 +190,22 @@ def main():
     in_bytes = 2 * (d_cont.numel() - 64) / n_reads + 4              # packed read + pointer as laid out in HBM
     alg_bytes = st["probed"] * bytes_per_kmer + n_reads * (in_bytes + 32)
     achieved = alg_bytes / kern_s / 1e9
+    # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, tools/profile_bench.sh); the
+    # counters cannot be read from inside this process, so the committed summary of the same workload is used.
+    traffic, traffic_src = None, None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_query_kernel.json")), reverse=True):
+        try:
+            pj = json.load(open(f))
+        except Exception:
+            continue
+        if pj.get("workload") == w["name"] and pj.get("reads_per_launch") == n_reads and not db_mode:
+            traffic = (pj["fetch_bytes_per_launch"] + pj["write_bytes_per_launch"]) / kern_s / 1e9
+            traffic_src = os.path.basename(f)
+            break
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": round(traffic, 1) if traffic else None,
+                "traffic_source": traffic_src,
                 "kernel": "query_kernel", "kernel_ms": round(kern_s * 1e3, 3),
                 "algorithmic_bytes_per_kmer": round(bytes_per_kmer, 2), "kmers_per_launch": st["kmers"],
                 "probes_per_launch": st["probed"], "hit_rate": round(h, 4), "mean_probed_bucket_len": round(lam_q, 3),
@@ -206,7 +218,8 @@ def main():
     truth = d_truth.cpu().numpy().view(np.uint32).reshape(-1, 2)
     gmask = truth[:, 0] > 0
     if not db_mode:
-        ok = (res[gmask, 1] == truth[gmask, 0]) & (res[gmask, 2] >= truth[gmask, 1])
+        # a genome read with w unmodified windows must report its genome's label with >= w hits (w = 0: no claim)
+        ok = (truth[gmask, 1] == 0) | ((res[gmask, 1] == truth[gmask, 0]) & (res[gmask, 2] >= truth[gmask, 1]))
         known = {"genome_reads": int(gmask.sum()), "label_and_count_ok": float(ok.mean()) if gmask.any() else 1.0,
                  "random_reads_no_hit": float((res[~gmask, 0] == 0).mean()) if (~gmask).any() else 1.0,
                  "tie_rate": float(((res[:, 2] == res[:, 4]) & (res[:, 2] > 0)).mean())}

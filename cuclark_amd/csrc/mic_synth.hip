@@ -212,6 +212,10 @@ int mic_synth_db_device(const mic_synth_spec* spec, uint8_t* d_sizes, void* d_ke
   if (!spec || !d_sizes || !d_keys || !d_labels || !n_elems) return MIC_E_INVALID;
   if (spec->k < 2 || spec->k > 32 || spec->n_genomes == 0 || spec->n_targets == 0 || spec->htsize < 2) return MIC_E_INVALID;
   if (spec->key_bytes != 4 && spec->key_bytes != 8) return MIC_E_INVALID;
+  {  // 4-byte keys must hold every quotient (main.cc:274-316 picks the width so that they do)
+    unsigned __int128 max_c = spec->k == 32 ? ~(unsigned __int128)0 >> 64 : (((unsigned __int128)1 << (2 * spec->k)) - 1);
+    if (spec->key_bytes == 4 && (uint64_t)(max_c / spec->htsize) >> 32) return MIC_E_INVALID;
+  }
   hipStream_t s = (hipStream_t)stream;
   int rc = MIC_OK;
   SynthDev sp;

@@ -1,0 +1,117 @@
+"""world_size-2 tests on gloo (CPU) of the multi-GPU plumbing (cuclark_amd/multi.py).  The per-shard sparse rows that
+the HIP kernel would produce are computed here by the oracle with the same shard filter (CuClarkDB.cu:1272-1274); the
+exchange, the ownership of read ranges, the fold order and the final gather are the product code under test."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_util as gu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rows_u32(o, counts, row_words):
+    rows = np.zeros((counts.shape[0], row_words), np.uint32)
+    for r in range(counts.shape[0]):
+        n, row = o.sparse_row(counts[r], row_words - 1)
+        assert n <= row_words - 1
+        rows[r, 0] = n
+        rows[r, 1:1 + n] = (row[2:2 + 2 * n:2].astype(np.uint32) << 16) | row[1:1 + 2 * n:2]
+    return rows
+
+
+def _merge_u32(a, b):
+    """reference merge (sum by target) on the product's u32 row format, numpy."""
+    out = np.zeros_like(a)
+    for r in range(a.shape[0]):
+        d = {}
+        for row in (a[r], b[r]):
+            for v in row[1:1 + row[0]]:
+                d[int(v) & 0xFFFF] = d.get(int(v) & 0xFFFF, 0) + (int(v) >> 16)
+        out[r, 0] = len(d)
+        for i, t in enumerate(sorted(d)):
+            out[r, 1 + i] = (d[t] << 16) | t
+    return out
+
+
+def _worker(rank, world, port, mode, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuclark_amd import multi
+        o = gu.oracle()
+        odb, meta = gu.oracle_db_from_golden("light_k31_u64")
+        data = open(os.path.join(gu.GOLDEN, "reads_k31.fa"), "rb").read()
+        ix = o.index_reads(data)
+        rp, ct = o.pack_batch(data, ix["seq_s"], ix["seq_e"], ix["length"], 31)
+        n, T, RW = rp.size - 1, 6, 16
+        whole, _ = odb.query_batch(31, rp, ct, T)
+        expect = o.result_from_counts(whole)
+        if mode == "db":
+            s0, s1 = multi.shard_range(meta["htsize"], world, rank)
+            counts, _ = odb.query_batch(31, rp, ct, T, part=(s0, s1))
+            rows = multi.padded_rows(n, world, RW, "cpu")
+            rows[:n] = torch.from_numpy(_rows_u32(o, counts, RW).astype(np.int64)).to(torch.int32)
+            recv = multi.exchange_rows(rows, world)
+            merged = multi.merge_exchanged(recv, lambda a, b: torch.from_numpy(
+                _merge_u32(a.numpy().view(np.uint32), b.numpy().view(np.uint32)).view(np.int32)))
+            lo, hi, per = multi.read_range(n, world, rank)
+            m = merged.numpy().view(np.uint32)
+            res = np.zeros((per, 8), np.uint32)
+            for i in range(hi - lo):
+                row16 = np.zeros(2 * RW, np.uint16)
+                row16[0] = m[i, 0]
+                row16[1:1 + 2 * m[i, 0]:2] = m[i, 1:1 + m[i, 0]] & 0xFFFF
+                row16[2:2 + 2 * m[i, 0]:2] = m[i, 1:1 + m[i, 0]] >> 16
+                res[i, :5] = o.result_from_row(row16)
+            allres = multi.gather_results(torch.from_numpy(res.view(np.int32)), world).numpy().view(np.uint32)
+            ok = bool((allres[:n, :5] == expect).all())
+        else:  # read-sharded: each rank classifies its own read range against the whole table; no collective
+            lo, hi, per = multi.read_range(n, world, rank)
+            mine = o.result_from_counts(whole[lo:hi])
+            ok = bool((mine == expect[lo:hi]).all()) and (hi - lo) > 0
+            t = torch.tensor([hi - lo])
+            dist.all_reduce(t)
+            ok = ok and int(t.item()) == n
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["db", "read"])
+def test_two_ranks_gloo(mode):
+    world = 2
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_ranges_cover_everything():
+    from cuclark_amd import multi
+    for H, W in ((1610612741, 8), (57777779, 4), (1009, 2), (7, 8)):
+        edges = [multi.shard_range(H, W, r) for r in range(W)]
+        assert edges[0][0] == 0 and max(e[1] for e in edges) == H
+        for a, b in zip(edges[:-1], edges[1:]):
+            assert a[1] == b[0] or b[0] >= H
+    for n, W in ((10_000_000, 8), (131, 2), (5, 8)):
+        got = sum(max(0, multi.read_range(n, W, r)[1] - multi.read_range(n, W, r)[0]) for r in range(W))
+        assert got == n

@@ -224,7 +224,9 @@ def test_shards_sum_to_whole():
         e.sync()
         merged = acc.cpu().numpy().view(np.uint32)
         results = results.cpu().numpy().view(np.uint32)
-    assert (merged == rows_whole).all()
+    assert (merged[:, 0] == rows_whole[:, 0]).all()
+    for r in range(n):  # words beyond n are unspecified
+        assert (merged[r, 1:1 + merged[r, 0]] == rows_whole[r, 1:1 + rows_whole[r, 0]]).all()
     assert (results[:, :5] == res_whole[:, :5]).all()
 
 
@@ -399,6 +401,6 @@ def test_synthetic_generator_matches_oracle():
     # constructive known answer: genome reads hit their own genome's label for every unmodified window
     g = truth[:, 0] > 0
     assert 0.7 < g.mean() < 0.9
-    ok = (res[g, 1] == truth[g, 0]) & (res[g, 2] >= truth[g, 1])
-    assert ok.mean() > 0.99
+    ok = (truth[g, 1] == 0) | ((res[g, 1] == truth[g, 0]) & (res[g, 2] >= truth[g, 1]))
+    assert ok.mean() > 0.999
     assert (res[~g, 0] == 0).mean() > 0.99

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (tools/profile_bench.sh) into profiles/<tag>_*.{csv,json}."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join("gpurun_out", f"prof_{tag}")
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+
+# 1. rocprofv3 --kernel-trace --stats summary, verbatim
+ks = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))[0]
+rows = list(csv.DictReader(open(ks)))
+with open(os.path.join(dst, f"{tag}_rocprof_kernel_stats.csv"), "w") as f:
+    w = csv.DictWriter(f, fieldnames=rows[0].keys())
+    w.writeheader()
+    w.writerows(rows)
+bench = json.load(open(os.path.join(src, "kt_bench.json")))
+
+# 2. PMC per-launch means for the query kernel
+pmc = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*", ""))):
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "query_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for c, v in agg.items():
+            pmc[c] = sum(v) / len(v)
+cal = {}
+for name in ("cal_fetch", "cal_rdreq"):
+    for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "gather_coop64_kernel<4>" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for c, v in agg.items():
+            cal[c] = v[-1]  # last launch = 8 GiB table
+q = [r for r in rows if "query_kernel" in r["Name"]][0]
+slots_cal = 256 * 8 * 256 // 4 * 16 * 4  # quads x iters x unroll of gather_coop64_kernel<4>
+out = {
+    "tag": tag, "workload": bench["config"]["workload"], "reads_per_launch": bench["config"]["reads_per_gpu"],
+    "kernel": "query_kernel<false>", "rocprof_calls": int(q["Calls"]), "rocprof_avg_ms": float(q["AverageNs"]) / 1e6,
+    "bench_hip_event_ms": bench["roofline"]["kernel_ms"],
+    "pmc_per_launch": pmc,
+    "fetch_bytes_per_launch": pmc.get("FETCH_SIZE", 0) * 1024,
+    "write_bytes_per_launch": pmc.get("WRITE_SIZE", 0) * 1024,
+    "rdreq_per_probe": pmc.get("TCC_EA0_RDREQ_sum", 0) / bench["roofline"]["probes_per_launch"],
+    "calibration": {"kernel": "gather_coop64_kernel<4> (tools/gather_bench.hip), 8 GiB table: 4 lanes x 16 B per random 64-B slot",
+                    "slots_loaded": slots_cal, "FETCH_SIZE_KB": cal.get("FETCH_SIZE"), "TCC_EA0_RDREQ_sum": cal.get("TCC_EA0_RDREQ_sum"),
+                    "bytes_per_slot_by_FETCH_SIZE": cal.get("FETCH_SIZE", 0) * 1024 / slots_cal,
+                    "note": "FETCH_SIZE*1024 equals 64 B x slots in this access shape (64-B requests, RDREQ_32B = 0): no x2 "
+                            "correction applies; the x2 of the guide is for 128-B streaming requests"},
+}
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_query_kernel.json"), "w"), indent=1)
+json.dump(bench, open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
