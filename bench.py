@@ -49,7 +49,7 @@ WORKLOADS = {
                  name="100k x 100bp synthetic reads vs 50-target toy table (plumbing)"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-RANDOM_SECTOR_GREQ = 47.5      # measured: random 64-B requests/s this chip sustains (tools/gather_bench.hip)
+RANDOM_SECTOR_GREQ = 51.4      # measured: random 64-B nontemporal requests/s this chip sustains (tools/gather_runs_bench.hip)
 
 
 def log(*a):
