@@ -16,6 +16,7 @@ MIC_RESULT_WORDS = 8
 MIC_FLAG_ROW_OVERFLOW = 1
 MIC_FLAG_DENSE_PATH = 2
 MIC_ROW_INVALID = 0xFFFFFFFF
+MIC_LAYOUT_AUTO, MIC_LAYOUT_DIRECT, MIC_LAYOUT_MINIMIZER = 0, 1, 2
 
 
 class MicError(RuntimeError):
@@ -26,14 +27,15 @@ class MicError(RuntimeError):
 
 class MicConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("k", C.c_int32), ("num_targets", C.c_uint32), ("num_batches", C.c_uint32),
-                ("row_words", C.c_uint32), ("reserved", C.c_uint32)]
+                ("row_words", C.c_uint32), ("layout", C.c_uint32)]
 
 
 class MicDbInfo(C.Structure):
     _fields_ = [("htsize", C.c_uint64), ("shard_start", C.c_uint64), ("shard_end", C.c_uint64),
                 ("n_elems", C.c_uint64), ("n_elems_file", C.c_uint64), ("n_slots", C.c_uint64),
                 ("n_overflow", C.c_uint64), ("hbm_bytes", C.c_uint64), ("key_bytes", C.c_int32),
-                ("slot_class", C.c_int32), ("max_bucket", C.c_uint32), ("sampling", C.c_uint32)]
+                ("slot_class", C.c_int32), ("max_bucket", C.c_uint32), ("sampling", C.c_uint32), ("layout", C.c_int32),
+                ("minimizer_len", C.c_int32), ("max_chain", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class MicSynthSpec(C.Structure):

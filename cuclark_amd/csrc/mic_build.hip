@@ -7,6 +7,7 @@
 //   B  per-tile overflow-slot demand / kept elements / max size -> host scan -> overflow bases
 //   C  slot construction (reachability filter, chain layout)
 #include "mic_internal.h"
+#include "mic_device.h"
 
 #include <stdio.h>
 #include <vector>
@@ -272,6 +273,230 @@ done:
   if (d_a) hipFree(d_a);
   if (d_b) hipFree(d_b);
   if (d_kept) hipFree(d_kept);
+  if (slots) hipFree(slots);
+  return rc;
+}
+
+
+// =====================================================================================================================
+// Minimizer-keyed table (layout 1).  Passes:
+//   A   (shared) per-tile element / non-empty sums            -> raw offsets, sampling ranks
+//   M1  per bucket: reachable entries -> canonical k-mer c = key*H + bucket -> slot(c) -> count[slot]++
+//   M2  per-tile sums of overflow-slot demand -> host scan -> per slot: headers of its whole chain (keys = ~0)
+//   M3  per bucket again: scatter (c, label) to chain position atomicAdd(cursor[slot])
+//   M4  per slot: sort the chain by c (shell sort over the virtual array)
+// =====================================================================================================================
+namespace {
+
+struct MSlot {
+  unsigned long long keys[MIC_MCAP];
+  unsigned short labels[MIC_MCAP];
+  unsigned int meta;
+  unsigned int next;
+};
+static_assert(sizeof(MSlot) == MIC_MSLOT_BYTES, "M-slot must be 128 bytes");
+
+struct MBuildArgs {
+  const uint8_t* sizes; uint64_t n_buckets; uint64_t bucket0; uint64_t htsize;
+  const void* keys; const uint16_t* labels;
+  const TileA* base_a; uint32_t sampling; uint64_t rank_base;
+  int k, m; uint64_t n_mslots;
+};
+
+// visit the reachable entries of this thread's bucket: f(c, label)
+template <typename RAW, typename F>
+__device__ inline void for_reachable(const MBuildArgs& a, F&& f) {
+  uint64_t i = (uint64_t)blockIdx.x * TILE + threadIdx.x;
+  uint32_t sz = i < a.n_buckets ? a.sizes[i] : 0;
+  uint32_t ea, eb, ta, tb;
+  block_scan2(sz, sz > 0, ea, eb, ta, tb);
+  if (i >= a.n_buckets || sz == 0) return;
+  uint64_t rank_incl = a.rank_base + a.base_a[blockIdx.x].nonzero + eb + 1;
+  if (!kept_bucket(sz, rank_incl, a.sampling)) return;
+  const uint64_t off = a.base_a[blockIdx.x].elems + ea;
+  const uint64_t last = raw_key<RAW>(a.keys, off + sz - 1);
+  uint64_t run = 0; bool first = true;
+  for (uint32_t e = 0; e < sz; ++e) {
+    uint64_t kv = raw_key<RAW>(a.keys, off + e);
+    bool reach = (first || kv > run) && kv <= last;   // CuClarkDB.cu:1291-1307
+    if (first || kv > run) { run = kv; first = false; }
+    if (reach) f(kv * a.htsize + (a.bucket0 + i), a.labels[off + e]);
+  }
+}
+
+template <typename RAW>
+__global__ void __launch_bounds__(TILE) m_count_kernel(MBuildArgs a, uint32_t* __restrict__ cnt,
+                                                       unsigned long long* __restrict__ kept) {
+  unsigned long long mine = 0;
+  for_reachable<RAW>(a, [&](uint64_t c, uint16_t) {
+    atomicAdd(&cnt[mslot_of_kmer(c, a.k, a.m, a.n_mslots)], 1u);
+    ++mine;
+  });
+  if (mine) atomicAdd(kept, mine);
+}
+
+__device__ inline uint32_t chain_ovf(uint32_t n) { return n > MIC_MCAP ? (n - MIC_MCAP + MIC_MCAP - 1) / MIC_MCAP : 0; }
+
+__global__ void __launch_bounds__(TILE) m_ovf_tile_kernel(const uint32_t* __restrict__ cnt, uint64_t n,
+                                                          unsigned long long* __restrict__ tile_sum,
+                                                          uint32_t* __restrict__ max_cnt) {
+  uint64_t i = (uint64_t)blockIdx.x * TILE + threadIdx.x;
+  uint32_t c = i < n ? cnt[i] : 0;
+  uint32_t ea, eb, ta, tb;
+  block_scan2(chain_ovf(c), 0, ea, eb, ta, tb);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = ta;
+  if (c) atomicMax(max_cnt, c);
+}
+
+__global__ void __launch_bounds__(TILE) m_header_kernel(const uint32_t* __restrict__ cnt, uint64_t n,
+                                                        const unsigned long long* __restrict__ tile_base,
+                                                        MSlot* __restrict__ slots) {
+  uint64_t i = (uint64_t)blockIdx.x * TILE + threadIdx.x;
+  uint32_t c = i < n ? cnt[i] : 0;
+  uint32_t ovf = chain_ovf(c);
+  uint32_t ea, eb, ta, tb;
+  block_scan2(ovf, 0, ea, eb, ta, tb);
+  if (i >= n) return;
+  uint64_t next = n + tile_base[blockIdx.x] + ea;  // first overflow slot of this chain
+  uint64_t slot = i; uint32_t left = c;
+  for (uint32_t j = 0; j <= ovf; ++j) {
+    uint32_t here = left > MIC_MCAP ? MIC_MCAP : left;
+    left -= here;
+    uint4* q = (uint4*)&slots[slot];
+#pragma unroll
+    for (int w = 0; w < 6; ++w) q[w] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    q[6] = make_uint4(0, 0, 0, 0);
+    q[7] = make_uint4(0, 0, here | (left ? 0x100u : 0u), (uint32_t)next);
+    slot = next; ++next;
+  }
+}
+
+template <typename RAW>
+__global__ void __launch_bounds__(TILE) m_scatter_kernel(MBuildArgs a, uint32_t* __restrict__ cursor,
+                                                         MSlot* __restrict__ slots) {
+  for_reachable<RAW>(a, [&](uint64_t c, uint16_t lb) {
+    uint64_t s = mslot_of_kmer(c, a.k, a.m, a.n_mslots);
+    uint32_t pos = atomicAdd(&cursor[s], 1u);
+    uint64_t slot = s; uint32_t e = pos;
+    if (pos >= MIC_MCAP) { slot = (uint64_t)slots[s].next + (pos - MIC_MCAP) / MIC_MCAP; e = (pos - MIC_MCAP) % MIC_MCAP; }
+    slots[slot].keys[e] = c;
+    slots[slot].labels[e] = lb;
+  });
+}
+
+// element i of the chain that starts at main slot s
+__device__ inline MSlot* chain_slot(MSlot* slots, uint64_t s, uint32_t first_ovf, uint32_t i) {
+  return i < MIC_MCAP ? &slots[s] : &slots[(uint64_t)first_ovf + (i - MIC_MCAP) / MIC_MCAP];
+}
+
+__global__ void m_sort_kernel(const uint32_t* __restrict__ cnt, uint64_t n, MSlot* __restrict__ slots) {
+  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t c = cnt[s];
+  if (c < 2) return;
+  const uint32_t fo = slots[s].next;
+  const uint32_t gaps[] = {701, 301, 132, 57, 23, 10, 4, 1};
+  for (int g = 0; g < 8; ++g) {
+    const uint32_t gap = gaps[g];
+    if (gap >= c) continue;
+    for (uint32_t i = gap; i < c; ++i) {
+      MSlot* si = chain_slot(slots, s, fo, i);
+      unsigned long long kv = si->keys[i % MIC_MCAP]; unsigned short lv = si->labels[i % MIC_MCAP];
+      uint32_t j = i;
+      while (j >= gap) {
+        MSlot* sj = chain_slot(slots, s, fo, j - gap);
+        unsigned long long kj = sj->keys[(j - gap) % MIC_MCAP];
+        if (kj <= kv) break;
+        MSlot* sd = chain_slot(slots, s, fo, j);
+        sd->keys[j % MIC_MCAP] = kj; sd->labels[j % MIC_MCAP] = sj->labels[(j - gap) % MIC_MCAP];
+        j -= gap;
+      }
+      MSlot* sd = chain_slot(slots, s, fo, j);
+      sd->keys[j % MIC_MCAP] = kv; sd->labels[j % MIC_MCAP] = lv;
+    }
+  }
+}
+
+}  // namespace
+
+int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
+                     int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
+                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap) {
+  int rc = 0;
+  const unsigned n_tiles = (unsigned)((n_buckets + TILE - 1) / TILE);
+  TileA* d_a = nullptr; uint32_t* d_cnt = nullptr; uint32_t* d_cur = nullptr; unsigned long long* d_tile = nullptr;
+  unsigned long long* d_kept = nullptr; uint32_t* d_max = nullptr; MSlot* slots = nullptr;
+  std::vector<TileA> h_a(n_tiles);
+  std::vector<unsigned long long> h_tile;
+  uint64_t tot_elems = 0, tot_nz = 0, n_mslots = 0, tot_ovf = 0; unsigned m_tiles = 0;
+  unsigned long long h_kept = 0; uint32_t h_max = 0;
+  MBuildArgs a;
+  HIPCK(hipMalloc(&d_a, sizeof(TileA) * n_tiles));
+  HIPCK(hipMalloc(&d_kept, 8));
+  HIPCK(hipMalloc(&d_max, 4));
+  HIPCK(hipMemsetAsync(d_kept, 0, 8, s));
+  HIPCK(hipMemsetAsync(d_max, 0, 4, s));
+  tile_a_kernel<<<n_tiles, TILE, 0, s>>>(d_sizes, n_buckets, d_a);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(h_a.data(), d_a, sizeof(TileA) * n_tiles, hipMemcpyDeviceToHost, s));
+  HIPCK(hipStreamSynchronize(s));
+  for (unsigned t = 0; t < n_tiles; ++t) {
+    uint64_t e = h_a[t].elems, z = h_a[t].nonzero;
+    h_a[t].elems = tot_elems; h_a[t].nonzero = tot_nz; tot_elems += e; tot_nz += z;
+  }
+  HIPCK(hipMemcpyAsync(d_a, h_a.data(), sizeof(TileA) * n_tiles, hipMemcpyHostToDevice, s));
+  // half-full slots on average; the clustering of k-mers by minimizer makes the load lumpy
+  n_mslots = tot_elems / (sampling > 1 ? 6ull * sampling : 6ull) + 64;
+  if (n_mslots > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many M-slots"); rc = -1; goto done; }
+  m_tiles = (unsigned)((n_mslots + TILE - 1) / TILE);
+  h_tile.resize(m_tiles);
+  HIPCK(hipMalloc(&d_cnt, n_mslots * 4));
+  HIPCK(hipMalloc(&d_tile, (size_t)m_tiles * 8));
+  HIPCK(hipMemsetAsync(d_cnt, 0, n_mslots * 4, s));
+  a.sizes = d_sizes; a.n_buckets = n_buckets; a.bucket0 = bucket0; a.htsize = htsize; a.keys = d_keys; a.labels = d_labels;
+  a.base_a = d_a; a.sampling = sampling; a.rank_base = rank_base; a.k = k; a.m = m; a.n_mslots = n_mslots;
+#define BY_RAW(KERN, ...) do { if (key_bytes == 8) KERN<uint64_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); \
+    else if (key_bytes == 4) KERN<uint32_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); \
+    else KERN<uint16_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); } while (0)
+  BY_RAW(m_count_kernel, a, d_cnt, d_kept);
+  HIPCK(hipGetLastError());
+  m_ovf_tile_kernel<<<m_tiles, TILE, 0, s>>>(d_cnt, n_mslots, d_tile, d_max);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(h_tile.data(), d_tile, (size_t)m_tiles * 8, hipMemcpyDeviceToHost, s));
+  HIPCK(hipMemcpyAsync(&h_kept, d_kept, 8, hipMemcpyDeviceToHost, s));
+  HIPCK(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
+  HIPCK(hipStreamSynchronize(s));
+  for (unsigned t = 0; t < m_tiles; ++t) { unsigned long long v = h_tile[t]; h_tile[t] = tot_ovf; tot_ovf += v; }
+  if (n_mslots + tot_ovf > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many M-slots"); rc = -1; goto done; }
+  HIPCK(hipMemcpyAsync(d_tile, h_tile.data(), (size_t)m_tiles * 8, hipMemcpyHostToDevice, s));
+  {
+    hipError_t e_ = hipMalloc(&slots, (size_t)(n_mslots + tot_ovf + 1) * sizeof(MSlot));
+    if (e_ != hipSuccess) {
+      snprintf(err, err_cap, "hipMalloc of %.2f GB for the minimizer table failed: %s",
+               (double)(n_mslots + tot_ovf + 1) * sizeof(MSlot) / 1e9, hipGetErrorString(e_));
+      rc = -3; goto done;
+    }
+  }
+  m_header_kernel<<<m_tiles, TILE, 0, s>>>(d_cnt, n_mslots, d_tile, slots);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMalloc(&d_cur, n_mslots * 4));
+  HIPCK(hipMemsetAsync(d_cur, 0, n_mslots * 4, s));
+  BY_RAW(m_scatter_kernel, a, d_cur, slots);
+  HIPCK(hipGetLastError());
+  m_sort_kernel<<<(unsigned)((n_mslots + 255) / 256), 256, 0, s>>>(d_cnt, n_mslots, slots);
+  HIPCK(hipGetLastError());
+  HIPCK(hipStreamSynchronize(s));
+#undef BY_RAW
+  out->slots = (uint4*)slots; slots = nullptr;
+  out->n_main = n_mslots; out->n_overflow = tot_ovf; out->n_elems = h_kept; out->n_elems_file = tot_elems;
+  out->max_bucket = 0; out->max_chain = h_max;
+done:
+  if (d_a) hipFree(d_a);
+  if (d_cnt) hipFree(d_cnt);
+  if (d_cur) hipFree(d_cur);
+  if (d_tile) hipFree(d_tile);
+  if (d_kept) hipFree(d_kept);
+  if (d_max) hipFree(d_max);
   if (slots) hipFree(slots);
   return rc;
 }

@@ -49,6 +49,7 @@ struct mic_engine {
   // table
   bool db_loaded = false;
   uint4* slots = nullptr;
+  uint8_t* d_sizes = nullptr;  // the shard's on-disk bucket sizes (statistics)
   MicTable table;
   int slot_class = 32;
   mic_db_info info;
@@ -74,7 +75,7 @@ int set_device(const mic_engine* e) {
 }
 
 void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s0, uint64_t s1, int key_bytes,
-                uint32_t sampling) {
+                uint32_t sampling, int layout, int m) {
   e->slots = b.slots;
   e->table.slots = b.slots;
   e->table.n_main = b.n_main;
@@ -82,12 +83,18 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   e->table.shard_end = s1;
   e->table.div = mic_make_div(htsize);
   e->table.k = e->cfg.k;
+  e->table.layout = layout == MIC_LAYOUT_MINIMIZER ? 1 : 0;
+  e->table.m = m;
+  e->table.sharded = (s0 != 0 || s1 != htsize) ? 1 : 0;
+  e->table.sizes = e->d_sizes;
   mic_db_info& i = e->info;
   i.htsize = htsize; i.shard_start = s0; i.shard_end = s1;
   i.n_elems = b.n_elems; i.n_elems_file = b.n_elems_file;
   i.n_slots = b.n_main + b.n_overflow; i.n_overflow = b.n_overflow;
-  i.hbm_bytes = (b.n_main + b.n_overflow + 1) * (uint64_t)MIC_SLOT_BYTES;
-  i.key_bytes = key_bytes; i.slot_class = e->slot_class; i.max_bucket = b.max_bucket; i.sampling = sampling;
+  i.hbm_bytes = (b.n_main + b.n_overflow + 1) * (uint64_t)(layout == MIC_LAYOUT_MINIMIZER ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
+  i.key_bytes = key_bytes; i.slot_class = layout == MIC_LAYOUT_MINIMIZER ? 128 : e->slot_class; i.max_bucket = b.max_bucket;
+  i.sampling = sampling; i.layout = layout; i.minimizer_len = layout == MIC_LAYOUT_MINIMIZER ? m : 0;
+  i.max_chain = layout == MIC_LAYOUT_MINIMIZER ? b.max_chain : 0; i.reserved = 0;
   e->db_loaded = true;
 }
 
@@ -130,11 +137,33 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
                       uint64_t rank_base) {
   e->slot_class = key_bytes == 8 ? 64 : 32;
   MicBuildOut b;
+  memset(&b, 0, sizeof(b));
   char err[256] = "";
-  int rc = mic_build_table(d_sizes_shard, s1 - s0, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
-                           e->slot_class, e->stream, &b, err, sizeof(err));
+  // layout: explicit request, else the environment (MIC_LAYOUT=direct|minimizer), else by k
+  int layout = (int)e->cfg.layout;
+  if (layout == MIC_LAYOUT_AUTO) {
+    const char* env = getenv("MIC_LAYOUT");
+    if (env && !strcmp(env, "direct")) layout = MIC_LAYOUT_DIRECT;
+    else if (env && !strcmp(env, "minimizer")) layout = MIC_LAYOUT_MINIMIZER;
+    else layout = e->cfg.k >= 25 ? MIC_LAYOUT_MINIMIZER : MIC_LAYOUT_DIRECT;
+  }
+  int m = 17;
+  if (const char* env = getenv("MIC_MINIMIZER_LEN")) m = atoi(env);
+  if (m > e->cfg.k - 4) m = e->cfg.k - 4;   // window w = k-m+1 >= 5
+  if (m > 31) m = 31;
+  if (layout == MIC_LAYOUT_MINIMIZER && (m < 8 || e->cfg.k - m + 1 > 64)) layout = MIC_LAYOUT_DIRECT;
+  if (e->d_sizes) { hipFree(e->d_sizes); e->d_sizes = nullptr; }
+  if (hipMalloc(&e->d_sizes, s1 - s0) == hipSuccess)
+    hipMemcpyAsync(e->d_sizes, d_sizes_shard, s1 - s0, hipMemcpyDeviceToDevice, e->stream);
+  int rc;
+  if (layout == MIC_LAYOUT_MINIMIZER)
+    rc = mic_build_mtable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
+                          e->cfg.k, m, e->stream, &b, err, sizeof(err));
+  else
+    rc = mic_build_table(d_sizes_shard, s1 - s0, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
+                         e->slot_class, e->stream, &b, err, sizeof(err));
   if (rc != 0) return fail(rc, "table build: %s", err);
-  fill_table(e, b, htsize, s0, s1, key_bytes, sampling);
+  fill_table(e, b, htsize, s0, s1, key_bytes, sampling, layout, m);
   return MIC_OK;
 }
 
@@ -209,6 +238,7 @@ int mic_create(const mic_config* cfg, mic_engine** out) {
   if (!cfg || !out) return fail(MIC_E_INVALID, "null argument");
   if (cfg->k < 2 || cfg->k > 32) return fail(MIC_E_INVALID, "The k-mer length should be in [2,32].");
   if (cfg->num_targets > 65535) return fail(MIC_E_INVALID, "too many targets (%u > 65535)", cfg->num_targets);
+  if (cfg->layout > MIC_LAYOUT_MINIMIZER) return fail(MIC_E_INVALID, "unknown table layout %u", cfg->layout);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
     return fail(MIC_E_NODEVICE, "no HIP device available: the MI355X engine cannot run (there is no CPU fallback)");
@@ -246,6 +276,7 @@ int mic_destroy(mic_engine* e) {
   hipDeviceSynchronize();
   free_batches(e);
   if (e->slots) hipFree(e->slots);
+  if (e->d_sizes) hipFree(e->d_sizes);
   if (e->d_flagged) hipFree(e->d_flagged);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -260,7 +291,8 @@ int mic_db_unload(mic_engine* e) {
   if (rc) return rc;
   hipDeviceSynchronize();
   if (e->slots) hipFree(e->slots);
-  e->slots = nullptr; e->db_loaded = false;
+  if (e->d_sizes) hipFree(e->d_sizes);
+  e->slots = nullptr; e->d_sizes = nullptr; e->db_loaded = false;
   memset(&e->info, 0, sizeof(e->info));
   return MIC_OK;
 }

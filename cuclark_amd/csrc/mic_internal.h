@@ -55,13 +55,32 @@ static inline __host__ __device__ uint64_t mic_div(uint64_t n, const MicDiv& dv)
 #define MIC_CAP32 8
 #define MIC_CAP64 4
 
+// ---- minimizer-keyed table ("M-table", layout 1) ---------------------------------------------------------------
+// A k-mer's slot is chosen by the smallest 32-bit order key among its w = k-m+1 canonical m-mers (mic_device.h), so
+// the ~ (w+1)/2 consecutive k-mers of a read that share a minimizer share ONE slot: the query kernel loads each
+// distinct slot of a 128-k-mer chunk once from HBM into LDS (8 lanes x 16 B) and every k-mer compares against the
+// staged entries.  Slots hold full canonical k-mers, so membership and labels are exact.
+//   128-byte slot: keys u64[12] (ascending along the chain, unused = ~0) | labels u16[12] | meta u32 | next u32
+//   meta: bits 0..7 = entries in this slot, bit 8 = chain continues at slot `next` (overflow slots are contiguous)
+#define MIC_MCAP 12
+#define MIC_MSLOT_BYTES 128
+#ifndef MIC_LAYOUT_MINIMIZER
+#define MIC_LAYOUT_AUTO 0
+#define MIC_LAYOUT_DIRECT 1
+#define MIC_LAYOUT_MINIMIZER 2
+#endif
+
 struct MicTable {
-  const uint4* slots;    // n_main + n_overflow slots
-  uint64_t n_main;       // = shard_end - shard_start
+  const uint4* slots;    // layout 0: 4 x uint4 per slot; layout 1: 8 x uint4 per slot
+  uint64_t n_main;       // layout 0: shard_end - shard_start; layout 1: number of main M-slots
   uint64_t shard_start;  // first bucket of the shard
   uint64_t shard_end;
   MicDiv div;            // division by htsize
   int k;
+  int layout;            // 0 = direct slots, 1 = minimizer-keyed slots
+  int m;                 // minimizer length (layout 1)
+  int sharded;           // 1 if [shard_start, shard_end) is a strict subset of the table
+  const uint8_t* sizes;  // kept copy of the shard's on-disk bucket sizes (statistics only)
 };
 
 struct MicQueryArgs {
@@ -96,12 +115,17 @@ struct MicBuildOut {
   uint4* slots;
   uint64_t n_main, n_overflow, n_elems, n_elems_file;
   uint32_t max_bucket;
+  uint32_t max_chain;   // layout 1: entries in the fullest slot chain
 };
 // d_sizes/d_keys/d_labels point at the first bucket / first element of the shard.
 // rank_base = number of non-empty buckets before the shard (sampling is defined on the whole table).
 int mic_build_table(const uint8_t* d_sizes, uint64_t n_buckets, const void* d_keys, int key_bytes,
                     const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int slot_class, hipStream_t s,
                     MicBuildOut* out, char* err, size_t err_cap);
+// Minimizer-keyed table from the same inputs.  bucket0 = index of the shard's first bucket in the whole table.
+int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
+                     int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
+                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap);
 // sums over d_sizes[0..n): total elements and non-empty buckets
 int mic_reduce_sizes(const uint8_t* d_sizes, uint64_t n, uint64_t* total, uint64_t* nonzero, hipStream_t s);
 

@@ -12,24 +12,11 @@
 //   * reads with more than 64 distinct targets, or whose row does not fit the caller's row pitch, are
 //     listed for the dense fallback kernels below, which are exact for any read.
 #include "mic_internal.h"
+#include "mic_device.h"
 
 #include <stdlib.h>
 
 namespace {
-
-__device__ __forceinline__ uint32_t bperm(int src_lane, uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
-}
-
-template <int CTRL>
-__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-#define QP_BCAST0 0x00
-#define QP_BCAST1 0x55
-#define QP_BCAST3 0xFF
-#define QP_XOR1 0xB1
-#define QP_XOR2 0x4E
 
 // Slot loads have no reuse (one random 64-byte request per probe): nontemporal loads keep them from displacing
 // the streamed read data in L2 and measured +4 % request rate (profiles/r01_gather_runs_microbench.csv).
@@ -37,18 +24,6 @@ __device__ __forceinline__ uint4 load_slot_quarter(const uint4* p) {
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
   u4 t = __builtin_nontemporal_load((const u4*)p);
   return make_uint4(t.x, t.y, t.z, t.w);
-}
-
-__device__ __forceinline__ uint64_t revcomp_bits(uint64_t x, int k) {
-  // reverse all 64 bits, then swap the two bits of every pair back: 2-bit groups reversed
-  uint64_t r = __builtin_bitreverse64(x);
-  r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
-  return (~r) >> (64 - 2 * k);
-}
-
-__device__ __forceinline__ uint64_t canonical(uint64_t kmer, int k) {
-  uint64_t rc = revcomp_bits(kmer, k);
-  return kmer < rc ? kmer : rc;
 }
 
 // k-mer value of nucleotides [nt, nt+k) of a stream whose 32-bit big-endian-in-nt dwords are d0,d1,d2
@@ -281,6 +256,159 @@ __global__ void __launch_bounds__(256) query_kernel(const MicQueryArgs a) {
   }
 }
 
+
+// =====================================================================================================================
+// query_kernel_m — minimizer-keyed table (layout 1).  Same work mapping, k-mer assembly, tally and result code as
+// query_kernel; the probe differs: consecutive k-mers that share a minimizer share a slot, so per 128-k-mer chunk the
+// wave (1) computes every k-mer's slot from a sliding minimum of 32-bit m-mer order keys, (2) finds the runs of equal
+// slots with ballot/popcount, (3) loads each distinct 128-byte slot ONCE (8 lanes x 16 B, up to 8 slots per
+// wave-instruction) and stages it in the wave's private LDS region, (4) lets every k-mer compare its canonical value
+// against the 12 staged keys, (5) repeats for the lanes whose chain continues.  HBM sees one 128-byte request per
+// distinct slot (~17 per 150-bp read) instead of one 64-byte request per k-mer (120).
+// =====================================================================================================================
+#define MIC_RMAX 32        // slots staged per round
+#define MIC_MSTRIDE 9      // uint4 per staged slot in LDS: 8 + 1 pad (bank spread)
+
+__device__ __forceinline__ void sliding_min3(uint32_t& a0, uint32_t& a1, uint32_t& a2, int w, int lane) {
+  // a_h(l) holds the order key of position 64h+l; afterwards a_h(l) = min over positions [64h+l, 64h+l+w)
+  auto step = [&](int s) {
+    const int src = (lane + s) & 63;
+    const bool wrap = lane + s >= 64;
+    uint32_t x0 = bperm(src, a0), x1 = bperm(src, a1), x2 = bperm(src, a2);
+    uint32_t n0 = wrap ? x1 : x0, n1 = wrap ? x2 : x1, n2 = wrap ? 0xFFFFFFFFu : x2;
+    a0 = n0 < a0 ? n0 : a0; a1 = n1 < a1 ? n1 : a1; a2 = n2 < a2 ? n2 : a2;
+  };
+  int cover = 1;
+  while (2 * cover <= w) { step(cover); cover *= 2; }
+  if (cover < w) step(w - cover);
+}
+
+__global__ void __launch_bounds__(256) query_kernel_m(const MicQueryArgs a) {
+  __shared__ uint4 s_stage[4][MIC_RMAX * MIC_MSTRIDE];
+  __shared__ uint32_t s_run[4][MIC_RMAX];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  uint4* stage = s_stage[wv];
+  uint32_t* runslot = s_run[wv];
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  const uint32_t n_waves = gridDim.x * 4;
+  const MicTable& t = a.t;
+  const int k = t.k, m = t.m, w = k - m + 1;
+  const uint4* __restrict__ slots = t.slots;
+  const uint16_t* __restrict__ cont = a.cont;
+  const uint64_t lane_le = lane == 63 ? ~0ULL : ((2ULL << lane) - 1);
+
+  for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
+    uint32_t pp = __builtin_amdgcn_readfirstlane(a.reads_ptr[r]);
+    const uint32_t pe = __builtin_amdgcn_readfirstlane(a.reads_ptr[r + 1]);
+    RowAcc acc; acc.label1 = 0; acc.count = 0;
+    uint32_t n_ent = 0, overflow = 0, total = 0;
+
+    while (pp < pe) {
+      const uint32_t plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
+      if (plen == 0) break;
+      const uint32_t first = pp + 1;
+      pp = first + (plen + 7) / 8;
+      if (plen < (uint32_t)k) continue;
+      const uint32_t nk = plen - k + 1;
+      const uint32_t cend = pp;
+      for (uint32_t base = 0; base < nk; base += 128) {
+        uint32_t wd = 0;
+        {
+          uint32_t ci = first + base / 8 + 2 * lane;
+          if (lane < 10) {
+            uint32_t hi = ci < cend ? cont[ci] : 0;
+            uint32_t lo = ci + 1 < cend ? cont[ci + 1] : 0;
+            wd = (hi << 16) | lo;
+          }
+        }
+        // k-mers of the two passes and the order keys of the m-mers at positions base+64h+lane, h = 0..2
+        uint64_t c[2]; bool act[2]; uint32_t hk0, hk1, hk2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int idx = 4 * h + (lane >> 4);
+          uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
+          uint64_t kmer = kmer_from_dwords(d0, d1, d2, lane & 15, k);
+          c[h] = canonical(kmer, k);
+          act[h] = base + 64 * h + lane < nk;
+          if (t.sharded) {
+            uint64_t q = mic_div(c[h], t.div);
+            uint64_t rem = c[h] - q * t.div.d;
+            act[h] = act[h] && rem >= t.shard_start && rem < t.shard_end;
+          }
+          uint32_t key = mmer_order_key(kmer >> (2 * (k - m)), m);
+          if (h == 0) hk0 = key; else hk1 = key;
+        }
+        {
+          const int idx = 8 + (lane >> 4);
+          uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
+          uint64_t mm = kmer_from_dwords(d0, d1, d2, lane & 15, m);
+          hk2 = lane < w - 1 ? mmer_order_key(mm, m) : 0xFFFFFFFFu;
+        }
+        sliding_min3(hk0, hk1, hk2, w, lane);
+        uint32_t sl0 = act[0] ? (uint32_t)mslot_of_key(hk0, t.n_main) : 0xFFFFFFFFu;
+        uint32_t sl1 = act[1] ? (uint32_t)mslot_of_key(hk1, t.n_main) : 0xFFFFFFFFu;
+        uint32_t res0 = 0, res1 = 0;
+
+        while (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {
+          // runs of equal slots over the 128 positions
+          uint32_t p0 = bperm((lane + 63) & 63, sl0), p1 = bperm((lane + 63) & 63, sl1);
+          uint32_t last0 = bperm(63, sl0);
+          if (lane == 0) { p0 = 0xFFFFFFFFu; p1 = last0; }
+          const bool f0 = sl0 != 0xFFFFFFFFu && sl0 != p0, f1 = sl1 != 0xFFFFFFFFu && sl1 != p1;
+          const uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
+          const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1);
+          const uint32_t rid0 = __popcll(b0 & lane_le) - 1, rid1 = R0 + __popcll(b1 & lane_le) - 1;
+          uint32_t nx0 = 0xFFFFFFFFu, nx1 = 0xFFFFFFFFu;   // slot to probe in the next round
+          for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
+            __builtin_amdgcn_wave_barrier();
+            if (f0 && rid0 - rbase < MIC_RMAX) runslot[rid0 - rbase] = sl0;
+            if (f1 && rid1 - rbase < MIC_RMAX) runslot[rid1 - rbase] = sl1;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t nrun = R - rbase < MIC_RMAX ? R - rbase : MIC_RMAX;
+#pragma unroll
+            for (int i = 0; i < MIC_RMAX / 8; ++i) {
+              const uint32_t rr = 8 * i + (lane >> 3);
+              if (8u * i < nrun && rr < nrun) {
+                const uint32_t sidx = runslot[rr];
+                stage[rr * MIC_MSTRIDE + (lane & 7)] = slots[(uint64_t)sidx * 8 + (lane & 7)];
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint32_t sl = h ? sl1 : sl0, rid = h ? rid1 : rid0;
+              if (sl != 0xFFFFFFFFu && rid - rbase < MIC_RMAX) {
+                const uint4* sp = stage + (rid - rbase) * MIC_MSTRIDE;
+                const uint4 meta = sp[7];
+                const uint32_t clo = (uint32_t)c[h], chi = (uint32_t)(c[h] >> 32);
+                uint32_t hit = 0;  // entry index + 1
+                uint4 kv5;
+#pragma unroll
+                for (int e2 = 0; e2 < 6; ++e2) {
+                  const uint4 kv = sp[e2];
+                  if (kv.x == clo && kv.y == chi) hit = 2 * e2 + 1;
+                  if (kv.z == clo && kv.w == chi) hit = 2 * e2 + 2;
+                  if (e2 == 5) kv5 = kv;
+                }
+                uint32_t out = 0;
+                if (hit) out = (uint32_t)((const uint16_t*)sp)[48 + hit - 1] + 1;   // labels start at byte 96
+                const uint64_t lastk = ((uint64_t)kv5.w << 32) | kv5.z;
+                const bool more = !hit && (meta.z & 0x100) && c[h] > lastk;
+                if (h) { res1 = out; nx1 = more ? meta.w : 0xFFFFFFFFu; }
+                else { res0 = out; nx0 = more ? meta.w : 0xFFFFFFFFu; }
+              }
+            }
+          }
+          sl0 = nx0; sl1 = nx1;
+        }
+        tally2(res0, res1, acc, n_ent, overflow, total, lane);
+      }
+    }
+    finish_read(acc, n_ent, total, overflow, r, a, lane);
+  }
+}
+
 // ---- merge / result on sparse rows ----------------------------------------------------------------
 // mergeKernel (CuClarkDB.cu:1321-1415): one thread per read, two-pointer merge by ascending target.
 __global__ void merge_rows_kernel(const uint32_t* __restrict__ ra, const uint32_t* __restrict__ rb,
@@ -354,6 +482,40 @@ __device__ inline uint32_t probe_scalar(const MicTable& t, uint64_t kmer) {
   }
 }
 
+// Sequential probe of the minimizer-keyed table (dense fallback, statistics): walk the sorted chain.
+__device__ inline uint32_t probe_scalar_m(const MicTable& t, uint64_t kmer) {
+  uint64_t c = canonical(kmer, t.k);
+  if (t.sharded) {
+    uint64_t q = mic_div(c, t.div);
+    uint64_t rem = c - q * t.div.d;
+    if (rem < t.shard_start || rem >= t.shard_end) return 0;
+  }
+  uint64_t slot = mslot_of_kmer(kmer, t.k, t.m, t.n_main);
+  for (;;) {
+    const uint4* q = t.slots + slot * 8;
+    const uint4 meta = q[7];
+    const uint32_t n = meta.z & 0xFF;
+    uint64_t lastk = 0;
+    for (uint32_t e = 0; e < n; ++e) {
+      uint4 kv = q[e >> 1];
+      uint64_t key = (e & 1) ? (((uint64_t)kv.w << 32) | kv.z) : (((uint64_t)kv.y << 32) | kv.x);
+      if (key == c) {
+        uint4 lw = q[6 + (e >> 3)];
+        uint32_t word = ((e & 7) >> 1) == 0 ? lw.x : ((e & 7) >> 1) == 1 ? lw.y : ((e & 7) >> 1) == 2 ? lw.z : lw.w;
+        return ((e & 1) ? (word >> 16) : (word & 0xFFFF)) + 1;
+      }
+      lastk = key;
+    }
+    if (!(meta.z & 0x100) || c < lastk) return 0;
+    slot = meta.w;
+  }
+}
+
+template <bool KEY64>
+__device__ inline uint32_t probe_any(const MicTable& t, uint64_t kmer) {
+  return t.layout ? probe_scalar_m(t, kmer) : probe_scalar<KEY64>(t, kmer);
+}
+
 template <bool KEY64>
 __global__ void __launch_bounds__(256) dense_count_kernel(const MicTable t, const uint32_t* __restrict__ reads_ptr,
                                                           const uint16_t* __restrict__ cont,
@@ -381,7 +543,7 @@ __global__ void __launch_bounds__(256) dense_count_kernel(const MicTable t, cons
       int s = 2 * (pos & 7);
       uint64_t x = s ? ((hi << s) | ((uint64_t)lo >> (16 - s))) : hi;
       uint64_t kmer = x >> (64 - 2 * k);
-      uint32_t m = probe_scalar<KEY64>(t, kmer);
+      uint32_t m = probe_any<KEY64>(t, kmer);
       if (m && m - 1 < n_targets) atomicAdd(&row[m - 1], 1u);
     }
   }
@@ -468,8 +630,9 @@ __global__ void __launch_bounds__(256) probe_stats_kernel(const MicTable t, cons
         uint64_t rem = c - q * t.div.d;
         if (rem < t.shard_start || rem >= t.shard_end) continue;
         ++np;
-        nb += t.slots[(rem - t.shard_start) * 4].w & 0xFF;
-        nh += probe_scalar<KEY64>(t, kmer) != 0;
+        nb += t.layout ? (t.sizes ? t.sizes[rem - t.shard_start] : 0)
+                                               : (t.slots[(rem - t.shard_start) * 4].w & 0xFF);
+        nh += probe_any<KEY64>(t, kmer) != 0;
       }
     }
   }
@@ -496,7 +659,8 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   static int per_cu = [] { const char* e = getenv("MIC_BLOCKS_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();
   unsigned cap = (unsigned)n_cu * (unsigned)per_cu;
   if (blocks > cap) blocks = cap;
-  if (slot_class == 64) query_kernel<true><<<blocks, 256, 0, s>>>(a);
+  if (a.t.layout) query_kernel_m<<<blocks, 256, 0, s>>>(a);
+  else if (slot_class == 64) query_kernel<true><<<blocks, 256, 0, s>>>(a);
   else query_kernel<false><<<blocks, 256, 0, s>>>(a);
   return hipGetLastError();
 }

@@ -23,13 +23,13 @@ def _as_np(ptr, shape, dtype):
 
 
 class MiClarkDB:
-    def __init__(self, k, num_targets, num_batches=1, device=-1, row_words=16):
+    def __init__(self, k, num_targets, num_batches=1, device=-1, row_words=16, layout=0):
         self.L = _lib.load()
         self.k = int(k)
         self.num_targets = int(num_targets)
         self.num_batches = int(num_batches)
         self.row_words = int(row_words)
-        cfg = MicConfig(device, self.k, self.num_targets, self.num_batches, self.row_words, 0)
+        cfg = MicConfig(device, self.k, self.num_targets, self.num_batches, self.row_words, int(layout))
         h = C.c_void_p()
         check(self.L.mic_create(C.byref(cfg), C.byref(h)))
         self.h = h

@@ -56,8 +56,12 @@ typedef struct mic_config {
   uint32_t num_targets; /* number of labels T (<= 65535)             dataType.hh:48   */
   uint32_t num_batches; /* batches of the batch API (>=1)            main.cc:220-226  */
   uint32_t row_words;   /* u32 words per sparse row (0 = default 16 => 15 pairs = MAXHITS, parameters.hh:44) */
-  uint32_t reserved;
+  uint32_t layout;      /* resident table layout: MIC_LAYOUT_AUTO / _DIRECT / _MINIMIZER */
 } mic_config;
+
+#define MIC_LAYOUT_AUTO 0      /* minimizer-keyed table when k >= 25, else direct */
+#define MIC_LAYOUT_DIRECT 1    /* one 64-byte slot per on-disk bucket (one HBM request per k-mer) */
+#define MIC_LAYOUT_MINIMIZER 2 /* 128-byte slots keyed by the k-mer's minimizer (one HBM request per ~7 k-mers) */
 
 typedef struct mic_db_info {
   uint64_t htsize;         /* buckets in the whole table (= size of .sz)               */
@@ -69,9 +73,13 @@ typedef struct mic_db_info {
   uint64_t n_overflow;     /* overflow slots                                            */
   uint64_t hbm_bytes;      /* bytes of HBM held by the table                            */
   int32_t key_bytes;       /* width of the keys on disk: 2, 4 or 8                      */
-  int32_t slot_class;      /* 32: 8 entries/slot (u32 quotients); 64: 4 entries/slot    */
+  int32_t slot_class;      /* 32: 8 entries/slot (u32 quotients); 64: 4 entries/slot; 128: minimizer table */
   uint32_t max_bucket;     /* largest kept bucket                                       */
   uint32_t sampling;
+  int32_t layout;          /* MIC_LAYOUT_DIRECT or MIC_LAYOUT_MINIMIZER                 */
+  int32_t minimizer_len;   /* m (layout MINIMIZER), else 0                              */
+  uint32_t max_chain;      /* entries in the fullest slot chain (layout MINIMIZER)      */
+  uint32_t reserved;
 } mic_db_info;
 
 /* ---- engine lifetime: CuClarkDB ctor/dtor (CuClarkDB.cu:85-253) ----------------------------- */

@@ -10,6 +10,14 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["direct", "minimizer"])
+def table_layout(request, monkeypatch):
+    """Every test runs against both resident layouts: one 64-byte slot per on-disk bucket, and the
+    minimizer-keyed 128-byte slots.  The engine reads MIC_LAYOUT when a table is built."""
+    monkeypatch.setenv("MIC_LAYOUT", request.param)
+    return request.param
+
+
 def _engine(k, n_targets, **kw):
     from cuclark_amd import MiClarkDB
     return MiClarkDB(k, n_targets, **kw)
@@ -51,6 +59,7 @@ def test_golden_queries_from_files(name, db_dir):
         info = e.info()
         assert info["htsize"] == meta["htsize"] and info["key_bytes"] == meta["key_bytes"]
         assert info["n_elems"] == meta["ky"].size
+        assert info["layout"] == {"direct": 1, "minimizer": 2}[os.environ["MIC_LAYOUT"]]
         rp, cont = _kmer_reads(q["kmers"], k)
         res = e.classify_packed(rp, cont)
     found = res[:, 0] == 1
@@ -110,7 +119,7 @@ def test_full_htsize_csv_equals_light(db_dir):
     rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], 31)
     with _engine(31, len(names)) as e:
         e.read_arrays(gu.golden_sizes(db), db["ky"], db["lb"])
-        assert e.info()["slot_class"] == 32
+        assert e.info()["slot_class"] == (32 if os.environ["MIC_LAYOUT"] == "direct" else 128)
         res = e.classify_packed(rp, cont)
     text = host.format_csv(data, idx, res, names, 31)
     assert text == open(os.path.join(gu.GOLDEN, "expected_k31_fa.csv"), "rb").read()
