@@ -10,6 +10,7 @@
 #include "mic_device.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 #define TILE 256
@@ -329,13 +330,17 @@ __global__ void __launch_bounds__(TILE) m_count_kernel(MBuildArgs a, uint32_t* _
                                                        unsigned long long* __restrict__ kept) {
   unsigned long long mine = 0;
   for_reachable<RAW>(a, [&](uint64_t c, uint16_t) {
-    atomicAdd(&cnt[mslot_of_kmer(c, a.k, a.m, a.n_mslots)], 1u);
+    atomicAdd(&cnt[mslot_of_kmer(c, a.k, a.m, (uint32_t)a.n_mslots)], 1u);
     ++mine;
   });
   if (mine) atomicAdd(kept, mine);
 }
 
-__device__ inline uint32_t chain_ovf(uint32_t n) { return n > MIC_MCAP ? (n - MIC_MCAP + MIC_MCAP - 1) / MIC_MCAP : 0; }
+// slots a bucket of n entries needs beyond its main slot: n <= 12 lives in the main slot (LEAF); otherwise the main
+// slot becomes directory 0 and the overflow area holds [directories 1..D-1][leaves 0..L-1], L = ceil(n/12), D = ceil(L/12)
+__device__ inline uint32_t m_leaves(uint32_t n) { return (n + MIC_MCAP - 1) / MIC_MCAP; }
+__device__ inline uint32_t m_dirs(uint32_t n) { return (m_leaves(n) + MIC_MCAP - 1) / MIC_MCAP; }
+__device__ inline uint32_t chain_ovf(uint32_t n) { return n > MIC_MCAP ? m_dirs(n) - 1 + m_leaves(n) : 0; }
 
 __global__ void __launch_bounds__(TILE) m_ovf_tile_kernel(const uint32_t* __restrict__ cnt, uint64_t n,
                                                           unsigned long long* __restrict__ tile_sum,
@@ -348,71 +353,98 @@ __global__ void __launch_bounds__(TILE) m_ovf_tile_kernel(const uint32_t* __rest
   if (c) atomicMax(max_cnt, c);
 }
 
+__device__ inline void m_write_empty(MSlot* sl, uint32_t meta, uint32_t next) {
+  uint4* q = (uint4*)sl;
+#pragma unroll
+  for (int w = 0; w < 6; ++w) q[w] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  q[6] = make_uint4(0, 0, 0, 0);
+  q[7] = make_uint4(0, 0, meta, next);
+}
+
+// Headers of every slot of every bucket; keys = ~0.  ovf_first[s] = first overflow slot of bucket s.
 __global__ void __launch_bounds__(TILE) m_header_kernel(const uint32_t* __restrict__ cnt, uint64_t n,
                                                         const unsigned long long* __restrict__ tile_base,
-                                                        MSlot* __restrict__ slots) {
+                                                        MSlot* __restrict__ slots, uint32_t* __restrict__ ovf_first) {
   uint64_t i = (uint64_t)blockIdx.x * TILE + threadIdx.x;
   uint32_t c = i < n ? cnt[i] : 0;
   uint32_t ovf = chain_ovf(c);
   uint32_t ea, eb, ta, tb;
   block_scan2(ovf, 0, ea, eb, ta, tb);
   if (i >= n) return;
-  uint64_t next = n + tile_base[blockIdx.x] + ea;  // first overflow slot of this chain
-  uint64_t slot = i; uint32_t left = c;
-  for (uint32_t j = 0; j <= ovf; ++j) {
-    uint32_t here = left > MIC_MCAP ? MIC_MCAP : left;
-    left -= here;
-    uint4* q = (uint4*)&slots[slot];
-#pragma unroll
-    for (int w = 0; w < 6; ++w) q[w] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    q[6] = make_uint4(0, 0, 0, 0);
-    q[7] = make_uint4(0, 0, here | (left ? 0x100u : 0u), (uint32_t)next);
-    slot = next; ++next;
+  const uint64_t base = n + tile_base[blockIdx.x] + ea;
+  ovf_first[i] = (uint32_t)base;
+  if (c <= MIC_MCAP) { m_write_empty(&slots[i], c, 0); return; }
+  const uint32_t L = m_leaves(c), D = m_dirs(c);
+  const uint64_t leaf0 = base + (D - 1);
+  for (uint32_t d = 0; d < D; ++d) {  // directories: separators are filled after the sort
+    const uint32_t nsep = (L - d * MIC_MCAP) > MIC_MCAP ? MIC_MCAP : (L - d * MIC_MCAP);
+    MSlot* sl = d == 0 ? &slots[i] : &slots[base + d - 1];
+    m_write_empty(sl, nsep | MIC_M_DIR | (d + 1 < D ? MIC_M_NEXTDIR : 0u), (uint32_t)(base + d));
+    ((uint4*)sl)[6].x = (uint32_t)(leaf0 + (uint64_t)d * MIC_MCAP);
+  }
+  for (uint32_t l = 0; l < L; ++l) {
+    const uint32_t here = (c - l * MIC_MCAP) > MIC_MCAP ? MIC_MCAP : (c - l * MIC_MCAP);
+    m_write_empty(&slots[leaf0 + l], here, 0);
   }
 }
 
+// element e of bucket s (n entries): in the main slot if n <= 12, else in leaf e/12
+__device__ inline MSlot* m_elem_slot(MSlot* slots, uint64_t s, uint32_t n, uint32_t first_ovf, uint32_t e) {
+  if (n <= MIC_MCAP) return &slots[s];
+  return &slots[(uint64_t)first_ovf + (m_dirs(n) - 1) + e / MIC_MCAP];
+}
+
 template <typename RAW>
-__global__ void __launch_bounds__(TILE) m_scatter_kernel(MBuildArgs a, uint32_t* __restrict__ cursor,
-                                                         MSlot* __restrict__ slots) {
+__global__ void __launch_bounds__(TILE) m_scatter_kernel(MBuildArgs a, const uint32_t* __restrict__ cnt,
+                                                         const uint32_t* __restrict__ ovf_first,
+                                                         uint32_t* __restrict__ cursor, MSlot* __restrict__ slots) {
   for_reachable<RAW>(a, [&](uint64_t c, uint16_t lb) {
-    uint64_t s = mslot_of_kmer(c, a.k, a.m, a.n_mslots);
+    uint32_t s = mslot_of_kmer(c, a.k, a.m, (uint32_t)a.n_mslots);
     uint32_t pos = atomicAdd(&cursor[s], 1u);
-    uint64_t slot = s; uint32_t e = pos;
-    if (pos >= MIC_MCAP) { slot = (uint64_t)slots[s].next + (pos - MIC_MCAP) / MIC_MCAP; e = (pos - MIC_MCAP) % MIC_MCAP; }
-    slots[slot].keys[e] = c;
-    slots[slot].labels[e] = lb;
+    MSlot* sl = m_elem_slot(slots, s, cnt[s], ovf_first[s], pos);
+    sl->keys[pos % MIC_MCAP] = c;
+    sl->labels[pos % MIC_MCAP] = lb;
   });
 }
 
-// element i of the chain that starts at main slot s
-__device__ inline MSlot* chain_slot(MSlot* slots, uint64_t s, uint32_t first_ovf, uint32_t i) {
-  return i < MIC_MCAP ? &slots[s] : &slots[(uint64_t)first_ovf + (i - MIC_MCAP) / MIC_MCAP];
-}
-
-__global__ void m_sort_kernel(const uint32_t* __restrict__ cnt, uint64_t n, MSlot* __restrict__ slots) {
+// sort the bucket's entries by key (shell sort over the virtual array), then write the directory separators
+__global__ void m_sort_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ovf_first, uint64_t n,
+                              MSlot* __restrict__ slots) {
   uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const uint32_t c = cnt[s];
   if (c < 2) return;
-  const uint32_t fo = slots[s].next;
+  const uint32_t fo = ovf_first[s];
   const uint32_t gaps[] = {701, 301, 132, 57, 23, 10, 4, 1};
   for (int g = 0; g < 8; ++g) {
     const uint32_t gap = gaps[g];
     if (gap >= c) continue;
     for (uint32_t i = gap; i < c; ++i) {
-      MSlot* si = chain_slot(slots, s, fo, i);
+      MSlot* si = m_elem_slot(slots, s, c, fo, i);
       unsigned long long kv = si->keys[i % MIC_MCAP]; unsigned short lv = si->labels[i % MIC_MCAP];
       uint32_t j = i;
       while (j >= gap) {
-        MSlot* sj = chain_slot(slots, s, fo, j - gap);
+        MSlot* sj = m_elem_slot(slots, s, c, fo, j - gap);
         unsigned long long kj = sj->keys[(j - gap) % MIC_MCAP];
         if (kj <= kv) break;
-        MSlot* sd = chain_slot(slots, s, fo, j);
+        MSlot* sd = m_elem_slot(slots, s, c, fo, j);
         sd->keys[j % MIC_MCAP] = kj; sd->labels[j % MIC_MCAP] = sj->labels[(j - gap) % MIC_MCAP];
         j -= gap;
       }
-      MSlot* sd = chain_slot(slots, s, fo, j);
+      MSlot* sd = m_elem_slot(slots, s, c, fo, j);
       sd->keys[j % MIC_MCAP] = kv; sd->labels[j % MIC_MCAP] = lv;
+    }
+  }
+  if (c <= MIC_MCAP) return;
+  const uint32_t L = m_leaves(c), D = m_dirs(c);
+  const uint64_t leaf0 = (uint64_t)fo + (D - 1);
+  for (uint32_t d = 0; d < D; ++d) {
+    MSlot* dir = d == 0 ? &slots[s] : &slots[(uint64_t)fo + d - 1];
+    for (uint32_t e = 0; e < MIC_MCAP && d * MIC_MCAP + e < L; ++e) dir->keys[e] = slots[leaf0 + d * MIC_MCAP + e].keys[0];
+    if (d + 1 < D) {
+      unsigned long long nfk = slots[leaf0 + (d + 1) * MIC_MCAP].keys[0];
+      uint4* q = (uint4*)dir;
+      q[6].y = (uint32_t)nfk; q[6].z = (uint32_t)(nfk >> 32);
     }
   }
 }
@@ -425,7 +457,7 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   int rc = 0;
   const unsigned n_tiles = (unsigned)((n_buckets + TILE - 1) / TILE);
   TileA* d_a = nullptr; uint32_t* d_cnt = nullptr; uint32_t* d_cur = nullptr; unsigned long long* d_tile = nullptr;
-  unsigned long long* d_kept = nullptr; uint32_t* d_max = nullptr; MSlot* slots = nullptr;
+  unsigned long long* d_kept = nullptr; uint32_t* d_max = nullptr; MSlot* slots = nullptr; uint32_t* d_of = nullptr;
   std::vector<TileA> h_a(n_tiles);
   std::vector<unsigned long long> h_tile;
   uint64_t tot_elems = 0, tot_nz = 0, n_mslots = 0, tot_ovf = 0; unsigned m_tiles = 0;
@@ -446,7 +478,11 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   }
   HIPCK(hipMemcpyAsync(d_a, h_a.data(), sizeof(TileA) * n_tiles, hipMemcpyHostToDevice, s));
   // half-full slots on average; the clustering of k-mers by minimizer makes the load lumpy
-  n_mslots = tot_elems / (sampling > 1 ? 6ull * sampling : 6ull) + 64;
+  {
+    unsigned long long load = 6;  // average entries per 12-entry main slot
+    if (const char* env = getenv("MIC_MSLOT_LOAD")) { long v = atol(env); if (v >= 1 && v <= 12) load = (unsigned long long)v; }
+    n_mslots = tot_elems / (sampling > 1 ? load * sampling : load) + 64;
+  }
   if (n_mslots > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many M-slots"); rc = -1; goto done; }
   m_tiles = (unsigned)((n_mslots + TILE - 1) / TILE);
   h_tile.resize(m_tiles);
@@ -477,13 +513,14 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       rc = -3; goto done;
     }
   }
-  m_header_kernel<<<m_tiles, TILE, 0, s>>>(d_cnt, n_mslots, d_tile, slots);
+  HIPCK(hipMalloc(&d_of, n_mslots * 4));
+  m_header_kernel<<<m_tiles, TILE, 0, s>>>(d_cnt, n_mslots, d_tile, slots, d_of);
   HIPCK(hipGetLastError());
   HIPCK(hipMalloc(&d_cur, n_mslots * 4));
   HIPCK(hipMemsetAsync(d_cur, 0, n_mslots * 4, s));
-  BY_RAW(m_scatter_kernel, a, d_cur, slots);
+  BY_RAW(m_scatter_kernel, a, d_cnt, d_of, d_cur, slots);
   HIPCK(hipGetLastError());
-  m_sort_kernel<<<(unsigned)((n_mslots + 255) / 256), 256, 0, s>>>(d_cnt, n_mslots, slots);
+  m_sort_kernel<<<(unsigned)((n_mslots + 255) / 256), 256, 0, s>>>(d_cnt, d_of, n_mslots, slots);
   HIPCK(hipGetLastError());
   HIPCK(hipStreamSynchronize(s));
 #undef BY_RAW
@@ -494,6 +531,7 @@ done:
   if (d_a) hipFree(d_a);
   if (d_cnt) hipFree(d_cnt);
   if (d_cur) hipFree(d_cur);
+  if (d_of) hipFree(d_of);
   if (d_tile) hipFree(d_tile);
   if (d_kept) hipFree(d_kept);
   if (d_max) hipFree(d_max);

@@ -31,23 +31,24 @@ __device__ __forceinline__ uint64_t canonical(uint64_t kmer, int k) {
 }
 
 // ---- minimizer-keyed table (M-table) ---------------------------------------------------------------------------
-// order key of an m-mer: 32-bit mix of its canonical value.  The slot of a k-mer is a function of the MINIMUM order
-// key over its w = k-m+1 m-mers only, so k-mer and reverse complement (same canonical m-mers) agree, and ties between
-// different m-mers are harmless.
-__device__ __forceinline__ uint32_t mmer_order_key(uint64_t mmer, int m) {
-  uint64_t u = canonical(mmer, m);
-  u *= 0x9E3779B97F4A7C15ULL; u ^= u >> 32; u *= 0xD6E8FEB86659FD93ULL; u ^= u >> 32;
-  return (uint32_t)u;
+// order key of an m-mer (m <= 31): 32-bit mix of its canonical value.  The slot of a k-mer is a function
+// of the MINIMUM order key over its w = k-m+1 m-mers only, so a k-mer and its reverse complement (same canonical
+// m-mers) agree, and ties between different m-mers are harmless.
+__device__ __forceinline__ uint32_t mmer_order_key(uint64_t x, int m) {
+  const uint64_t u = canonical(x, m);
+  uint32_t h = (uint32_t)u * 0x9E3779B1u ^ ((uint32_t)(u >> 32) * 0x85EBCA77u + 0x27D4EB2Fu);
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
 }
 
-__device__ __forceinline__ uint64_t mslot_of_key(uint32_t min_key, uint64_t n_slots) {
-  uint64_t z = (uint64_t)min_key * 0xD1B54A32D192ED03ULL + 0x9E3779B97F4A7C15ULL;
-  z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 32;
-  return __umul64hi(z, n_slots);
+__device__ __forceinline__ uint32_t mslot_of_key(uint32_t min_key, uint32_t n_slots) {
+  uint32_t z = min_key * 0xC2B2AE3Du + 0x27D4EB2Fu;
+  z ^= z >> 16; z *= 0x165667B1u; z ^= z >> 15;
+  return __umulhi(z, n_slots);
 }
 
 // sequential form (table build, dense fallback, statistics)
-__device__ __forceinline__ uint64_t mslot_of_kmer(uint64_t kmer, int k, int m, uint64_t n_slots) {
+__device__ __forceinline__ uint32_t mslot_of_kmer(uint64_t kmer, int k, int m, uint32_t n_slots) {
   const uint64_t mask = (1ULL << (2 * m)) - 1;
   uint32_t best = 0xFFFFFFFFu;
   for (int j = 0; j + m <= k; ++j) {
@@ -56,5 +57,11 @@ __device__ __forceinline__ uint64_t mslot_of_kmer(uint64_t kmer, int k, int m, u
   }
   return mslot_of_key(best, n_slots);
 }
+
+// M-slot words (uint4 q[8]): q[0..5] = 12 keys (u64, ascending, unused = ~0); q[6], q[7].xy = 12 labels (u16) in a
+// LEAF, or {leaf_base, next_dir_first_key lo, hi} in a DIRECTORY slot; q[7].z = meta; q[7].w = next directory slot.
+#define MIC_M_N(meta) ((meta) & 0xFFu)
+#define MIC_M_DIR 0x100u      /* keys are separators: first key of each of this directory's leaves */
+#define MIC_M_NEXTDIR 0x200u  /* the directory continues in slot q[7].w */
 
 #endif

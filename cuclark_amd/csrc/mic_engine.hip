@@ -147,7 +147,7 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
     else if (env && !strcmp(env, "minimizer")) layout = MIC_LAYOUT_MINIMIZER;
     else layout = MIC_LAYOUT_DIRECT;  // measured faster so far; the minimizer table is opt-in
   }
-  int m = 17;
+  int m = 20;   // measured best for k = 31: minimizers long enough to be nearly unique in the table
   if (const char* env = getenv("MIC_MINIMIZER_LEN")) m = atoi(env);
   if (m > e->cfg.k - 4) m = e->cfg.k - 4;   // window w = k-m+1 >= 5
   if (m > 31) m = 31;

@@ -35,6 +35,40 @@ __device__ __forceinline__ uint64_t kmer_from_dwords(uint32_t d0, uint32_t d1, u
   return x >> (64 - 2 * k);
 }
 
+
+// ---- software prefetch of the next read --------------------------------------------------------------------------
+// Per read the wave needs reads_ptr[r..r+1] -> part header -> first window: three dependent loads before any probe.
+// They are issued one (window) and two (pointers) reads ahead, so the current read's probes overlap them.
+// The window of the first part is loaded without knowing the part length: callers keep >= 32 readable containers
+// after the last one of a batch (include/mi_clark.h), and containers past the part are masked off at use.
+struct ReadAhead { uint32_t pp, pe, hdr, w; };   // w = containers (2*lane, 2*lane+1) of the first part, packed
+
+__device__ __forceinline__ void ahead_ptr(const MicQueryArgs& a, uint32_t r, ReadAhead& x) {
+  if (r < a.n_reads) { x.pp = a.reads_ptr[r]; x.pe = a.reads_ptr[r + 1]; } else { x.pp = 0; x.pe = 0; }
+}
+
+__device__ __forceinline__ void ahead_window(const uint16_t* __restrict__ cont, uint32_t r, uint32_t n_reads, int lane,
+                                             ReadAhead& x) {
+  x.hdr = 0; x.w = 0;
+  if (r < n_reads) {
+    const uint32_t pp = __builtin_amdgcn_readfirstlane(x.pp);
+    x.hdr = cont[pp];
+    if (lane < 10) x.w = ((uint32_t)cont[pp + 1 + 2 * lane] << 16) | cont[pp + 2 + 2 * lane];
+  }
+}
+
+// window dword of chunk `base` of the part starting at container `first` (cend = one past its last container)
+__device__ __forceinline__ uint32_t window_word(const uint16_t* __restrict__ cont, uint32_t first, uint32_t cend,
+                                                uint32_t base, int lane, bool use_ahead, const ReadAhead& x) {
+  uint32_t w = 0;
+  const uint32_t ci = first + base / 8 + 2 * lane;
+  if (use_ahead) w = x.w;
+  else if (lane < 10) w = ((ci < cend ? (uint32_t)cont[ci] : 0u) << 16) | (ci + 1 < cend ? (uint32_t)cont[ci + 1] : 0u);
+  if (lane >= 10 || ci >= cend) w &= 0x0000FFFFu;
+  if (lane >= 10 || ci + 1 >= cend) w &= 0xFFFF0000u;
+  return w;
+}
+
 struct Probe {  // what a pass lane knows about its k-mer
   uint32_t slot;  // slot index relative to the shard, 0xFFFFFFFF = nothing to probe
   uint32_t qlo, qhi;
@@ -193,13 +227,19 @@ __global__ void __launch_bounds__(256) query_kernel(const MicQueryArgs a) {
   const uint16_t* __restrict__ cont = a.cont;
 
   for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
-    uint32_t pp = __builtin_amdgcn_readfirstlane(a.reads_ptr[r]);
-    const uint32_t pe = __builtin_amdgcn_readfirstlane(a.reads_ptr[r + 1]);
+    ReadAhead cur;   // header and first window are fetched together (one latency instead of two)
+    ahead_ptr(a, r, cur);
+    ahead_window(cont, r, a.n_reads, lane, cur);
+    uint32_t pp = __builtin_amdgcn_readfirstlane(cur.pp);
+    const uint32_t pe = __builtin_amdgcn_readfirstlane(cur.pe);
     RowAcc acc; acc.label1 = 0; acc.count = 0;
     uint32_t n_ent = 0, overflow = 0, total = 0;
+    bool first_part = true;
 
     while (pp < pe) {  // parts of the read (CuClarkDB.cu:1090-1097)
-      const uint32_t plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
+      const uint32_t plen = __builtin_amdgcn_readfirstlane(first_part ? cur.hdr : (uint32_t)cont[pp]);
+      const bool ahead_ok = first_part;
+      first_part = false;
       if (plen == 0) break;
       const uint32_t first = pp + 1;
       pp = first + (plen + 7) / 8;
@@ -208,15 +248,7 @@ __global__ void __launch_bounds__(256) query_kernel(const MicQueryArgs a) {
       const uint32_t cend = pp;
       for (uint32_t base = 0; base < nk; base += 128) {
         // 10 dwords (160 nt) cover the 128 + k - 1 nucleotides of this chunk; lane i holds dword i
-        uint32_t w = 0;
-        {
-          uint32_t ci = first + base / 8 + 2 * lane;
-          if (lane < 10) {
-            uint32_t hi = ci < cend ? cont[ci] : 0;
-            uint32_t lo = ci + 1 < cend ? cont[ci + 1] : 0;
-            w = (hi << 16) | lo;
-          }
-        }
+        const uint32_t w = window_word(cont, first, cend, base, lane, ahead_ok && base == 0, cur);
         Probe pr[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -283,7 +315,7 @@ __device__ __forceinline__ void sliding_min3(uint32_t& a0, uint32_t& a1, uint32_
   if (cover < w) step(w - cover);
 }
 
-__global__ void __launch_bounds__(256) query_kernel_m(const MicQueryArgs a) {
+__global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
   __shared__ uint4 s_stage[4][MIC_RMAX * MIC_MSTRIDE];
   __shared__ uint32_t s_run[4][MIC_RMAX];
   const int lane = threadIdx.x & 63;
@@ -298,14 +330,23 @@ __global__ void __launch_bounds__(256) query_kernel_m(const MicQueryArgs a) {
   const uint16_t* __restrict__ cont = a.cont;
   const uint64_t lane_le = lane == 63 ? ~0ULL : ((2ULL << lane) - 1);
 
+  ReadAhead cur, nxt, nn;
+  ahead_ptr(a, wave0, cur);
+  ahead_window(cont, wave0, a.n_reads, lane, cur);
+  ahead_ptr(a, wave0 + n_waves, nxt);
   for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
-    uint32_t pp = __builtin_amdgcn_readfirstlane(a.reads_ptr[r]);
-    const uint32_t pe = __builtin_amdgcn_readfirstlane(a.reads_ptr[r + 1]);
+    ahead_window(cont, r + n_waves, a.n_reads, lane, nxt);
+    ahead_ptr(a, r + 2 * n_waves, nn);
+    uint32_t pp = __builtin_amdgcn_readfirstlane(cur.pp);
+    const uint32_t pe = __builtin_amdgcn_readfirstlane(cur.pe);
     RowAcc acc; acc.label1 = 0; acc.count = 0;
     uint32_t n_ent = 0, overflow = 0, total = 0;
+    bool first_part = true;
 
     while (pp < pe) {
-      const uint32_t plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
+      const uint32_t plen = __builtin_amdgcn_readfirstlane(first_part ? cur.hdr : (uint32_t)cont[pp]);
+      const bool ahead_ok = first_part;
+      first_part = false;
       if (plen == 0) break;
       const uint32_t first = pp + 1;
       pp = first + (plen + 7) / 8;
@@ -313,15 +354,7 @@ __global__ void __launch_bounds__(256) query_kernel_m(const MicQueryArgs a) {
       const uint32_t nk = plen - k + 1;
       const uint32_t cend = pp;
       for (uint32_t base = 0; base < nk; base += 128) {
-        uint32_t wd = 0;
-        {
-          uint32_t ci = first + base / 8 + 2 * lane;
-          if (lane < 10) {
-            uint32_t hi = ci < cend ? cont[ci] : 0;
-            uint32_t lo = ci + 1 < cend ? cont[ci + 1] : 0;
-            wd = (hi << 16) | lo;
-          }
-        }
+        const uint32_t wd = window_word(cont, first, cend, base, lane, ahead_ok && base == 0, cur);
         // k-mers of the two passes and the order keys of the m-mers at positions base+64h+lane, h = 0..2
         uint64_t c[2]; bool act[2]; uint32_t hk0, hk1, hk2;
 #pragma unroll
@@ -346,8 +379,8 @@ __global__ void __launch_bounds__(256) query_kernel_m(const MicQueryArgs a) {
           hk2 = lane < w - 1 ? mmer_order_key(mm, m) : 0xFFFFFFFFu;
         }
         sliding_min3(hk0, hk1, hk2, w, lane);
-        uint32_t sl0 = act[0] ? (uint32_t)mslot_of_key(hk0, t.n_main) : 0xFFFFFFFFu;
-        uint32_t sl1 = act[1] ? (uint32_t)mslot_of_key(hk1, t.n_main) : 0xFFFFFFFFu;
+        uint32_t sl0 = act[0] ? mslot_of_key(hk0, (uint32_t)t.n_main) : 0xFFFFFFFFu;
+        uint32_t sl1 = act[1] ? mslot_of_key(hk1, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         uint32_t res0 = 0, res1 = 0;
 
         while (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {
@@ -380,23 +413,25 @@ __global__ void __launch_bounds__(256) query_kernel_m(const MicQueryArgs a) {
               const uint32_t sl = h ? sl1 : sl0, rid = h ? rid1 : rid0;
               if (sl != 0xFFFFFFFFu && rid - rbase < MIC_RMAX) {
                 const uint4* sp = stage + (rid - rbase) * MIC_MSTRIDE;
+                const unsigned long long* keys = (const unsigned long long*)sp;
                 const uint4 meta = sp[7];
-                const uint32_t clo = (uint32_t)c[h], chi = (uint32_t)(c[h] >> 32);
-                uint32_t hit = 0;  // entry index + 1
-                uint4 kv5;
-#pragma unroll
-                for (int e2 = 0; e2 < 6; ++e2) {
-                  const uint4 kv = sp[e2];
-                  if (kv.x == clo && kv.y == chi) hit = 2 * e2 + 1;
-                  if (kv.z == clo && kv.w == chi) hit = 2 * e2 + 2;
-                  if (e2 == 5) kv5 = kv;
+                const uint64_t cc = c[h];
+                // count of keys <= cc among the 12 ascending keys (unused = ~0), remembering the last key <= cc
+                uint32_t pos = 0; uint64_t lastle = ~0ULL;
+                { uint64_t kx = keys[7]; if (kx <= cc) { pos = 8; lastle = kx; } }
+                { uint32_t i = pos + 3; uint64_t kx = i < 12 ? keys[i] : ~0ULL; if (kx <= cc) { pos += 4; lastle = kx; } }
+                { uint32_t i = pos + 1; uint64_t kx = i < 12 ? keys[i] : ~0ULL; if (kx <= cc) { pos += 2; lastle = kx; } }
+                { uint32_t i = pos;     uint64_t kx = i < 12 ? keys[i] : ~0ULL; if (kx <= cc) { pos += 1; lastle = kx; } }
+                uint32_t out = 0, nxt = 0xFFFFFFFFu;
+                if (!(meta.z & MIC_M_DIR)) {
+                  if (pos && lastle == cc) out = (uint32_t)((const uint16_t*)sp)[48 + pos - 1] + 1;  // labels at byte 96
+                } else {
+                  const uint4 d = sp[6];
+                  const uint64_t nfk = ((uint64_t)d.z << 32) | d.y;
+                  if ((meta.z & MIC_M_NEXTDIR) && cc >= nfk) nxt = meta.w;
+                  else if (pos) nxt = d.x + (pos - 1);
                 }
-                uint32_t out = 0;
-                if (hit) out = (uint32_t)((const uint16_t*)sp)[48 + hit - 1] + 1;   // labels start at byte 96
-                const uint64_t lastk = ((uint64_t)kv5.w << 32) | kv5.z;
-                const bool more = !hit && (meta.z & 0x100) && c[h] > lastk;
-                if (h) { res1 = out; nx1 = more ? meta.w : 0xFFFFFFFFu; }
-                else { res0 = out; nx0 = more ? meta.w : 0xFFFFFFFFu; }
+                if (h) { res1 = out; nx1 = nxt; } else { res0 = out; nx0 = nxt; }
               }
             }
           }
@@ -406,6 +441,7 @@ __global__ void __launch_bounds__(256) query_kernel_m(const MicQueryArgs a) {
       }
     }
     finish_read(acc, n_ent, total, overflow, r, a, lane);
+    cur = nxt; nxt = nn;
   }
 }
 
@@ -482,7 +518,7 @@ __device__ inline uint32_t probe_scalar(const MicTable& t, uint64_t kmer) {
   }
 }
 
-// Sequential probe of the minimizer-keyed table (dense fallback, statistics): walk the sorted chain.
+// Sequential probe of the minimizer-keyed table (dense fallback, statistics).
 __device__ inline uint32_t probe_scalar_m(const MicTable& t, uint64_t kmer) {
   uint64_t c = canonical(kmer, t.k);
   if (t.sharded) {
@@ -490,24 +526,31 @@ __device__ inline uint32_t probe_scalar_m(const MicTable& t, uint64_t kmer) {
     uint64_t rem = c - q * t.div.d;
     if (rem < t.shard_start || rem >= t.shard_end) return 0;
   }
-  uint64_t slot = mslot_of_kmer(kmer, t.k, t.m, t.n_main);
+  uint64_t slot = mslot_of_kmer(kmer, t.k, t.m, (uint32_t)t.n_main);
   for (;;) {
     const uint4* q = t.slots + slot * 8;
     const uint4 meta = q[7];
-    const uint32_t n = meta.z & 0xFF;
-    uint64_t lastk = 0;
+    const uint32_t n = MIC_M_N(meta.z);
+    uint32_t cnt = 0;  // keys <= c
+    bool eq = false;
     for (uint32_t e = 0; e < n; ++e) {
       uint4 kv = q[e >> 1];
       uint64_t key = (e & 1) ? (((uint64_t)kv.w << 32) | kv.z) : (((uint64_t)kv.y << 32) | kv.x);
-      if (key == c) {
-        uint4 lw = q[6 + (e >> 3)];
-        uint32_t word = ((e & 7) >> 1) == 0 ? lw.x : ((e & 7) >> 1) == 1 ? lw.y : ((e & 7) >> 1) == 2 ? lw.z : lw.w;
-        return ((e & 1) ? (word >> 16) : (word & 0xFFFF)) + 1;
-      }
-      lastk = key;
+      if (key <= c) { ++cnt; eq = key == c; }
     }
-    if (!(meta.z & 0x100) || c < lastk) return 0;
-    slot = meta.w;
+    if (!(meta.z & MIC_M_DIR)) {
+      if (!eq) return 0;
+      const uint32_t e = cnt - 1;
+      uint4 lw = q[6 + (e >> 3)];
+      uint32_t wi = (e & 7) >> 1;
+      uint32_t word = wi == 0 ? lw.x : wi == 1 ? lw.y : wi == 2 ? lw.z : lw.w;
+      return ((e & 1) ? (word >> 16) : (word & 0xFFFF)) + 1;
+    }
+    const uint4 d = q[6];
+    const uint64_t nfk = ((uint64_t)d.z << 32) | d.y;
+    if ((meta.z & MIC_M_NEXTDIR) && c >= nfk) { slot = meta.w; continue; }
+    if (cnt == 0) return 0;
+    slot = (uint64_t)d.x + (cnt - 1);
   }
 }
 
