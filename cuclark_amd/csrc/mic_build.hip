@@ -336,11 +336,26 @@ __global__ void __launch_bounds__(TILE) m_count_kernel(MBuildArgs a, uint32_t* _
   if (mine) atomicAdd(kept, mine);
 }
 
-// slots a bucket of n entries needs beyond its main slot: n <= 12 lives in the main slot (LEAF); otherwise the main
-// slot becomes directory 0 and the overflow area holds [directories 1..D-1][leaves 0..L-1], L = ceil(n/12), D = ceil(L/12)
-__device__ inline uint32_t m_leaves(uint32_t n) { return (n + MIC_MCAP - 1) / MIC_MCAP; }
-__device__ inline uint32_t m_dirs(uint32_t n) { return (m_leaves(n) + MIC_MCAP - 1) / MIC_MCAP; }
-__device__ inline uint32_t chain_ovf(uint32_t n) { return n > MIC_MCAP ? m_dirs(n) - 1 + m_leaves(n) : 0; }
+// A bucket of n entries is a fan-out-12 tree rooted in its main slot.  n <= 12: the root is a LEAF (entries inline).
+// Otherwise level 0 = ceil(n/12) leaves, level l = ceil(level(l-1)/12) directories, up to a single root; all levels
+// except the root live in the overflow area, highest level first, leaves last.  A directory's keys are the smallest
+// key below each of its (contiguous) children; lookups descend one slot per level: 1 + ceil(log12(n/12)) slots.
+struct MTree { uint32_t height; uint32_t cnt[8]; uint32_t off[8]; uint32_t total; };   // cnt/off per level (0 = leaves)
+
+__device__ inline MTree m_tree(uint32_t n) {
+  MTree t; t.height = 0; t.total = 0;
+  for (int i = 0; i < 8; ++i) { t.cnt[i] = 0; t.off[i] = 0; }
+  if (n <= MIC_MCAP) return t;
+  uint32_t c = (n + MIC_MCAP - 1) / MIC_MCAP; int l = 0;
+  while (c > 1) { t.cnt[l++] = c; c = (c + MIC_MCAP - 1) / MIC_MCAP; }
+  t.height = (uint32_t)l;  // root sits at level `height` in the main slot
+  uint32_t o = 0;
+  for (int i = l - 1; i >= 0; --i) { t.off[i] = o; o += t.cnt[i]; }
+  t.total = o;
+  return t;
+}
+
+__device__ inline uint32_t chain_ovf(uint32_t n) { return m_tree(n).total; }
 
 __global__ void __launch_bounds__(TILE) m_ovf_tile_kernel(const uint32_t* __restrict__ cnt, uint64_t n,
                                                           unsigned long long* __restrict__ tile_sum,
@@ -353,12 +368,12 @@ __global__ void __launch_bounds__(TILE) m_ovf_tile_kernel(const uint32_t* __rest
   if (c) atomicMax(max_cnt, c);
 }
 
-__device__ inline void m_write_empty(MSlot* sl, uint32_t meta, uint32_t next) {
+__device__ inline void m_write_empty(MSlot* sl, uint32_t meta, uint32_t child_base) {
   uint4* q = (uint4*)sl;
 #pragma unroll
   for (int w = 0; w < 6; ++w) q[w] = make_uint4(~0u, ~0u, ~0u, ~0u);
-  q[6] = make_uint4(0, 0, 0, 0);
-  q[7] = make_uint4(0, 0, meta, next);
+  q[6] = make_uint4(child_base, 0, 0, 0);
+  q[7] = make_uint4(0, 0, meta, 0);
 }
 
 // Headers of every slot of every bucket; keys = ~0.  ovf_first[s] = first overflow slot of bucket s.
@@ -367,31 +382,31 @@ __global__ void __launch_bounds__(TILE) m_header_kernel(const uint32_t* __restri
                                                         MSlot* __restrict__ slots, uint32_t* __restrict__ ovf_first) {
   uint64_t i = (uint64_t)blockIdx.x * TILE + threadIdx.x;
   uint32_t c = i < n ? cnt[i] : 0;
-  uint32_t ovf = chain_ovf(c);
+  const MTree t = m_tree(c);
   uint32_t ea, eb, ta, tb;
-  block_scan2(ovf, 0, ea, eb, ta, tb);
+  block_scan2(t.total, 0, ea, eb, ta, tb);
   if (i >= n) return;
   const uint64_t base = n + tile_base[blockIdx.x] + ea;
   ovf_first[i] = (uint32_t)base;
-  if (c <= MIC_MCAP) { m_write_empty(&slots[i], c, 0); return; }
-  const uint32_t L = m_leaves(c), D = m_dirs(c);
-  const uint64_t leaf0 = base + (D - 1);
-  for (uint32_t d = 0; d < D; ++d) {  // directories: separators are filled after the sort
-    const uint32_t nsep = (L - d * MIC_MCAP) > MIC_MCAP ? MIC_MCAP : (L - d * MIC_MCAP);
-    MSlot* sl = d == 0 ? &slots[i] : &slots[base + d - 1];
-    m_write_empty(sl, nsep | MIC_M_DIR | (d + 1 < D ? MIC_M_NEXTDIR : 0u), (uint32_t)(base + d));
-    ((uint4*)sl)[6].x = (uint32_t)(leaf0 + (uint64_t)d * MIC_MCAP);
+  if (t.height == 0) { m_write_empty(&slots[i], c, 0); return; }
+  // root (level `height`) has cnt[height-1] children starting at off[height-1]
+  m_write_empty(&slots[i], t.cnt[t.height - 1] | MIC_M_DIR, (uint32_t)(base + t.off[t.height - 1]));
+  for (uint32_t l = t.height - 1; l >= 1; --l) {          // inner directory levels
+    for (uint32_t j = 0; j < t.cnt[l]; ++j) {
+      const uint32_t kids = (t.cnt[l - 1] - j * MIC_MCAP) > MIC_MCAP ? MIC_MCAP : (t.cnt[l - 1] - j * MIC_MCAP);
+      m_write_empty(&slots[base + t.off[l] + j], kids | MIC_M_DIR, (uint32_t)(base + t.off[l - 1] + j * MIC_MCAP));
+    }
   }
-  for (uint32_t l = 0; l < L; ++l) {
-    const uint32_t here = (c - l * MIC_MCAP) > MIC_MCAP ? MIC_MCAP : (c - l * MIC_MCAP);
-    m_write_empty(&slots[leaf0 + l], here, 0);
+  for (uint32_t j = 0; j < t.cnt[0]; ++j) {               // leaves
+    const uint32_t here = (c - j * MIC_MCAP) > MIC_MCAP ? MIC_MCAP : (c - j * MIC_MCAP);
+    m_write_empty(&slots[base + t.off[0] + j], here, 0);
   }
 }
 
 // element e of bucket s (n entries): in the main slot if n <= 12, else in leaf e/12
 __device__ inline MSlot* m_elem_slot(MSlot* slots, uint64_t s, uint32_t n, uint32_t first_ovf, uint32_t e) {
   if (n <= MIC_MCAP) return &slots[s];
-  return &slots[(uint64_t)first_ovf + (m_dirs(n) - 1) + e / MIC_MCAP];
+  return &slots[(uint64_t)first_ovf + (chain_ovf(n) - (n + MIC_MCAP - 1) / MIC_MCAP) + e / MIC_MCAP];
 }
 
 template <typename RAW>
@@ -436,16 +451,20 @@ __global__ void m_sort_kernel(const uint32_t* __restrict__ cnt, const uint32_t* 
     }
   }
   if (c <= MIC_MCAP) return;
-  const uint32_t L = m_leaves(c), D = m_dirs(c);
-  const uint64_t leaf0 = (uint64_t)fo + (D - 1);
-  for (uint32_t d = 0; d < D; ++d) {
-    MSlot* dir = d == 0 ? &slots[s] : &slots[(uint64_t)fo + d - 1];
-    for (uint32_t e = 0; e < MIC_MCAP && d * MIC_MCAP + e < L; ++e) dir->keys[e] = slots[leaf0 + d * MIC_MCAP + e].keys[0];
-    if (d + 1 < D) {
-      unsigned long long nfk = slots[leaf0 + (d + 1) * MIC_MCAP].keys[0];
-      uint4* q = (uint4*)dir;
-      q[6].y = (uint32_t)nfk; q[6].z = (uint32_t)(nfk >> 32);
+  const MTree t = m_tree(c);
+  const uint64_t leaf0 = (uint64_t)fo + t.off[0];
+  uint32_t span = 1;  // leaves below one child of a level-l directory = 12^(l-1)
+  for (uint32_t l = 1; l <= t.height; ++l) {
+    const uint32_t nodes = l == t.height ? 1 : t.cnt[l];
+    for (uint32_t j = 0; j < nodes; ++j) {
+      MSlot* dir = l == t.height ? &slots[s] : &slots[(uint64_t)fo + t.off[l] + j];
+      for (uint32_t e = 0; e < MIC_MCAP; ++e) {
+        const uint64_t child = (uint64_t)j * MIC_MCAP + e;          // index within level l-1
+        if (child >= t.cnt[l - 1]) break;
+        dir->keys[e] = slots[leaf0 + child * span].keys[0];
+      }
     }
+    span *= MIC_MCAP;
   }
 }
 

@@ -59,9 +59,8 @@ __device__ __forceinline__ uint32_t mslot_of_kmer(uint64_t kmer, int k, int m, u
 }
 
 // M-slot words (uint4 q[8]): q[0..5] = 12 keys (u64, ascending, unused = ~0); q[6], q[7].xy = 12 labels (u16) in a
-// LEAF, or {leaf_base, next_dir_first_key lo, hi} in a DIRECTORY slot; q[7].z = meta; q[7].w = next directory slot.
+// LEAF, or q[6].x = index of the first child slot in a DIRECTORY; q[7].z = meta (bits 0..7 = entries / children).
 #define MIC_M_N(meta) ((meta) & 0xFFu)
-#define MIC_M_DIR 0x100u      /* keys are separators: first key of each of this directory's leaves */
-#define MIC_M_NEXTDIR 0x200u  /* the directory continues in slot q[7].w */
+#define MIC_M_DIR 0x100u      /* keys are separators: the smallest key below each (contiguous) child slot */
 
 #endif

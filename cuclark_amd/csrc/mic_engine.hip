@@ -145,7 +145,7 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
     const char* env = getenv("MIC_LAYOUT");
     if (env && !strcmp(env, "direct")) layout = MIC_LAYOUT_DIRECT;
     else if (env && !strcmp(env, "minimizer")) layout = MIC_LAYOUT_MINIMIZER;
-    else layout = MIC_LAYOUT_DIRECT;  // measured faster so far; the minimizer table is opt-in
+    else layout = e->cfg.k >= 24 ? MIC_LAYOUT_MINIMIZER : MIC_LAYOUT_DIRECT;  // measured: DESIGN.md §3.2
   }
   int m = 20;   // measured best for k = 31: minimizers long enough to be nearly unique in the table
   if (const char* env = getenv("MIC_MINIMIZER_LEN")) m = atoi(env);

@@ -425,11 +425,8 @@ __global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
                 uint32_t out = 0, nxt = 0xFFFFFFFFu;
                 if (!(meta.z & MIC_M_DIR)) {
                   if (pos && lastle == cc) out = (uint32_t)((const uint16_t*)sp)[48 + pos - 1] + 1;  // labels at byte 96
-                } else {
-                  const uint4 d = sp[6];
-                  const uint64_t nfk = ((uint64_t)d.z << 32) | d.y;
-                  if ((meta.z & MIC_M_NEXTDIR) && cc >= nfk) nxt = meta.w;
-                  else if (pos) nxt = d.x + (pos - 1);
+                } else if (pos) {
+                  nxt = sp[6].x + (pos - 1);   // descend into the child whose range holds cc
                 }
                 if (h) { res1 = out; nx1 = nxt; } else { res0 = out; nx0 = nxt; }
               }
@@ -546,11 +543,8 @@ __device__ inline uint32_t probe_scalar_m(const MicTable& t, uint64_t kmer) {
       uint32_t word = wi == 0 ? lw.x : wi == 1 ? lw.y : wi == 2 ? lw.z : lw.w;
       return ((e & 1) ? (word >> 16) : (word & 0xFFFF)) + 1;
     }
-    const uint4 d = q[6];
-    const uint64_t nfk = ((uint64_t)d.z << 32) | d.y;
-    if ((meta.z & MIC_M_NEXTDIR) && c >= nfk) { slot = meta.w; continue; }
-    if (cnt == 0) return 0;
-    slot = (uint64_t)d.x + (cnt - 1);
+    if (cnt == 0) return 0;                     // smaller than every key below this directory
+    slot = (uint64_t)q[6].x + (cnt - 1);        // descend into the child whose range holds c
   }
 }
 

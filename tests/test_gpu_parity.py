@@ -413,3 +413,39 @@ def test_synthetic_generator_matches_oracle():
     ok = (truth[g, 1] == 0) | ((res[g, 1] == truth[g, 0]) & (res[g, 2] >= truth[g, 1]))
     assert ok.mean() > 0.999
     assert (res[~g, 0] == 0).mean() > 0.99
+
+
+def test_skewed_minimizer_bucket():
+    """Thousands of k-mers that share a 25-nt core (hence, for about half of them, the minimizer): in the minimizer
+    layout they pile into one bucket, which becomes a multi-level directory tree; results must stay exact."""
+    import itertools
+    rng = np.random.default_rng(17)
+    k, T, htsize = 31, 11, 1000003
+    o = gu.oracle()
+    core = "".join(rng.choice(list("ACGT"), 25))
+    kmers = []
+    for tail in itertools.product("ACGT", repeat=6):
+        s = core + "".join(tail)
+        kmers.append(int("".join(str("TGCA".index(ch)) for ch in s), 4))
+    extra = [int(rng.integers(0, 1 << 62, dtype=np.uint64)) for _ in range(3000)]
+    canon = sorted({o.canonical(v, k) for v in kmers + extra}, key=lambda c: (c % htsize, c // htsize))
+    sizes = np.zeros(htsize, np.int64)
+    for c in canon:
+        sizes[c % htsize] += 1
+    assert sizes.max() < 255
+    keys = np.array([c // htsize for c in canon], dtype=np.uint64)
+    labels = rng.integers(0, T, len(canon)).astype(np.uint16)
+    odb = o.db_from_arrays(sizes.astype(np.uint8), keys, labels)
+    # queries: every stored k-mer in both orientations, plus neighbours that are absent
+    q = np.array(kmers + [o.revcomp(v, k) for v in kmers[::3]] + [v ^ 1 for v in kmers[::5]] + extra[:500], dtype=np.uint64)
+    rp, cont = _kmer_reads(q, k)
+    f, l = odb.find_many(q, k)
+    with _engine(k, T) as e:
+        e.read_arrays(sizes.astype(np.uint8), keys, labels)
+        info = e.info()
+        res = e.classify_packed(rp, cont)
+    if info["layout"] == 2:
+        assert info["max_chain"] > 500           # one bucket holds a large share of the 4096 core k-mers (3-level tree)
+    assert ((res[:, 0] == 1) == (f == 1)).all()
+    assert (res[f == 1, 1] == l[f == 1].astype(np.uint32) + 1).all()
+    assert f[:4096].all()
