@@ -192,26 +192,30 @@ def main():
     achieved = alg_bytes / kern_s / 1e9
     # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, tools/profile_bench.sh); the
     # counters cannot be read from inside this process, so the committed summary of the same workload is used.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, rdreq = None, None, None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_query_kernel.json")), reverse=True):
         try:
             pj = json.load(open(f))
         except Exception:
             continue
-        if pj.get("workload") == w["name"] and pj.get("reads_per_launch") == n_reads and not db_mode:
+        if (pj.get("workload") == w["name"] and pj.get("reads_per_launch") == n_reads and pj.get("layout") == info["layout"]
+                and not db_mode):
             traffic = (pj["fetch_bytes_per_launch"] + pj["write_bytes_per_launch"]) / kern_s / 1e9
+            rdreq = pj["pmc_per_launch"].get("TCC_EA0_RDREQ_sum")
             traffic_src = os.path.basename(f)
             break
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": round(traffic, 1) if traffic else None,
                 "traffic_source": traffic_src,
-                "kernel": "query_kernel", "kernel_ms": round(kern_s * 1e3, 3),
+                "kernel": "query_kernel_m" if info["layout"] == 2 else "query_kernel", "kernel_ms": round(kern_s * 1e3, 3),
                 "algorithmic_bytes_per_kmer": round(bytes_per_kmer, 2), "kmers_per_launch": st["kmers"],
                 "probes_per_launch": st["probed"], "hit_rate": round(h, 4), "mean_probed_bucket_len": round(lam_q, 3),
-                "random_sector_requests_per_s_G": round(st["probed"] / kern_s / 1e9, 2),
-                "random_sector_roof_G": RANDOM_SECTOR_GREQ,
-                "frac_of_random_sector_roof": round(st["probed"] / kern_s / 1e9 / RANDOM_SECTOR_GREQ, 4)}
+                "probes_per_s_G": round(st["probed"] / kern_s / 1e9, 2),
+                # the chip serves ~51 G random HBM requests/s (64 or 128 B alike): how close is the kernel?
+                "hbm_requests_per_s_G": round(rdreq / kern_s / 1e9, 2) if rdreq else None,
+                "random_request_roof_G": RANDOM_SECTOR_GREQ,
+                "frac_of_random_request_roof": round(rdreq / kern_s / 1e9 / RANDOM_SECTOR_GREQ, 4) if rdreq else None}
 
     # ---- constructive known answer at full size: genome reads must hit their genome's label
     res = d_res.cpu().numpy().view(np.uint32)
@@ -261,6 +265,8 @@ def main():
                        "mode": ("table-sharded by bucket range + all_to_all of sparse rows" if db_mode else
                                 ("read-sharded, table replicated" if world > 1 else "single GPU, table resident")),
                        "table": {"htsize": info["htsize"], "kmers": info["n_elems"], "slot_class": info["slot_class"],
+                                 "layout": {1: "direct: one 64-B slot per on-disk bucket", 2: "minimizer-keyed 128-B slots"}[info["layout"]],
+                                 "minimizer_len": info["minimizer_len"], "largest_minimizer_bucket": info["max_chain"],
                                  "hbm_GB": round(info["hbm_bytes"] / 1e9, 2), "overflow_slots": info["n_overflow"],
                                  "max_bucket": info["max_bucket"], "on_disk_equiv_GB": round((info["htsize"] + n_el * (key_b + 2)) / 1e9, 2)},
                        "flagged_reads_dense_path": flagged,

@@ -34,12 +34,13 @@ __device__ __forceinline__ uint64_t canonical(uint64_t kmer, int k) {
 // order key of an m-mer (m <= 31): 32-bit mix of its canonical value.  The slot of a k-mer is a function
 // of the MINIMUM order key over its w = k-m+1 m-mers only, so a k-mer and its reverse complement (same canonical
 // m-mers) agree, and ties between different m-mers are harmless.
-__device__ __forceinline__ uint32_t mmer_order_key(uint64_t x, int m) {
-  const uint64_t u = canonical(x, m);
+__device__ __forceinline__ uint32_t mmer_order_key_canon(uint64_t u) {   // u = canonical m-mer value
   uint32_t h = (uint32_t)u * 0x9E3779B1u ^ ((uint32_t)(u >> 32) * 0x85EBCA77u + 0x27D4EB2Fu);
   h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
   return h;
 }
+
+__device__ __forceinline__ uint32_t mmer_order_key(uint64_t x, int m) { return mmer_order_key_canon(canonical(x, m)); }
 
 __device__ __forceinline__ uint32_t mslot_of_key(uint32_t min_key, uint32_t n_slots) {
   uint32_t z = min_key * 0xC2B2AE3Du + 0x27D4EB2Fu;

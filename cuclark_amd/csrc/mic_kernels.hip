@@ -362,14 +362,17 @@ __global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
           const int idx = 4 * h + (lane >> 4);
           uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
           uint64_t kmer = kmer_from_dwords(d0, d1, d2, lane & 15, k);
-          c[h] = canonical(kmer, k);
+          const uint64_t rck = revcomp_bits(kmer, k);
+          c[h] = kmer < rck ? kmer : rck;
           act[h] = base + 64 * h + lane < nk;
           if (t.sharded) {
             uint64_t q = mic_div(c[h], t.div);
             uint64_t rem = c[h] - q * t.div.d;
             act[h] = act[h] && rem >= t.shard_start && rem < t.shard_end;
           }
-          uint32_t key = mmer_order_key(kmer >> (2 * (k - m)), m);
+          // m-mer at this position = first m nt of the k-mer; its reverse complement = last m nt of rc(k-mer)
+          const uint64_t mf = kmer >> (2 * (k - m)), mr = rck & ((1ULL << (2 * m)) - 1);
+          uint32_t key = mmer_order_key_canon(mf < mr ? mf : mr);
           if (h == 0) hk0 = key; else hk1 = key;
         }
         {

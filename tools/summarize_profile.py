@@ -44,12 +44,14 @@ q = [r for r in rows if "query_kernel" in r["Name"]][0]
 slots_cal = 256 * 8 * 256 // 4 * 16 * 4  # quads x iters x unroll of gather_coop64_kernel<4>
 out = {
     "tag": tag, "workload": bench["config"]["workload"], "reads_per_launch": bench["config"]["reads_per_gpu"],
-    "kernel": "query_kernel<false>", "rocprof_calls": int(q["Calls"]), "rocprof_avg_ms": float(q["AverageNs"]) / 1e6,
+    "layout": 2 if bench["config"]["table"]["slot_class"] == 128 else 1,
+    "kernel": q["Name"], "rocprof_calls": int(q["Calls"]), "rocprof_avg_ms": float(q["AverageNs"]) / 1e6,
     "bench_hip_event_ms": bench["roofline"]["kernel_ms"],
     "pmc_per_launch": pmc,
     "fetch_bytes_per_launch": pmc.get("FETCH_SIZE", 0) * 1024,
     "write_bytes_per_launch": pmc.get("WRITE_SIZE", 0) * 1024,
     "rdreq_per_probe": pmc.get("TCC_EA0_RDREQ_sum", 0) / bench["roofline"]["probes_per_launch"],
+    "rdreq_per_read": pmc.get("TCC_EA0_RDREQ_sum", 0) / bench["config"]["reads_per_gpu"],
     "calibration": {"kernel": "gather_coop64_kernel<4> (tools/gather_bench.hip), 8 GiB table: 4 lanes x 16 B per random 64-B slot",
                     "slots_loaded": slots_cal, "FETCH_SIZE_KB": cal.get("FETCH_SIZE"), "TCC_EA0_RDREQ_sum": cal.get("TCC_EA0_RDREQ_sum"),
                     "bytes_per_slot_by_FETCH_SIZE": cal.get("FETCH_SIZE", 0) * 1024 / slots_cal,
