@@ -7,6 +7,7 @@
 #include "classifier.hpp"
 
 #include <fcntl.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -243,6 +244,15 @@ void Classifier::run_buffer(const uint8_t* map, size_t nb, const std::string& re
   if (!fout) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return; }
   struct timeval t0, t1;
   gettimeofday(&t0, nullptr);
+  const bool timing = getenv("MIC_CLI_TIMING") != nullptr;
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    struct timeval t; gettimeofday(&t, nullptr);
+    static double last = 0;
+    double now = (t.tv_sec - t0.tv_sec) + (t.tv_usec - t0.tv_usec) / 1e6;
+    std::cerr << "[timing] " << what << ": " << (now - last) << " s (t=" << now << ")" << std::endl;
+    last = now;
+  };
 
   // ---- index (CuCLARK_hh.hh:1339-1534)
   if (map[0] != '>' && map[0] != '@') { std::cerr << "Failed to recognize the format of the file." << std::endl; exit(-1); }
@@ -251,12 +261,14 @@ void Classifier::run_buffer(const uint8_t* map, size_t nb, const std::string& re
   long n_reads;
   for (;;) {
     name_s.resize(cap); name_e.resize(cap); seq_s.resize(cap); seq_e.resize(cap); length.resize(cap);
-    n_reads = mic_index_reads(map, nb, cap, name_s.data(), name_e.data(), seq_s.data(), seq_e.data(), length.data());
+    n_reads = mic_index_reads_parallel(map, nb, (int)opt_.threads, cap, name_s.data(), name_e.data(), seq_s.data(), seq_e.data(),
+                                       length.data());
     if (n_reads < 0) { std::cerr << "Failed to recognize the format of the file." << std::endl; exit(-1); }
     if ((size_t)n_reads <= cap) break;
     cap = (size_t)n_reads;
   }
   n_objects_ = (size_t)n_reads;
+  lap("index reads");
   const size_t N = n_objects_;
   const int k = (int)opt_.k;
   const size_t n_eng = engines_.size();
@@ -293,6 +305,7 @@ void Classifier::run_buffer(const uint8_t* map, size_t nb, const std::string& re
     for (size_t lb = 0; lb < local_batches; ++lb) { L.rp[lb] = rp[lb]; L.ct[lb] = ct[lb]; }
   }
 
+  lap("allocate batches");
   // ---- header
   {
     std::vector<const char*> nm(names_.size());
@@ -360,8 +373,10 @@ void Classifier::run_buffer(const uint8_t* map, size_t nb, const std::string& re
       ++next_write;
     }
   }
+  lap("pack + query + format + write");
   fclose(fout);
   for (mic_engine* e : engines_) mic_batches_free(e);
+  lap("free batches");
   if (!err.empty()) die(err);
 
   gettimeofday(&t1, nullptr);

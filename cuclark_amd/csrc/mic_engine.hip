@@ -55,6 +55,7 @@ struct mic_engine {
   mic_db_info info;
   // batches
   std::vector<Batch> batches;
+  void* h_block = nullptr; void* d_block = nullptr;   // one pinned and one device allocation carved into all buffers
   uint32_t* h_results = nullptr; uint32_t* h_rows = nullptr;
   size_t num_reads_total = 0;
   std::mutex submit_mu;
@@ -169,20 +170,13 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
 
 void free_batches(mic_engine* e) {
   for (Batch& b : e->batches) {
-    if (b.h_rp) hipHostFree(b.h_rp);
-    if (b.h_cont) hipHostFree(b.h_cont);
-    if (b.h_flagged) hipHostFree(b.h_flagged);
-    if (b.d_rp) hipFree(b.d_rp);
-    if (b.d_cont) hipFree(b.d_cont);
-    if (b.d_results) hipFree(b.d_results);
-    if (b.d_rows) hipFree(b.d_rows);
-    if (b.d_flagged) hipFree(b.d_flagged);
     if (b.done) hipEventDestroy(b.done);
     if (b.stream) hipStreamDestroy(b.stream);
   }
   e->batches.clear();
-  if (e->h_results) { hipHostFree(e->h_results); e->h_results = nullptr; }
-  if (e->h_rows) { hipHostFree(e->h_rows); e->h_rows = nullptr; }
+  if (e->h_block) { hipHostFree(e->h_block); e->h_block = nullptr; }
+  if (e->d_block) { hipFree(e->d_block); e->d_block = nullptr; }
+  e->h_results = nullptr; e->h_rows = nullptr;
   e->num_reads_total = 0;
 }
 
@@ -402,22 +396,32 @@ int mic_batches_alloc(mic_engine* e, size_t num_reads_total, size_t max_reads, s
   const size_t nb = e->cfg.num_batches;
   const uint32_t rw = e->cfg.row_words;
   e->num_reads_total = num_reads_total;
-  HIPTRY(hipHostMalloc((void**)&e->h_results, (num_reads_total + 1) * MIC_RESULT_WORDS * 4, hipHostMallocDefault));
-  if (extended) HIPTRY(hipHostMalloc((void**)&e->h_rows, (num_reads_total + 1) * (size_t)rw * 4, hipHostMallocDefault));
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  // sizes of the per-batch pieces
+  const size_t sz_rp = up((max_reads + 2) * 4), sz_ct = up((max_containers + 64) * 2), sz_fl = up((size_t)(kFlaggedCap + 1) * 4);
+  const size_t sz_res = up((max_reads + 1) * MIC_RESULT_WORDS * 4), sz_rows = extended ? up((max_reads + 1) * (size_t)rw * 4) : 0;
+  const size_t h_res = up((num_reads_total + 1) * MIC_RESULT_WORDS * 4), h_rows = extended ? up((num_reads_total + 1) * (size_t)rw * 4) : 0;
+  const size_t h_total = h_res + h_rows + nb * (sz_rp + sz_ct + sz_fl);
+  const size_t d_total = nb * (sz_rp + sz_ct + sz_res + sz_rows + sz_fl);
+  HIPTRY(hipHostMalloc(&e->h_block, h_total, hipHostMallocDefault));
+  HIPTRY(hipMalloc(&e->d_block, d_total));
+  char* hp = (char*)e->h_block; char* dp = (char*)e->d_block;
+  e->h_results = (uint32_t*)hp; hp += h_res;
+  if (extended) { e->h_rows = (uint32_t*)hp; hp += h_rows; }
   e->batches.resize(nb);
   for (size_t b = 0; b < nb; ++b) {
     Batch& B = e->batches[b];
     B.first_read = index_batches[b];
     B.max_reads = max_reads; B.max_cont = max_containers;
     B.extended = extended != 0;
-    HIPTRY(hipHostMalloc((void**)&B.h_rp, (max_reads + 2) * 4, hipHostMallocDefault));
-    HIPTRY(hipHostMalloc((void**)&B.h_cont, (max_containers + 64) * 2, hipHostMallocDefault));
-    HIPTRY(hipHostMalloc((void**)&B.h_flagged, (size_t)(kFlaggedCap + 1) * 4, hipHostMallocDefault));
-    HIPTRY(hipMalloc(&B.d_rp, (max_reads + 2) * 4));
-    HIPTRY(hipMalloc(&B.d_cont, (max_containers + 64) * 2));
-    HIPTRY(hipMalloc(&B.d_results, (max_reads + 1) * MIC_RESULT_WORDS * 4));
-    if (extended) HIPTRY(hipMalloc(&B.d_rows, (max_reads + 1) * (size_t)rw * 4));
-    HIPTRY(hipMalloc(&B.d_flagged, (size_t)(kFlaggedCap + 1) * 4));
+    B.h_rp = (uint32_t*)hp; hp += sz_rp;
+    B.h_cont = (uint16_t*)hp; hp += sz_ct;
+    B.h_flagged = (uint32_t*)hp; hp += sz_fl;
+    B.d_rp = (uint32_t*)dp; dp += sz_rp;
+    B.d_cont = (uint16_t*)dp; dp += sz_ct;
+    B.d_results = (uint32_t*)dp; dp += sz_res;
+    if (extended) { B.d_rows = (uint32_t*)dp; dp += sz_rows; }
+    B.d_flagged = (uint32_t*)dp; dp += sz_fl;
     HIPTRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
     HIPTRY(hipEventCreateWithFlags(&B.done, hipEventDisableTiming));
     reads_pointer[b] = B.h_rp;
@@ -460,7 +464,7 @@ int mic_batch_query(mic_engine* e, size_t batch, int extended, int followup) {
   if (extended)
     HIPTRY(hipMemcpyAsync(e->h_rows + B.first_read * (size_t)e->cfg.row_words, B.d_rows,
                           B.n_reads * (size_t)e->cfg.row_words * 4, hipMemcpyDeviceToHost, s));
-  HIPTRY(hipMemcpyAsync(B.h_flagged, B.d_flagged, (size_t)(kFlaggedCap + 1) * 4, hipMemcpyDeviceToHost, s));
+  HIPTRY(hipMemcpyAsync(B.h_flagged, B.d_flagged, 4, hipMemcpyDeviceToHost, s));   // count only; ids stay on the device
   HIPTRY(hipEventRecord(B.done, s));
   B.scheduled = true; B.resolved = false; B.extended = extended != 0;
   return MIC_OK;

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 // ---- division magic ---------------------------------------------------------------------------------
@@ -33,6 +34,16 @@ MicDiv mic_make_div(uint64_t d) {
   return r;
 }
 
+// run f(0..n-1) on n std::threads (the library does not use OpenMP: its callers may bring their own runtime)
+template <typename F>
+static void run_threads(int n, F&& f) {
+  std::vector<std::thread> th;
+  th.reserve(n > 1 ? n - 1 : 0);
+  for (int t = 1; t < n; ++t) th.emplace_back([&f, t] { f(t); });
+  f(0);
+  for (auto& x : th) x.join();
+}
+
 extern "C" {
 
 // main.cc:274-316.  t_b is computed in double exactly as the reference does.
@@ -47,45 +58,119 @@ int mic_key_bytes_rule(uint64_t htsize, int k) {
 // ---- read indexer (CuCLARK_hh.hh:1339-1534 for a single batch) -----------------------------------------
 static inline bool name_sep(uint8_t c) { return c == ' ' || c == '\t' || c == '\n'; }  // CuCLARK_hh.hh:300
 
+struct Rec { uint64_t ns, ne, ss, se, len; };
+
+// Parse the record whose marker ('>' or '@') is at map[i-1]; returns the position of the next record's marker
+// (FASTA) / of the byte after the quality line (FASTQ), or a value >= nb at the end of the file.
+static inline size_t parse_record(const uint8_t* map, size_t nb, bool fasta, size_t i, Rec& r) {
+  r.ns = i;  // name: from the byte after the marker up to the first separator found strictly after it
+  while (i + 1 < nb && !name_sep(map[i + 1])) ++i;
+  ++i;
+  if (i > nb) i = nb;
+  r.ne = i;
+  while (i < nb && map[i++] != '\n') {}  // rest of the header line
+  size_t s = i, e = i;
+  if (fasta) {
+    size_t lines = 0;
+    while (i < nb && map[i] != '>') {  // sequence lines until a line that starts the next record
+      while (i < nb && map[i] != '\n') ++i;
+      ++lines;
+      e = i++;
+    }
+    r.len = (e - s + 1) - lines;  // non-newline bytes (CuCLARK_hh.hh:1385-1389)
+  } else {
+    while (i < nb && map[i] != '\n') ++i;
+    e = i < nb ? i : nb;
+    ++i;
+    r.len = e - s;
+    while (i < nb && map[i++] != '\n') {}  // '+' line
+    while (i < nb && map[i++] != '\n') {}  // quality line
+  }
+  r.ss = s; r.se = e;
+  return i;
+}
+
+static inline void store_rec(const Rec& r, size_t n, size_t cap, uint64_t* name_s, uint64_t* name_e, uint64_t* seq_s,
+                             uint64_t* seq_e, uint64_t* length) {
+  if (n < cap) { name_s[n] = r.ns; name_e[n] = r.ne; seq_s[n] = r.ss; seq_e[n] = r.se; length[n] = r.len; }
+}
+
 long mic_index_reads(const uint8_t* map, size_t nb, size_t cap, uint64_t* name_s, uint64_t* name_e, uint64_t* seq_s,
                      uint64_t* seq_e, uint64_t* length) {
   if (!map || nb == 0 || (map[0] != '>' && map[0] != '@')) return MIC_E_INVALID;
   const bool fasta = map[0] == '>';
   size_t n = 0, i = 1;
   for (;;) {
-    // name: from the byte after the marker up to the first separator found strictly after it
-    const size_t ns = i;
-    while (i + 1 < nb && !name_sep(map[i + 1])) ++i;
-    ++i;
-    if (i > nb) i = nb;
-    const size_t ne = i;
-    while (i < nb && map[i++] != '\n') {}  // rest of the header line
-    size_t s = i, e = i, len;
-    if (fasta) {
-      size_t lines = 0;
-      while (i < nb && map[i] != '>') {  // sequence lines until the next record
-        while (i < nb && map[i] != '\n') ++i;
-        ++lines;
-        e = i++;
-      }
-      len = (e - s + 1) - lines;  // non-newline bytes (CuCLARK_hh.hh:1385-1389)
-    } else {
-      while (i < nb && map[i] != '\n') ++i;
-      e = i < nb ? i : nb;
-      ++i;
-      len = e - s;
-      while (i < nb && map[i++] != '\n') {}  // '+' line
-      while (i < nb && map[i++] != '\n') {}  // quality line
-    }
-    if (n < cap) { name_s[n] = ns; name_e[n] = ne; seq_s[n] = s; seq_e[n] = e; length[n] = len; }
+    Rec r;
+    i = parse_record(map, nb, fasta, i, r);
+    store_rec(r, n, cap, name_s, name_e, seq_s, seq_e, length);
     ++n;
-    if (fasta) {
-      if (i >= nb) break;
-      ++i;  // skip '>'
-    } else {
-      if (++i >= nb) break;  // skip '@'
-    }
+    if (fasta) { if (i >= nb) break; ++i; }   // skip '>'
+    else { if (++i >= nb) break; }             // skip '@'
   }
+  return (long)n;
+}
+
+// First record marker at or after `from` (from > 0).  FASTA: a '>' at the start of a line.  FASTQ: the reference's
+// batch-start heuristic (CuCLARK_hh.hh:1409-1471): a line that starts with '@', whose next line holds only letters
+// and whose line after that starts with '+'.  Returns nb if there is none.
+static size_t find_record_start(const uint8_t* map, size_t nb, bool fasta, size_t from) {
+  size_t p = from;
+  while (p < nb && map[p - 1] != '\n') ++p;  // first line start >= from
+  while (p < nb) {
+    if (fasta) {
+      if (map[p] == '>') return p;
+    } else if (map[p] == '@') {
+      size_t q = p;
+      while (q < nb && map[q] != '\n') ++q;
+      size_t s = q + 1, e = s;
+      bool letters = s < nb;
+      while (e < nb && map[e] != '\n') { uint8_t c = map[e]; letters = letters && ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z')); ++e; }
+      if (letters && e > s && e + 1 < nb && map[e + 1] == '+') return p;
+    }
+    while (p < nb && map[p] != '\n') ++p;
+    ++p;
+  }
+  return nb;
+}
+
+// Parallel form of mic_index_reads: the file is cut into `n_threads` byte ranges, each range is indexed from the first
+// record that starts in it.  Same output as the serial function for well-formed FASTA/FASTQ.
+long mic_index_reads_parallel(const uint8_t* map, size_t nb, int n_threads, size_t cap, uint64_t* name_s, uint64_t* name_e,
+                              uint64_t* seq_s, uint64_t* seq_e, uint64_t* length) {
+  if (!map || nb == 0 || (map[0] != '>' && map[0] != '@')) return MIC_E_INVALID;
+  if (n_threads < 1) n_threads = 1;
+  if ((size_t)n_threads > nb / 65536 + 1) n_threads = (int)(nb / 65536 + 1);
+  if (n_threads == 1) return mic_index_reads(map, nb, cap, name_s, name_e, seq_s, seq_e, length);
+  const bool fasta = map[0] == '>';
+  std::vector<size_t> start(n_threads + 1, nb);
+  start[0] = 0;
+  std::vector<std::vector<Rec>> recs(n_threads);
+  run_threads(n_threads, [&](int t) { if (t > 0) start[t] = find_record_start(map, nb, fasta, (size_t)t * (nb / n_threads)); });
+  run_threads(n_threads, [&](int t) {
+    size_t lo = start[t], hi = nb;
+    for (int u = t + 1; u <= n_threads; ++u) if (start[u] > lo) { hi = start[u]; break; }
+    bool dup = false;                                  // empty range (a record longer than the range)
+    for (int u = 0; u < t; ++u) dup = dup || start[u] == lo;
+    if (dup || lo >= nb) return;
+    std::vector<Rec>& out = recs[t];
+    out.reserve((hi - lo) / 64 + 16);
+    size_t i = lo + 1;
+    for (;;) {
+      Rec r;
+      i = parse_record(map, nb, fasta, i, r);
+      out.push_back(r);
+      if (fasta) { if (i >= nb || i >= hi) break; ++i; }
+      else { if (i + 1 >= nb || i >= hi) break; ++i; }
+    }
+  });
+  size_t n = 0;
+  std::vector<size_t> base(n_threads + 1, 0);
+  for (int t = 0; t < n_threads; ++t) { base[t] = n; n += recs[t].size(); }
+  if (n <= cap)
+    run_threads(n_threads, [&](int t) {
+      for (size_t j = 0; j < recs[t].size(); ++j) store_rec(recs[t][j], base[t] + j, cap, name_s, name_e, seq_s, seq_e, length);
+    });
   return (long)n;
 }
 

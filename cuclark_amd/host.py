@@ -15,14 +15,17 @@ def key_bytes_rule(htsize, k):
     return int(_lib.load().mic_key_bytes_rule(int(htsize), int(k)))
 
 
-def index_reads(data):
+def index_reads(data, threads=1):
     """CuCLARK_hh.hh:1339-1534 (one batch).  Returns dict of u64 arrays or None for an unknown format."""
     L = _lib.load()
     buf = np.frombuffer(data, np.uint8)
     cap = max(16, buf.size // 64)
     while True:
         arrs = [np.zeros(cap, np.uint64) for _ in range(5)]
-        n = L.mic_index_reads(buf.ctypes.data, buf.size, cap, *[a.ctypes.data for a in arrs])
+        if threads > 1:
+            n = L.mic_index_reads_parallel(buf.ctypes.data, buf.size, threads, cap, *[a.ctypes.data for a in arrs])
+        else:
+            n = L.mic_index_reads(buf.ctypes.data, buf.size, cap, *[a.ctypes.data for a in arrs])
         if n < 0:
             return None
         if n <= cap:

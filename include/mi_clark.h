@@ -175,6 +175,10 @@ int mic_key_bytes_rule(uint64_t htsize, int k);
  * is neither '>' nor '@'. */
 long mic_index_reads(const uint8_t* map, size_t nb, size_t cap, uint64_t* name_s, uint64_t* name_e, uint64_t* seq_s,
                      uint64_t* seq_e, uint64_t* length);
+/* Same result, indexed by n_threads OpenMP threads over byte ranges of the file (record boundaries inside a range are
+ * found like the reference finds its batch starts, CuCLARK_hh.hh:1409-1471). */
+long mic_index_reads_parallel(const uint8_t* map, size_t nb, int n_threads, size_t cap, uint64_t* name_s, uint64_t* name_e,
+                              uint64_t* seq_s, uint64_t* seq_e, uint64_t* length);
 /* Upper bound of containers mic_pack_reads can emit for these reads. */
 size_t mic_pack_bound(const uint64_t* seq_s, const uint64_t* seq_e, size_t n_reads, int k);
 /* Read packer, CuCLARK_hh.hh:1616-1716.  Returns containers written or (size_t)-1 if cap is too small. */

@@ -107,3 +107,30 @@ def test_csv_formatting_matches_golden(case, lib):
                  for r in range(results.shape[0])}
     text = host.format_csv(data, idx, res8, names, k, paired=paired, extended=ext, dense=dense)
     assert text == open(os.path.join(gu.GOLDEN, f"expected_{case}.csv"), "rb").read()
+
+
+def test_parallel_indexer_equals_serial(lib):
+    """mic_index_reads_parallel cuts the file into byte ranges; the result must equal the serial indexer's."""
+    from cuclark_amd import host
+    rng = np.random.default_rng(8)
+    # FASTQ with quality lines that start with '@' and '+', FASTA with wrapped lines and long records
+    fq = []
+    for i in range(20000):
+        L = int(rng.integers(30, 200))
+        seq = "".join(rng.choice(list("ACGTN"), L))
+        qual = "".join(rng.choice(list("@+IJ#5"), L))
+        fq.append(f"@read{i} len={L}\n{seq}\n+\n{qual}\n")
+    fq = "".join(fq).encode()
+    fa = []
+    for i in range(3000):
+        L = int(rng.integers(1, 3000))
+        seq = "".join(rng.choice(list("ACGT"), L))
+        fa.append(f">rec{i}\n" + "\n".join(seq[j:j + 60] for j in range(0, L, 60)) + "\n")
+    fa = "".join(fa).encode()
+    for data in (fq, fa, fq[:-1], b">one\n" + b"ACGT" * 100000 + b"\n"):
+        a = host.index_reads(data)
+        for t in (2, 3, 8, 37):
+            b = host.index_reads(data, threads=t)
+            assert len(b["length"]) == len(a["length"])
+            for f in a:
+                assert (a[f] == b[f]).all(), (t, f)
