@@ -13,12 +13,14 @@
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <condition_variable>
 #include <fstream>
 #include <iostream>
 #include <mutex>
+#include <sstream>
 #include <stdexcept>
 
 #ifdef _OPENMP
@@ -71,11 +73,37 @@ bool file_exists(const std::string& p) {
   return true;
 }
 
+bool is_gzip(const std::string& p) {
+  FILE* f = fopen(p.c_str(), "rb");
+  if (!f) return false;
+  unsigned char m[2] = {0, 0};
+  size_t n = fread(m, 1, 2, f);
+  fclose(f);
+  return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
+}
+
+// whole file in memory, inflating gzip input (what classify_metagenome.sh --gzipped does with cp + gunzip,
+// classify_metagenome.sh:116-142, without the temporary copy)
+bool slurp(const std::string& p, std::string& out) {
+  out.clear();
+  gzFile g = gzopen(p.c_str(), "rb");   // reads plain files transparently too
+  if (!g) return false;
+  gzbuffer(g, 1 << 20);
+  std::vector<char> buf(8u << 20);
+  int n;
+  while ((n = gzread(g, buf.data(), (unsigned)buf.size())) > 0) out.append(buf.data(), (size_t)n);
+  gzclose(g);
+  return n == 0;
+}
+
 }  // namespace
 
 std::string merge_paired(const std::string& file1, const std::string& file2) {
-  std::ifstream f1(file1), f2(file2);
+  std::string b1, b2;
+  if (!slurp(file1, b1) || !slurp(file2, b2)) die("Error: Found read without sequence");
+  std::istringstream f1(b1), f2(b2);
   std::string l1, l2, out;
+  out.reserve(b1.size() / 2 + b2.size() / 2 + 64);
   if (!get_line(f1, l1) || !get_line(f2, l2)) die("Error: Found read without sequence");
   if (l1.empty() || l2.empty() || l1[0] != l2[0]) die("Error: the files have different format!");
   if (l1[0] != '@') die("Error: paired-end reads must be FASTQ files!");
@@ -108,10 +136,20 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
 
   const std::string db = db_name();
   if (!(file_exists(db + ".sz") && file_exists(db + ".ky") && file_exists(db + ".lb"))) {
-    // The reference would now build the database from the target genomes (makeSpecificTargetSets,
-    // CuCLARK_hh.hh:691-1329).  DB construction is outside this engine's scope.
-    std::cerr << "Failed to find the database." << std::endl;
-    die("database files " + db + ".{sz,ky,lb} not found; build them with CLARK/CuCLARK (DB creation is not part of this engine)");
+    // first run: build the database from the target genomes (reference: makeSpecificTargetSets,
+    // CuCLARK_hh.hh:304-309,691-1329) — here on the GPU (mic_db_build)
+    std::cerr << "Starting the creation of the database of targets specific " << opt_.k << "-mers from input files..." << std::endl;
+    std::vector<const char*> files; std::vector<uint16_t> labs;
+    for (const auto& t : targets_id_) {
+      files.push_back(t.first.c_str());
+      labs.push_back((uint16_t)(std::find(labels_.begin(), labels_.end(), t.second) - labels_.begin()));
+    }
+    uint64_t n_kmers = 0;
+    int rc = mic_db_build(files.data(), labs.data(), files.size(), (int)opt_.k, opt_.htsize, 0, opt_.min_count_t, db.c_str(), 0,
+                          (int)opt_.threads, 0, &n_kmers);
+    if (rc != MIC_OK) die(std::string("Failed to create the database: ") + mic_db_build_error());
+    std::cerr << "Creating database in disk..." << std::endl;
+    std::cerr << n_kmers << " " << opt_.k << "-mers successfully stored in database." << std::endl;
   }
   int n_dev = 0;
   check(mic_device_count(&n_dev), "device discovery");
@@ -173,6 +211,12 @@ void Classifier::parse_targets() {
 
 void Classifier::run(const std::string& objects, const std::string& results) {
   auto simple = [&](const std::string& obj, const std::string& res) {
+    if (is_gzip(obj)) {
+      std::string data;
+      if (!slurp(obj, data) || data.empty()) { std::cerr << "Failed to uncompress input objects." << std::endl; return; }
+      run_buffer((const uint8_t*)data.data(), data.size(), res, false);
+      return;
+    }
     int fd = open(obj.c_str(), O_RDONLY);
     struct stat st;
     if (fd == -1 || fstat(fd, &st) != 0 || st.st_size == 0) {

@@ -190,6 +190,18 @@ int mic_csv_line(char* buf, size_t cap, const uint8_t* name, size_t name_len, ui
                  const uint32_t* result /*MIC_RESULT_WORDS*/, const char* const* target_names, uint32_t n_targets,
                  int extended, const uint32_t* row /*sparse row or NULL*/, const uint32_t* dense /*or NULL*/);
 
+/* ---- database construction on the GPU ------------------------------------------------------
+ * Builds <out_prefix>.sz/.ky/.lb from target FASTA/FASTQ files exactly as the reference's first run does
+ * (makeSpecificTargetSets + RemoveCommon + Write, CuCLARK_hh.hh:691-1329, HashTableStorage_hh.hh:241-292,483-523,
+ * hashTable_hh.hh:590-663): a canonical k-mer is stored iff all its occurrences belong to one label and its
+ * occurrence count (saturating at 254) exceeds min_count.  target_labels[i] = label index of target_files[i]
+ * (first-appearance order of the labels in the targets file).  key_bytes 0 => rule of main.cc:274-316.
+ * parts 0 => as many passes over disjoint bucket ranges as the free HBM requires.  Synchronous. */
+int mic_db_build(const char* const* target_files, const uint16_t* target_labels, size_t n_files, int k, uint64_t htsize,
+                 int key_bytes, uint32_t min_count, const char* out_prefix, int device, int threads, uint32_t parts,
+                 uint64_t* n_kmers_out);
+const char* mic_db_build_error(void);
+
 /* ---- synthetic workload generation in HBM (bench.py / tests) ------------------- */
 typedef struct mic_synth_spec {
   uint64_t seed;

@@ -77,7 +77,33 @@ def test_light_cli_matches_golden(tmp_path):
 
 
 @pytest.mark.gpu
-def test_full_cli_matches_golden_and_missing_db(tmp_path):
+def test_gzip_input_and_launcher_script(tmp_path):
+    """gzip input is inflated by the binary; classify_metagenome.sh reads .settings like the reference's script."""
+    import gzip
+    import shutil
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "light_k27_u32", light=True)
+    t = _targets_file(tmp)
+    gz = os.path.join(tmp, "reads.fa.gz")
+    with open(os.path.join(gu.GOLDEN, "reads_k27.fa"), "rb") as fi, gzip.open(gz, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    open(os.path.join(tmp, ".settings"), "w").write(f"-T {t}\n-D {d}/\n")
+    script = os.path.join(gu.ROOT, "classify_metagenome.sh")
+    r = _run([script, "-O", gz, "-R", os.path.join(tmp, "viascript"), "--light", "--gzipped", "-n", "2"], cwd=tmp)
+    assert r.returncode == 0, r.stderr
+    assert open(os.path.join(tmp, "viascript.csv"), "rb").read() == open(os.path.join(gu.GOLDEN, "expected_k27_fa.csv"), "rb").read()
+    # paired gz
+    p1, p2 = os.path.join(tmp, "p1.fq.gz"), os.path.join(tmp, "p2.fq.gz")
+    for src, dst in ((os.path.join(gu.GOLDEN, "pairs_k27_1.fq"), p1), (os.path.join(gu.GOLDEN, "pairs_k27_2.fq"), p2)):
+        with open(src, "rb") as fi, gzip.open(dst, "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+    r = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", os.path.join(tmp, "pairs")])
+    assert r.returncode == 0, r.stderr
+    assert open(os.path.join(tmp, "pairs.csv"), "rb").read() == open(os.path.join(gu.GOLDEN, "expected_k27_pairs.csv"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_full_cli_matches_golden_and_missing_targets(tmp_path):
     tmp = str(tmp_path)
     d = _db_dir(tmp, "full_k31_u32", light=False)
     t = _targets_file(tmp)
@@ -97,5 +123,8 @@ def test_full_cli_matches_golden_and_missing_db(tmp_path):
         for f in os.listdir(d):
             if f.endswith(ext):
                 os.remove(os.path.join(d, f))
-    r = _run([EXE, "-k", "31", "-T", t, "-D", d, "-O", os.path.join(gu.GOLDEN, "reads_k31.fa"), "-R", out])
-    assert r.returncode != 0 and "Failed to find the database." in r.stderr
+    # no database and unreadable target genomes -> the reference's message for a missing target file
+    bad = os.path.join(tmp, "bad_targets.txt")
+    open(bad, "w").write("/nonexistent/genome.fa L1\n")
+    r = _run([EXE, "-k", "31", "-T", bad, "-D", d, "-O", os.path.join(gu.GOLDEN, "reads_k31.fa"), "-R", out])
+    assert r.returncode != 0 and "Failed to open file: /nonexistent/genome.fa defined in" in r.stderr
