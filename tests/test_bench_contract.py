@@ -1,0 +1,42 @@
+"""bench.py prints one JSON line with the driver's contract (plus `roofline` and `cpu_baseline`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import golden_util as gu
+
+
+@pytest.mark.gpu
+def test_bench_tiny_json_contract():
+    r = subprocess.run([sys.executable, os.path.join(gu.ROOT, "bench.py"), "--workload", "tiny", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "Mreads/s" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] == "port" and cb["parity_with_gpu_on_sample"] is True
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["reads_per_gpu"] / d["ms_per_step"] / 1e3) / d["value"] < 0.02
+    assert d["known_answer"]["label_and_count_ok"] == 1.0
+
+
+def test_bench_has_the_contract_flags():
+    src = open(os.path.join(gu.ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in src
+    assert "oracle" in src and "cpu_baseline" in src and "no_cpu" in src
