@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) query_kernel(const MicQueryArgs a) {
 // distinct slot (~17 per 150-bp read) instead of one 64-byte request per k-mer (120).
 // =====================================================================================================================
 #define MIC_RMAX 32        // slots staged per round
-#define MIC_MSTRIDE 9      // uint4 per staged slot in LDS: 8 + 1 pad (bank spread)
+#define MIC_MSTRIDE 8      // uint4 per staged slot in LDS (linear: LDS-DMA writes lane L at base + 16*L)
 
 __device__ __forceinline__ void sliding_min3(uint32_t& a0, uint32_t& a1, uint32_t& a2, int w, int lane) {
   // a_h(l) holds the order key of position 64h+l; afterwards a_h(l) = min over positions [64h+l, 64h+l+w)
@@ -402,14 +402,20 @@ __global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
             if (f1 && rid1 - rbase < MIC_RMAX) runslot[rid1 - rbase] = sl1;
             __builtin_amdgcn_wave_barrier();
             const uint32_t nrun = R - rbase < MIC_RMAX ? R - rbase : MIC_RMAX;
+            // every distinct slot goes HBM -> LDS directly (global_load_lds_dwordx4: lane L lands at base + 16*L, no
+            // VGPRs): all staging loads of the round are in flight together and are awaited once.  (Staging through
+            // registers put each load in its own basic block: load, wait, ds_write, next load - up to four serialized
+            // HBM latencies per round; rotating the quarters to dodge LDS bank conflicts measured slower.)
+            uint32_t sidx[MIC_RMAX / 8];
+#pragma unroll
+            for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = runslot[8 * i + (lane >> 3)];
 #pragma unroll
             for (int i = 0; i < MIC_RMAX / 8; ++i) {
-              const uint32_t rr = 8 * i + (lane >> 3);
-              if (8u * i < nrun && rr < nrun) {
-                const uint32_t sidx = runslot[rr];
-                stage[rr * MIC_MSTRIDE + (lane & 7)] = slots[(uint64_t)sidx * 8 + (lane & 7)];
-              }
+              if (8u * i + (lane >> 3) < nrun)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
+                                                 (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
