@@ -13,7 +13,12 @@ dst = "profiles"
 os.makedirs(dst, exist_ok=True)
 
 # 1. rocprofv3 --kernel-trace --stats summary, verbatim
-ks = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))[0]
+def newest(pattern):
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] if files else []
+
+
+ks = newest(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(ks)))
 with open(os.path.join(dst, f"{tag}_rocprof_kernel_stats.csv"), "w") as f:
     w = csv.DictWriter(f, fieldnames=rows[0].keys())
@@ -24,7 +29,7 @@ bench = json.load(open(os.path.join(src, "kt_bench.json")))
 # 2. PMC per-launch means for the query kernel
 pmc = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*", ""))):
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(d, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "query_kernel" in r["Kernel_Name"]:
@@ -33,7 +38,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*", ""))):
             pmc[c] = sum(v) / len(v)
 cal = {}
 for name in ("cal_fetch", "cal_rdreq"):
-    for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(src, name, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "gather_coop64_kernel<4>" in r["Kernel_Name"]:
