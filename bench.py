@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="override the number of reads per GPU")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo stages the row exchange through host memory (validation on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,10 +75,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from cuclark_amd import MiClarkDB, _lib, multi
     L = _lib.load()
@@ -140,7 +146,11 @@ def main():
             return
         # table-sharded: local sparse rows -> all_to_all by read range -> merge (sum by target) -> best/second
         eng.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), d_rows.data_ptr(), sptr)
-        multi.exchange_rows(d_rows, world, out=d_recv)
+        if args.backend == "nccl":
+            multi.exchange_rows(d_rows, world, out=d_recv)
+        else:
+            torch.cuda.synchronize()
+            d_recv.copy_(multi.exchange_rows(d_rows.cpu(), world))
         cur = d_recv[0]
         for r in range(1, world):
             out = d_acc[r & 1]
@@ -149,6 +159,7 @@ def main():
         eng.result_from_rows_device(cur.data_ptr(), d_res_part.data_ptr(), per_r, sptr)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -172,7 +183,7 @@ def main():
         kernel_ms.append(eng.last_query_ms())
     torch.cuda.synchronize()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -228,7 +239,14 @@ def main():
                  "random_reads_no_hit": float((res[~gmask, 0] == 0).mean()) if (~gmask).any() else 1.0,
                  "tie_rate": float(((res[:, 2] == res[:, 4]) & (res[:, 2] > 0)).mean())}
     else:
-        known = None
+        # table-sharded: every rank finalised 1/N of the reads; gather them in read order and apply the same check
+        torch.cuda.synchronize()
+        part = d_res_part if args.backend == "nccl" else d_res_part.cpu()
+        allres = multi.gather_results(part, world)[:n_reads].cpu().numpy().view(np.uint32)
+        ok = (truth[gmask, 1] == 0) | ((allres[gmask, 1] == truth[gmask, 0]) & (allres[gmask, 2] >= truth[gmask, 1]))
+        known = {"genome_reads": int(gmask.sum()), "label_and_count_ok": float(ok.mean()) if gmask.any() else 1.0,
+                 "random_reads_no_hit": float((allres[~gmask, 0] == 0).mean()) if (~gmask).any() else 1.0,
+                 "tie_rate": float(((allres[:, 2] == allres[:, 4]) & (allres[:, 2] > 0)).mean())}
 
     # ---- CPU baseline (rank 0, N=1): the oracle on this box's host cores, bounded sample; doubles as parity check
     cpu = None

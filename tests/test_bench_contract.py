@@ -40,3 +40,23 @@ def test_bench_has_the_contract_flags():
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in src
     assert "oracle" in src and "cpu_baseline" in src and "no_cpu" in src
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["db", "read"])
+def test_bench_two_ranks_on_one_gpu(mode):
+    """The N>1 code paths of bench.py with two ranks sharing cuda:0 (rows exchanged through host memory with gloo):
+    table-sharded mode must reproduce the constructive known answer after exchange + merge + gather."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", os.path.join(gu.ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--workload", "tiny", "--mode", mode, "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2
+    assert d["scaling"] == ("strong" if mode == "db" else "weak")
+    assert d["known_answer"]["label_and_count_ok"] == 1.0 and d["known_answer"]["random_reads_no_hit"] == 1.0
+    per = d["config"]["reads_per_gpu"]
+    total = per * (2 if mode == "read" else 1)
+    assert abs(d["value"] - total / d["ms_per_step"] / 1e3) / d["value"] < 0.02
