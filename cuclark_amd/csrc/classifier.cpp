@@ -22,6 +22,7 @@
 #include <mutex>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -82,44 +83,7 @@ bool is_gzip(const std::string& p) {
   return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
 }
 
-// whole file in memory, inflating gzip input (what classify_metagenome.sh --gzipped does with cp + gunzip,
-// classify_metagenome.sh:116-142, without the temporary copy)
-bool slurp(const std::string& p, std::string& out) {
-  out.clear();
-  gzFile g = gzopen(p.c_str(), "rb");   // reads plain files transparently too
-  if (!g) return false;
-  gzbuffer(g, 1 << 20);
-  std::vector<char> buf(8u << 20);
-  int n;
-  while ((n = gzread(g, buf.data(), (unsigned)buf.size())) > 0) out.append(buf.data(), (size_t)n);
-  gzclose(g);
-  return n == 0;
-}
-
 }  // namespace
-
-std::string merge_paired(const std::string& file1, const std::string& file2) {
-  std::string b1, b2;
-  if (!slurp(file1, b1) || !slurp(file2, b2)) die("Error: Found read without sequence");
-  std::istringstream f1(b1), f2(b2);
-  std::string l1, l2, out;
-  out.reserve(b1.size() / 2 + b2.size() / 2 + 64);
-  if (!get_line(f1, l1) || !get_line(f2, l2)) die("Error: Found read without sequence");
-  if (l1.empty() || l2.empty() || l1[0] != l2[0]) die("Error: the files have different format!");
-  if (l1[0] != '@') die("Error: paired-end reads must be FASTQ files!");
-  const std::string seps = " /\t@";
-  f1.clear(); f1.seekg(0); f2.clear(); f2.seekg(0);
-  while (get_line(f1, l1) && get_line(f2, l2)) {
-    if (l1.empty() || l2.empty() || l1[0] != '@' || l2[0] != '@') continue;
-    std::vector<std::string> e1 = split_seps(l1, seps), e2 = split_seps(l2, seps);
-    if (e1.empty() || e2.empty() || e1[0] != e2[0]) die("Error: read id does not match between files!");
-    out += ">" + e1[0] + "\n";
-    if (!(get_line(f1, l1) && get_line(f2, l2))) die("Error: Found read without sequence");
-    out += l1 + "N" + l2 + "\n";  // NBN = 1 separator (parameters.hh:41)
-    if (get_line(f1, l1) && get_line(f2, l2)) { get_line(f1, l1); get_line(f2, l2); }
-  }
-  return out;
-}
 
 Classifier::Classifier(const Options& opt) : opt_(opt) {
 #ifdef _OPENMP
@@ -128,6 +92,8 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
   opt_.threads = 1;
 #endif
   parse_targets();
+  if (const char* env = getenv("MIC_SEGMENT_MB")) { long v = atol(env); if (v >= 1) segment_bytes_ = (size_t)v << 20; }
+  if (const char* env = getenv("MIC_SEGMENT_KB")) { long v = atol(env); if (v >= 1) segment_bytes_ = (size_t)v << 10; }
   std::cerr << "CuCLARK version 1.1 (MI355X engine mi-clark; CuCLARK (c) 2016 Robin Kobus)" << std::endl;
   std::cerr << "Based on CLARK version 1.1.3 (UCR CS&E. Copyright 2013-2016 Rachid Ounit, rouni001@cs.ucr.edu) " << std::endl;
   if (opt_.min_count_t > 0) std::cerr << "Minimum k-mers occurences in Targets is set to " << opt_.min_count_t << std::endl;
@@ -209,27 +175,168 @@ void Classifier::parse_targets() {
   names_.insert(names_.end(), labels_c_.begin(), labels_c_.end());
 }
 
+// ---- segment sources ------------------------------------------------------------------------------------------------
+namespace {
+
+// plain file: zero-copy views of the mapping, cut at record starts
+class MmapSource : public Classifier::SegmentSource {
+ public:
+  MmapSource(const std::string& path, size_t seg) : seg_(seg) {
+    fd_ = open(path.c_str(), O_RDONLY);
+    struct stat st;
+    if (fd_ == -1 || fstat(fd_, &st) != 0 || st.st_size == 0) return;
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd_, 0);
+    if (m == MAP_FAILED) return;
+    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    map_ = (const uint8_t*)m; nb_ = (size_t)st.st_size;
+  }
+  ~MmapSource() override { if (map_) munmap((void*)map_, nb_); if (fd_ != -1) close(fd_); }
+  bool ok() const { return map_ != nullptr; }
+  bool next(Classifier::Segment& s) override {
+    if (!map_ || pos_ >= nb_) return false;
+    size_t end = nb_;
+    if (nb_ - pos_ > seg_ + seg_ / 4) {
+      end = mic_find_record_start(map_, nb_, pos_ + seg_);
+      if (end <= pos_) end = nb_;
+    }
+    s.p = map_ + pos_; s.n = end - pos_; s.own.clear();
+    pos_ = end;
+    return true;
+  }
+ private:
+  int fd_ = -1; const uint8_t* map_ = nullptr; size_t nb_ = 0, pos_ = 0, seg_;
+};
+
+// gzip (or plain) file through zlib: inflate ~seg bytes, keep the incomplete last record for the next segment
+class GzSource : public Classifier::SegmentSource {
+ public:
+  GzSource(const std::string& path, size_t seg) : seg_(seg) { g_ = gzopen(path.c_str(), "rb"); if (g_) gzbuffer(g_, 1 << 20); }
+  ~GzSource() override { if (g_) gzclose(g_); }
+  bool ok() const { return g_ != nullptr; }
+  bool next(Classifier::Segment& s) override {
+    if (!g_ || (eof_ && carry_.empty())) return false;
+    std::string buf;
+    buf.swap(carry_);
+    size_t want = seg_;
+    for (;;) {
+      while (!eof_ && buf.size() < want) {
+        size_t old = buf.size();
+        buf.resize(old + (8u << 20));
+        int n = gzread(g_, &buf[old], 8u << 20);
+        buf.resize(old + (n > 0 ? (size_t)n : 0));
+        if (n <= 0) eof_ = true;
+      }
+      if (eof_) break;
+      // last record start in the buffer: everything from there on is carried over
+      const uint8_t* b = (const uint8_t*)buf.data();
+      size_t last = 0, from = buf.size() > (1u << 20) ? buf.size() - (1u << 20) : 1;
+      for (;;) {
+        size_t p = mic_find_record_start(b, buf.size(), from);
+        size_t q = p;
+        while (q < buf.size()) { last = q; q = mic_find_record_start(b, buf.size(), q + 1); }
+        if (last > 0 || from <= 1) break;
+        from = from > (8u << 20) ? from - (8u << 20) : 1;   // records longer than the window: look further back
+      }
+      if (last > 0) { carry_.assign(buf, last, std::string::npos); buf.resize(last); break; }
+      want = buf.size() * 2;   // one record larger than the segment: keep reading
+    }
+    if (buf.empty()) return false;
+    s.own.swap(buf); s.p = (const uint8_t*)s.own.data(); s.n = s.own.size();
+    return true;
+  }
+ private:
+  gzFile g_ = nullptr; std::string carry_; bool eof_ = false; size_t seg_;
+};
+
+// line reader over zlib (plain files are read transparently)
+class GzLines {
+ public:
+  explicit GzLines(const std::string& path) : buf_(1 << 20) { g_ = gzopen(path.c_str(), "rb"); if (g_) gzbuffer(g_, 1 << 20); }
+  ~GzLines() { if (g_) gzclose(g_); }
+  bool ok() const { return g_ != nullptr; }
+  bool line(std::string& out) {   // getLineFromFile semantics: strip one trailing '\n' (file.cc:124-141)
+    out.clear();
+    for (;;) {
+      if (pos_ == len_) {
+        if (!g_) return !out.empty();
+        int n = gzread(g_, buf_.data(), (unsigned)buf_.size());
+        if (n <= 0) return !out.empty() || false;
+        pos_ = 0; len_ = (size_t)n;
+      }
+      const char* b = buf_.data() + pos_;
+      const char* nl = (const char*)memchr(b, '\n', len_ - pos_);
+      if (nl) { out.append(b, (size_t)(nl - b)); pos_ += (size_t)(nl - b) + 1; return true; }
+      out.append(b, len_ - pos_); pos_ = len_;
+    }
+  }
+ private:
+  gzFile g_ = nullptr; std::vector<char> buf_; size_t pos_ = 0, len_ = 0;
+};
+
+// paired-end FASTQ -> segments of the merged FASTA text ">id\nseq1Nseq2\n" (file.cc:205-268)
+class PairedSource : public Classifier::SegmentSource {
+ public:
+  PairedSource(const std::string& f1, const std::string& f2, size_t seg) : a_(f1), b_(f2), seg_(seg) {}
+  bool ok() const { return a_.ok() && b_.ok(); }
+  bool next(Classifier::Segment& s) override {
+    if (done_) return false;
+    std::string out;
+    out.reserve(seg_ + (1u << 16));
+    std::string l1, l2;
+    const std::string seps = " /\t@";
+    while (out.size() < seg_) {
+      if (!(a_.line(l1) && b_.line(l2))) { done_ = true; break; }
+      if (first_) {
+        first_ = false;
+        if (l1.empty() || l2.empty() || l1[0] != l2[0]) die("Error: the files have different format!");
+        if (l1[0] != '@') die("Error: paired-end reads must be FASTQ files!");
+      }
+      if (l1.empty() || l2.empty() || l1[0] != '@' || l2[0] != '@') continue;
+      std::vector<std::string> e1 = split_seps(l1, seps), e2 = split_seps(l2, seps);
+      if (e1.empty() || e2.empty() || e1[0] != e2[0]) die("Error: read id does not match between files!");
+      out += ">"; out += e1[0]; out += "\n";
+      if (!(a_.line(l1) && b_.line(l2))) die("Error: Found read without sequence");
+      out += l1; out += "N"; out += l2; out += "\n";   // NBN = 1 separator (parameters.hh:41)
+      if (a_.line(l1) && b_.line(l2)) { a_.line(l1); b_.line(l2); }
+    }
+    if (out.empty()) return false;
+    s.own.swap(out); s.p = (const uint8_t*)s.own.data(); s.n = s.own.size();
+    return true;
+  }
+ private:
+  GzLines a_, b_; size_t seg_; bool done_ = false, first_ = true;
+};
+
+class OneBuffer : public Classifier::SegmentSource {
+ public:
+  OneBuffer(const uint8_t* p, size_t n) : p_(p), n_(n) {}
+  bool next(Classifier::Segment& s) override { if (!p_) return false; s.p = p_; s.n = n_; s.own.clear(); p_ = nullptr; return true; }
+ private:
+  const uint8_t* p_; size_t n_;
+};
+
+}  // namespace
+
+std::string merge_paired(const std::string& file1, const std::string& file2) {
+  PairedSource src(file1, file2, ~(size_t)0 >> 1);
+  if (!src.ok()) die("Error: Found read without sequence");
+  Classifier::Segment s;
+  std::string out;
+  while (src.next(s)) out += s.own;
+  return out;
+}
+
 void Classifier::run(const std::string& objects, const std::string& results) {
   auto simple = [&](const std::string& obj, const std::string& res) {
     if (is_gzip(obj)) {
-      std::string data;
-      if (!slurp(obj, data) || data.empty()) { std::cerr << "Failed to uncompress input objects." << std::endl; return; }
-      run_buffer((const uint8_t*)data.data(), data.size(), res, false);
+      GzSource src(obj, segment_bytes_);
+      if (!src.ok()) { std::cerr << "Failed to uncompress input objects." << std::endl; return; }
+      run_segments(src, res, false);
       return;
     }
-    int fd = open(obj.c_str(), O_RDONLY);
-    struct stat st;
-    if (fd == -1 || fstat(fd, &st) != 0 || st.st_size == 0) {
-      if (fd != -1) close(fd);
-      std::cerr << "Failed to open " << obj << std::endl;
-      return;
-    }
-    void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    if (map == MAP_FAILED) { close(fd); std::cerr << "Failed to mmapping the file." << std::endl; return; }
-    madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
-    run_buffer((const uint8_t*)map, (size_t)st.st_size, res, false);
-    munmap(map, (size_t)st.st_size);
-    close(fd);
+    MmapSource src(obj, segment_bytes_);
+    if (!src.ok()) { std::cerr << "Failed to open " << obj << std::endl; return; }
+    run_segments(src, res, false);
   };
   if (!file_exists(results)) {
     std::cout << "Processing file '" << objects << "' in " << opt_.batches << " batches using " << opt_.threads
@@ -237,9 +344,9 @@ void Classifier::run(const std::string& objects, const std::string& results) {
     simple(objects, results);
     return;
   }
-  std::ifstream in(objects);
+  GzLines in(objects);
   std::string line;
-  get_line(in, line);
+  in.line(line);
   std::vector<std::string> ele = split_seps(line, " \t,");
   if ((!line.empty() && (line[0] == '>' || line[0] == '@')) || ele.size() == 2) {
     std::cout << "Processing file'" << objects << "' in " << opt_.batches << " batches using " << opt_.threads
@@ -259,19 +366,19 @@ void Classifier::run(const std::string& objects, const std::string& results) {
 
 void Classifier::run_paired(const std::string& f1, const std::string& f2, const std::string& results) {
   auto one = [&](const std::string& a, const std::string& b, const std::string& res, bool list_mode) {
-    const std::string merged_name = a + "_ConcatenatedByCLARK.fa";
-    std::string merged = merge_paired(a, b);
+    const std::string merged_name = a + "_ConcatenatedByCLARK.fa";   // the reference's temporary file (CuCLARK_hh.hh:445-446)
     if (list_mode) std::cout << "> Processing file: '" << merged_name << "' in " << opt_.batches << " batches." << std::endl;
     else std::cout << "Processing file: '" << merged_name << "' in " << opt_.batches << " batches using " << opt_.threads
                    << " CPU thread(s)." << std::endl;
-    if (merged.empty()) { std::cerr << "Failed to open " << merged_name << std::endl; return; }
-    run_buffer((const uint8_t*)merged.data(), merged.size(), res, true);
+    PairedSource src(a, b, segment_bytes_);
+    if (!src.ok()) { std::cerr << "Failed to open " << merged_name << std::endl; return; }
+    run_segments(src, res, true);
   };
   bool list_mode = false;
   if (file_exists(results)) {
-    std::ifstream in(f1);
+    GzLines in(f1);
     std::string line;
-    get_line(in, line);
+    in.line(line);
     std::vector<std::string> ele = split_seps(line, " \t,");
     list_mode = !((!line.empty() && (line[0] == '>' || line[0] == '@')) || ele.size() == 2);
   }
@@ -283,23 +390,94 @@ void Classifier::run_paired(const std::string& f1, const std::string& f2, const 
 }
 
 void Classifier::run_buffer(const uint8_t* map, size_t nb, const std::string& results_base, bool paired) {
+  OneBuffer src(map, nb);
+  run_segments(src, results_base, paired);
+}
+
+void Classifier::release_batches() {
+  for (mic_engine* e : engines_) mic_batches_free(e);
+  lent_.clear();
+  slot_reads_ = slot_cont_ = 0;
+}
+
+// batch slots are allocated once and reused by every segment; they grow when a segment needs more
+void Classifier::ensure_batches(size_t max_reads, size_t max_cont) {
+  if (!lent_.empty() && max_reads <= slot_reads_ && max_cont <= slot_cont_) return;
+  release_batches();
+  const size_t n_eng = engines_.size();
+  slots_per_engine_ = (opt_.batches + n_eng - 1) / n_eng;
+  slot_reads_ = max_reads + max_reads / 8 + 64;
+  slot_cont_ = max_cont + max_cont / 8 + 64;
+  row_words_ = opt_.extended ? (uint32_t)std::min<size_t>(names_.size() + 1, 65) : 16;
+  lent_.resize(n_eng);
+  std::vector<uint32_t> index(slots_per_engine_ + 1);
+  for (size_t i = 0; i <= slots_per_engine_; ++i) index[i] = (uint32_t)(i * slot_reads_);   // fixed stride: slot i owns rows [i*S, (i+1)*S)
+  for (size_t d = 0; d < n_eng; ++d) {
+    Lent& L = lent_[d];
+    L.rp.resize(slots_per_engine_); L.ct.resize(slots_per_engine_);
+    check(mic_batches_alloc(engines_[d], slots_per_engine_ * slot_reads_, slot_reads_, slot_cont_, index.data(), opt_.extended ? 1 : 0,
+                            &L.results, &L.rows, L.rp.data(), L.ct.data()), "batch allocation");
+  }
+}
+
+void Classifier::run_segments(SegmentSource& src, const std::string& results_base, bool paired) {
   const std::string csv = results_base + ".csv";  // CuCLARK_hh.hh:539-540
   FILE* fout = fopen(csv.c_str(), "w");
   if (!fout) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return; }
   struct timeval t0, t1;
   gettimeofday(&t0, nullptr);
+  n_objects_ = 0;
+  {  // header (CuCLARK_hh.hh:1957-1972)
+    std::vector<const char*> nm(names_.size());
+    size_t cap = 256;
+    for (size_t t = 0; t < names_.size(); ++t) { nm[t] = names_[t].c_str(); cap += names_[t].size() + 2; }
+    std::vector<char> hb(cap);
+    int w = mic_csv_header(hb.data(), hb.size(), opt_.extended ? 1 : 0, nm.data(), (uint32_t)names_.size());
+    if (w > 0) fwrite(hb.data(), 1, (size_t)w, fout);
+  }
+  // double buffering: segment i+1 is produced on a side thread while segment i is classified
+  Segment cur, nxt;
+  bool have = src.next(cur);
+  std::string err;
+  while (have) {
+    bool have_next = false;
+    std::string reader_err;
+    std::thread reader([&] {
+      try { have_next = src.next(nxt); } catch (const std::exception& ex) { reader_err = ex.what(); }
+    });
+    try { process_segment(cur.p, cur.n, paired, fout); } catch (const std::exception& ex) { if (err.empty()) err = ex.what(); }
+    reader.join();
+    if (err.empty() && !reader_err.empty()) err = reader_err;
+    if (!err.empty()) break;
+    std::swap(cur, nxt);
+    if (!cur.own.empty()) cur.p = (const uint8_t*)cur.own.data();
+    nxt = Segment();
+    have = have_next;
+  }
+  fclose(fout);
+  release_batches();
+  if (!err.empty()) die(err);
+  gettimeofday(&t1, nullptr);
+  const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
+  std::cout << " - Assignment time: " << diff << " s. Speed: ";  // CuCLARK_hh.hh:1938-1944
+  std::cout << (size_t)(((double)n_objects_) / (diff) * 60.0) << " objects/min. (" << n_objects_ << " objects)." << std::endl;
+  std::cout << " - Results stored in " << csv << std::endl;
+}
+
+void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FILE* fout) {
+  struct timeval t0;
+  gettimeofday(&t0, nullptr);
   const bool timing = getenv("MIC_CLI_TIMING") != nullptr;
+  double last = 0;
   auto lap = [&](const char* what) {
     if (!timing) return;
     struct timeval t; gettimeofday(&t, nullptr);
-    static double last = 0;
     double now = (t.tv_sec - t0.tv_sec) + (t.tv_usec - t0.tv_usec) / 1e6;
-    std::cerr << "[timing] " << what << ": " << (now - last) << " s (t=" << now << ")" << std::endl;
+    std::cerr << "[timing] " << what << ": " << (now - last) << " s" << std::endl;
     last = now;
   };
-
   // ---- index (CuCLARK_hh.hh:1339-1534)
-  if (map[0] != '>' && map[0] != '@') { std::cerr << "Failed to recognize the format of the file." << std::endl; exit(-1); }
+  if (nb == 0 || (map[0] != '>' && map[0] != '@')) { std::cerr << "Failed to recognize the format of the file." << std::endl; exit(-1); }
   size_t cap = std::max<size_t>(1024, nb / 96);
   std::vector<uint64_t> name_s, name_e, seq_s, seq_e, length;
   long n_reads;
@@ -311,54 +489,30 @@ void Classifier::run_buffer(const uint8_t* map, size_t nb, const std::string& re
     if ((size_t)n_reads <= cap) break;
     cap = (size_t)n_reads;
   }
-  n_objects_ = (size_t)n_reads;
+  const size_t N = (size_t)n_reads;
+  n_objects_ += N;
   lap("index reads");
-  const size_t N = n_objects_;
   const int k = (int)opt_.k;
   const size_t n_eng = engines_.size();
   const size_t nb_total = std::max<size_t>(1, std::min(opt_.batches, std::max<size_t>(N, 1)));
   const size_t per = (N + nb_total - 1) / nb_total;
   std::vector<size_t> cut(nb_total + 1);
   for (size_t b = 0; b <= nb_total; ++b) cut[b] = std::min(N, b * per);
-
-  // ---- per-engine batch tables
-  struct Lent { uint32_t* results = nullptr; uint32_t* rows = nullptr; std::vector<uint32_t*> rp; std::vector<uint16_t*> ct;
-                std::vector<uint32_t> index; };
-  std::vector<Lent> lent(n_eng);
   size_t max_reads = 0, max_cont = 0;
-  for (size_t b = 0; b < nb_total; ++b) {
-    max_reads = std::max(max_reads, cut[b + 1] - cut[b]);
-    max_cont = std::max(max_cont, mic_pack_bound(seq_s.data() + cut[b], seq_e.data() + cut[b], cut[b + 1] - cut[b], k));
-  }
-  const size_t local_batches = (nb_total + n_eng - 1) / n_eng;
-  for (size_t d = 0; d < n_eng; ++d) {
-    Lent& L = lent[d];
-    L.index.assign(local_batches + 1, 0);
-    for (size_t lb = 0; lb < local_batches; ++lb) {
-      size_t b = lb * n_eng + d;
-      size_t cnt = b < nb_total ? cut[b + 1] - cut[b] : 0;
-      L.index[lb + 1] = L.index[lb] + (uint32_t)cnt;
-    }
-    // the engine owns ceil(batches/devices) batch slots; a file with fewer reads than batches leaves some empty
-    L.rp.resize(local_batches); L.ct.resize(local_batches);
-    std::vector<uint32_t> full_index(((opt_.batches + n_eng - 1) / n_eng) + 1, L.index.back());
-    for (size_t i = 0; i < L.index.size(); ++i) full_index[i] = L.index[i];
-    std::vector<uint32_t*> rp(full_index.size() - 1); std::vector<uint16_t*> ct(full_index.size() - 1);
-    check(mic_batches_alloc(engines_[d], L.index.back(), max_reads, max_cont, full_index.data(), opt_.extended ? 1 : 0,
-                            &L.results, &L.rows, rp.data(), ct.data()), "batch allocation");
-    for (size_t lb = 0; lb < local_batches; ++lb) { L.rp[lb] = rp[lb]; L.ct[lb] = ct[lb]; }
-  }
-
-  lap("allocate batches");
-  // ---- header
   {
-    std::vector<const char*> nm(names_.size());
-    for (size_t t = 0; t < names_.size(); ++t) nm[t] = names_[t].c_str();
-    std::vector<char> hb(256 + names_.size() * 64);
-    for (size_t t = 0; t < names_.size(); ++t) hb.resize(hb.size() + names_[t].size());
-    int w = mic_csv_header(hb.data(), hb.size(), opt_.extended ? 1 : 0, nm.data(), (uint32_t)names_.size());
-    if (w > 0) fwrite(hb.data(), 1, (size_t)w, fout);
+    std::vector<size_t> bound(nb_total);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (long b = 0; b < (long)nb_total; ++b)
+      bound[b] = mic_pack_bound(seq_s.data() + cut[b], seq_e.data() + cut[b], cut[b + 1] - cut[b], k);
+    for (size_t b = 0; b < nb_total; ++b) {
+      max_reads = std::max(max_reads, cut[b + 1] - cut[b]);
+      max_cont = std::max(max_cont, bound[b]);
+    }
   }
+  ensure_batches(max_reads, max_cont);
+  lap("batch slots");
 
   // ---- batches: pack -> query -> wait -> format; ordered write
   std::vector<std::string> out(nb_total);
@@ -369,7 +523,7 @@ void Classifier::run_buffer(const uint8_t* map, size_t nb, const std::string& re
   const uint32_t T = (uint32_t)names_.size();
   std::vector<const char*> nm(names_.size());
   for (size_t t = 0; t < names_.size(); ++t) nm[t] = names_[t].c_str();
-  const uint32_t row_words = opt_.extended ? (uint32_t)std::min<size_t>(names_.size() + 1, 65) : 16;
+  const uint32_t row_words = row_words_;
   const size_t line_cap = 512 + (opt_.extended ? (size_t)T * 12 : 0);
 
 #ifdef _OPENMP
@@ -377,10 +531,10 @@ void Classifier::run_buffer(const uint8_t* map, size_t nb, const std::string& re
 #endif
   for (long bi = 0; bi < (long)nb_total; ++bi) {
     const size_t b = (size_t)bi, d = b % n_eng, lb = b / n_eng;
-    Lent& L = lent[d];
+    Lent& L = lent_[d];
     const size_t r0 = cut[b], cnt = cut[b + 1] - cut[b];
     try {
-      size_t m = mic_pack_reads(map, seq_s.data() + r0, seq_e.data() + r0, length.data() + r0, cnt, k, L.rp[lb], L.ct[lb], max_cont);
+      size_t m = mic_pack_reads(map, seq_s.data() + r0, seq_e.data() + r0, length.data() + r0, cnt, k, L.rp[lb], L.ct[lb], slot_cont_);
       if (m == (size_t)-1) die("ERROR: Batch overflow. Please increase the number of batches (-b <numberofbatches>).");
       check(mic_batch_ready(engines_[d], lb, cnt, m), "readyBatch");
       check(mic_batch_query(engines_[d], lb, opt_.extended ? 1 : 0, 0), "queryBatch");
@@ -389,8 +543,8 @@ void Classifier::run_buffer(const uint8_t* map, size_t nb, const std::string& re
       s.reserve(cnt * (opt_.extended ? 64 + 3 * (size_t)T : 72));
       std::vector<char> line(line_cap);
       std::vector<uint32_t> dense;
-      const uint32_t* res = L.results + (size_t)L.index[lb] * MIC_RESULT_WORDS;
-      const uint32_t* rows = L.rows ? L.rows + (size_t)L.index[lb] * row_words : nullptr;
+      const uint32_t* res = L.results + lb * slot_reads_ * MIC_RESULT_WORDS;
+      const uint32_t* rows = L.rows ? L.rows + lb * slot_reads_ * row_words : nullptr;
       for (size_t i = 0; i < cnt; ++i) {
         const size_t r = r0 + i;
         const uint32_t* row = rows ? rows + i * row_words : nullptr;
@@ -418,16 +572,7 @@ void Classifier::run_buffer(const uint8_t* map, size_t nb, const std::string& re
     }
   }
   lap("pack + query + format + write");
-  fclose(fout);
-  for (mic_engine* e : engines_) mic_batches_free(e);
-  lap("free batches");
   if (!err.empty()) die(err);
-
-  gettimeofday(&t1, nullptr);
-  const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
-  std::cout << " - Assignment time: " << diff << " s. Speed: ";  // CuCLARK_hh.hh:1938-1944
-  std::cout << (size_t)(((double)n_objects_) / (diff) * 60.0) << " objects/min. (" << n_objects_ << " objects)." << std::endl;
-  std::cout << " - Results stored in " << csv << std::endl;
 }
 
 }  // namespace mic

@@ -39,14 +39,27 @@ class Classifier {
   void run(const std::string& objects, const std::string& results);
   void run_paired(const std::string& f1, const std::string& f2, const std::string& results);
 
-  // CuCLARK::runSimple (:512-574) on an in-memory FASTA/FASTQ image; `shown_name` is what the messages print.
+  // CuCLARK::runSimple (:512-574) on an in-memory FASTA/FASTQ image.
   void run_buffer(const uint8_t* map, size_t nb, const std::string& results_base, bool paired);
+  // The same over a stream of segments (whole records each): the next segment is read / inflated / merged on a side
+  // thread while the current one is indexed, packed, queried and written.  Memory is bounded by two segments.
+  struct Segment { const uint8_t* p = nullptr; size_t n = 0; std::string own; };
+  class SegmentSource { public: virtual ~SegmentSource() {} virtual bool next(Segment& s) = 0; };
+  void run_segments(SegmentSource& src, const std::string& results_base, bool paired);
 
   std::string db_name() const;  // getdbName, CuCLARK_hh.hh:580-591
   const std::vector<std::string>& target_names() const { return names_; }
 
  private:
   void parse_targets();  // getTargetsData, CuCLARK_hh.hh:1795-1906
+  void process_segment(const uint8_t* map, size_t nb, bool paired, FILE* fout);
+  void ensure_batches(size_t max_reads, size_t max_cont);
+  void release_batches();
+  struct Lent { uint32_t* results = nullptr; uint32_t* rows = nullptr; std::vector<uint32_t*> rp; std::vector<uint16_t*> ct; };
+  std::vector<Lent> lent_;
+  size_t slot_reads_ = 0, slot_cont_ = 0, slots_per_engine_ = 0;
+  uint32_t row_words_ = 16;
+  size_t segment_bytes_ = 512u << 20;
   Options opt_;
   std::vector<std::pair<std::string, std::string>> targets_id_;
   std::vector<std::string> labels_, labels_c_, names_;

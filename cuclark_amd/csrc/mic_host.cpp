@@ -134,6 +134,13 @@ static size_t find_record_start(const uint8_t* map, size_t nb, bool fasta, size_
   return nb;
 }
 
+// exported form: position of the first record marker at or after `from`, or nb
+size_t mic_find_record_start(const uint8_t* map, size_t nb, size_t from) {
+  if (!map || nb == 0 || (map[0] != '>' && map[0] != '@')) return nb;
+  if (from == 0) return 0;
+  return find_record_start(map, nb, map[0] == '>', from);
+}
+
 // Parallel form of mic_index_reads: the file is cut into `n_threads` byte ranges, each range is indexed from the first
 // record that starts in it.  Same output as the serial function for well-formed FASTA/FASTQ.
 long mic_index_reads_parallel(const uint8_t* map, size_t nb, int n_threads, size_t cap, uint64_t* name_s, uint64_t* name_e,

@@ -179,6 +179,9 @@ long mic_index_reads(const uint8_t* map, size_t nb, size_t cap, uint64_t* name_s
  * found like the reference finds its batch starts, CuCLARK_hh.hh:1409-1471). */
 long mic_index_reads_parallel(const uint8_t* map, size_t nb, int n_threads, size_t cap, uint64_t* name_s, uint64_t* name_e,
                               uint64_t* seq_s, uint64_t* seq_e, uint64_t* length);
+/* Position of the first record ('>' at a line start; '@' line followed by a letters-only line and a '+' line) at or
+ * after byte `from`, or nb: lets callers cut a large input into segments of whole records. */
+size_t mic_find_record_start(const uint8_t* map, size_t nb, size_t from);
 /* Upper bound of containers mic_pack_reads can emit for these reads. */
 size_t mic_pack_bound(const uint64_t* seq_s, const uint64_t* seq_e, size_t n_reads, int k);
 /* Read packer, CuCLARK_hh.hh:1616-1716.  Returns containers written or (size_t)-1 if cap is too small. */

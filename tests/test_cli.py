@@ -128,3 +128,27 @@ def test_full_cli_matches_golden_and_missing_targets(tmp_path):
     open(bad, "w").write("/nonexistent/genome.fa L1\n")
     r = _run([EXE, "-k", "31", "-T", bad, "-D", d, "-O", os.path.join(gu.GOLDEN, "reads_k31.fa"), "-R", out])
     assert r.returncode != 0 and "Failed to open file: /nonexistent/genome.fa defined in" in r.stderr
+
+
+@pytest.mark.gpu
+def test_streaming_segments_give_identical_csv(tmp_path):
+    """Inputs are processed as a stream of segments (whole records each); tiny segments must not change a byte."""
+    import gzip
+    import shutil
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "light_k27_u32", light=True)
+    t = _targets_file(tmp)
+    gz = os.path.join(tmp, "reads.fq.gz")
+    with open(os.path.join(gu.GOLDEN, "reads_k27.fq"), "rb") as fi, gzip.open(gz, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    cases = [(["-O", os.path.join(gu.GOLDEN, "reads_k27.fa")], "expected_k27_fa.csv"),
+             (["-O", os.path.join(gu.GOLDEN, "reads_k27.fq")], "expected_k27_fq.csv"),
+             (["-O", gz], "expected_k27_fq.csv"),
+             (["-P", os.path.join(gu.GOLDEN, "pairs_k27_1.fq"), os.path.join(gu.GOLDEN, "pairs_k27_2.fq")], "expected_k27_pairs.csv")]
+    for seg_kb in ("1", "3"):
+        for src, exp in cases:
+            out = os.path.join(tmp, f"s{seg_kb}_{exp}")
+            r = _run([EXE_L, "-T", t, "-D", d, *src, "-R", out, "-n", "3", "-b", "4"], env=dict(os.environ, MIC_SEGMENT_KB=seg_kb))
+            assert r.returncode == 0, r.stderr
+            assert open(out + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, exp), "rb").read(), (seg_kb, exp)
+            assert "(131 objects)" in r.stdout or "(80 objects)" in r.stdout or "(40 objects)" in r.stdout
