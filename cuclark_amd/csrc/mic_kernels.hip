@@ -451,263 +451,6 @@ __global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
   }
 }
 
-// =====================================================================================================================
-// query_kernel_m2 — query_kernel_m software-pipelined across chunks.
-// The wave walks a stream of items (CHUNK = up to 128 k-mers of one part, END = end of a read).  While item i waits for
-// its second-level slots (round 2) and is tallied / finished, the first-level slots of item i+1 are already in flight:
-//   Q1(i):   s_waitcnt vmcnt(0)            round-1 slots of i are in LDS area A (issued one iteration ago)
-//            compare round 1, issue round-2 DMA of i into area B            (always M2_NG2 instructions)
-//   P(i+1):  k-mers, minimizers, slots of i+1; run detection; round-1 DMA of i+1 into area A (always M2_NG1 instructions)
-//   Q2(i):   s_waitcnt vmcnt(M2_NG1)       everything older than the M2_NG1 youngest loads has landed: round 2 of i
-//            compare round 2, deeper rounds (synchronous, rare), tally / finish_read
-// LDS-DMA (global_load_lds_dwordx4) moves slots HBM -> LDS without VGPRs, which is what makes two streams affordable.
-// Every iteration issues exactly M2_NG2 + M2_NG1 DMA instructions with all lanes active (idle lanes re-fetch a staged
-// slot), so the counted wait is exact.
-// =====================================================================================================================
-#define M2_RMAX1 32
-#define M2_RMAX2 16
-#define M2_NG1 (M2_RMAX1 / 8)
-#define M2_NG2 (M2_RMAX2 / 8)
-
-struct M2Item {   // wave-uniform
-  uint32_t kind;   // 0 = end of stream, 1 = chunk, 2 = end of read
-  uint32_t r, first, cend, base, nk;
-  bool ahead;      // first chunk of the read's first part: window comes from the read-ahead registers
-};
-
-__global__ void __launch_bounds__(256, 7) query_kernel_m2(const MicQueryArgs a) {
-  __shared__ uint4 s_stage_a[4][M2_RMAX1 * 8];
-  __shared__ uint4 s_stage_b[4][M2_RMAX2 * 8];
-  __shared__ uint32_t s_run_a[4][M2_RMAX1];
-  __shared__ uint32_t s_run_b[4][M2_RMAX2];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  uint4* stage_a = s_stage_a[wv];
-  uint4* stage_b = s_stage_b[wv];
-  uint32_t* run_a = s_run_a[wv];
-  uint32_t* run_b = s_run_b[wv];
-  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
-  const uint32_t n_waves = gridDim.x * 4;
-  const MicTable& t = a.t;
-  const int k = t.k, m = t.m, w = k - m + 1;
-  const uint4* __restrict__ slots = t.slots;
-  const uint16_t* __restrict__ cont = a.cont;
-  const uint64_t lane_le = lane == 63 ? ~0ULL : ((2ULL << lane) - 1);
-
-  // ---- helpers ------------------------------------------------------------------------------------------------------
-  auto detect = [&](uint32_t s0, uint32_t s1, bool& f0, bool& f1, uint32_t& rid0, uint32_t& rid1, uint32_t& R) {
-    uint32_t p0 = bperm((lane + 63) & 63, s0), p1 = bperm((lane + 63) & 63, s1);
-    uint32_t last0 = bperm(63, s0);
-    if (lane == 0) { p0 = 0xFFFFFFFFu; p1 = last0; }
-    f0 = s0 != 0xFFFFFFFFu && s0 != p0; f1 = s1 != 0xFFFFFFFFu && s1 != p1;
-    const uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
-    const uint32_t R0 = __popcll(b0);
-    R = R0 + __popcll(b1);
-    rid0 = __popcll(b0 & lane_le) - 1; rid1 = R0 + __popcll(b1 & lane_le) - 1;
-  };
-  // publish the slots of runs [rbase, rbase+CAP) and fetch them into `stage` with exactly CAP/8 DMA instructions
-  auto stage_runs = [&](uint32_t* runslot, uint4* stage, int cap, bool f0, bool f1, uint32_t rid0, uint32_t rid1, uint32_t s0,
-                        uint32_t s1, uint32_t rbase, uint32_t R) {
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) runslot[0] = 0;                                  // something valid to fetch when there is no run
-    __builtin_amdgcn_wave_barrier();
-    if (f0 && rid0 - rbase < (uint32_t)cap) runslot[rid0 - rbase] = s0;
-    if (f1 && rid1 - rbase < (uint32_t)cap) runslot[rid1 - rbase] = s1;
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t nrun = R > rbase ? (R - rbase < (uint32_t)cap ? R - rbase : (uint32_t)cap) : 0;
-    for (int i = 0; i < cap / 8; ++i) {
-      uint32_t rr = 8 * i + (lane >> 3);
-      if (rr >= nrun) rr = 0;                                        // idle lanes duplicate run 0: EXEC stays full
-      const uint32_t sidx = runslot[rr];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx * 8 + (lane & 7)),
-                                       (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
-    }
-  };
-  // search the staged slot `rl` for cc: label+1 on a leaf hit, child slot for a directory, else nothing
-  auto lookup = [&](const uint4* stage, uint32_t rl, uint64_t cc, uint32_t& out, uint32_t& nxt) {
-    const uint4* sp = stage + rl * 8;
-    const unsigned long long* keys = (const unsigned long long*)sp;
-    const uint4 meta = sp[7];
-    uint32_t pos = 0; uint64_t lastle = ~0ULL;
-    { uint64_t kx = keys[7]; if (kx <= cc) { pos = 8; lastle = kx; } }
-    { uint32_t i = pos + 3; uint64_t kx = i < 12 ? keys[i] : ~0ULL; if (kx <= cc) { pos += 4; lastle = kx; } }
-    { uint32_t i = pos + 1; uint64_t kx = i < 12 ? keys[i] : ~0ULL; if (kx <= cc) { pos += 2; lastle = kx; } }
-    { uint32_t i = pos;     uint64_t kx = i < 12 ? keys[i] : ~0ULL; if (kx <= cc) { pos += 1; lastle = kx; } }
-    out = 0; nxt = 0xFFFFFFFFu;
-    if (!(meta.z & MIC_M_DIR)) {
-      if (pos && lastle == cc) out = (uint32_t)((const uint16_t*)sp)[48 + pos - 1] + 1;
-    } else if (pos) {
-      nxt = sp[6].x + (pos - 1);
-    }
-  };
-
-  // ---- item stream (wave-uniform state) --------------------------------------------------------------------------------
-  ReadAhead cur, nxt, nn;
-  uint32_t rd = wave0;                 // read the iterator is inside
-  ahead_ptr(a, rd, cur);
-  ahead_window(cont, rd, a.n_reads, lane, cur);
-  ahead_ptr(a, rd + n_waves, nxt);
-  ahead_window(cont, rd + n_waves, a.n_reads, lane, nxt);
-  ahead_ptr(a, rd + 2 * n_waves, nn);
-  uint32_t it_pp = __builtin_amdgcn_readfirstlane(cur.pp), it_pe = __builtin_amdgcn_readfirstlane(cur.pe);
-  uint32_t it_hdr = __builtin_amdgcn_readfirstlane(cur.hdr), it_w = cur.w;   // header / window of the read's first part
-  bool it_first_part = true, it_in_part = false, it_ahead = false;
-  uint32_t it_first = 0, it_cend = 0, it_nk = 0, it_base = 0;
-  auto next_item = [&](M2Item& it) {
-    for (;;) {
-      if (rd >= a.n_reads) { it.kind = 0; return; }
-      if (it_in_part) {
-        if (it_base < it_nk) {
-          it.kind = 1; it.r = rd; it.first = it_first; it.cend = it_cend; it.base = it_base; it.nk = it_nk;
-          it.ahead = it_ahead && it_base == 0;
-          it_base += 128;
-          return;
-        }
-        it_in_part = false;
-      }
-      if (it_pp < it_pe) {
-        const uint32_t plen = it_first_part ? it_hdr : __builtin_amdgcn_readfirstlane((uint32_t)cont[it_pp]);
-        it_ahead = it_first_part;
-        it_first_part = false;
-        if (plen == 0) { it_pp = it_pe; continue; }
-        it_first = it_pp + 1; it_pp = it_first + (plen + 7) / 8; it_cend = it_pp;
-        if (plen < (uint32_t)k) continue;
-        it_nk = plen - k + 1; it_base = 0; it_in_part = true;
-        continue;
-      }
-      it.kind = 2; it.r = rd;          // end of this read; move the iterator (and the read-ahead chain) to the next one
-      rd += n_waves;
-      cur = nxt; nxt = nn;
-      ahead_window(cont, rd + n_waves, a.n_reads, lane, nxt);
-      ahead_ptr(a, rd + 2 * n_waves, nn);
-      it_pp = __builtin_amdgcn_readfirstlane(cur.pp); it_pe = __builtin_amdgcn_readfirstlane(cur.pe);
-      it_hdr = __builtin_amdgcn_readfirstlane(cur.hdr); it_w = cur.w;
-      it_first_part = true; it_in_part = false;
-      return;
-    }
-  };
-
-  // per-lane state of a chunk in flight
-  struct Chunk { uint64_t c0, c1; uint32_t sl0, sl1, rid0, rid1, R; };
-  // P: k-mers / minimizers / slots of `it`, run detection, round-1 DMA into area A (always M2_NG1 instructions)
-  auto stage_p = [&](const M2Item& it, uint32_t wd_ahead, Chunk& ch) {
-    ch.c0 = ch.c1 = 0; ch.sl0 = ch.sl1 = 0xFFFFFFFFu; ch.rid0 = ch.rid1 = 0; ch.R = 0;
-    bool f0 = false, f1 = false;
-    if (it.kind == 1) {
-      ReadAhead ra; ra.pp = 0; ra.pe = 0; ra.hdr = 0; ra.w = wd_ahead;
-      const uint32_t wd = window_word(cont, it.first, it.cend, it.base, lane, it.ahead, ra);
-      uint64_t c[2]; bool act[2]; uint32_t hk0 = 0, hk1 = 0, hk2;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int idx = 4 * h + (lane >> 4);
-        uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
-        uint64_t kmer = kmer_from_dwords(d0, d1, d2, lane & 15, k);
-        const uint64_t rck = revcomp_bits(kmer, k);
-        c[h] = kmer < rck ? kmer : rck;
-        act[h] = it.base + 64 * h + lane < it.nk;
-        if (t.sharded) {
-          uint64_t q = mic_div(c[h], t.div);
-          uint64_t rem = c[h] - q * t.div.d;
-          act[h] = act[h] && rem >= t.shard_start && rem < t.shard_end;
-        }
-        const uint64_t mf = kmer >> (2 * (k - m)), mr = rck & ((1ULL << (2 * m)) - 1);
-        uint32_t key = mmer_order_key_canon(mf < mr ? mf : mr);
-        if (h == 0) hk0 = key; else hk1 = key;
-      }
-      {
-        const int idx = 8 + (lane >> 4);
-        uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
-        uint64_t mm = kmer_from_dwords(d0, d1, d2, lane & 15, m);
-        hk2 = lane < w - 1 ? mmer_order_key(mm, m) : 0xFFFFFFFFu;
-      }
-      sliding_min3(hk0, hk1, hk2, w, lane);
-      ch.c0 = c[0]; ch.c1 = c[1];
-      ch.sl0 = act[0] ? mslot_of_key(hk0, (uint32_t)t.n_main) : 0xFFFFFFFFu;
-      ch.sl1 = act[1] ? mslot_of_key(hk1, (uint32_t)t.n_main) : 0xFFFFFFFFu;
-      detect(ch.sl0, ch.sl1, f0, f1, ch.rid0, ch.rid1, ch.R);
-    }
-    stage_runs(run_a, stage_a, M2_RMAX1, f0, f1, ch.rid0, ch.rid1, ch.sl0, ch.sl1, 0, ch.R);
-  };
-
-  RowAcc acc; acc.label1 = 0; acc.count = 0;
-  uint32_t n_ent = 0, overflow = 0, total = 0;
-
-  M2Item item, nitem;
-  Chunk ch, nch;
-  next_item(item);
-  stage_p(item, it_w, ch);              // note: it_w belongs to the read the iterator is in; item is its first chunk at most
-  uint32_t w_for_next = it_w;
-
-  while (item.kind != 0) {
-    // ---- Q1: round-1 slots of `item` have landed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    next_item(nitem);                    // may issue read-ahead loads: older than the DMA below
-    w_for_next = it_w;
-    uint32_t res0 = 0, res1 = 0, nx0 = 0xFFFFFFFFu, nx1 = 0xFFFFFFFFu;
-    if (item.kind == 1) {
-      if (ch.sl0 != 0xFFFFFFFFu && ch.rid0 < M2_RMAX1) lookup(stage_a, ch.rid0, ch.c0, res0, nx0);
-      if (ch.sl1 != 0xFFFFFFFFu && ch.rid1 < M2_RMAX1) lookup(stage_a, ch.rid1, ch.c1, res1, nx1);
-      for (uint32_t rbase = M2_RMAX1; rbase < ch.R; rbase += M2_RMAX1) {   // more than 32 runs in a chunk: synchronous, rare
-        bool f0, f1; uint32_t r0, r1, RR;
-        detect(ch.sl0, ch.sl1, f0, f1, r0, r1, RR);
-        stage_runs(run_a, stage_a, M2_RMAX1, f0, f1, r0, r1, ch.sl0, ch.sl1, rbase, RR);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        if (ch.sl0 != 0xFFFFFFFFu && r0 - rbase < M2_RMAX1) lookup(stage_a, r0 - rbase, ch.c0, res0, nx0);
-        if (ch.sl1 != 0xFFFFFFFFu && r1 - rbase < M2_RMAX1) lookup(stage_a, r1 - rbase, ch.c1, res1, nx1);
-      }
-    }
-    // round 2 of `item` into area B (always M2_NG2 instructions)
-    bool g0, g1; uint32_t q0, q1, R2;
-    detect(nx0, nx1, g0, g1, q0, q1, R2);
-    stage_runs(run_b, stage_b, M2_RMAX2, g0, g1, q0, q1, nx0, nx1, 0, R2);
-    // ---- P: next item, round 1 into area A (always M2_NG1 instructions)
-    stage_p(nitem, w_for_next, nch);
-    // ---- Q2: everything but the M2_NG1 youngest loads has landed
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(M2_NG1) : "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (item.kind == 1) {
-      uint32_t s0 = nx0, s1 = nx1;
-      uint32_t rb = 0;
-      while (__ballot(s0 != 0xFFFFFFFFu) | __ballot(s1 != 0xFFFFFFFFu)) {
-        uint32_t y0 = 0xFFFFFFFFu, y1 = 0xFFFFFFFFu;
-        if (s0 != 0xFFFFFFFFu && q0 - rb < M2_RMAX2) { uint32_t o; lookup(stage_b, q0 - rb, ch.c0, o, y0); res0 = o; s0 = 0xFFFFFFFEu; }
-        if (s1 != 0xFFFFFFFFu && q1 - rb < M2_RMAX2) { uint32_t o; lookup(stage_b, q1 - rb, ch.c1, o, y1); res1 = o; s1 = 0xFFFFFFFEu; }
-        // lanes marked 0xFFFFFFFE were served this pass; others (run index beyond the staged window) wait for the next
-        const bool more_window = (__ballot(s0 != 0xFFFFFFFFu && s0 != 0xFFFFFFFEu) | __ballot(s1 != 0xFFFFFFFFu && s1 != 0xFFFFFFFEu)) != 0;
-        if (more_window) {               // more than 16 second-level runs: stage the next window synchronously
-          rb += M2_RMAX2;
-          const uint32_t t0 = s0 == 0xFFFFFFFEu ? 0xFFFFFFFFu : s0, t1 = s1 == 0xFFFFFFFEu ? 0xFFFFFFFFu : s1;
-          // keep run numbering of this round: lanes already served are excluded by their window test
-          stage_runs(run_b, stage_b, M2_RMAX2, g0, g1, q0, q1, nx0, nx1, rb, R2);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_wave_barrier();
-          s0 = t0; s1 = t1;
-          // carry the children found so far
-          if (y0 != 0xFFFFFFFFu || y1 != 0xFFFFFFFFu) { /* handled below after the window loop */ }
-          nx0 = (s0 == 0xFFFFFFFFu) ? y0 : nx0; nx1 = (s1 == 0xFFFFFFFFu) ? y1 : nx1;
-          continue;
-        }
-        // this round is complete: descend (round 3+, synchronous)
-        nx0 = y0; nx1 = y1; s0 = y0; s1 = y1;
-        if (__ballot(s0 != 0xFFFFFFFFu) | __ballot(s1 != 0xFFFFFFFFu)) {
-          detect(nx0, nx1, g0, g1, q0, q1, R2);
-          rb = 0;
-          stage_runs(run_b, stage_b, M2_RMAX2, g0, g1, q0, q1, nx0, nx1, 0, R2);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      tally2(res0, res1, acc, n_ent, overflow, total, lane);
-    } else {
-      finish_read(acc, n_ent, total, overflow, item.r, a, lane);
-      acc.label1 = 0; acc.count = 0; n_ent = 0; overflow = 0; total = 0;
-    }
-    item = nitem; ch = nch;
-  }
-}
-
 // ---- merge / result on sparse rows ----------------------------------------------------------------
 // mergeKernel (CuClarkDB.cu:1321-1415): one thread per read, two-pointer merge by ascending target.
 __global__ void merge_rows_kernel(const uint32_t* __restrict__ ra, const uint32_t* __restrict__ rb,
@@ -962,9 +705,7 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   static int per_cu = [] { const char* e = getenv("MIC_BLOCKS_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();
   unsigned cap = (unsigned)n_cu * (unsigned)per_cu;
   if (blocks > cap) blocks = cap;
-  static int mkernel = [] { const char* e = getenv("MIC_MKERNEL"); return e ? atoi(e) : 2; }();
-  if (a.t.layout && mkernel == 2) query_kernel_m2<<<blocks, 256, 0, s>>>(a);
-  else if (a.t.layout) query_kernel_m<<<blocks, 256, 0, s>>>(a);
+  if (a.t.layout) query_kernel_m<<<blocks, 256, 0, s>>>(a);
   else if (slot_class == 64) query_kernel<true><<<blocks, 256, 0, s>>>(a);
   else query_kernel<false><<<blocks, 256, 0, s>>>(a);
   return hipGetLastError();
