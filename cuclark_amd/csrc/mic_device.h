@@ -19,10 +19,12 @@ __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
 #define QP_XOR2 0x4E
 
 // reverse complement of a k-mer value: reverse all 64 bits, swap the two bits of every pair back, complement
+// (written on the 32-bit halves so that each pair swap is shift, shift, v_bfi: the query kernel is VALU-issue bound)
 __device__ __forceinline__ uint64_t revcomp_bits(uint64_t x, int k) {
-  uint64_t r = __builtin_bitreverse64(x);
-  r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
-  return (~r) >> (64 - 2 * k);
+  uint32_t rh = __builtin_bitreverse32((uint32_t)x), rl = __builtin_bitreverse32((uint32_t)(x >> 32));
+  rh = ((rh >> 1) & 0x55555555u) | ((rh << 1) & ~0x55555555u);
+  rl = ((rl >> 1) & 0x55555555u) | ((rl << 1) & ~0x55555555u);
+  return (((uint64_t)~rh << 32) | (uint32_t)~rl) >> (64 - 2 * k);
 }
 
 __device__ __forceinline__ uint64_t canonical(uint64_t kmer, int k) {
@@ -36,15 +38,16 @@ __device__ __forceinline__ uint64_t canonical(uint64_t kmer, int k) {
 // m-mers) agree, and ties between different m-mers are harmless.
 __device__ __forceinline__ uint32_t mmer_order_key_canon(uint64_t u) {   // u = canonical m-mer value
   uint32_t h = (uint32_t)u * 0x9E3779B1u ^ ((uint32_t)(u >> 32) * 0x85EBCA77u + 0x27D4EB2Fu);
-  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  h ^= h >> 15; h *= 0x2C1B3C6Du;      // one multiply-xorshift round: the order only has to look random
   return h;
 }
 
 __device__ __forceinline__ uint32_t mmer_order_key(uint64_t x, int m) { return mmer_order_key_canon(canonical(x, m)); }
 
 __device__ __forceinline__ uint32_t mslot_of_key(uint32_t min_key, uint32_t n_slots) {
-  uint32_t z = min_key * 0xC2B2AE3Du + 0x27D4EB2Fu;
-  z ^= z >> 16; z *= 0x165667B1u; z ^= z >> 15;
+  // the minimum of w hashes is small: remix before taking the high bits
+  uint32_t z = min_key * 0xC2B2AE3Du;
+  z ^= z >> 15; z *= 0x165667B1u;
   return __umulhi(z, n_slots);
 }
 
