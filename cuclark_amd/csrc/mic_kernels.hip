@@ -69,6 +69,17 @@ __device__ __forceinline__ uint32_t window_word(const uint16_t* __restrict__ con
   return w;
 }
 
+__device__ __forceinline__ uint32_t window_word_w(const uint16_t* __restrict__ cont, uint32_t first, uint32_t cend,
+                                                  uint32_t base, int lane, bool use_ahead, uint32_t ahead_w) {
+  uint32_t w = 0;
+  const uint32_t ci = first + base / 8 + 2 * lane;
+  if (use_ahead) w = ahead_w;
+  else if (lane < 10) w = ((ci < cend ? (uint32_t)cont[ci] : 0u) << 16) | (ci + 1 < cend ? (uint32_t)cont[ci + 1] : 0u);
+  if (lane >= 10 || ci >= cend) w &= 0x0000FFFFu;
+  if (lane >= 10 || ci + 1 >= cend) w &= 0xFFFF0000u;
+  return w;
+}
+
 struct Probe {  // what a pass lane knows about its k-mer
   uint32_t slot;  // slot index relative to the shard, 0xFFFFFFFF = nothing to probe
   uint32_t qlo, qhi;
@@ -208,7 +219,10 @@ __device__ __forceinline__ void finish_read(const RowAcc& acc, uint32_t n_ent, u
     hi.y = n_ent; hi.z = flags; hi.w = 0;
     uint4* out = (uint4*)(a.results + (size_t)r * 8);
     out[0] = lo; out[1] = hi;
-    if (flags && a.flagged) {
+  }
+  // wave-uniform branch: the wait for the atomic's return value must not sit on the common path
+  if (__builtin_amdgcn_readfirstlane(flags) && a.flagged) {
+    if (lane == 0) {
       uint32_t pos = atomicAdd(&a.flagged[0], 1u);
       if (pos < a.flagged_cap) a.flagged[1 + pos] = r;
     }
@@ -315,9 +329,22 @@ __device__ __forceinline__ void sliding_min3(uint32_t& a0, uint32_t& a1, uint32_
   if (cover < w) step(w - cover);
 }
 
+// -DMIC_PHASE_TIMING: per-phase cycle sums of query_kernel_m (s_memtime around each phase, one atomicAdd per wave),
+// printed by the launcher.  A measuring build only: the counter reads themselves cost ~5 %.
+#ifdef MIC_PHASE_TIMING
+__device__ unsigned long long g_phase[8];
+#define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ph_t0 = ph_t;
+#define PH(i) { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[i] += n_ - ph_t; ph_t = n_; }
+#define PH_END { ph_acc[7] = __builtin_readcyclecounter() - ph_t0; if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase[i_], ph_acc[i_]); }
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_END
+#endif
 __global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
   __shared__ uint4 s_stage[4][MIC_RMAX * MIC_MSTRIDE];
   __shared__ uint32_t s_run[4][MIC_RMAX];
+  __shared__ uint32_t s_ahead[4][2][64];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   uint4* stage = s_stage[wv];
@@ -330,21 +357,55 @@ __global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
   const uint16_t* __restrict__ cont = a.cont;
   const uint64_t lane_le = lane == 63 ? ~0ULL : ((2ULL << lane) - 1);
 
-  ReadAhead cur, nxt, nn;
-  ahead_ptr(a, wave0, cur);
-  ahead_window(cont, wave0, a.n_reads, lane, cur);
-  ahead_ptr(a, wave0 + n_waves, nxt);
+  PH_DECL
+  // Read-ahead through LDS (global_load_lds_dword): no VGPR lives across a read and no load result is touched near its
+  // issue, so nothing waits for it.  One DMA instruction per read fetches {header + first window of read j+2 (lanes
+  // 0..11, aligned dwords), reads_ptr of read j+3 (lanes 12, 13)}; it is taken one read later, before the result stores
+  // of finish_read (stores count in vmcnt too - waiting for the entry after them would wait for their acknowledgement).
+  uint32_t* ahead0 = s_ahead[wv][0];
+  uint32_t* ahead1 = s_ahead[wv][1];
+  auto ahead_issue = [&](uint32_t* entry, uint32_t pp_w, uint32_t r_ptr) {
+    const uint64_t abase = ((uint64_t)(cont + pp_w)) & ~3ULL;
+    const uint32_t rr = r_ptr < a.n_reads ? r_ptr : a.n_reads - 1;
+    uint64_t addr = abase + 4 * (lane < 12 ? lane : 0);
+    if (lane == 12) addr = (uint64_t)(a.reads_ptr + rr);
+    if (lane == 13) addr = (uint64_t)(a.reads_ptr + rr + 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
+                                     (__attribute__((address_space(3))) void*)entry, 4, 0, 0);
+  };
+  auto ahead_take = [&](const uint32_t* entry, uint32_t pp_w, uint32_t& hdr, uint32_t& wword, uint32_t& npp, uint32_t& npe) {
+    const uint32_t raw = entry[lane];
+    npp = __builtin_amdgcn_readlane(raw, 12); npe = __builtin_amdgcn_readlane(raw, 13);
+    const bool odd = (((uint64_t)(cont + pp_w)) >> 1) & 1;      // is container pp_w the high half of its dword?
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw, 0x101, 0xF, 0xF, true);   // row_shl:1 = lane+1
+    const uint32_t first = __builtin_amdgcn_readfirstlane(raw);
+    hdr = odd ? first >> 16 : first & 0xFFFFu;
+    // window word of lane L = (container pp+1+2L) << 16 | container pp+2+2L
+    wword = odd ? ((up << 16) | (up >> 16)) : ((raw & 0xFFFF0000u) | (up & 0xFFFFu));
+  };
+  uint32_t cur_pp, cur_pe, cur_hdr, cur_w;   // read r: pointers, first part header, first window
+  uint32_t n_pp, n_pe;                       // pointers of read r + n_waves
+  uint32_t ahead_sel;
+  {
+    const uint32_t r0 = wave0 < a.n_reads ? wave0 : a.n_reads - 1;
+    cur_pp = __builtin_amdgcn_readfirstlane(a.reads_ptr[r0]); cur_pe = __builtin_amdgcn_readfirstlane(a.reads_ptr[r0 + 1]);
+    ahead_issue(ahead0, cur_pp, wave0 + n_waves);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    ahead_take(ahead0, cur_pp, cur_hdr, cur_w, n_pp, n_pe);
+    ahead_issue(ahead1, n_pp, wave0 + 2 * n_waves);
+    ahead_sel = 1;
+  }
   for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
-    ahead_window(cont, r + n_waves, a.n_reads, lane, nxt);
-    ahead_ptr(a, r + 2 * n_waves, nn);
-    uint32_t pp = __builtin_amdgcn_readfirstlane(cur.pp);
-    const uint32_t pe = __builtin_amdgcn_readfirstlane(cur.pe);
+    PH(6)
+    uint32_t pp = cur_pp;
+    const uint32_t pe = cur_pe;
     RowAcc acc; acc.label1 = 0; acc.count = 0;
     uint32_t n_ent = 0, overflow = 0, total = 0;
     bool first_part = true;
 
     while (pp < pe) {
-      const uint32_t plen = __builtin_amdgcn_readfirstlane(first_part ? cur.hdr : (uint32_t)cont[pp]);
+      const uint32_t plen = __builtin_amdgcn_readfirstlane(first_part ? cur_hdr : (uint32_t)cont[pp]);
       const bool ahead_ok = first_part;
       first_part = false;
       if (plen == 0) break;
@@ -354,7 +415,7 @@ __global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
       const uint32_t nk = plen - k + 1;
       const uint32_t cend = pp;
       for (uint32_t base = 0; base < nk; base += 128) {
-        const uint32_t wd = window_word(cont, first, cend, base, lane, ahead_ok && base == 0, cur);
+        const uint32_t wd = window_word_w(cont, first, cend, base, lane, ahead_ok && base == 0, cur_w);
         // k-mers of the two passes and the order keys of the m-mers at positions base+64h+lane, h = 0..2
         uint64_t c[2]; bool act[2]; uint32_t hk0, hk1, hk2;
 #pragma unroll
@@ -385,6 +446,7 @@ __global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
         uint32_t sl0 = act[0] ? mslot_of_key(hk0, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         uint32_t sl1 = act[1] ? mslot_of_key(hk1, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         uint32_t res0 = 0, res1 = 0;
+        PH(0)
 
         while (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {
           // runs of equal slots over the 128 positions
@@ -415,40 +477,67 @@ __global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
                                                  (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
             }
+            PH(1)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const uint32_t sl = h ? sl1 : sl0, rid = h ? rid1 : rid0;
-              if (sl != 0xFFFFFFFFu && rid - rbase < MIC_RMAX) {
-                const uint4* sp = stage + (rid - rbase) * MIC_MSTRIDE;
-                const unsigned long long* keys = (const unsigned long long*)sp;
-                const uint4 meta = sp[7];
-                const uint64_t cc = c[h];
-                // count of keys <= cc among the 12 ascending keys (unused = ~0), remembering the last key <= cc
-                uint32_t pos = 0; uint64_t lastle = ~0ULL;
-                { uint64_t kx = keys[7]; if (kx <= cc) { pos = 8; lastle = kx; } }
-                { uint32_t i = pos + 3; uint64_t kx = i < 12 ? keys[i] : ~0ULL; if (kx <= cc) { pos += 4; lastle = kx; } }
-                { uint32_t i = pos + 1; uint64_t kx = i < 12 ? keys[i] : ~0ULL; if (kx <= cc) { pos += 2; lastle = kx; } }
-                { uint32_t i = pos;     uint64_t kx = i < 12 ? keys[i] : ~0ULL; if (kx <= cc) { pos += 1; lastle = kx; } }
-                uint32_t out = 0, nxt = 0xFFFFFFFFu;
-                if (!(meta.z & MIC_M_DIR)) {
-                  if (pos && lastle == cc) out = (uint32_t)((const uint16_t*)sp)[48 + pos - 1] + 1;  // labels at byte 96
-                } else if (pos) {
-                  nxt = sp[6].x + (pos - 1);   // descend into the child whose range holds cc
-                }
-                if (h) { res1 = out; nx1 = nxt; } else { res0 = out; nx0 = nxt; }
+            PH(2)
+            // Both k-mers of the lane search their staged slot in lockstep: five LDS round trips per round
+            // (binary, two reads per step) instead of five per k-mer one
+            // after the other.  Lanes without a search read slot 0 of the area and discard.
+            {
+              const bool v0 = sl0 != 0xFFFFFFFFu && rid0 - rbase < MIC_RMAX, v1 = sl1 != 0xFFFFFFFFu && rid1 - rbase < MIC_RMAX;
+              const uint4* sp0 = stage + (v0 ? rid0 - rbase : 0) * MIC_MSTRIDE;
+              const uint4* sp1 = stage + (v1 ? rid1 - rbase : 0) * MIC_MSTRIDE;
+              const unsigned long long* k0 = (const unsigned long long*)sp0;
+              const unsigned long long* k1 = (const unsigned long long*)sp1;
+              const uint64_t c0 = c[0], c1 = c[1];
+              const uint32_t mz0 = sp0[7].z, mz1 = sp1[7].z;
+              uint32_t pos0 = 0, pos1 = 0; bool eq0 = false, eq1 = false;
+              { const uint64_t x = k0[7], y = k1[7];
+                if (x <= c0) pos0 = 8; if (y <= c1) pos1 = 8; eq0 = x == c0; eq1 = y == c1; }
+              { const uint64_t x = k0[pos0 + 3], y = k1[pos1 + 3];                                  // index <= 11
+                if (x <= c0) pos0 += 4; if (y <= c1) pos1 += 4; eq0 = eq0 || x == c0; eq1 = eq1 || y == c1; }
+              { const uint32_t i = pos0 + 1, j = pos1 + 1;
+                const uint64_t x = k0[i < 11 ? i : 11], y = k1[j < 11 ? j : 11];
+                if (i < 12 && x <= c0) pos0 += 2; if (j < 12 && y <= c1) pos1 += 2; eq0 = eq0 || x == c0; eq1 = eq1 || y == c1; }
+              { const uint32_t i = pos0, j = pos1;
+                const uint64_t x = k0[i < 11 ? i : 11], y = k1[j < 11 ? j : 11];
+                if (i < 12 && x <= c0) pos0 += 1; if (j < 12 && y <= c1) pos1 += 1; eq0 = eq0 || x == c0; eq1 = eq1 || y == c1; }
+              const bool leaf0 = !(mz0 & MIC_M_DIR), leaf1 = !(mz1 & MIC_M_DIR);
+              // third trip: the label of key pos-1 (u16 at byte 96 + 2(pos-1)) or the child base (u32 at byte 96)
+              const uint32_t p0 = pos0 ? pos0 - 1 : 0, p1 = pos1 ? pos1 - 1 : 0;
+              const uint32_t w0 = ((const uint32_t*)sp0)[24 + (leaf0 ? p0 >> 1 : 0)], w1 = ((const uint32_t*)sp1)[24 + (leaf1 ? p1 >> 1 : 0)];
+              if (v0) {
+                res0 = 0; nx0 = 0xFFFFFFFFu;
+                if (pos0) { if (leaf0) { if (eq0) res0 = ((p0 & 1) ? w0 >> 16 : w0 & 0xFFFFu) + 1; } else nx0 = w0 + p0; }
+              }
+              if (v1) {
+                res1 = 0; nx1 = 0xFFFFFFFFu;
+                if (pos1) { if (leaf1) { if (eq1) res1 = ((p1 & 1) ? w1 >> 16 : w1 & 0xFFFFu) + 1; } else nx1 = w1 + p1; }
               }
             }
           }
+          PH(3)
           sl0 = nx0; sl1 = nx1;
         }
         tally2(res0, res1, acc, n_ent, overflow, total, lane);
+        PH(4)
       }
     }
+    // next read's header/window and the pointers of the one after it: take before the stores below, issue after
+    uint32_t t_hdr, t_w, t_pp, t_pe;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_w, t_pp, t_pe);
+    __builtin_amdgcn_wave_barrier();
+    PH(4)
     finish_read(acc, n_ent, total, overflow, r, a, lane);
-    cur = nxt; nxt = nn;
+    ahead_issue(ahead_sel ? ahead0 : ahead1, t_pp, r + 3 * n_waves);
+    ahead_sel ^= 1;
+    cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; cur_w = t_w; n_pp = t_pp; n_pe = t_pe;
+    PH(5)
   }
+  PH_END
 }
 
 // ---- merge / result on sparse rows ----------------------------------------------------------------
@@ -705,7 +794,19 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   static int per_cu = [] { const char* e = getenv("MIC_BLOCKS_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();
   unsigned cap = (unsigned)n_cu * (unsigned)per_cu;
   if (blocks > cap) blocks = cap;
-  if (a.t.layout) query_kernel_m<<<blocks, 256, 0, s>>>(a);
+  if (a.t.layout) {
+    query_kernel_m<<<blocks, 256, 0, s>>>(a);
+#ifdef MIC_PHASE_TIMING
+    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipStreamSynchronize(s);
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+    fprintf(stderr, "[phase cycles, %% of wave time] reads=%zu waves=%u:", (size_t)a.n_reads, blocks * 4);
+    const char* nm[8] = {"kmers+minimizers", "runs+dma issue", "wait hbm", "slot search", "tally+take", "finish", "read setup", "total"};
+    for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * h[i] / (double)h[7]);
+    fprintf(stderr, " | cycles/read/wave %.0f\n", (double)h[7] / (double)a.n_reads);
+#endif
+  }
   else if (slot_class == 64) query_kernel<true><<<blocks, 256, 0, s>>>(a);
   else query_kernel<false><<<blocks, 256, 0, s>>>(a);
   return hipGetLastError();
