@@ -331,6 +331,31 @@ __device__ __forceinline__ void sliding_min3(uint32_t& a0, uint32_t& a1, uint32_
 
 // -DMIC_PHASE_TIMING: per-phase cycle sums of query_kernel_m (s_memtime around each phase, one atomicAdd per wave),
 // printed by the launcher.  A measuring build only: the counter reads themselves cost ~5 %.
+// -DMIC_PERTURB: sensitivity analysis.  MIC_PERTURB_VALU / _LDS / _SALU = number of 8-instruction groups of dummy
+// v_bfi_b32 / ds_bpermute_b32 / s_add_u32 added to every chunk; the slowdown per added instruction says which unit
+// the kernel is actually short of.
+#ifdef MIC_PERTURB
+#define PERTURB_PARAMS , int pert_v, int pert_l, int pert_s
+#define PERTURB_POINT                                                                                               \
+  {                                                                                                                 \
+    uint32_t pv_ = lane, ps_ = 0;                                                                                   \
+    for (int i_ = 0; i_ < pert_v; ++i_)                                                                       \
+      asm volatile("v_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0\n\t" \
+                   "v_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0" : "+v"(pv_)); \
+    for (int i_ = 0; i_ < pert_l; ++i_) {                                                                     \
+      asm volatile("ds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\t" \
+                   "ds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\t" \
+                   "s_waitcnt lgkmcnt(0)" : "+v"(pv_));                                                                \
+    }                                                                                                               \
+    for (int i_ = 0; i_ < pert_s; ++i_)                                                                       \
+      asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\t"          \
+                   "s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1" : "+s"(ps_) : : "scc"); \
+    if (pv_ == 0x7FFFFFF1u && ps_ == 0x7FFFFFF1u) total += 1;                                                       \
+  }
+#else
+#define PERTURB_POINT
+#define PERTURB_PARAMS
+#endif
 #ifdef MIC_PHASE_TIMING
 __device__ unsigned long long g_phase[8];
 #define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ph_t0 = ph_t;
@@ -341,7 +366,7 @@ __device__ unsigned long long g_phase[8];
 #define PH(i)
 #define PH_END
 #endif
-__global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
+__global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a PERTURB_PARAMS) {
   __shared__ uint4 s_stage[4][MIC_RMAX * MIC_MSTRIDE];
   __shared__ uint32_t s_run[4][MIC_RMAX];
   __shared__ uint32_t s_ahead[4][2][64];
@@ -446,6 +471,7 @@ __global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a) {
         uint32_t sl0 = act[0] ? mslot_of_key(hk0, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         uint32_t sl1 = act[1] ? mslot_of_key(hk1, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         uint32_t res0 = 0, res1 = 0;
+        PERTURB_POINT
         PH(0)
 
         while (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {
@@ -795,7 +821,18 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   unsigned cap = (unsigned)n_cu * (unsigned)per_cu;
   if (blocks > cap) blocks = cap;
   if (a.t.layout) {
+#ifdef MIC_PERTURB
+    {
+      int pv[4] = {0, 0, 0, 0};
+      const char* e;
+      if ((e = getenv("MIC_PERTURB_VALU"))) pv[0] = atoi(e);
+      if ((e = getenv("MIC_PERTURB_LDS"))) pv[1] = atoi(e);
+      if ((e = getenv("MIC_PERTURB_SALU"))) pv[2] = atoi(e);
+      query_kernel_m<<<blocks, 256, 0, s>>>(a, pv[0], pv[1], pv[2]);
+    }
+#else
     query_kernel_m<<<blocks, 256, 0, s>>>(a);
+#endif
 #ifdef MIC_PHASE_TIMING
     unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipStreamSynchronize(s);
