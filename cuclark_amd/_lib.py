@@ -80,8 +80,8 @@ SYMBOLS = [
     ("mic_csv_header", C.c_int, [C.c_char_p, _SZ, C.c_int, C.POINTER(C.c_char_p), C.c_uint32]),
     ("mic_csv_line", C.c_int, [C.c_char_p, _SZ, _VP, _SZ, C.c_uint64, C.c_int, C.c_int, _VP, C.POINTER(C.c_char_p),
                                C.c_uint32, C.c_int, _VP, _VP]),
-    ("mic_db_build", C.c_int, [C.POINTER(C.c_char_p), _VP, _SZ, C.c_int, C.c_uint64, C.c_int, C.c_uint32, C.c_char_p, C.c_int,
-                               C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("mic_db_build", C.c_int, [C.POINTER(C.c_char_p), _VP, _SZ, C.c_int, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_char_p,
+                               C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("mic_db_build_error", C.c_char_p, []),
     ("mic_synth_db_device", C.c_int, [C.POINTER(MicSynthSpec), _VP, _VP, _VP, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
     ("mic_synth_read_pitch", C.c_uint32, [C.c_uint32, C.c_int]),

@@ -111,10 +111,11 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
       labs.push_back((uint16_t)(std::find(labels_.begin(), labels_.end(), t.second) - labels_.begin()));
     }
     uint64_t n_kmers = 0;
-    int rc = mic_db_build(files.data(), labs.data(), files.size(), (int)opt_.k, opt_.htsize, 0, opt_.min_count_t, db.c_str(), 0,
-                          (int)opt_.threads, 0, &n_kmers);
+    // cuCLARK-l samples the targets (every gap-th non-overlapping k-block, CuCLARK_hh.hh:694-895)
+    int rc = mic_db_build(files.data(), labs.data(), files.size(), (int)opt_.k, opt_.htsize, 0, opt_.min_count_t,
+                          opt_.light ? (uint32_t)opt_.gap : 0u, db.c_str(), 0, (int)opt_.threads, 0, &n_kmers);
     if (rc != MIC_OK) die(std::string("Failed to create the database: ") + mic_db_build_error());
-    std::cerr << "Creating database in disk..." << std::endl;
+    std::cerr << (opt_.light ? "Creating light database in disk..." : "Creating database in disk...") << std::endl;
     std::cerr << n_kmers << " " << opt_.k << "-mers successfully stored in database." << std::endl;
   }
   int n_dev = 0;

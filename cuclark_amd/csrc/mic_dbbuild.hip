@@ -33,12 +33,12 @@ namespace {
 
 thread_local char g_berr[512] = "";
 
-struct PartDesc { uint32_t first; uint32_t len; };   // first data container, nucleotides
+struct PartDesc { uint32_t first; uint32_t len; uint32_t p0; };   // first data container, nucleotides, first emitted position
 
 // one thread per k-mer position of the batch; positions are located by binary search in the per-part prefix sums
 __global__ void emit_kmers_kernel(const uint16_t* __restrict__ cont, const PartDesc* __restrict__ parts,
                                   const unsigned long long* __restrict__ pos_prefix, uint32_t n_parts,
-                                  unsigned long long n_pos, int k, MicDiv div, uint64_t rem_lo, uint64_t rem_hi,
+                                  unsigned long long n_pos, int k, uint32_t stride, MicDiv div, uint64_t rem_lo, uint64_t rem_hi,
                                   uint16_t label, unsigned long long* __restrict__ out_k, uint16_t* __restrict__ out_l,
                                   unsigned long long* __restrict__ cursor, unsigned long long cap) {
   unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,7 +46,7 @@ __global__ void emit_kmers_kernel(const uint16_t* __restrict__ cont, const PartD
   if (t < n_pos) {
     uint32_t lo = 0, hi = n_parts;           // last part with pos_prefix[p] <= t
     while (hi - lo > 1) { uint32_t mid = (lo + hi) / 2; if (pos_prefix[mid] <= t) lo = mid; else hi = mid; }
-    const uint32_t pos = (uint32_t)(t - pos_prefix[lo]);
+    const uint32_t pos = parts[lo].p0 + (uint32_t)(t - pos_prefix[lo]) * stride;   // stride 1: every k-mer; k*gap: light
     const uint32_t c0 = parts[lo].first + pos / 8;
     uint64_t h64 = 0;
 #pragma unroll
@@ -131,7 +131,7 @@ int bfail(int code, const char* fmt, const char* a = "", const char* b = "") {
 }
 
 // index + pack one target file with the read machinery; every record becomes parts of >= k nucleotides
-int pack_target(const char* path, int k, int threads, PackedTarget& out) {
+int pack_target(const char* path, int k, int threads, uint32_t light_gap, PackedTarget& out) {
   int fd = open(path, O_RDONLY);
   struct stat st;
   if (fd == -1 || fstat(fd, &st) != 0) { if (fd != -1) close(fd); return bfail(MIC_E_IO, "Failed to open %s", path); }
@@ -140,6 +140,7 @@ int pack_target(const char* path, int k, int threads, PackedTarget& out) {
   if (map == MAP_FAILED) { close(fd); return bfail(MIC_E_IO, "Failed to map %s", path); }
   const size_t nb = (size_t)st.st_size;
   int rc = MIC_OK;
+  std::vector<uint64_t> run_off, run_len;   // per part: offset in its ACGTU run, length of the run
   if (map[0] != '>' && map[0] != '@') {
     rc = bfail(MIC_E_INVALID, "%s: targets must be FASTA or FASTQ (k-mer spectrum targets are not supported)", path);
   } else {
@@ -159,13 +160,14 @@ int pack_target(const char* path, int k, int threads, PackedTarget& out) {
       else {
         std::vector<uint32_t> rp((size_t)n + 1);
         out.cont.resize(bound + 8);
-        size_t m = mic_pack_reads(map, ss.data(), se.data(), ln.data(), (size_t)n, k, rp.data(), out.cont.data(), bound);
+        size_t m = mic_pack_reads_runs(map, ss.data(), se.data(), ln.data(), (size_t)n, k, rp.data(), out.cont.data(), bound,
+                                       &run_off, &run_len);
         if (m == (size_t)-1) rc = bfail(MIC_E_INVALID, "%s: packing failed", path);
         else {
           out.cont.resize(m + 8);
           for (size_t p = 0; p < m;) {  // walk the parts
             uint32_t len = out.cont[p];
-            out.parts.push_back({(uint32_t)(p + 1), len});
+            out.parts.push_back({(uint32_t)(p + 1), len, 0u});
             p += 1 + (len + 7) / 8;
           }
         }
@@ -175,8 +177,32 @@ int pack_target(const char* path, int k, int threads, PackedTarget& out) {
   munmap((void*)map, nb);
   close(fd);
   out.prefix.assign(out.parts.size() + 1, 0);
-  for (size_t i = 0; i < out.parts.size(); ++i)
-    out.prefix[i + 1] = out.prefix[i] + (out.parts[i].len >= (uint32_t)k ? out.parts[i].len - k + 1 : 0);
+  if (!light_gap) {
+    for (size_t i = 0; i < out.parts.size(); ++i)
+      out.prefix[i + 1] = out.prefix[i] + (out.parts[i].len >= (uint32_t)k ? out.parts[i].len - k + 1 : 0);
+    return rc;
+  }
+  // Light database (CuCLARK_hh.hh:705-735, 780-797): a run is cut into consecutive blocks of k nucleotides, the blocks
+  // of the whole FILE are numbered in order (`iter`), and block number i is used iff i % gap == 0.  A run of L
+  // nucleotides completes L / k blocks; runs shorter than k complete none and were not packed.  Sub-parts of a long
+  // run overlap by k-1, so every block lies in exactly one of them.
+  if (rc == MIC_OK && run_off.size() != out.parts.size()) rc = bfail(MIC_E_INVALID, "%s: part bookkeeping mismatch", path);
+  if (rc != MIC_OK) return rc;
+  uint64_t done = 0, cur_blocks = 0;   // blocks completed before the current run; blocks of the current run
+  for (size_t i = 0; i < out.parts.size(); ++i) {
+    const uint64_t off = run_off[i], L = run_len[i], plen = out.parts[i].len, nblocks = L / (uint64_t)k;
+    if (off == 0) { done += cur_blocks; cur_blocks = nblocks; }
+    uint64_t cnt = 0, b = 0;
+    if (plen >= (uint64_t)k && nblocks) {
+      const uint64_t b_lo = (off + (uint64_t)k - 1) / (uint64_t)k;
+      uint64_t b_hi = (off + plen - (uint64_t)k) / (uint64_t)k;
+      if (b_hi > nblocks - 1) b_hi = nblocks - 1;
+      b = b_lo + (light_gap - (done + b_lo) % light_gap) % light_gap;
+      if (b <= b_hi) cnt = (b_hi - b) / light_gap + 1;
+    }
+    out.parts[i].p0 = cnt ? (uint32_t)(b * (uint64_t)k - off) : 0u;
+    out.prefix[i + 1] = out.prefix[i] + cnt;
+  }
   return rc;
 }
 
@@ -198,8 +224,8 @@ extern "C" {
 const char* mic_db_build_error(void) { return g_berr; }
 
 int mic_db_build(const char* const* target_files, const uint16_t* target_labels, size_t n_files, int k, uint64_t htsize,
-                 int key_bytes, uint32_t min_count, const char* out_prefix, int device, int threads, uint32_t parts,
-                 uint64_t* n_kmers_out) {
+                 int key_bytes, uint32_t min_count, uint32_t light_gap, const char* out_prefix, int device, int threads,
+                 uint32_t parts, uint64_t* n_kmers_out) {
   if (!target_files || !target_labels || !out_prefix || k < 2 || k > 32 || htsize < 2 || htsize > 0xFFFFFFF0ull)
     return bfail(MIC_E_INVALID, "bad argument");
   if (key_bytes == 0) key_bytes = mic_key_bytes_rule(htsize, k);
@@ -212,7 +238,7 @@ int mic_db_build(const char* const* target_files, const uint16_t* target_labels,
   unsigned long long total_pos = 0, max_pos = 0; size_t max_cont = 0, max_parts = 0;
   for (size_t f = 0; f < n_files; ++f) {
     tg[f].label = target_labels[f];
-    int rc0 = pack_target(target_files[f], k, threads, tg[f]);
+    int rc0 = pack_target(target_files[f], k, threads, light_gap, tg[f]);
     if (rc0 != MIC_OK) return rc0;
     total_pos += tg[f].prefix.back();
     if (tg[f].prefix.back() > max_pos) max_pos = tg[f].prefix.back();
@@ -283,7 +309,7 @@ int mic_db_build(const char* const* target_files, const uint16_t* target_labels,
       BHIP(hipMemcpy(d_cont, t.cont.data(), t.cont.size() * 2, hipMemcpyHostToDevice));
       BHIP(hipMemcpy(d_parts, t.parts.data(), t.parts.size() * sizeof(PartDesc), hipMemcpyHostToDevice));
       BHIP(hipMemcpy(d_prefix, t.prefix.data(), t.prefix.size() * 8, hipMemcpyHostToDevice));
-      emit_kmers_kernel<<<(unsigned)((npos + 255) / 256), 256>>>(d_cont, d_parts, d_prefix, (uint32_t)t.parts.size(), npos, k, div,
+      emit_kmers_kernel<<<(unsigned)((npos + 255) / 256), 256>>>(d_cont, d_parts, d_prefix, (uint32_t)t.parts.size(), npos, k, light_gap ? (uint32_t)k * light_gap : 1u, div,
                                                                  rem_lo, rem_hi, t.label, d_k[0], d_l[0], d_cursor, cap);
       BHIP(hipGetLastError());
     }

@@ -211,11 +211,12 @@ struct Sink {
 };
 
 // one maximal ACGTU run -> one or more parts [len][containers...]
-void emit_run(Sink& s, const uint8_t* codes, size_t len, int k) {
+void emit_run(Sink& s, const uint8_t* codes, size_t len, int k, std::vector<uint64_t>* run_off, std::vector<uint64_t>* run_len) {
   size_t start = 0;
   for (;;) {
     size_t plen = len - start;
     if (plen > MIC_MAX_PART) plen = MIC_MAX_PART;
+    if (run_off) { run_off->push_back(start); run_len->push_back(len); }
     s.put((uint16_t)plen);
     size_t i = 0;
     for (; i + 8 <= plen; i += 8) {
@@ -235,6 +236,16 @@ void emit_run(Sink& s, const uint8_t* codes, size_t len, int k) {
 
 size_t mic_pack_reads(const uint8_t* map, const uint64_t* seq_s, const uint64_t* seq_e, const uint64_t* length,
                       size_t n_reads, int k, uint32_t* reads_pointer, uint16_t* containers, size_t cap) {
+  return mic_pack_reads_runs(map, seq_s, seq_e, length, n_reads, k, reads_pointer, containers, cap, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+// internal: the packer, optionally recording for every part the offset of its first nucleotide inside its maximal
+// ACGTU run and the length of that run (the light database builder needs the run structure)
+size_t mic_pack_reads_runs(const uint8_t* map, const uint64_t* seq_s, const uint64_t* seq_e, const uint64_t* length,
+                           size_t n_reads, int k, uint32_t* reads_pointer, uint16_t* containers, size_t cap,
+                           std::vector<uint64_t>* run_off, std::vector<uint64_t>* run_len) {
   Sink s{containers, cap, 0, false};
   std::vector<uint8_t> codes;
   for (size_t r = 0; r < n_reads; ++r) {
@@ -248,14 +259,16 @@ size_t mic_pack_reads(const uint8_t* map, const uint64_t* seq_s, const uint64_t*
       const int c = nt_code(p[i]);
       if (c >= 0) { codes[run++] = (uint8_t)c; continue; }
       if (p[i] == '\n') continue;  // line breaks are transparent (CuCLARK_hh.hh:1674-1678)
-      if (run >= (size_t)k) emit_run(s, codes.data(), run, k);  // any other byte ends the part
+      if (run >= (size_t)k) emit_run(s, codes.data(), run, k, run_off, run_len);  // any other byte ends the part
       run = 0;
     }
-    if (run >= (size_t)k) emit_run(s, codes.data(), run, k);
+    if (run >= (size_t)k) emit_run(s, codes.data(), run, k, run_off, run_len);
   }
   reads_pointer[n_reads] = (uint32_t)s.n;
   return s.overflow ? (size_t)-1 : s.n;
 }
+
+extern "C" {
 
 // ---- CSV (CuCLARK_hh.hh:1951-2139) ---------------------------------------------------------------------
 int mic_csv_header(char* buf, size_t cap, int extended, const char* const* target_names, uint32_t n_targets) {

@@ -22,6 +22,14 @@ struct MicDiv {
 
 MicDiv mic_make_div(uint64_t d);
 
+#ifdef __cplusplus
+#include <vector>
+// mic_host.cpp: mic_pack_reads plus, per part, the offset of its first nucleotide in its ACGTU run and the run's length
+size_t mic_pack_reads_runs(const uint8_t* map, const uint64_t* seq_s, const uint64_t* seq_e, const uint64_t* length,
+                           size_t n_reads, int k, uint32_t* reads_pointer, uint16_t* containers, size_t cap,
+                           std::vector<uint64_t>* run_off, std::vector<uint64_t>* run_len);
+#endif
+
 static inline __host__ __device__ uint64_t mic_mulhi64(uint64_t a, uint64_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __umul64hi(a, b);

@@ -76,14 +76,16 @@ def format_csv(data, idx, results, target_names, k, paired=False, extended=False
     return b"".join(out)
 
 
-def build_db(target_files, target_labels, k, htsize, out_prefix, key_bytes=0, min_count=0, device=-1, threads=4, parts=0):
-    """GPU database builder (mic_db_build): target_labels[i] is the label index of target_files[i].  Returns #k-mers."""
+def build_db(target_files, target_labels, k, htsize, out_prefix, key_bytes=0, min_count=0, device=-1, threads=4, parts=0,
+             light_gap=0):
+    """GPU database builder (mic_db_build): target_labels[i] is the label index of target_files[i].  Returns #k-mers.
+    light_gap > 0 builds cuCLARK-l's light database (non-overlapping k-blocks, every light_gap-th one)."""
     L = _lib.load()
     files = (C.c_char_p * len(target_files))(*[f.encode() for f in target_files])
     labels = np.ascontiguousarray(target_labels, np.uint16)
     n = C.c_uint64(0)
     rc = L.mic_db_build(files, labels.ctypes.data, len(target_files), int(k), int(htsize), int(key_bytes), int(min_count),
-                        out_prefix.encode(), int(device), int(threads), int(parts), C.byref(n))
+                        int(light_gap), out_prefix.encode(), int(device), int(threads), int(parts), C.byref(n))
     if rc != 0:
         raise RuntimeError(f"mic_db_build failed ({rc}): {L.mic_db_build_error().decode(errors='replace')}")
     return int(n.value)

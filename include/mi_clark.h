@@ -199,10 +199,13 @@ int mic_csv_line(char* buf, size_t cap, const uint8_t* name, size_t name_len, ui
  * hashTable_hh.hh:590-663): a canonical k-mer is stored iff all its occurrences belong to one label and its
  * occurrence count (saturating at 254) exceeds min_count.  target_labels[i] = label index of target_files[i]
  * (first-appearance order of the labels in the targets file).  key_bytes 0 => rule of main.cc:274-316.
+ * light_gap 0 => every k-mer (cuCLARK); g > 0 => the light database of cuCLARK-l (CuCLARK_hh.hh:694-895): each maximal
+ * ACGT run is cut into consecutive non-overlapping blocks of k nucleotides, numbered through the whole file, and
+ * block i is used iff i % g == 0.
  * parts 0 => as many passes over disjoint bucket ranges as the free HBM requires.  Synchronous. */
 int mic_db_build(const char* const* target_files, const uint16_t* target_labels, size_t n_files, int k, uint64_t htsize,
-                 int key_bytes, uint32_t min_count, const char* out_prefix, int device, int threads, uint32_t parts,
-                 uint64_t* n_kmers_out);
+                 int key_bytes, uint32_t min_count, uint32_t light_gap, const char* out_prefix, int device, int threads,
+                 uint32_t parts, uint64_t* n_kmers_out);
 const char* mic_db_build_error(void);
 
 /* ---- synthetic workload generation in HBM (bench.py / tests) ------------------- */

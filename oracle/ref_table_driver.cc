@@ -14,7 +14,7 @@
 //
 // Usage:
 //   ref_table_X info
-//   ref_table_X build <k> <key_bytes> <out_prefix> <targets.tsv> [min_count]
+//   ref_table_X build <k> <key_bytes> <out_prefix> <targets.tsv> [min_count] [light_gap]
 //         targets.tsv lines: <fasta path>\t<label>     (labels in first-appearance order)
 //   ref_table_X query <k> <key_bytes> <prefix> <kmers.txt> [sampling] [mmap]
 //         kmers.txt: one forward-strand k-mer value (decimal u64) per line
@@ -45,7 +45,7 @@ static int code_of(unsigned char c) {
 }
 
 template <typename KEY>
-static int do_build(int k, const char* prefix, const char* targets_tsv, size_t min_count) {
+static int do_build(int k, const char* prefix, const char* targets_tsv, size_t min_count, size_t gap) {
   std::vector<std::pair<std::string, std::string> > targets;
   std::vector<std::string> labels, labels_c;
   {
@@ -69,6 +69,7 @@ static int do_build(int k, const char* prefix, const char* targets_tsv, size_t m
     if (!in) { fprintf(stderr, "Failed to open %s\n", targets[t].first.c_str()); return 4; }
     std::string line;
     uint64_t kmer = 0; int run = 0;
+    uint64_t iter = 0;   // light: completed k-blocks of this file (CuCLARK_hh.hh:709)
     while (std::getline(in, line)) {
       if (!line.empty() && line[0] == '>') { kmer = 0; run = 0; continue; }
       for (size_t i = 0; i < line.size(); ++i) {
@@ -76,7 +77,12 @@ static int do_build(int k, const char* prefix, const char* targets_tsv, size_t m
         if (c < 0) { kmer = 0; run = 0; ++nt; continue; }
         ++nt;
         kmer = ((kmer << 2) | (uint64_t)c) & mask;
-        if (++run >= k) table.addElement(kmer, targets[t].second, (size_t)1);
+        if (gap == 0) {                       // every k-mer (CuCLARK_hh.hh:920-950)
+          if (++run >= k) table.addElement(kmer, targets[t].second, (size_t)1);
+        } else if (++run == k) {              // light: non-overlapping blocks, every gap-th (CuCLARK_hh.hh:721-731)
+          if (iter % gap == 0) table.addElement(kmer, targets[t].second, (size_t)1);
+          ++iter; kmer = 0; run = 0;
+        }
       }
     }
   }
@@ -112,9 +118,10 @@ int main(int argc, char** argv) {
   if (argc >= 6 && std::string(argv[1]) == "build") {
     int k = atoi(argv[2]), kb = atoi(argv[3]);
     size_t minc = argc > 6 ? (size_t)atol(argv[6]) : 0;
-    if (kb == 2) return do_build<T16>(k, argv[4], argv[5], minc);
-    if (kb == 4) return do_build<T32>(k, argv[4], argv[5], minc);
-    if (kb == 8) return do_build<T64>(k, argv[4], argv[5], minc);
+    size_t gap = argc > 7 ? (size_t)atol(argv[7]) : 0;
+    if (kb == 2) return do_build<T16>(k, argv[4], argv[5], minc, gap);
+    if (kb == 4) return do_build<T32>(k, argv[4], argv[5], minc, gap);
+    if (kb == 8) return do_build<T64>(k, argv[4], argv[5], minc, gap);
   }
   if (argc >= 6 && std::string(argv[1]) == "query") {
     int k = atoi(argv[2]), kb = atoi(argv[3]);
@@ -124,7 +131,7 @@ int main(int argc, char** argv) {
     if (kb == 4) return do_query<T32>(k, argv[4], argv[5], s, mm);
     if (kb == 8) return do_query<T64>(k, argv[4], argv[5], s, mm);
   }
-  fprintf(stderr, "usage: %s info | build <k> <key_bytes> <out_prefix> <targets.tsv> [min_count] | "
+  fprintf(stderr, "usage: %s info | build <k> <key_bytes> <out_prefix> <targets.tsv> [min_count] [light_gap] | "
                   "query <k> <key_bytes> <prefix> <kmers.txt> [sampling] [mmap]\n", argv[0]);
   return 1;
 }

@@ -99,13 +99,13 @@ def run(cmd, **kw):
     return r.stdout
 
 
-def build_db(binary, k, key_bytes, files, tmp, name):
+def build_db(binary, k, key_bytes, files, tmp, name, gap=0):
     tsv = os.path.join(tmp, f"{name}.tsv")
     with open(tsv, "w") as f:
         for fn, label in files:
             f.write(f"{os.path.join(HERE, 'targets', fn)}\t{label}\n")
     prefix = os.path.join(tmp, name)
-    n = int(run([binary, "build", str(k), str(key_bytes), prefix, tsv]).strip().splitlines()[-1])
+    n = int(run([binary, "build", str(k), str(key_bytes), prefix, tsv, "0", str(gap)]).strip().splitlines()[-1])
     sz = np.fromfile(prefix + ".sz", dtype=np.uint8)
     ky = np.fromfile(prefix + ".ky", dtype={2: np.uint16, 4: np.uint32, 8: np.uint64}[key_bytes])
     lb = np.fromfile(prefix + ".lb", dtype=np.uint16)
@@ -210,12 +210,26 @@ def make_reads(rng, genomes, k):
                 f.write(f"@pair{i}/{mate}\n{s}\n+\n{q}\n")
 
 
+# light databases as cuCLARK-l builds them (CuCLARK_hh.hh:694-895); gap 4 is its default
+LIGHT_GAP_CONFIGS = [("lightgap4_k27_u32", 27, 4, 4), ("lightgap5_k31_u64", 31, 8, 5), ("lightgap1_k20_u16", 20, 2, 1)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also build the HTSIZE=1610612741 fixture")
     ap.add_argument("--tmp", default="/tmp/mic_golden")
+    ap.add_argument("--only-light-gap", action="store_true",
+                    help="only (re)build the cuCLARK-l style databases (non-overlapping k-blocks, every gap-th) from the "
+                         "target files already in tests/golden/targets")
     args = ap.parse_args()
     os.makedirs(args.tmp, exist_ok=True)
+    if args.only_light_gap:
+        import golden_util as gu
+        files = [(os.path.basename(fn), label) for fn, label in gu.target_files_and_labels()]
+        for name, k, kb, gap in LIGHT_GAP_CONFIGS:
+            _, n = build_db(REF_LIGHT, k, kb, files, args.tmp, name, gap=gap)
+            print(f"{name}: {n} elements")
+        return
     rng = np.random.default_rng(20241003)
     files, genomes = make_targets(rng)
 
@@ -223,6 +237,8 @@ def main():
                ("light_k20_u16", REF_LIGHT, 20, 2), ("light_k32_u64", REF_LIGHT, 32, 8)]
     if args.full:
         configs.append(("full_k31_u32", REF_FULL, 31, 4))
+    for name, k, kb, gap in LIGHT_GAP_CONFIGS:
+        build_db(REF_LIGHT, k, kb, files, args.tmp, name, gap=gap)
     for name, binary, k, kb in configs:
         prefix, n = build_db(binary, k, kb, files, args.tmp, name)
         kmers = make_queries(np.random.default_rng(1000 + k), genomes, k)

@@ -11,7 +11,7 @@ import golden_util as gu
 REF_LIGHT = os.path.join(gu.ROOT, "oracle", "_ref", "ref_table_light")
 
 
-@pytest.mark.parametrize("name", gu.golden_db_names())
+@pytest.mark.parametrize("name", [n for n in gu.golden_db_names() if not n.startswith("lightgap")])
 def test_oracle_matches_reference_queries(name):
     """Golden vectors = answers of the reference's EHashtable::queryElement on the DB the reference wrote."""
     if name.startswith("full"):
