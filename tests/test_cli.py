@@ -152,3 +152,47 @@ def test_streaming_segments_give_identical_csv(tmp_path):
             assert r.returncode == 0, r.stderr
             assert open(out + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, exp), "rb").read(), (seg_kb, exp)
             assert "(131 objects)" in r.stdout or "(80 objects)" in r.stdout or "(40 objects)" in r.stdout
+
+
+@pytest.mark.gpu
+def test_set_targets_then_classify_end_to_end(tmp_path):
+    """The reference's user flow on a fresh directory: set_targets.sh <dir> custom (taxonomy already downloaded), then
+    classify_metagenome.sh builds the database on first use and classifies; targets are species taxonomy IDs.  The
+    expectation is the oracle's CSV on the reference-written golden database with the labels in targets.txt order."""
+    import shutil
+    import numpy as np
+    import test_targets_tools as tt
+    tmp = str(tmp_path)
+    db = os.path.join(tmp, "DBD")
+    tax = os.path.join(db, "taxonomy")
+    os.makedirs(os.path.join(db, "Custom"))
+    golden = gu.target_files_and_labels()
+    names_golden = gu.target_names()
+    species = {lab: 5000 + i for i, lab in enumerate(names_golden)}          # one species ID per golden label
+    tt.make_taxonomy(tax)
+    with open(os.path.join(tax, "nodes.dmp"), "a") as f:
+        for s in species.values():
+            f.write(f"{s}\t|\t561\t|\tspecies\t|\tXX\t|\n")
+    with open(os.path.join(tax, "nucl_accss"), "a") as f:
+        for i, (fn, lab) in enumerate(golden):
+            f.write(f"rec{i}a\trec{i}a.1\t{species[lab]}\t{100 + i}\n")
+            shutil.copy(fn, os.path.join(db, "Custom", os.path.basename(fn)))
+    open(os.path.join(db, ".taxondata"), "w").close()
+    r = _run([os.path.join(gu.ROOT, "set_targets.sh"), db, "custom"], cwd=tmp)
+    assert r.returncode == 0, r.stdout + r.stderr
+    order = []                                                               # taxonomy IDs in targets.txt order
+    for line in open(os.path.join(db, "targets.txt")).read().splitlines():
+        t = line.split("\t")[1]
+        if t not in order:
+            order.append(t)
+    assert sorted(order) == sorted(str(s) for s in species.values())
+    reads = os.path.join(gu.GOLDEN, "reads_k27.fa")
+    r = _run([os.path.join(gu.ROOT, "classify_metagenome.sh"), "-O", reads, "-R", os.path.join(tmp, "out"), "-k", "27",
+              "--htsize", "57777779"], cwd=tmp)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.path.exists(os.path.join(db, "custom_0_canonical", f"db_central_k27_t{len(order)}_s57777779_m0.tsk.ky"))
+    g = gu.load_golden_db("light_k27_u32")
+    perm = np.array([order.index(str(species[lab])) for lab in names_golden], np.uint16)   # golden label -> new index
+    odb = gu.oracle().db_from_arrays(gu.golden_sizes(g), g["ky"], perm[g["lb"]], 1)
+    text, _ = odb.classify_file(27, open(reads, "rb").read(), order, False, False)
+    assert open(os.path.join(tmp, "out.csv"), "rb").read() == text
