@@ -480,10 +480,12 @@ void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FIL
   // ---- index (CuCLARK_hh.hh:1339-1534)
   if (nb == 0 || (map[0] != '>' && map[0] != '@')) { std::cerr << "Failed to recognize the format of the file." << std::endl; exit(-1); }
   size_t cap = std::max<size_t>(1024, nb / 96);
-  std::vector<uint64_t> name_s, name_e, seq_s, seq_e, length;
+  // index arrays live across segments: resizing a fresh vector zero-fills ~200 MB per 512 MB segment
+  std::vector<uint64_t>&name_s = ix_[0], &name_e = ix_[1], &seq_s = ix_[2], &seq_e = ix_[3], &length = ix_[4];
+  if (name_s.size() > cap) cap = name_s.size();
   long n_reads;
   for (;;) {
-    name_s.resize(cap); name_e.resize(cap); seq_s.resize(cap); seq_e.resize(cap); length.resize(cap);
+    if (name_s.size() < cap) { name_s.resize(cap); name_e.resize(cap); seq_s.resize(cap); seq_e.resize(cap); length.resize(cap); }
     n_reads = mic_index_reads_parallel(map, nb, (int)opt_.threads, cap, name_s.data(), name_e.data(), seq_s.data(), seq_e.data(),
                                        length.data());
     if (n_reads < 0) { std::cerr << "Failed to recognize the format of the file." << std::endl; exit(-1); }
@@ -527,19 +529,25 @@ void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FIL
   const uint32_t row_words = row_words_;
   const size_t line_cap = 512 + (opt_.extended ? (size_t)T * 12 : 0);
 
+  double t_pack = 0, t_query = 0, t_format = 0, t_write = 0;   // thread-seconds, MIC_CLI_TIMING only
+  auto now_s = [] { struct timeval t; gettimeofday(&t, nullptr); return t.tv_sec + t.tv_usec / 1e6; };
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) reduction(+ : t_pack, t_query, t_format, t_write)
 #endif
   for (long bi = 0; bi < (long)nb_total; ++bi) {
+    double ts = timing ? now_s() : 0;
+    auto tick = [&](double& acc) { if (timing) { const double n = now_s(); acc += n - ts; ts = n; } };
     const size_t b = (size_t)bi, d = b % n_eng, lb = b / n_eng;
     Lent& L = lent_[d];
     const size_t r0 = cut[b], cnt = cut[b + 1] - cut[b];
     try {
       size_t m = mic_pack_reads(map, seq_s.data() + r0, seq_e.data() + r0, length.data() + r0, cnt, k, L.rp[lb], L.ct[lb], slot_cont_);
       if (m == (size_t)-1) die("ERROR: Batch overflow. Please increase the number of batches (-b <numberofbatches>).");
+      tick(t_pack);
       check(mic_batch_ready(engines_[d], lb, cnt, m), "readyBatch");
       check(mic_batch_query(engines_[d], lb, opt_.extended ? 1 : 0, 0), "queryBatch");
       check(mic_batch_wait(engines_[d], lb), "waitForBatch");
+      tick(t_query);
       std::string& s = out[b];
       s.reserve(cnt * (opt_.extended ? 64 + 3 * (size_t)T : 72));
       std::vector<char> line(line_cap);
@@ -564,6 +572,7 @@ void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FIL
       std::lock_guard<std::mutex> lk(wmu);
       if (err.empty()) err = ex.what();
     }
+    tick(t_format);
     std::lock_guard<std::mutex> lk(wmu);
     ready[b] = 1;
     while (next_write < nb_total && ready[next_write]) {
@@ -571,8 +580,12 @@ void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FIL
       std::string().swap(out[next_write]);
       ++next_write;
     }
+    tick(t_write);
   }
   lap("pack + query + format + write");
+  if (timing)
+    std::cerr << "[timing]   thread-seconds: pack " << t_pack << ", copy+query+wait " << t_query << ", format " << t_format
+              << ", ordered write " << t_write << std::endl;
   if (!err.empty()) die(err);
 }
 

@@ -57,6 +57,7 @@ class Classifier {
   void release_batches();
   struct Lent { uint32_t* results = nullptr; uint32_t* rows = nullptr; std::vector<uint32_t*> rp; std::vector<uint16_t*> ct; };
   std::vector<Lent> lent_;
+  std::vector<uint64_t> ix_[5];   // name_s, name_e, seq_s, seq_e, length of the current segment (reused)
   size_t slot_reads_ = 0, slot_cont_ = 0, slots_per_engine_ = 0;
   uint32_t row_words_ = 16;
   size_t segment_bytes_ = 512u << 20;

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <thread>
+#include <memory>
 #include <vector>
 
 // ---- division magic ---------------------------------------------------------------------------------
@@ -62,29 +63,38 @@ struct Rec { uint64_t ns, ne, ss, se, len; };
 
 // Parse the record whose marker ('>' or '@') is at map[i-1]; returns the position of the next record's marker
 // (FASTA) / of the byte after the quality line (FASTQ), or a value >= nb at the end of the file.
+static inline size_t find_nl(const uint8_t* map, size_t nb, size_t i) {   // first '\n' at or after i, or nb
+  if (i >= nb) return nb;
+  const void* q = memchr(map + i, '\n', nb - i);
+  return q ? (size_t)((const uint8_t*)q - map) : nb;
+}
+
 static inline size_t parse_record(const uint8_t* map, size_t nb, bool fasta, size_t i, Rec& r) {
   r.ns = i;  // name: from the byte after the marker up to the first separator found strictly after it
   while (i + 1 < nb && !name_sep(map[i + 1])) ++i;
   ++i;
   if (i > nb) i = nb;
   r.ne = i;
-  while (i < nb && map[i++] != '\n') {}  // rest of the header line
+  i = find_nl(map, nb, i);  // rest of the header line
+  if (i < nb) ++i;
   size_t s = i, e = i;
   if (fasta) {
     size_t lines = 0;
     while (i < nb && map[i] != '>') {  // sequence lines until a line that starts the next record
-      while (i < nb && map[i] != '\n') ++i;
+      i = find_nl(map, nb, i);
       ++lines;
       e = i++;
     }
     r.len = (e - s + 1) - lines;  // non-newline bytes (CuCLARK_hh.hh:1385-1389)
   } else {
-    while (i < nb && map[i] != '\n') ++i;
-    e = i < nb ? i : nb;
+    i = find_nl(map, nb, i);
+    e = i;
     ++i;
     r.len = e - s;
-    while (i < nb && map[i++] != '\n') {}  // '+' line
-    while (i < nb && map[i++] != '\n') {}  // quality line
+    i = find_nl(map, nb, i);  // '+' line
+    if (i < nb) ++i;
+    i = find_nl(map, nb, i);  // quality line
+    if (i < nb) ++i;
   }
   r.ss = s; r.se = e;
   return i;
@@ -192,6 +202,24 @@ static inline int nt_code(uint8_t c) {
   }
 }
 
+}  // extern "C"
+namespace {
+struct CodeTable {
+  enum { kNewline = 0x40, kOther = 0x80 };
+  uint8_t code[256];   // 0..3 = nucleotide code (m_rTable), kNewline, kOther
+};
+const CodeTable& code_table() {
+  static const CodeTable t = [] {
+    CodeTable x;
+    for (int c = 0; c < 256; ++c) { const int v = nt_code((uint8_t)c); x.code[c] = v >= 0 ? (uint8_t)v : (uint8_t)CodeTable::kOther; }
+    x.code[(unsigned char)'\n'] = CodeTable::kNewline;
+    return x;
+  }();
+  return t;
+}
+}  // namespace
+extern "C" {
+
 size_t mic_pack_bound(const uint64_t* seq_s, const uint64_t* seq_e, size_t n_reads, int k) {
   // a part of L nt takes 1 + ceil(L/8) containers; parts need >= k nt and are separated by >= 1 byte;
   // sub-part splitting adds one header and k-1 nt per MIC_MAX_PART nt.
@@ -248,11 +276,58 @@ size_t mic_pack_reads_runs(const uint8_t* map, const uint64_t* seq_s, const uint
                            std::vector<uint64_t>* run_off, std::vector<uint64_t>* run_len) {
   Sink s{containers, cap, 0, false};
   std::vector<uint8_t> codes;
+  const CodeTable& tab = code_table();
   for (size_t r = 0; r < n_reads; ++r) {
     reads_pointer[r] = (uint32_t)s.n;
     if (length[r] < (uint64_t)k) continue;  // reads without a k-mer store nothing (CuCLARK_hh.hh:1633)
     const uint8_t* p = map + seq_s[r];
     const size_t nb = (size_t)(seq_e[r] - seq_s[r]);
+    if (nb <= MIC_MAX_PART) {
+      // Streaming path (no part can need splitting): containers are written as the bytes are read, eight nucleotides
+      // per step when the next eight bytes are all nucleotides; a run that ends below k nucleotides is rolled back.
+      size_t hdr = s.n, run = 0;   // header position of the open part, its nucleotides so far
+      uint32_t acc = 0;            // the (run & 7) nucleotides not yet stored, 2 bits each
+      s.put(0);
+      auto close_part = [&]() {
+        if (run >= (size_t)k) {
+          if (run & 7) s.put((uint16_t)(acc << (2 * (8 - (run & 7)))));
+          if (hdr < s.cap) s.out[hdr] = (uint16_t)run;
+          if (run_off) { run_off->push_back(0); run_len->push_back(run); }
+          hdr = s.n;
+          s.put(0);
+        } else {
+          s.n = hdr + 1;            // drop what was written for this run, keep the header slot
+        }
+        run = 0; acc = 0;
+      };
+      size_t i = 0;
+      while (i < nb) {
+        if (i + 8 <= nb) {
+          const uint8_t c0 = tab.code[p[i]], c1 = tab.code[p[i + 1]], c2 = tab.code[p[i + 2]], c3 = tab.code[p[i + 3]],
+                        c4 = tab.code[p[i + 4]], c5 = tab.code[p[i + 5]], c6 = tab.code[p[i + 6]], c7 = tab.code[p[i + 7]];
+          if (!((c0 | c1 | c2 | c3 | c4 | c5 | c6 | c7) & 0xFC)) {
+            const uint32_t v = (uint32_t)((c0 << 14) | (c1 << 12) | (c2 << 10) | (c3 << 8) | (c4 << 6) | (c5 << 4) | (c6 << 2) | c7);
+            const unsigned have = (unsigned)(run & 7);               // nucleotides waiting in acc
+            s.put((uint16_t)((acc << (2 * (8 - have))) | (v >> (2 * have))));
+            acc = v & ((1u << (2 * have)) - 1);
+            run += 8; i += 8;
+            continue;
+          }
+        }
+        const uint8_t c = tab.code[p[i]];
+        ++i;
+        if (c < 4) {
+          acc = (acc << 2) | c;
+          if ((++run & 7) == 0) { s.put((uint16_t)acc); acc = 0; }
+          continue;
+        }
+        if (c == CodeTable::kNewline) continue;  // line breaks are transparent (CuCLARK_hh.hh:1674-1678)
+        close_part();                            // any other byte ends the part
+      }
+      close_part();
+      s.n -= 1;                                  // the header slot opened for a part that never came
+      continue;
+    }
     if (codes.size() < nb) codes.resize(nb * 2 + 64);
     size_t run = 0;
     for (size_t i = 0; i < nb; ++i) {
@@ -271,6 +346,36 @@ size_t mic_pack_reads_runs(const uint8_t* map, const uint64_t* seq_s, const uint
 extern "C" {
 
 // ---- CSV (CuCLARK_hh.hh:1951-2139) ---------------------------------------------------------------------
+}  // extern "C"
+namespace {
+inline int put_u32(char* p, uint32_t v) {
+  char t[10]; int n = 0;
+  do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  for (int i = 0; i < n; ++i) p[i] = t[n - 1 - i];
+  return n;
+}
+// "%g" of value = num / den for integers 0 <= num < 256, 1 <= den < 256, cached; anything else goes through snprintf
+struct RatioCache { uint8_t len[256][256]; char text[256][256][14]; };
+inline int put_ratio(char* p, uint32_t num, double den, double value, char* tmp) {
+  thread_local std::unique_ptr<RatioCache> cache;
+  const int di = (den >= 1.0 && den < 256.0 && den == (double)(int)den) ? (int)den : 0;
+  if (di && num < 256) {
+    if (!cache) { cache.reset(new RatioCache); memset(cache->len, 0, sizeof(cache->len)); }
+    uint8_t& l = cache->len[num][di];
+    if (!l) {
+      int w = snprintf(tmp, 64, "%g", value);
+      if (w > 0 && w < 14) { memcpy(cache->text[num][di], tmp, (size_t)w); l = (uint8_t)w; }
+      else { memcpy(p, tmp, (size_t)w); return w; }
+    }
+    memcpy(p, cache->text[num][di], l);
+    return l;
+  }
+  const int w = snprintf(tmp, 64, "%g", value);
+  memcpy(p, tmp, (size_t)w);
+  return w;
+}
+}  // namespace
+extern "C" {
 int mic_csv_header(char* buf, size_t cap, int extended, const char* const* target_names, uint32_t n_targets) {
   size_t n = 0;
   auto app = [&](const char* s) { size_t l = strlen(s); if (n + l < cap) memcpy(buf + n, s, l); n += l; };
@@ -311,9 +416,23 @@ int mic_csv_line(char* buf, size_t cap, const uint8_t* name, size_t name_len, ui
   delta = (delta < 0.001) ? 0 : ((double)best) / delta;
   const char* n1 = (ib == 0 || ib > n_targets) ? "NA" : target_names[ib - 1];
   const char* n2 = (is == 0 || is > n_targets) ? "NA" : target_names[is - 1];
-  int w = snprintf(buf + (n < cap ? n : cap), n < cap ? cap - n : 0, ",%u,%g,%s,%u,%s,%u,%g\n", norm, gamma, n1, best, n2,
-                   sbest, delta);
-  n += (size_t)w;
+  // The two %g fields are ratios of small integers: their printf images are cached per thread (filled by snprintf
+  // itself, so the text is identical); the rest is assembled by hand.
+  const double den_g = ((double)norm - (double)k) + 1.0;
+  const uint32_t den_d = best + sbest;
+  char tmp[64];
+  if (n + 128 + strlen(n1) + strlen(n2) >= cap) return -1;
+  char* p = buf + n;
+  *p++ = ','; p += put_u32(p, norm);
+  *p++ = ','; p += put_ratio(p, total, den_g, gamma, tmp);
+  *p++ = ','; { size_t l = strlen(n1); memcpy(p, n1, l); p += l; }
+  *p++ = ','; p += put_u32(p, best);
+  *p++ = ','; { size_t l = strlen(n2); memcpy(p, n2, l); p += l; }
+  *p++ = ','; p += put_u32(p, sbest);
+  *p++ = ','; p += put_ratio(p, den_d ? best : 0u, den_d ? (double)den_d : 1.0, delta, tmp);   // no hits: delta = 0
+  *p++ = '\n';
+  *p = 0;
+  n = (size_t)(p - buf);
   return n < cap ? (int)n : -1;
 }
 

@@ -90,6 +90,40 @@ def test_pack_long_part_split(lib, orc):
         assert len(lens) == 3 and sum(lens) == 150000 + 2 * (k - 1) and max(lens) == 65528
 
 
+def test_pack_random_records_match_oracle(lib, orc):
+    """The streaming packer (eight nucleotides per step, roll-back of short runs) against the oracle's byte-by-byte one:
+    random line widths (containers straddle line breaks), Ns and other bytes, lower case, U, runs around k, empty
+    lines, records around the 65528-nt limit where the packer switches to the splitting path."""
+    from cuclark_amd import host
+    rng = np.random.default_rng(77)
+    recs = []
+    for i in range(400):
+        n = int(rng.choice([0, 1, 7, 8, 9, 30, 31, 32, 33, 64, 100, 151, 250, 1000]))
+        seq = rng.choice(list("ACGTacgtUu"), n)
+        for pos in rng.integers(0, max(n, 1), int(rng.integers(0, 4))):
+            if n:
+                seq[pos] = rng.choice(list("NnRY-*. "))
+        body = "".join(seq)
+        width = int(rng.choice([1, 7, 8, 13, 60, 70, 80, 10 ** 6]))
+        lines = [body[a:a + width] for a in range(0, len(body), width)] or [""]
+        if rng.random() < 0.1:
+            lines.insert(int(rng.integers(0, len(lines) + 1)), "")
+        recs.append(f">r{i} d\n" + "\n".join(lines) + "\n")
+    for n in (65527, 65528, 65529, 65600):
+        seq = rng.choice(list("ACGT"), n)
+        seq[n // 3] = "N"
+        body = "".join(seq)
+        recs.append(f">long{n}\n" + "\n".join(body[a:a + 70] for a in range(0, n, 70)) + "\n")
+        recs.append(f">solid{n}\n" + "".join(rng.choice(list("ACGT"), n)) + "\n")
+    data = "".join(recs).encode()
+    ix = host.index_reads(data)
+    assert ix["seq_s"].size == len(recs)
+    for k in (4, 8, 9, 21, 31, 32):
+        rp, ct = host.pack_reads(data, ix["seq_s"], ix["seq_e"], ix["length"], k)
+        rp2, ct2 = orc.pack_batch(data, ix["seq_s"], ix["seq_e"], ix["length"], k)
+        assert (rp == rp2).all() and ct.size == ct2.size and (ct == ct2).all(), k
+
+
 @pytest.mark.parametrize("case", [c[0] for c in gu.expected_csv_cases()])
 def test_csv_formatting_matches_golden(case, lib):
     """C++ CSV writer fed with the oracle's results reproduces the committed CSV byte for byte."""
