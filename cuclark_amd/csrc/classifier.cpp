@@ -201,6 +201,19 @@ class MmapSource : public Classifier::SegmentSource {
       if (end <= pos_) end = nb_;
     }
     s.p = map_ + pos_; s.n = end - pos_; s.own.clear();
+    // fault the segment in here (this runs on the side thread, ahead of the indexer's 32 threads taking the faults)
+    {
+      const uintptr_t a = (uintptr_t)(map_ + pos_) & ~(uintptr_t)4095, b = (uintptr_t)(map_ + end);
+      bool done = false;
+#ifdef MADV_POPULATE_READ
+      done = madvise((void*)a, (size_t)(b - a), MADV_POPULATE_READ) == 0;
+#endif
+      if (!done) {
+        unsigned sum = 0;
+        for (uintptr_t q = a; q < b; q += 4096) sum += *(volatile const uint8_t*)q;
+        (void)sum;
+      }
+    }
     pos_ = end;
     return true;
   }

@@ -10,6 +10,7 @@
 
 #include <thread>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 // ---- division magic ---------------------------------------------------------------------------------
@@ -162,7 +163,15 @@ long mic_index_reads_parallel(const uint8_t* map, size_t nb, int n_threads, size
   const bool fasta = map[0] == '>';
   std::vector<size_t> start(n_threads + 1, nb);
   start[0] = 0;
-  std::vector<std::vector<Rec>> recs(n_threads);
+  // Per-range record buffers are kept between calls (one pool, taken by whoever gets the lock): a fresh 10 MB vector
+  // per thread per call is returned to the kernel on free and faulted in again, which cost more than the parsing.
+  static std::mutex pool_mu;
+  static std::vector<std::vector<Rec>> pool;
+  std::vector<std::vector<Rec>> local;
+  std::unique_lock<std::mutex> pool_lock(pool_mu, std::try_to_lock);
+  std::vector<std::vector<Rec>>& recs = pool_lock.owns_lock() ? pool : local;
+  if (recs.size() < (size_t)n_threads) recs.resize(n_threads);
+  for (auto& v : recs) v.clear();
   run_threads(n_threads, [&](int t) { if (t > 0) start[t] = find_record_start(map, nb, fasta, (size_t)t * (nb / n_threads)); });
   run_threads(n_threads, [&](int t) {
     size_t lo = start[t], hi = nb;
