@@ -496,33 +496,63 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     h_a[t].elems = tot_elems; h_a[t].nonzero = tot_nz; tot_elems += e; tot_nz += z;
   }
   HIPCK(hipMemcpyAsync(d_a, h_a.data(), sizeof(TileA) * n_tiles, hipMemcpyHostToDevice, s));
-  // half-full slots on average; the clustering of k-mers by minimizer makes the load lumpy
-  {
-    unsigned long long load = 6;  // average entries per 12-entry main slot
-    if (const char* env = getenv("MIC_MSLOT_LOAD")) { long v = atol(env); if (v >= 1 && v <= 12) load = (unsigned long long)v; }
-    n_mslots = tot_elems / (sampling > 1 ? load * sampling : load) + 64;
-  }
-  if (n_mslots > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many M-slots"); rc = -1; goto done; }
-  m_tiles = (unsigned)((n_mslots + TILE - 1) / TILE);
-  h_tile.resize(m_tiles);
-  HIPCK(hipMalloc(&d_cnt, n_mslots * 4));
-  HIPCK(hipMalloc(&d_tile, (size_t)m_tiles * 8));
-  HIPCK(hipMemsetAsync(d_cnt, 0, n_mslots * 4, s));
+  // Average entries per 12-entry main slot.  6 (half-full slots) is the measured optimum when memory allows: the
+  // clustering of k-mers by minimizer makes the load lumpy and overflowing slots cost a second round.  When the table
+  // would not fit in the free HBM the load is raised step by step (each trial is one counting pass, exact size).
   a.sizes = d_sizes; a.n_buckets = n_buckets; a.bucket0 = bucket0; a.htsize = htsize; a.keys = d_keys; a.labels = d_labels;
-  a.base_a = d_a; a.sampling = sampling; a.rank_base = rank_base; a.k = k; a.m = m; a.n_mslots = n_mslots;
+  a.base_a = d_a; a.sampling = sampling; a.rank_base = rank_base; a.k = k; a.m = m;
 #define BY_RAW(KERN, ...) do { if (key_bytes == 8) KERN<uint64_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); \
     else if (key_bytes == 4) KERN<uint32_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); \
     else KERN<uint16_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); } while (0)
-  BY_RAW(m_count_kernel, a, d_cnt, d_kept);
-  HIPCK(hipGetLastError());
-  m_ovf_tile_kernel<<<m_tiles, TILE, 0, s>>>(d_cnt, n_mslots, d_tile, d_max);
-  HIPCK(hipGetLastError());
-  HIPCK(hipMemcpyAsync(h_tile.data(), d_tile, (size_t)m_tiles * 8, hipMemcpyDeviceToHost, s));
-  HIPCK(hipMemcpyAsync(&h_kept, d_kept, 8, hipMemcpyDeviceToHost, s));
-  HIPCK(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
-  HIPCK(hipStreamSynchronize(s));
-  for (unsigned t = 0; t < m_tiles; ++t) { unsigned long long v = h_tile[t]; h_tile[t] = tot_ovf; tot_ovf += v; }
-  if (n_mslots + tot_ovf > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many M-slots"); rc = -1; goto done; }
+  {
+    unsigned long long loads[5] = {6, 7, 8, 9, 10};   // beyond ~9 the overflow trees outgrow what the main slots save
+    int n_loads = 5;
+    if (const char* env = getenv("MIC_MSLOT_LOAD")) { long v = atol(env); if (v >= 1 && v <= 12) { loads[0] = (unsigned long long)v; n_loads = 1; } }
+    bool fits = false;
+    double least_need = 0, avail_b = 0;
+    for (int li = 0; li < n_loads && !fits; ++li) {
+      const unsigned long long load = loads[li];
+      n_mslots = tot_elems / (sampling > 1 ? load * sampling : load) + 64;
+      if (n_mslots > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many M-slots"); rc = -1; goto done; }
+      m_tiles = (unsigned)((n_mslots + TILE - 1) / TILE);
+      h_tile.resize(m_tiles);
+      if (d_cnt) { hipFree(d_cnt); d_cnt = nullptr; }
+      if (d_tile) { hipFree(d_tile); d_tile = nullptr; }
+      if (hipMalloc(&d_cnt, n_mslots * 4) != hipSuccess || hipMalloc(&d_tile, (size_t)m_tiles * 8) != hipSuccess) { (void)hipGetLastError(); continue; }
+      HIPCK(hipMemsetAsync(d_cnt, 0, n_mslots * 4, s));
+      HIPCK(hipMemsetAsync(d_kept, 0, 8, s));
+      HIPCK(hipMemsetAsync(d_max, 0, 4, s));
+      a.n_mslots = n_mslots;
+      BY_RAW(m_count_kernel, a, d_cnt, d_kept);
+      HIPCK(hipGetLastError());
+      m_ovf_tile_kernel<<<m_tiles, TILE, 0, s>>>(d_cnt, n_mslots, d_tile, d_max);
+      HIPCK(hipGetLastError());
+      HIPCK(hipMemcpyAsync(h_tile.data(), d_tile, (size_t)m_tiles * 8, hipMemcpyDeviceToHost, s));
+      HIPCK(hipMemcpyAsync(&h_kept, d_kept, 8, hipMemcpyDeviceToHost, s));
+      HIPCK(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
+      HIPCK(hipStreamSynchronize(s));
+      tot_ovf = 0;
+      for (unsigned t = 0; t < m_tiles; ++t) { unsigned long long v = h_tile[t]; h_tile[t] = tot_ovf; tot_ovf += v; }
+      if (n_mslots + tot_ovf > 0xFFFFFF00ull) continue;
+      size_t free_b = 0, total_b = 0;
+      HIPCK(hipMemGetInfo(&free_b, &total_b));
+      // room for the slots = free HBM minus the two per-slot cursors of the scatter and the query batches afterwards
+      double avail = (double)free_b - (double)n_mslots * 8 - 1.5e9;
+      if (const char* env = getenv("MIC_HBM_LIMIT_GB")) {   // test hook: pretend only this much is available for the slots
+        const double lim = atof(env) * 1e9;
+        if (lim > 0 && avail > lim) avail = lim;
+      }
+      const double need = (double)(n_mslots + tot_ovf + 1) * sizeof(MSlot);
+      if (least_need == 0 || need < least_need) least_need = need;
+      avail_b = avail;
+      fits = need <= avail;
+    }
+    if (!fits) {
+      snprintf(err, err_cap, "the minimizer table needs at least %.3f GB, %.3f GB of HBM are available for it", least_need / 1e9,
+               avail_b / 1e9);
+      rc = -3; goto done;
+    }
+  }
   HIPCK(hipMemcpyAsync(d_tile, h_tile.data(), (size_t)m_tiles * 8, hipMemcpyHostToDevice, s));
   {
     hipError_t e_ = hipMalloc(&slots, (size_t)(n_mslots + tot_ovf + 1) * sizeof(MSlot));

@@ -142,11 +142,12 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   char err[256] = "";
   // layout: explicit request, else the environment (MIC_LAYOUT=direct|minimizer), else by k
   int layout = (int)e->cfg.layout;
+  bool by_default = false;   // nobody asked for this layout: a table that does not fit may fall back to the other one
   if (layout == MIC_LAYOUT_AUTO) {
     const char* env = getenv("MIC_LAYOUT");
     if (env && !strcmp(env, "direct")) layout = MIC_LAYOUT_DIRECT;
     else if (env && !strcmp(env, "minimizer")) layout = MIC_LAYOUT_MINIMIZER;
-    else layout = e->cfg.k >= 24 ? MIC_LAYOUT_MINIMIZER : MIC_LAYOUT_DIRECT;  // measured: DESIGN.md §3.2
+    else { layout = e->cfg.k >= 24 ? MIC_LAYOUT_MINIMIZER : MIC_LAYOUT_DIRECT; by_default = true; }  // measured: DESIGN.md §3.2
   }
   int m = 20;   // measured best for k = 31: minimizers long enough to be nearly unique in the table
   if (const char* env = getenv("MIC_MINIMIZER_LEN")) m = atoi(env);
@@ -156,11 +157,14 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   if (e->d_sizes) { hipFree(e->d_sizes); e->d_sizes = nullptr; }
   if (hipMalloc(&e->d_sizes, s1 - s0) == hipSuccess)
     hipMemcpyAsync(e->d_sizes, d_sizes_shard, s1 - s0, hipMemcpyDeviceToDevice, e->stream);
-  int rc;
-  if (layout == MIC_LAYOUT_MINIMIZER)
+  int rc = 0;
+  if (layout == MIC_LAYOUT_MINIMIZER) {
     rc = mic_build_mtable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
                           e->cfg.k, m, e->stream, &b, err, sizeof(err));
-  else
+    // -3: even the densest minimizer table exceeds the free HBM; the direct layout is ~40 % smaller (64 B per bucket)
+    if (rc == -3 && by_default) { layout = MIC_LAYOUT_DIRECT; memset(&b, 0, sizeof(b)); }
+  }
+  if (layout != MIC_LAYOUT_MINIMIZER)
     rc = mic_build_table(d_sizes_shard, s1 - s0, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
                          e->slot_class, e->stream, &b, err, sizeof(err));
   if (rc != 0) return fail(rc, "table build: %s", err);

@@ -449,3 +449,35 @@ def test_skewed_minimizer_bucket():
     assert ((res[:, 0] == 1) == (f == 1)).all()
     assert (res[f == 1, 1] == l[f == 1].astype(np.uint32) + 1).all()
     assert f[:4096].all()
+
+
+def test_table_adapts_to_the_free_hbm(monkeypatch):
+    """A table that does not fit at half-full slots is built denser (exact counting pass per setting); when even the
+    densest minimizer table does not fit and nobody asked for that layout, the engine falls back to the direct one.
+    MIC_HBM_LIMIT_GB is the test hook that pretends less HBM is available.  Results stay identical."""
+    if os.environ["MIC_LAYOUT"] != "minimizer":
+        pytest.skip("sizing of the minimizer table")
+    rng = np.random.default_rng(23)
+    k, T, htsize = 31, 9, 2000003
+    sizes, keys, labels, canon = gu.random_db(rng, htsize, 150000, k, 8, T)
+    q = np.concatenate([canon[::7], rng.integers(0, 1 << 62, 2000, dtype=np.uint64)])
+    rp, cont = _kmer_reads(q, k)
+
+    def run():
+        with _engine(k, T) as e:
+            e.read_arrays(sizes, keys, labels)
+            return e.info(), e.classify_packed(rp, cont)
+    base_info, base = run()
+    assert base_info["layout"] == 2
+    table_gb = base_info["hbm_bytes"] / 1e9
+    monkeypatch.setenv("MIC_HBM_LIMIT_GB", repr(table_gb * 0.9))      # random k-mers: 7 per slot is ~11 % smaller than 6
+    info, res = run()
+    assert info["layout"] == 2 and info["n_slots"] < base_info["n_slots"] and info["hbm_bytes"] <= table_gb * 0.9e9
+    assert (res == base).all()
+    monkeypatch.setenv("MIC_HBM_LIMIT_GB", repr(table_gb * 0.05))
+    with pytest.raises(Exception, match="minimizer table needs at least"):     # the layout was requested explicitly (MIC_LAYOUT)
+        run()
+    monkeypatch.delenv("MIC_LAYOUT")                                   # by default: fall back to the direct layout
+    info, res = run()
+    assert info["layout"] == 1
+    assert (res[:, :5] == base[:, :5]).all()
