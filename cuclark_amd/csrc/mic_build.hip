@@ -429,6 +429,43 @@ __global__ void m_sort_kernel(const uint32_t* __restrict__ cnt, const uint32_t* 
   if (s >= n) return;
   const uint32_t c = cnt[s];
   if (c < 2) return;
+  if (c <= MIC_MCAP) {
+    // The common case, a bucket that fits its main slot: the 128 bytes are read once into registers, sorted by a
+    // fixed 12-input network (39 compare-exchanges, every index static; unused keys are ~0 and sink to the end) and
+    // written back once.  The in-memory shell sort below walked the slot with dependent loads and stores.
+    uint4* q = (uint4*)&slots[s];
+    uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4], w5 = q[5], w6 = q[6], w7 = q[7];
+    unsigned long long k0 = w0.x | ((unsigned long long)w0.y << 32), k1 = w0.z | ((unsigned long long)w0.w << 32),
+                       k2 = w1.x | ((unsigned long long)w1.y << 32), k3 = w1.z | ((unsigned long long)w1.w << 32),
+                       k4 = w2.x | ((unsigned long long)w2.y << 32), k5 = w2.z | ((unsigned long long)w2.w << 32),
+                       k6 = w3.x | ((unsigned long long)w3.y << 32), k7 = w3.z | ((unsigned long long)w3.w << 32),
+                       k8 = w4.x | ((unsigned long long)w4.y << 32), k9 = w4.z | ((unsigned long long)w4.w << 32),
+                       k10 = w5.x | ((unsigned long long)w5.y << 32), k11 = w5.z | ((unsigned long long)w5.w << 32);
+    uint32_t l0 = w6.x & 0xFFFF, l1 = w6.x >> 16, l2 = w6.y & 0xFFFF, l3 = w6.y >> 16, l4 = w6.z & 0xFFFF, l5 = w6.z >> 16,
+             l6 = w6.w & 0xFFFF, l7 = w6.w >> 16, l8 = w7.x & 0xFFFF, l9 = w7.x >> 16, l10 = w7.y & 0xFFFF, l11 = w7.y >> 16;
+#define CE(a, b) { const bool sw_ = k##a > k##b; const unsigned long long tk_ = sw_ ? k##b : k##a; k##b = sw_ ? k##a : k##b; k##a = tk_; \
+                   const uint32_t tl_ = sw_ ? l##b : l##a; l##b = sw_ ? l##a : l##b; l##a = tl_; }
+    CE(0, 8) CE(1, 7) CE(2, 6) CE(3, 11) CE(4, 10) CE(5, 9)
+    CE(0, 1) CE(2, 5) CE(3, 4) CE(6, 9) CE(7, 8) CE(10, 11)
+    CE(0, 2) CE(1, 6) CE(5, 10) CE(9, 11)
+    CE(0, 3) CE(1, 2) CE(4, 6) CE(5, 7) CE(8, 11) CE(9, 10)
+    CE(1, 4) CE(3, 5) CE(6, 8) CE(7, 10)
+    CE(1, 3) CE(2, 5) CE(6, 9) CE(8, 10)
+    CE(2, 3) CE(4, 5) CE(6, 7) CE(8, 9)
+    CE(4, 6) CE(5, 7)
+    CE(3, 4) CE(5, 6) CE(7, 8)
+#undef CE
+#define LO(v) (uint32_t)(v)
+#define HI(v) (uint32_t)((v) >> 32)
+    q[0] = make_uint4(LO(k0), HI(k0), LO(k1), HI(k1)); q[1] = make_uint4(LO(k2), HI(k2), LO(k3), HI(k3));
+    q[2] = make_uint4(LO(k4), HI(k4), LO(k5), HI(k5)); q[3] = make_uint4(LO(k6), HI(k6), LO(k7), HI(k7));
+    q[4] = make_uint4(LO(k8), HI(k8), LO(k9), HI(k9)); q[5] = make_uint4(LO(k10), HI(k10), LO(k11), HI(k11));
+    q[6] = make_uint4(l0 | (l1 << 16), l2 | (l3 << 16), l4 | (l5 << 16), l6 | (l7 << 16));
+    q[7] = make_uint4(l8 | (l9 << 16), l10 | (l11 << 16), w7.z, w7.w);
+#undef LO
+#undef HI
+    return;
+  }
   const uint32_t fo = ovf_first[s];
   const uint32_t gaps[] = {701, 301, 132, 57, 23, 10, 4, 1};
   for (int g = 0; g < 8; ++g) {
