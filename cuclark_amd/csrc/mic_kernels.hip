@@ -366,16 +366,19 @@ __device__ unsigned long long g_phase[8];
 #define PH(i)
 #define PH_END
 #endif
-__global__ void __launch_bounds__(256, 8) query_kernel_m(const MicQueryArgs a PERTURB_PARAMS) {
-  __shared__ uint4 s_stage[4][MIC_RMAX * MIC_MSTRIDE];
-  __shared__ uint32_t s_run[4][MIC_RMAX];
-  __shared__ uint32_t s_ahead[4][2][64];
+#ifndef MIC_M_WPB
+#define MIC_M_WPB 4        // waves per block of query_kernel_m (measured: 1: 778, 2: 757, 4: 824-834 Mreads/s; tools/wpb_sweep.sh)
+#endif
+__global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m(const MicQueryArgs a PERTURB_PARAMS) {
+  __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE];
+  __shared__ uint32_t s_run[MIC_M_WPB][MIC_RMAX];
+  __shared__ uint32_t s_ahead[MIC_M_WPB][2][64];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   uint4* stage = s_stage[wv];
   uint32_t* runslot = s_run[wv];
-  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
-  const uint32_t n_waves = gridDim.x * 4;
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * MIC_M_WPB + wv);
+  const uint32_t n_waves = gridDim.x * MIC_M_WPB;
   const MicTable& t = a.t;
   const int k = t.k, m = t.m, w = k - m + 1;
   const uint4* __restrict__ slots = t.slots;
@@ -831,10 +834,10 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
       if ((e = getenv("MIC_PERTURB_VALU"))) pv[0] = atoi(e);
       if ((e = getenv("MIC_PERTURB_LDS"))) pv[1] = atoi(e);
       if ((e = getenv("MIC_PERTURB_SALU"))) pv[2] = atoi(e);
-      query_kernel_m<<<blocks, 256, 0, s>>>(a, pv[0], pv[1], pv[2]);
+      query_kernel_m<<<(blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, 64 * MIC_M_WPB, 0, s>>>(a, pv[0], pv[1], pv[2]);
     }
 #else
-    query_kernel_m<<<blocks, 256, 0, s>>>(a);
+    query_kernel_m<<<(blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, 64 * MIC_M_WPB, 0, s>>>(a);
 #endif
 #ifdef MIC_PHASE_TIMING
     unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
