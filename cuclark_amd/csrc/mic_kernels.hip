@@ -393,11 +393,13 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
   uint32_t* ahead0 = s_ahead[wv][0];
   uint32_t* ahead1 = s_ahead[wv][1];
   auto ahead_issue = [&](uint32_t* entry, uint32_t pp_w, uint32_t r_ptr) {
+    // lanes 0..11: aligned dwords of the window; lanes 12, 13: reads_ptr[rr], reads_ptr[rr + 1]; the rest repeat lane 0.
+    // One select between two wave-uniform bases, then base + 4 * lane (the pointer base is pre-biased by -48).
     const uint64_t abase = ((uint64_t)(cont + pp_w)) & ~3ULL;
     const uint32_t rr = r_ptr < a.n_reads ? r_ptr : a.n_reads - 1;
-    uint64_t addr = abase + 4 * (lane < 12 ? lane : 0);
-    if (lane == 12) addr = (uint64_t)(a.reads_ptr + rr);
-    if (lane == 13) addr = (uint64_t)(a.reads_ptr + rr + 1);
+    const uint64_t pbase = (uint64_t)(a.reads_ptr + rr) - 48;
+    const uint32_t li = lane < 14 ? (uint32_t)lane : 0u;
+    const uint64_t addr = (li < 12 ? abase : pbase) + 4 * li;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
                                      (__attribute__((address_space(3))) void*)entry, 4, 0, 0);
   };
