@@ -179,8 +179,9 @@ __device__ __forceinline__ void tally2(uint32_t r0, uint32_t r1, RowAcc& acc, ui
 
 // Scalar top-2 over the row under the order (count desc, target asc) — equivalent to resultKernel's
 // ascending scan with strict '>' (CuClarkDB.cu:1440-1459), see DESIGN.md §4.
+template <typename ARGS>   // MicQueryArgs, or the cold fields re-read from the kernarg segment (query_kernel_m)
 __device__ __forceinline__ void finish_read(const RowAcc& acc, uint32_t n_ent, uint32_t total, uint32_t overflow,
-                                            uint32_t r, const MicQueryArgs& a, int lane) {
+                                            uint32_t r, const ARGS& a, int lane) {
   uint64_t best = 0, second = 0;
   for (uint32_t i = 0; i < n_ent; ++i) {
     uint32_t l1 = __builtin_amdgcn_readlane(acc.label1, i);
@@ -456,10 +457,15 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
           const uint64_t rck = revcomp_bits(kmer, k);
           c[h] = kmer < rck ? kmer : rck;
           act[h] = base + 64 * h + lane < nk;
-          if (t.sharded) {
-            uint64_t q = mic_div(c[h], t.div);
-            uint64_t rem = c[h] - q * t.div.d;
-            act[h] = act[h] && rem >= t.shard_start && rem < t.shard_end;
+          if (t.sharded) {   // table-sharded mode only: divisor and bounds are re-read from the kernarg segment (see finish)
+            uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+            MicDiv dv; dv.d = kc->t.div.d; dv.magic = kc->t.div.magic; dv.shift = kc->t.div.shift; dv.add = kc->t.div.add;
+            const uint64_t s_lo = kc->t.shard_start, s_hi = kc->t.shard_end;
+            uint64_t q = mic_div(c[h], dv);
+            uint64_t rem = c[h] - q * dv.d;
+            act[h] = act[h] && rem >= s_lo && rem < s_hi;
           }
           // m-mer at this position = first m nt of the k-mer; its reverse complement = last m nt of rc(k-mer)
           const uint64_t mf = kmer >> (2 * (k - m)), mr = rck & ((1ULL << (2 * m)) - 1);
@@ -562,7 +568,17 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
     ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_w, t_pp, t_pe);
     __builtin_amdgcn_wave_barrier();
     PH(4)
-    finish_read(acc, n_ent, total, overflow, r, a, lane);
+    {
+      // The output pointers are needed once per read: they are re-read from the kernarg segment here (scalar loads
+      // that hit the scalar cache) instead of living in SGPRs for the whole kernel - the kernel was spilling 35 SGPRs
+      // into VGPR lanes, ~58 v_readlane/v_writelane per read.  The asm keeps the loads from being hoisted.
+      uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));
+      const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+      struct { uint32_t* results; uint32_t* rows; uint32_t* flagged; uint32_t row_words, flagged_cap; } fa;
+      fa.results = kc->results; fa.rows = kc->rows; fa.flagged = kc->flagged; fa.row_words = kc->row_words; fa.flagged_cap = kc->flagged_cap;
+      finish_read(acc, n_ent, total, overflow, r, fa, lane);
+    }
     ahead_issue(ahead_sel ? ahead0 : ahead1, t_pp, r + 3 * n_waves);
     ahead_sel ^= 1;
     cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; cur_w = t_w; n_pp = t_pp; n_pe = t_pe;
