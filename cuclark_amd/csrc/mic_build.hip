@@ -422,14 +422,62 @@ __global__ void __launch_bounds__(TILE) m_scatter_kernel(MBuildArgs a, const uin
   });
 }
 
-// sort the bucket's entries by key (shell sort over the virtual array), then write the directory separators
-__global__ void m_sort_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ovf_first, uint64_t n,
-                              MSlot* __restrict__ slots) {
-  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  const uint32_t c = cnt[s];
-  if (c < 2) return;
-  if (c <= MIC_MCAP) {
+// ---- sorting the entries of every bucket, then the directory separators of the tree buckets ------------------------
+// serial form: shell sort over the bucket's virtual array (entry e lives in leaf e / 12)
+__device__ void m_sort_bucket_serial(MSlot* __restrict__ slots, uint64_t s, uint32_t c, uint32_t fo) {
+  const uint32_t gaps[] = {701, 301, 132, 57, 23, 10, 4, 1};
+  for (int g = 0; g < 8; ++g) {
+    const uint32_t gap = gaps[g];
+    if (gap >= c) continue;
+    for (uint32_t i = gap; i < c; ++i) {
+      MSlot* si = m_elem_slot(slots, s, c, fo, i);
+      unsigned long long kv = si->keys[i % MIC_MCAP]; unsigned short lv = si->labels[i % MIC_MCAP];
+      uint32_t j = i;
+      while (j >= gap) {
+        MSlot* sj = m_elem_slot(slots, s, c, fo, j - gap);
+        unsigned long long kj = sj->keys[(j - gap) % MIC_MCAP];
+        if (kj <= kv) break;
+        MSlot* sd = m_elem_slot(slots, s, c, fo, j);
+        sd->keys[j % MIC_MCAP] = kj; sd->labels[j % MIC_MCAP] = sj->labels[(j - gap) % MIC_MCAP];
+        j -= gap;
+      }
+      MSlot* sd = m_elem_slot(slots, s, c, fo, j);
+      sd->keys[j % MIC_MCAP] = kv; sd->labels[j % MIC_MCAP] = lv;
+    }
+  }
+  const MTree t = m_tree(c);
+  const uint64_t leaf0 = (uint64_t)fo + t.off[0];
+  uint32_t span = 1;  // leaves below one child of a level-l directory = 12^(l-1)
+  for (uint32_t l = 1; l <= t.height; ++l) {
+    const uint32_t nodes = l == t.height ? 1 : t.cnt[l];
+    for (uint32_t j = 0; j < nodes; ++j) {
+      MSlot* dir = l == t.height ? &slots[s] : &slots[(uint64_t)fo + t.off[l] + j];
+      for (uint32_t e = 0; e < MIC_MCAP; ++e) {
+        const uint64_t child = (uint64_t)j * MIC_MCAP + e;          // index within level l-1
+        if (child >= t.cnt[l - 1]) break;
+        dir->keys[e] = slots[leaf0 + child * span].keys[0];
+      }
+    }
+    span *= MIC_MCAP;
+  }
+}
+
+// One lane per main slot for the buckets that fit it (sorting network in registers); the tree buckets of the wave's 64
+// slots are then sorted one after the other by the whole wave: entries to LDS, rank of every entry by counting the
+// smaller ones (LDS broadcast reads), scatter to the final position, separators from the sorted copy.  Buckets beyond
+// MSORT_CAP entries fall back to the serial form on one lane.  (The serial form for every tree bucket took 4.2 s of
+// the 5.7 s table build of the headline table: divergent waves waiting for their slowest lane.)
+#define MSORT_CAP 256
+__global__ void __launch_bounds__(256) m_sort_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ovf_first,
+                                                     uint64_t n, MSlot* __restrict__ slots) {
+  __shared__ unsigned long long s_key[4][MSORT_CAP];
+  __shared__ unsigned long long s_sorted[4][MSORT_CAP];
+  __shared__ unsigned short s_lab[4][MSORT_CAP];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = s < n ? cnt[s] : 0;
+  const uint32_t fo_lane = (s < n && c > MIC_MCAP) ? ovf_first[s] : 0;
+  if (c >= 2 && c <= MIC_MCAP) {
     // The common case, a bucket that fits its main slot: the 128 bytes are read once into registers, sorted by a
     // fixed 12-input network (39 compare-exchanges, every index static; unused keys are ~0 and sink to the end) and
     // written back once.  The in-memory shell sort below walked the slot with dependent loads and stores.
@@ -464,44 +512,42 @@ __global__ void m_sort_kernel(const uint32_t* __restrict__ cnt, const uint32_t* 
     q[7] = make_uint4(l8 | (l9 << 16), l10 | (l11 << 16), w7.z, w7.w);
 #undef LO
 #undef HI
-    return;
   }
-  const uint32_t fo = ovf_first[s];
-  const uint32_t gaps[] = {701, 301, 132, 57, 23, 10, 4, 1};
-  for (int g = 0; g < 8; ++g) {
-    const uint32_t gap = gaps[g];
-    if (gap >= c) continue;
-    for (uint32_t i = gap; i < c; ++i) {
-      MSlot* si = m_elem_slot(slots, s, c, fo, i);
-      unsigned long long kv = si->keys[i % MIC_MCAP]; unsigned short lv = si->labels[i % MIC_MCAP];
-      uint32_t j = i;
-      while (j >= gap) {
-        MSlot* sj = m_elem_slot(slots, s, c, fo, j - gap);
-        unsigned long long kj = sj->keys[(j - gap) % MIC_MCAP];
-        if (kj <= kv) break;
-        MSlot* sd = m_elem_slot(slots, s, c, fo, j);
-        sd->keys[j % MIC_MCAP] = kj; sd->labels[j % MIC_MCAP] = sj->labels[(j - gap) % MIC_MCAP];
-        j -= gap;
-      }
-      MSlot* sd = m_elem_slot(slots, s, c, fo, j);
-      sd->keys[j % MIC_MCAP] = kv; sd->labels[j % MIC_MCAP] = lv;
+  unsigned long long* key = s_key[wv]; unsigned long long* sorted = s_sorted[wv]; unsigned short* lab = s_lab[wv];
+  for (unsigned long long todo = __ballot(c > MIC_MCAP); todo; todo &= todo - 1) {
+    const int b = __builtin_ctzll(todo);
+    const uint32_t cb = __builtin_amdgcn_readlane(c, b), fo = __builtin_amdgcn_readlane(fo_lane, b);
+    const uint64_t sb = s - lane + b;
+    if (cb > MSORT_CAP) {
+      if (lane == 0) m_sort_bucket_serial(slots, sb, cb, fo);
+      continue;
     }
-  }
-  if (c <= MIC_MCAP) return;
-  const MTree t = m_tree(c);
-  const uint64_t leaf0 = (uint64_t)fo + t.off[0];
-  uint32_t span = 1;  // leaves below one child of a level-l directory = 12^(l-1)
-  for (uint32_t l = 1; l <= t.height; ++l) {
-    const uint32_t nodes = l == t.height ? 1 : t.cnt[l];
-    for (uint32_t j = 0; j < nodes; ++j) {
-      MSlot* dir = l == t.height ? &slots[s] : &slots[(uint64_t)fo + t.off[l] + j];
-      for (uint32_t e = 0; e < MIC_MCAP; ++e) {
-        const uint64_t child = (uint64_t)j * MIC_MCAP + e;          // index within level l-1
-        if (child >= t.cnt[l - 1]) break;
-        dir->keys[e] = slots[leaf0 + child * span].keys[0];
-      }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = lane; e < cb; e += 64) {
+      const MSlot* sl = m_elem_slot(slots, sb, cb, fo, e);
+      key[e] = sl->keys[e % MIC_MCAP]; lab[e] = sl->labels[e % MIC_MCAP];
     }
-    span *= MIC_MCAP;
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt/lgkmcnt 0: the LDS writes above are visible to the wave
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = lane; e < cb; e += 64) {
+      const unsigned long long ke = key[e];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < cb; ++j) { const unsigned long long kj = key[j]; rank += (kj < ke || (kj == ke && j < e)) ? 1u : 0u; }
+      MSlot* sd = m_elem_slot(slots, sb, cb, fo, rank);
+      sd->keys[rank % MIC_MCAP] = ke; sd->labels[rank % MIC_MCAP] = lab[e];
+      sorted[rank] = ke;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const MTree t = m_tree(cb);
+    uint32_t span = 1;
+    for (uint32_t l = 1; l <= t.height; ++l) {
+      for (uint32_t child = lane; child < t.cnt[l - 1]; child += 64) {       // child = index within level l-1
+        MSlot* dir = l == t.height ? &slots[sb] : &slots[(uint64_t)fo + t.off[l] + child / MIC_MCAP];
+        dir->keys[child % MIC_MCAP] = sorted[(uint64_t)child * span * MIC_MCAP];   // first key of the child's first leaf
+      }
+      span *= MIC_MCAP;
+    }
   }
 }
 
