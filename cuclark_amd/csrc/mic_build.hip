@@ -11,6 +11,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <vector>
 
 #define TILE 256
@@ -565,6 +566,15 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   uint64_t tot_elems = 0, tot_nz = 0, n_mslots = 0, tot_ovf = 0; unsigned m_tiles = 0;
   unsigned long long h_kept = 0; uint32_t h_max = 0;
   MBuildArgs a;
+  const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
+  struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    hipStreamSynchronize(s);
+    struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    fprintf(stderr, "[load]   %s: %.3f s\n", what, (t.tv_sec - t_prev.tv_sec) + (t.tv_nsec - t_prev.tv_nsec) / 1e9);
+    t_prev = t;
+  };
   HIPCK(hipMalloc(&d_a, sizeof(TileA) * n_tiles));
   HIPCK(hipMalloc(&d_kept, 8));
   HIPCK(hipMalloc(&d_max, 4));
@@ -636,6 +646,7 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       rc = -3; goto done;
     }
   }
+  lap("bucket sums + slot counts (sizing)");
   HIPCK(hipMemcpyAsync(d_tile, h_tile.data(), (size_t)m_tiles * 8, hipMemcpyHostToDevice, s));
   {
     hipError_t e_ = hipMalloc(&slots, (size_t)(n_mslots + tot_ovf + 1) * sizeof(MSlot));
@@ -645,16 +656,20 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       rc = -3; goto done;
     }
   }
+  lap("hipMalloc of the slots");
   HIPCK(hipMalloc(&d_of, n_mslots * 4));
   m_header_kernel<<<m_tiles, TILE, 0, s>>>(d_cnt, n_mslots, d_tile, slots, d_of);
   HIPCK(hipGetLastError());
+  lap("headers");
   HIPCK(hipMalloc(&d_cur, n_mslots * 4));
   HIPCK(hipMemsetAsync(d_cur, 0, n_mslots * 4, s));
   BY_RAW(m_scatter_kernel, a, d_cnt, d_of, d_cur, slots);
   HIPCK(hipGetLastError());
+  lap("scatter");
   m_sort_kernel<<<(unsigned)((n_mslots + 255) / 256), 256, 0, s>>>(d_cnt, d_of, n_mslots, slots);
   HIPCK(hipGetLastError());
   HIPCK(hipStreamSynchronize(s));
+  lap("sort + separators");
 #undef BY_RAW
   out->slots = (uint4*)slots; slots = nullptr;
   out->n_main = n_mslots; out->n_overflow = tot_ovf; out->n_elems = h_kept; out->n_elems_file = tot_elems;

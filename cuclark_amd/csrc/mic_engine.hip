@@ -9,9 +9,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <mutex>
 #include <string>
+#include <atomic>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -107,14 +111,16 @@ int check_shard(uint64_t htsize, uint64_t& s0, uint64_t& s1) {
   return MIC_OK;
 }
 
-// stream a byte range of a file into device memory through two pinned staging buffers
+// stream a byte range of a file into device memory through two pinned staging buffers; every chunk is read by several
+// threads (pread on disjoint slices): one fread stream moves ~6 GB/s out of the page cache, the link takes ~50
 int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStream_t s, const char* what) {
-  const size_t CH = 64u << 20;
+  const size_t CH = 256u << 20;
+  const int fd = fileno(f);
+  static const int n_readers = [] { const char* e = getenv("MIC_LOAD_THREADS"); int v = e ? atoi(e) : 0; return v > 0 ? (v > 64 ? 64 : v) : 8; }();
   void* stage[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};
   int rc = MIC_OK;
   if (bytes == 0) return MIC_OK;
-  if (fseeko(f, (off_t)off, SEEK_SET) != 0) return fail(MIC_E_IO, "seek failed in %s", what);
   for (int i = 0; i < 2 && rc == MIC_OK; ++i) {
     if (hipHostMalloc(&stage[i], CH, hipHostMallocDefault) != hipSuccess) rc = fail(MIC_E_NOMEM, "pinned staging alloc failed");
     else if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(MIC_E_HIP, "event create failed");
@@ -123,7 +129,26 @@ int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStrea
   while (rc == MIC_OK && done < bytes) {
     size_t n = (size_t)((bytes - done) < CH ? (bytes - done) : CH);
     if (used[cur] && hipEventSynchronize(ev[cur]) != hipSuccess) { rc = fail(MIC_E_HIP, "event sync failed"); break; }
-    if (fread(stage[cur], 1, n, f) != n) { rc = fail(MIC_E_IO, "%s is shorter than the bucket sizes imply", what); break; }
+    {
+      std::atomic<bool> short_read(false);
+      const size_t per = ((n + (size_t)n_readers - 1) / (size_t)n_readers + 4095) & ~(size_t)4095;
+      std::vector<std::thread> th;
+      for (int t = 0; t < n_readers; ++t) {
+        const size_t lo = (size_t)t * per;
+        if (lo >= n) break;
+        const size_t len = n - lo < per ? n - lo : per;
+        th.emplace_back([&, lo, len] {
+          size_t got = 0;
+          while (got < len) {
+            const ssize_t r = pread(fd, (char*)stage[cur] + lo + got, len - got, (off_t)(off + done + lo + got));
+            if (r <= 0) { short_read = true; return; }
+            got += (size_t)r;
+          }
+        });
+      }
+      for (auto& t : th) t.join();
+      if (short_read) { rc = fail(MIC_E_IO, "%s is shorter than the bucket sizes imply", what); break; }
+    }
     if (hipMemcpyAsync((char*)dst + done, stage[cur], n, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipEventRecord(ev[cur], s) != hipSuccess) { rc = fail(MIC_E_HIP, "H2D copy failed"); break; }
     used[cur] = true; cur ^= 1; done += n;
@@ -352,6 +377,14 @@ int mic_db_load_files(mic_engine* e, const char* prefix, int key_bytes, uint32_t
   FILE* fk = fopen((p + ".ky").c_str(), "rb");
   FILE* fl = fopen((p + ".lb").c_str(), "rb");
   uint8_t* h_sz = nullptr; uint8_t* d_sz = nullptr; void* d_ky = nullptr; uint16_t* d_lb = nullptr;
+  const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
+  struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    fprintf(stderr, "[load] %s: %.3f s\n", what, (t.tv_sec - t_prev.tv_sec) + (t.tv_nsec - t_prev.tv_nsec) / 1e9);
+    t_prev = t;
+  };
   do {
     // reference: "Failed to open <file>" and read() returns false (CuClarkDB.cu:490-495)
     if (!fs) { rc = fail(MIC_E_IO, "Failed to open %s.sz", prefix); break; }
@@ -366,18 +399,24 @@ int mic_db_load_files(mic_engine* e, const char* prefix, int key_bytes, uint32_t
     h_sz = (uint8_t*)malloc(htsize);
     if (!h_sz) { rc = fail(MIC_E_NOMEM, "out of host memory for bucket sizes"); break; }
     if (fread(h_sz, 1, htsize, fs) != htsize) { rc = fail(MIC_E_IO, "short read on %s.sz", prefix); break; }
+    lap("read .sz");
     uint64_t base_elems = 0, base_rank = 0, n_el = 0;
     for (uint64_t i = 0; i < s0; ++i) { base_elems += h_sz[i]; base_rank += h_sz[i] > 0; }
     for (uint64_t i = s0; i < s1; ++i) n_el += h_sz[i];
+    lap("sum bucket sizes");
     if (e->db_loaded) mic_db_unload(e);
     hipError_t he = hipMalloc(&d_sz, s1 - s0);
     if (he == hipSuccess) he = hipMalloc(&d_ky, n_el * key_bytes + 16);
     if (he == hipSuccess) he = hipMalloc(&d_lb, n_el * 2 + 16);
     if (he == hipSuccess) he = hipMemcpy(d_sz, h_sz + s0, s1 - s0, hipMemcpyHostToDevice);
     if (he != hipSuccess) { rc = fail(he == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "DB image allocation: %s", hipGetErrorString(he)); break; }
+    lap("allocate + upload .sz");
     if ((rc = upload_file_range(fk, base_elems * key_bytes, n_el * key_bytes, d_ky, e->stream, "the .ky file"))) break;
+    lap("upload .ky");
     if ((rc = upload_file_range(fl, base_elems * 2, n_el * 2, d_lb, e->stream, "the .lb file"))) break;
+    lap("upload .lb");
     rc = build_from_device(e, d_sz, htsize, s0, s1, d_ky, key_bytes, d_lb, sampling, base_rank);
+    lap("table build");
   } while (0);
   if (fs) fclose(fs);
   if (fk) fclose(fk);
