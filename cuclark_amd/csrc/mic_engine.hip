@@ -601,6 +601,7 @@ int mic_query_device(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont
   if (!e || !d_rp || !d_cont || !d_results) return fail(MIC_E_INVALID, "null argument");
   if (!e->db_loaded) return fail(MIC_E_STATE, "no database loaded");
   if (n_reads > 0xFFFFFFF0ull) return fail(MIC_E_INVALID, "too many reads in one call");
+  if (((uintptr_t)d_cont & 3) || ((uintptr_t)d_rp & 3)) return fail(MIC_E_INVALID, "d_containers and d_reads_pointer must be 4-byte aligned");
   int rc = set_device(e);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : e->stream;

@@ -140,7 +140,8 @@ int mic_batches_free(mic_engine* e);
  *   d_results: n_reads*MIC_RESULT_WORDS u32.  d_rows: n_reads*row_words u32 or NULL.
  *   Reads whose register row (64 distinct targets) or sparse row overflowed are flagged and listed in an
  *   engine-owned device list; mic_resolve_flagged_device completes them exactly with the dense path.
- *   d_containers must be readable for 32 elements past the last container (the kernel prefetches windows).
+ *   d_containers must be 4-byte aligned and readable for 32 elements past the last container (the kernel prefetches
+ *   windows as aligned dwords); MIC_E_INVALID otherwise.
  *   stream: a hipStream_t (NULL = the engine's stream).  Asynchronous. */
 int mic_query_device(mic_engine* e, const uint32_t* d_reads_pointer, const uint16_t* d_containers, size_t n_reads,
                      uint32_t* d_results, uint32_t* d_rows, void* stream);
