@@ -844,6 +844,14 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   static int per_cu = [] { const char* e = getenv("MIC_BLOCKS_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
   unsigned cap = (unsigned)n_cu * (unsigned)per_cu;
   if (blocks > cap) blocks = cap;
+  {
+    // Small launches (a CLI batch): a wave pays two dependent loads before its first read, so do not shrink below ~8
+    // reads per wave unless that would leave resident block slots empty.
+    const unsigned fill = (unsigned)n_cu * 8u;                       // one generation of resident blocks
+    const unsigned by_work = (unsigned)((a.n_reads + 31) / 32);      // 8 reads per wave
+    unsigned want = by_work > fill ? by_work : fill;
+    if (blocks > want) blocks = want;
+  }
   if (a.t.layout) {
 #ifdef MIC_PERTURB
     {

@@ -481,3 +481,89 @@ def test_table_adapts_to_the_free_hbm(monkeypatch):
     info, res = run()
     assert info["layout"] == 1
     assert (res[:, :5] == base[:, :5]).all()
+
+
+def test_properties_at_scale():
+    """200 M-k-mer table, 2 M reads (a scale the oracle cannot sweep in a test): the two table layouts give identical
+    result rows and sparse rows; two bucket-range shards merged on the device equal the whole table; a second pass is
+    bit-identical; the oracle agrees on a 20 000-read sample; the constructive known answer holds."""
+    if os.environ["MIC_LAYOUT"] != "minimizer":
+        pytest.skip("one run covers both layouts")
+    import ctypes as C
+    import torch
+    from cuclark_amd import _lib, MiClarkDB
+    L = _lib.load()
+    dev = torch.device("cuda:0")
+    T, k, htsize, nt = 300, 31, 57777779, 200_000_000
+    spec = _lib.MicSynthSpec(seed=21, htsize=htsize, genome_nt=nt, n_targets=T, n_genomes=2 * T, k=k, key_bytes=8)
+    cap = nt + 1024
+    d_sizes = torch.empty(htsize, dtype=torch.uint8, device=dev)
+    d_keys = torch.empty(cap, dtype=torch.int64, device=dev)
+    d_labels = torch.empty(cap, dtype=torch.int16, device=dev)
+    n_el = C.c_uint64(0)
+    torch.cuda.synchronize()
+    assert L.mic_synth_db_device(C.byref(spec), d_sizes.data_ptr(), d_keys.data_ptr(), d_labels.data_ptr(), cap, C.byref(n_el), None) == 0
+    n_el = n_el.value
+    n_reads, read_len = 2_000_000, 150
+    pitch = L.mic_synth_read_pitch(read_len, k)
+    d_rp = torch.empty(n_reads + 1, dtype=torch.int32, device=dev)
+    d_cont = torch.zeros(n_reads * pitch + 64, dtype=torch.int16, device=dev)
+    d_truth = torch.zeros(n_reads * 2, dtype=torch.int32, device=dev)
+    assert L.mic_synth_reads_device(C.byref(spec), 5, n_reads, read_len, 0.2, 0.01, 0.002, d_rp.data_ptr(), d_cont.data_ptr(),
+                                    d_cont.numel(), d_truth.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+
+    def run(layout, shard=None):
+        with MiClarkDB(k, T, layout=layout) as e:
+            if shard is None:
+                e.read_device(d_sizes.data_ptr(), htsize, d_keys.data_ptr(), 8, d_labels.data_ptr())
+            else:
+                e.read_device(d_sizes.data_ptr(), htsize, d_keys.data_ptr(), 8, d_labels.data_ptr(), shard=shard)
+            res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
+            rows = torch.zeros((n_reads, 16), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            e.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, res.data_ptr(), rows.data_ptr())
+            e.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), res.data_ptr(), rows.data_ptr())
+            e.sync()
+            first = res.clone()
+            e.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, res.data_ptr(), rows.data_ptr())
+            e.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), res.data_ptr(), rows.data_ptr())
+            e.sync()
+            assert torch.equal(first, res)                      # a second pass is bit-identical
+            return res, rows, e
+    res_m, rows_m, _ = run(2)
+    res_d, rows_d, _ = run(1)
+    assert torch.equal(res_m[:, :6], res_d[:, :6])              # words 0..5: sum, best/second, targets hit
+    valid = (rows_m[:, 0] != -1) & (rows_d[:, 0] != -1)
+    assert valid.float().mean() > 0.999 and torch.equal(rows_m[valid], rows_d[valid])
+    # two shards merged on the device == the whole table
+    half = htsize // 2
+    _, rows_a, _ = run(2, (0, half))
+    _, rows_b, _ = run(2, (half, htsize))
+    with MiClarkDB(k, T) as e:
+        e.read_device(d_sizes.data_ptr(), htsize, d_keys.data_ptr(), 8, d_labels.data_ptr(), shard=(0, 1000))
+        merged = torch.zeros_like(rows_a)
+        res2 = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.merge_rows_device(rows_a.data_ptr(), rows_b.data_ptr(), merged.data_ptr(), n_reads)
+        e.result_from_rows_device(merged.data_ptr(), res2.data_ptr(), n_reads)
+        e.sync()
+    ok_rows = (merged[:, 0] != -1) & valid
+    assert ok_rows.float().mean() > 0.999
+    assert torch.equal(merged[ok_rows], rows_m[ok_rows]) and torch.equal(res2[ok_rows][:, :5], res_m[ok_rows][:, :5])
+    # oracle on a sample
+    ns = 20000
+    sizes = d_sizes.cpu().numpy()
+    keys = d_keys[:n_el].cpu().numpy().view(np.uint64)
+    labels = d_labels[:n_el].cpu().numpy().view(np.uint16)
+    rp = d_rp[:ns + 1].cpu().numpy().view(np.uint32)
+    cont = d_cont[:int(rp[-1]) + 64].cpu().numpy().view(np.uint16)
+    odb = gu.oracle().db_from_arrays(sizes, keys, labels)
+    _, expect = _oracle_results(odb, k, rp, cont, T)
+    assert (res_m[:ns, :5].cpu().numpy().view(np.uint32) == expect).all()
+    # constructive known answer over all reads
+    truth = d_truth.cpu().numpy().view(np.uint32).reshape(-1, 2)
+    r = res_m.cpu().numpy().view(np.uint32)
+    g = truth[:, 0] > 0
+    okk = (truth[g, 1] == 0) | ((r[g, 1] == truth[g, 0]) & (r[g, 2] >= truth[g, 1]))
+    assert okk.mean() > 0.999 and (r[~g, 0] == 0).mean() > 0.99
