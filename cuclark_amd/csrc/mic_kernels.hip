@@ -472,7 +472,10 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
           uint32_t key = mmer_order_key_canon(mf < mr ? mf : mr);
           if (h == 0) hk0 = key; else hk1 = key;
         }
-        {
+        // m-mers at positions base+128 .. base+128+w-2 end the windows of the chunk's last k-mers; a chunk of at most
+        // 129-w k-mers (every 100/125-bp read) never looks past position 127 and skips this third pass
+        hk2 = 0xFFFFFFFFu;
+        if (nk - base > (uint32_t)(129 - w)) {
           const int idx = 8 + (lane >> 4);
           uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
           uint64_t mm = kmer_from_dwords(d0, d1, d2, lane & 15, m);
