@@ -60,3 +60,10 @@ def test_bench_two_ranks_on_one_gpu(mode):
     per = d["config"]["reads_per_gpu"]
     total = per * (2 if mode == "read" else 1)
     assert abs(d["value"] - total / d["ms_per_step"] / 1e3) / d["value"] < 0.02
+    if mode == "read":   # the extra table-sharded leg rides along and must reproduce the known answer too
+        ts = d["table_sharded"]
+        assert "error" not in ts, ts
+        assert ts["scaling"] == "strong" and ts["value"] > 0
+        assert ts["known_answer"]["label_and_count_ok"] == 1.0 and ts["known_answer"]["random_reads_no_hit"] == 1.0
+    else:
+        assert "table_sharded" not in d
