@@ -38,6 +38,7 @@ struct Batch {
   uint32_t* d_rp = nullptr; uint16_t* d_cont = nullptr;
   uint32_t* d_results = nullptr; uint32_t* d_rows = nullptr;
   uint32_t* d_flagged = nullptr; uint32_t* h_flagged = nullptr;
+  uint32_t* d_peer = nullptr; uint32_t* d_acc = nullptr;   // table-sharded merge: another engine's rows, the running sum
   size_t first_read = 0, n_reads = 0, n_cont = 0, max_reads = 0, max_cont = 0;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
@@ -201,6 +202,8 @@ void free_batches(mic_engine* e) {
   for (Batch& b : e->batches) {
     if (b.done) hipEventDestroy(b.done);
     if (b.stream) hipStreamDestroy(b.stream);
+    if (b.d_peer) hipFree(b.d_peer);
+    if (b.d_acc) hipFree(b.d_acc);
   }
   e->batches.clear();
   if (e->h_block) { hipHostFree(e->h_block); e->h_block = nullptr; }
@@ -564,6 +567,51 @@ int mic_batch_dense_counts(mic_engine* e, size_t batch, size_t read_in_batch, ui
   hipFree(d_counts);
   if (d_id) hipFree(d_id);
   if (he != hipSuccess) return fail(MIC_E_HIP, "dense counts: %s", hipGetErrorString(he));
+  return MIC_OK;
+}
+
+// Table-sharded batches (the reference's multi-GPU mode, CuClarkDB.cu:934-1001: queryBatch on every device, the
+// partial rows copied to device 0 with cudaMemcpyPeer and summed there by mergeKernel, then resultKernel).
+int mic_batch_merge_shards(mic_engine* const* engines, size_t n_engines, size_t batch) {
+  if (!engines || n_engines == 0 || !engines[0]) return fail(MIC_E_INVALID, "bad argument");
+  mic_engine* dst = engines[0];
+  if (batch >= dst->batches.size()) return fail(MIC_E_INVALID, "bad batch id");
+  Batch& D = dst->batches[batch];
+  if (!D.d_rows || !dst->h_rows) return fail(MIC_E_STATE, "batches must be allocated and queried with extended = 1");
+  const uint32_t rw = dst->cfg.row_words;
+  for (size_t i = 0; i < n_engines; ++i) {
+    mic_engine* e = engines[i];
+    if (!e || batch >= e->batches.size()) return fail(MIC_E_INVALID, "bad engine or batch id");
+    const Batch& B = e->batches[batch];
+    if (!B.d_rows || e->cfg.row_words != rw || B.n_reads != D.n_reads || !B.extended)
+      return fail(MIC_E_STATE, "engine %zu: batch %zu does not match (rows, row width or read count)", i, batch);
+    int rc = mic_batch_wait(e, batch);          // kernels done, flagged reads resolved inside their shard
+    if (rc) return rc;
+  }
+  int rc = set_device(dst);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(dst->submit_mu);
+  const size_t bytes = D.n_reads * (size_t)rw * 4;
+  if (n_engines > 1 && !D.d_peer) {
+    HIPTRY(hipMalloc(&D.d_peer, (D.max_reads + 1) * (size_t)rw * 4));
+    HIPTRY(hipMalloc(&D.d_acc, (D.max_reads + 1) * (size_t)rw * 4));
+  }
+  uint32_t* buf[2] = {D.d_rows, D.d_acc};   // running sum ping-pongs between the batch's own rows and the spare buffer
+  int c = 0;
+  for (size_t i = 1; i < n_engines && bytes; ++i) {
+    const Batch& B = engines[i]->batches[batch];
+    HIPTRY(hipMemcpyPeerAsync(D.d_peer, dst->device, B.d_rows, engines[i]->device, bytes, D.stream));
+    HIPTRY(mic_launch_merge_rows(buf[c], D.d_peer, buf[c ^ 1], rw, D.n_reads, nullptr, D.stream));
+    c ^= 1;
+  }
+  uint32_t* cur = buf[c];
+  if (bytes) {
+    HIPTRY(mic_launch_result_from_rows(cur, rw, D.d_results, D.n_reads, D.stream));
+    HIPTRY(hipMemcpyAsync(dst->h_results + D.first_read * MIC_RESULT_WORDS, D.d_results, D.n_reads * MIC_RESULT_WORDS * 4,
+                          hipMemcpyDeviceToHost, D.stream));
+    HIPTRY(hipMemcpyAsync(dst->h_rows + D.first_read * (size_t)rw, cur, bytes, hipMemcpyDeviceToHost, D.stream));
+    HIPTRY(hipStreamSynchronize(D.stream));
+  }
   return MIC_OK;
 }
 

@@ -113,6 +113,14 @@ class MiClarkDB:
         check(self.L.mic_batch_wait(self.h, batch))
         return True
 
+    @staticmethod
+    def merge_shards(engines, batch):
+        """Table-sharded batches (CuClarkDB.cu:934-1001): sum the sparse rows of `batch` of every engine into engines[0]
+        and finish best / second-best there.  Every engine must have queried the same reads with extended=True."""
+        L = engines[0].L
+        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        check(L.mic_batch_merge_shards(arr, len(engines), batch))
+
     def checkBatch(self, batch):
         d = C.c_int(0)
         check(self.L.mic_batch_check(self.h, batch, C.byref(d)))

@@ -132,6 +132,15 @@ int mic_batch_wait(mic_engine* e, size_t batch);
  * the row (CuClarkDB.cu:1200-1211).  Synchronous; valid until the batch is queried again or freed. */
 int mic_batch_dense_counts(mic_engine* e, size_t batch, size_t read_in_batch, uint32_t* counts);
 int mic_batch_check(mic_engine* e, size_t batch, int* done);
+/* Table-sharded batches: the reference's multi-device mode (CuClarkDB.cu:934-1001 - queryBatch on every device, the
+ * partial result rows copied to device 0 with cudaMemcpyPeer, summed by mergeKernel, finished by resultKernel).
+ * Every engine holds one bucket range of the same database (mic_db_load_*: shard_start, shard_end), the same batch
+ * geometry (mic_batches_alloc with extended = 1) and was given the same packed reads for `batch`
+ * (mic_batch_ready + mic_batch_query(extended = 1) on each).  The call waits for all of them, sums the sparse rows
+ * into engines[0] and leaves best / second-best and the merged rows in engines[0]'s host arrays.  A read whose merged
+ * row does not fit (MIC_FLAG_ROW_OVERFLOW in its results word 6, row[0] == MIC_ROW_INVALID) is completed by the
+ * caller: the sum over the engines of mic_batch_dense_counts.  Synchronous.  Engines may share a device. */
+int mic_batch_merge_shards(mic_engine* const* engines, size_t n_engines, size_t batch);
 int mic_sync(mic_engine* e);
 int mic_batches_free(mic_engine* e);
 

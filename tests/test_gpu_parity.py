@@ -567,3 +567,45 @@ def test_properties_at_scale():
     g = truth[:, 0] > 0
     okk = (truth[g, 1] == 0) | ((r[g, 1] == truth[g, 0]) & (r[g, 2] >= truth[g, 1]))
     assert okk.mean() > 0.999 and (r[~g, 0] == 0).mean() > 0.99
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_batch_merge_shards_equals_whole_table(n_shards):
+    """The reference's multi-device mode through the batch API: every engine holds a bucket range, all get the same
+    packed reads, mic_batch_merge_shards sums the rows into engine 0 - identical to one engine holding everything.
+    (Engines share cuda:0 here; the peer copy is the same call.)"""
+    from cuclark_amd import MiClarkDB, host
+    name, k = "light_k31_u64", 31
+    db = gu.load_golden_db(name)
+    names = gu.target_names()
+    T = len(names)
+    data = open(os.path.join(gu.GOLDEN, "reads_k31.fa"), "rb").read()
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    n = rp.size - 1
+    sizes = gu.golden_sizes(db)
+    with MiClarkDB(k, T) as whole:
+        whole.read_arrays(sizes, db["ky"], db["lb"])
+        ref_res, ref_rows = whole.classify_packed(rp, cont, extended=True)
+    H = int(db["htsize"])
+    cuts = [H * i // n_shards for i in range(n_shards + 1)]
+    engines = [MiClarkDB(k, T) for _ in range(n_shards)]
+    try:
+        for e, lo, hi in zip(engines, cuts[:-1], cuts[1:]):
+            e.read_arrays(sizes, db["ky"], db["lb"], shard=(lo, hi))
+            bufs = e.malloc(n, n, max(cont.size, 1), [0, n], True)
+            bufs["reads_pointer"][0][: n + 1] = rp
+            bufs["containers"][0][: cont.size] = cont
+            e.readyBatch(0, n, cont.size)
+            e.queryBatch(0, True)
+        MiClarkDB.merge_shards(engines, 0)
+        res = engines[0]._bufs["results"].copy()
+        rows = engines[0]._bufs["rows"].copy()
+    finally:
+        for e in engines:
+            e.close()
+    assert (res[:, :6] == ref_res[:, :6]).all()
+    assert (rows[:, 0] != 0xFFFFFFFF).all() and (ref_rows[:, 0] != 0xFFFFFFFF).all()
+    for r in range(n):
+        m = int(rows[r, 0])
+        assert m == int(ref_rows[r, 0]) and (rows[r, 1:1 + m] == ref_rows[r, 1:1 + m]).all()
