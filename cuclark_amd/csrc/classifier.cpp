@@ -122,19 +122,32 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
   check(mic_device_count(&n_dev), "device discovery");
   if (n_dev == 0) die("No HIP device found.");
   size_t use = opt_.devices == 0 ? (size_t)n_dev : std::min(opt_.devices, (size_t)n_dev);
-  if (opt_.batches < use) use = std::max<size_t>(1, opt_.batches);
+  // --db-sharded: the reference's multi-device mode (every device holds a bucket range, CuClarkDB.cu:566-574).
+  // MIC_SHARD_ENGINES=<n> forces n engines (round-robin over the devices) - used to test the mode on one GPU.
+  if (opt_.db_sharded) {
+    if (const char* env = getenv("MIC_SHARD_ENGINES")) { long v = atol(env); if (v >= 1 && v <= 64) use = (size_t)v; }
+  } else if (opt_.batches < use) {
+    use = std::max<size_t>(1, opt_.batches);
+  }
   std::cerr << "Loading database [" << db << ".*] (s=" << opt_.sampling << ")..." << std::endl;
-  const size_t per_engine_batches = (opt_.batches + use - 1) / use;
+  const size_t per_engine_batches = opt_.db_sharded ? std::max<size_t>(1, opt_.batches) : (opt_.batches + use - 1) / use;
+  uint64_t htsize = 0;
+  if (opt_.db_sharded) {
+    struct stat st;
+    if (stat((db + ".sz").c_str(), &st) != 0) die("Failed to open " + db + ".sz");
+    htsize = (uint64_t)st.st_size;
+  }
   for (size_t d = 0; d < use; ++d) {
     mic_config cfg;
     memset(&cfg, 0, sizeof(cfg));
-    cfg.device = (int)d; cfg.k = (int)opt_.k; cfg.num_targets = (uint32_t)(names_.size());
+    cfg.device = (int)(d % (size_t)n_dev); cfg.k = (int)opt_.k; cfg.num_targets = (uint32_t)(names_.size());
     cfg.num_batches = (uint32_t)per_engine_batches;
     cfg.row_words = opt_.extended ? (uint32_t)std::min<size_t>(names_.size() + 1, 65) : 16;
     mic_engine* e = nullptr;
     check(mic_create(&cfg, &e), "engine creation");
     engines_.push_back(e);
-    int rc = mic_db_load_files(e, db.c_str(), 0, opt_.sampling, 0, 0);
+    const uint64_t s0 = opt_.db_sharded ? htsize * d / use : 0, s1 = opt_.db_sharded ? htsize * (d + 1) / use : 0;
+    int rc = mic_db_load_files(e, db.c_str(), 0, opt_.sampling, s0, s1);
     if (rc != MIC_OK) die(std::string("Failed to load the database: ") + mic_last_error());
   }
   mic_db_info info;
@@ -419,7 +432,7 @@ void Classifier::ensure_batches(size_t max_reads, size_t max_cont) {
   if (!lent_.empty() && max_reads <= slot_reads_ && max_cont <= slot_cont_) return;
   release_batches();
   const size_t n_eng = engines_.size();
-  slots_per_engine_ = (opt_.batches + n_eng - 1) / n_eng;
+  slots_per_engine_ = opt_.db_sharded ? std::max<size_t>(1, opt_.batches) : (opt_.batches + n_eng - 1) / n_eng;
   slot_reads_ = max_reads + max_reads / 8 + 64;
   slot_cont_ = max_cont + max_cont / 8 + 64;
   row_words_ = opt_.extended ? (uint32_t)std::min<size_t>(names_.size() + 1, 65) : 16;
@@ -429,7 +442,8 @@ void Classifier::ensure_batches(size_t max_reads, size_t max_cont) {
   for (size_t d = 0; d < n_eng; ++d) {
     Lent& L = lent_[d];
     L.rp.resize(slots_per_engine_); L.ct.resize(slots_per_engine_);
-    check(mic_batches_alloc(engines_[d], slots_per_engine_ * slot_reads_, slot_reads_, slot_cont_, index.data(), opt_.extended ? 1 : 0,
+    check(mic_batches_alloc(engines_[d], slots_per_engine_ * slot_reads_, slot_reads_, slot_cont_, index.data(),
+                            (opt_.extended || opt_.db_sharded) ? 1 : 0,
                             &L.results, &L.rows, L.rp.data(), L.ct.data()), "batch allocation");
   }
 }
@@ -550,16 +564,30 @@ void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FIL
   for (long bi = 0; bi < (long)nb_total; ++bi) {
     double ts = timing ? now_s() : 0;
     auto tick = [&](double& acc) { if (timing) { const double n = now_s(); acc += n - ts; ts = n; } };
-    const size_t b = (size_t)bi, d = b % n_eng, lb = b / n_eng;
+    const bool sharded = opt_.db_sharded;
+    const size_t b = (size_t)bi, d = sharded ? 0 : b % n_eng, lb = sharded ? b : b / n_eng;
     Lent& L = lent_[d];
     const size_t r0 = cut[b], cnt = cut[b + 1] - cut[b];
     try {
       size_t m = mic_pack_reads(map, seq_s.data() + r0, seq_e.data() + r0, length.data() + r0, cnt, k, L.rp[lb], L.ct[lb], slot_cont_);
       if (m == (size_t)-1) die("ERROR: Batch overflow. Please increase the number of batches (-b <numberofbatches>).");
       tick(t_pack);
-      check(mic_batch_ready(engines_[d], lb, cnt, m), "readyBatch");
-      check(mic_batch_query(engines_[d], lb, opt_.extended ? 1 : 0, 0), "queryBatch");
-      check(mic_batch_wait(engines_[d], lb), "waitForBatch");
+      if (!sharded) {
+        check(mic_batch_ready(engines_[d], lb, cnt, m), "readyBatch");
+        check(mic_batch_query(engines_[d], lb, opt_.extended ? 1 : 0, 0), "queryBatch");
+        check(mic_batch_wait(engines_[d], lb), "waitForBatch");
+      } else {
+        // every engine probes the same reads against its bucket range; rows are summed into engine 0
+        for (size_t g = 0; g < n_eng; ++g) {
+          if (g) {
+            memcpy(lent_[g].rp[lb], L.rp[lb], (cnt + 1) * sizeof(uint32_t));
+            memcpy(lent_[g].ct[lb], L.ct[lb], m * sizeof(uint16_t));
+          }
+          check(mic_batch_ready(engines_[g], lb, cnt, m), "readyBatch");
+          check(mic_batch_query(engines_[g], lb, 1, 0), "queryBatch");
+        }
+        check(mic_batch_merge_shards(engines_.data(), n_eng, lb), "merge of the table shards");
+      }
       tick(t_query);
       std::string& s = out[b];
       s.reserve(cnt * (opt_.extended ? 64 + 3 * (size_t)T : 72));
@@ -571,13 +599,36 @@ void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FIL
         const size_t r = r0 + i;
         const uint32_t* row = rows ? rows + i * row_words : nullptr;
         const uint32_t* dn = nullptr;
+        const uint32_t* rr = res + i * MIC_RESULT_WORDS;
+        uint32_t fixed[MIC_RESULT_WORDS];
         if (row && row[0] == MIC_ROW_INVALID) {
           dense.resize(T);
-          check(mic_batch_dense_counts(engines_[d], lb, i, dense.data()), "dense counts");
+          if (!sharded) {
+            check(mic_batch_dense_counts(engines_[d], lb, i, dense.data()), "dense counts");
+          } else {
+            // more targets than a sparse row holds: dense counts of every shard, summed; best / second-best under the
+            // reference's order (count descending, target ascending)
+            std::vector<uint32_t> part(T);
+            std::fill(dense.begin(), dense.end(), 0u);
+            for (size_t g = 0; g < n_eng; ++g) {
+              check(mic_batch_dense_counts(engines_[g], lb, i, part.data()), "dense counts");
+              for (uint32_t t2 = 0; t2 < T; ++t2) dense[t2] += part[t2];
+            }
+            uint32_t sum = 0, best = 0, ib = 0, sb = 0, is = 0, hit = 0;
+            for (uint32_t t2 = 0; t2 < T; ++t2) {
+              const uint32_t sc = dense[t2];
+              if (!sc) continue;
+              ++hit; sum += sc;
+              if (sc > best) { sb = best; is = ib; best = sc; ib = t2 + 1; }
+              else if (sc > sb) { sb = sc; is = t2 + 1; }
+            }
+            fixed[0] = sum; fixed[1] = ib; fixed[2] = best; fixed[3] = is; fixed[4] = sb; fixed[5] = hit; fixed[6] = rr[6]; fixed[7] = 0;
+            rr = fixed;
+          }
           dn = dense.data();
         }
         int w = mic_csv_line(line.data(), line.size(), map + name_s[r], (size_t)(name_e[r] - name_s[r]), length[r], paired ? 1 : 0,
-                             k, res + i * MIC_RESULT_WORDS, nm.data(), T, opt_.extended ? 1 : 0, row, dn);
+                             k, rr, nm.data(), T, opt_.extended ? 1 : 0, row, dn);
         if (w < 0) die("CSV line too long");
         s.append(line.data(), (size_t)w);
       }

@@ -24,6 +24,7 @@ struct Options {
   bool tsk = false;           // --tsk
   bool extended = false;      // --extended
   bool light = false;         // cuCLARK-l
+  bool db_sharded = false;    // --db-sharded: every device holds a bucket range of the table (the reference's -d mode)
   uint64_t htsize = 1610612741ull;  // parameters.hh:39 / parameters_light_hh:40; --htsize overrides
   std::string targets, folder, objects, objects2, results;
 };

@@ -41,7 +41,7 @@ static void print_usage(const char* prog) {
   std::cout << "-d <numberofdevices> GPUs to use (default: all)\n";
   std::cout << "-g <iteration>,      gap for the light database name (>= 4)\n";
   std::cout << "-s <factor>,         sampling factor in [2," << SFACTORMAX << "]\n";
-  std::cout << "--tsk, --extended, --light, --htsize <n>, --help, --version\n\n";
+  std::cout << "--tsk, --extended, --light, --htsize <n>, --db-sharded, --help, --version\n\n";
 }
 
 int main(int argc, char** argv) {
@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
   bool ext = false, tsk = false;
   bool light = prog.size() >= 2 && prog.compare(prog.size() - 2, 2, "-l") == 0;
   uint64_t htsize_override = 0;
+  bool db_sharded = false;
   int i_targets = -1, i_objects = -1, i_objects2 = -1, i_folder = -1, i_results = -1;
 
   for (int i = 1; i < argc; i++) {
@@ -95,6 +96,7 @@ int main(int argc, char** argv) {
     }
     if (val == "--tsk") { tsk = true; continue; }
     if (val == "--extended") { ext = true; continue; }
+    if (val == "--db-sharded") { db_sharded = true; continue; }
     if (val == "--light") { light = true; continue; }
     if (val == "--htsize") {
       need("Please specify the table size!");
@@ -173,7 +175,7 @@ int main(int argc, char** argv) {
     exit(1);
   }
   o.k = k; o.min_count_t = minT; o.threads = cpu; o.batches = batches; o.devices = devices; o.sampling = sfactor; o.gap = gap;
-  o.tsk = tsk; o.extended = ext; o.light = light;
+  o.tsk = tsk; o.extended = ext; o.light = light; o.db_sharded = db_sharded;
   o.htsize = htsize_override ? htsize_override : (light ? HTSIZE_LIGHT : HTSIZE_FULL);
   o.targets = argv[i_targets];
   o.folder = argv[i_folder];

@@ -196,3 +196,69 @@ def test_set_targets_then_classify_end_to_end(tmp_path):
     odb = gu.oracle().db_from_arrays(gu.golden_sizes(g), g["ky"], perm[g["lb"]], 1)
     text, _ = odb.classify_file(27, open(reads, "rb").read(), order, False, False)
     assert open(os.path.join(tmp, "out.csv"), "rb").read() == text
+
+
+@pytest.mark.gpu
+def test_db_sharded_cli_matches_golden(tmp_path):
+    """--db-sharded: every engine holds a bucket range of the table (the reference's multi-device mode); three engines
+    share the one GPU here (MIC_SHARD_ENGINES).  CSVs identical to the whole-table ones, plain, extended, paired, with
+    sampling, and with 80 targets (rows that do not fit 15 entries: dense counts summed over the shards)."""
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "light_k27_u32", light=True)
+    t = _targets_file(tmp)
+    env = dict(os.environ, MIC_SHARD_ENGINES="3")
+    for flag, src, exp in (([], ["-O", os.path.join(gu.GOLDEN, "reads_k27.fa")], "expected_k27_fa.csv"),
+                           (["--extended", "-n", "2", "-b", "4"], ["-O", os.path.join(gu.GOLDEN, "reads_k27.fa")], "expected_k27_fa_ext.csv"),
+                           (["-b", "3"], ["-P", os.path.join(gu.GOLDEN, "pairs_k27_1.fq"), os.path.join(gu.GOLDEN, "pairs_k27_2.fq")],
+                            "expected_k27_pairs.csv")):
+        out = os.path.join(tmp, "sh_" + exp)
+        r = _run([EXE_L, "-T", t, "-D", d, *src, "-R", out, "--db-sharded", *flag], env=env)
+        assert r.returncode == 0, r.stderr
+        assert "on 3 device(s)" in r.stderr
+        assert open(out + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, exp), "rb").read(), exp
+    # sampling: whole table vs shards
+    outs = []
+    for extra, e in ((["-s", "3"], dict(os.environ)), (["-s", "3", "--db-sharded"], env)):
+        out = os.path.join(tmp, "samp%d" % len(outs))
+        r = _run([EXE, "-k", "27", "--htsize", "57777779", "-T", t, "-D", _db_dir(os.path.join(tmp, "full"), "light_k27_u32", light=False),
+                  "-O", os.path.join(gu.GOLDEN, "reads_k27.fa"), "-R", out, *extra], env=e)
+        assert r.returncode == 0, r.stderr
+        outs.append(open(out + ".csv", "rb").read())
+    assert outs[0] == outs[1] and outs[0].count(b"\n") == 132
+    # many targets: one read made of k-mers of 80 different targets
+    import numpy as np
+    rng = np.random.default_rng(3)
+    k, T, htsize = 27, 80, 99991
+    o = gu.oracle()
+    seqs = ["".join(rng.choice(list("ACGT"), k + 4)) for _ in range(T)]
+    canon = {}
+    for lab, s_ in enumerate(seqs):
+        for i in range(len(s_) - k + 1):
+            canon[o.canonical(int("".join(str("TGCA".index(c)) for c in s_[i:i + k]), 4), k)] = lab
+    items = sorted(canon.items(), key=lambda kv: (kv[0] % htsize, kv[0] // htsize))
+    sizes = np.zeros(htsize, np.uint8)
+    for c, _ in items:
+        sizes[c % htsize] += 1
+    dd = os.path.join(tmp, "DB80")
+    os.makedirs(dd)
+    base = os.path.join(dd, f"db_central_k{k}_t{T}_s{htsize}_m0.tsk")
+    sizes.tofile(base + ".sz")
+    from cuclark_amd import host
+    np.array([c // htsize for c, _ in items], dtype=gu.KEY_DTYPE[host.key_bytes_rule(htsize, k)]).tofile(base + ".ky")
+    np.array([l for _, l in items], np.uint16).tofile(base + ".lb")
+    tt = os.path.join(tmp, "t80.txt")
+    with open(tt, "w") as f:
+        for lab in range(T):
+            f.write(f"{os.path.join(gu.GOLDEN, 'targets', 'genome_0.fa')} L{lab:02d}\n")
+    reads = os.path.join(tmp, "r80.fa")
+    with open(reads, "w") as f:
+        f.write(">all\n" + "N".join(seqs) + "\n>few\n" + "N".join(seqs[:3]) + "\n")
+    res = []
+    for extra, e in (([], dict(os.environ)), (["--db-sharded"], env)):
+        for ext in ([], ["--extended"]):
+            out = os.path.join(tmp, "t80_%d" % len(res))
+            r = _run([EXE, "-k", str(k), "--htsize", str(htsize), "-T", tt, "-D", dd, "-O", reads, "-R", out, *extra, *ext], env=e)
+            assert r.returncode == 0, r.stderr
+            res.append(open(out + ".csv", "rb").read())
+    assert res[0] == res[2] and res[1] == res[3]
+    assert res[0].splitlines()[1].startswith(b"all,") and b",L00,5," in res[0].splitlines()[1]
