@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--workload", default="full", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="read", choices=["read", "db"])
     ap.add_argument("--reads", type=int, default=0, help="override the number of reads per GPU")
+    ap.add_argument("--read-len", type=int, default=0, help="override the read length (exploration only: the headline is 150 bp)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -91,6 +92,9 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.reads:
         w["n_reads"] = args.reads
+    if args.read_len:
+        w["read_len"] = args.read_len
+        w["name"] = w["name"].replace("150bp", f"{args.read_len}bp")
     k, T = w["k"], w["n_targets"]
     n_reads, read_len = w["n_reads"], w["read_len"]
     t_setup = time.time()
@@ -344,7 +348,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Mreads/sec (10M x 150bp, k=31)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
+            "metric": f"Mreads/sec (10M x {read_len}bp, k=31)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if db_mode else "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
