@@ -177,6 +177,22 @@ __device__ __forceinline__ void tally2(uint32_t r0, uint32_t r1, RowAcc& acc, ui
   }
 }
 
+// the same over three arrays (the third holds the hits found below the first tree level)
+__device__ __forceinline__ void tally3(uint32_t r0, uint32_t r1, uint32_t r2, RowAcc& acc, uint32_t& n_ent, uint32_t& overflow,
+                                       uint32_t& total, int lane) {
+  uint64_t m0 = __ballot(r0 != 0), m1 = __ballot(r1 != 0), m2 = __ballot(r2 != 0);
+  total += __popcll(m0) + __popcll(m1) + __popcll(m2);
+  while (m0 | m1 | m2) {
+    uint32_t l1;
+    if (m0) l1 = __builtin_amdgcn_readlane(r0, __builtin_ctzll(m0));
+    else if (m1) l1 = __builtin_amdgcn_readlane(r1, __builtin_ctzll(m1));
+    else l1 = __builtin_amdgcn_readlane(r2, __builtin_ctzll(m2));
+    uint64_t e0 = __ballot(r0 == l1), e1 = __ballot(r1 == l1), e2 = __ballot(r2 == l1);
+    m0 &= ~e0; m1 &= ~e1; m2 &= ~e2;
+    row_add(acc, n_ent, overflow, l1, __popcll(e0) + __popcll(e1) + __popcll(e2), lane);
+  }
+}
+
 // Scalar top-2 over the row under the order (count desc, target asc) — equivalent to resultKernel's
 // ascending scan with strict '>' (CuClarkDB.cu:1440-1459), see DESIGN.md §4.
 template <typename ARGS>   // MicQueryArgs, or the cold fields re-read from the kernarg segment (query_kernel_m)
@@ -375,7 +391,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
   __shared__ uint32_t s_run[MIC_M_WPB][MIC_RMAX];
   __shared__ uint32_t s_ahead[MIC_M_WPB][2][64];
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: LDS bases stay in SGPRs
   uint4* stage = s_stage[wv];
   uint32_t* runslot = s_run[wv];
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * MIC_M_WPB + wv);
@@ -384,7 +400,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
   const int k = t.k, m = t.m, w = k - m + 1;
   const uint4* __restrict__ slots = t.slots;
   const uint16_t* __restrict__ cont = a.cont;
-  const uint64_t lane_le = lane == 63 ? ~0ULL : ((2ULL << lane) - 1);
+  // number of set bits of a 64-bit lane mask below this lane (v_mbcnt_lo/hi: no mask register to keep alive)
+  auto below = [](uint64_t mask) { return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
 
   PH_DECL
   // Read-ahead through LDS (global_load_lds_dword): no VGPR lives across a read and no load result is touched near its
@@ -484,24 +501,25 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
         sliding_min3(hk0, hk1, hk2, w, lane);
         uint32_t sl0 = act[0] ? mslot_of_key(hk0, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         uint32_t sl1 = act[1] ? mslot_of_key(hk1, (uint32_t)t.n_main) : 0xFFFFFFFFu;
-        uint32_t res0 = 0, res1 = 0;
+        uint32_t res0 = 0, res1 = 0, res2 = 0;   // label + 1 of the hit: passes 0, 1 and the compacted deeper levels
         PERTURB_POINT
         PH(0)
 
-        while (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {
+        // one level of the table on both passes: runs of equal slots, LDS-DMA of the distinct slots, lockstep search
+        auto level = [&](uint32_t s0_, uint32_t s1_, uint64_t k0_, uint64_t k1_, uint32_t& o0_, uint32_t& o1_, uint32_t& y0_, uint32_t& y1_) {
           // runs of equal slots over the 128 positions
-          uint32_t p0 = bperm((lane + 63) & 63, sl0), p1 = bperm((lane + 63) & 63, sl1);
-          uint32_t last0 = bperm(63, sl0);
+          uint32_t p0 = bperm((lane + 63) & 63, s0_), p1 = bperm((lane + 63) & 63, s1_);
+          uint32_t last0 = bperm(63, s0_);
           if (lane == 0) { p0 = 0xFFFFFFFFu; p1 = last0; }
-          const bool f0 = sl0 != 0xFFFFFFFFu && sl0 != p0, f1 = sl1 != 0xFFFFFFFFu && sl1 != p1;
+          const bool f0 = s0_ != 0xFFFFFFFFu && s0_ != p0, f1 = s1_ != 0xFFFFFFFFu && s1_ != p1;
           const uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
           const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1);
-          const uint32_t rid0 = __popcll(b0 & lane_le) - 1, rid1 = R0 + __popcll(b1 & lane_le) - 1;
-          uint32_t nx0 = 0xFFFFFFFFu, nx1 = 0xFFFFFFFFu;   // slot to probe in the next round
+          const uint32_t rid0 = below(b0) + (f0 ? 1u : 0u) - 1, rid1 = R0 + below(b1) + (f1 ? 1u : 0u) - 1;
+          y0_ = 0xFFFFFFFFu; y1_ = 0xFFFFFFFFu;   // slots to probe at the next level
           for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
             __builtin_amdgcn_wave_barrier();
-            if (f0 && rid0 - rbase < MIC_RMAX) runslot[rid0 - rbase] = sl0;
-            if (f1 && rid1 - rbase < MIC_RMAX) runslot[rid1 - rbase] = sl1;
+            if (f0 && rid0 - rbase < MIC_RMAX) runslot[rid0 - rbase] = s0_;
+            if (f1 && rid1 - rbase < MIC_RMAX) runslot[rid1 - rbase] = s1_;
             __builtin_amdgcn_wave_barrier();
             const uint32_t nrun = R - rbase < MIC_RMAX ? R - rbase : MIC_RMAX;
             // every distinct slot goes HBM -> LDS directly (global_load_lds_dwordx4: lane L lands at base + 16*L, no
@@ -517,20 +535,18 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
                                                  (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
             }
-            PH(1)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            PH(2)
             // Both k-mers of the lane search their staged slot in lockstep: five LDS round trips per round
             // (binary, two reads per step) instead of five per k-mer one
             // after the other.  Lanes without a search read slot 0 of the area and discard.
             {
-              const bool v0 = sl0 != 0xFFFFFFFFu && rid0 - rbase < MIC_RMAX, v1 = sl1 != 0xFFFFFFFFu && rid1 - rbase < MIC_RMAX;
+              const bool v0 = s0_ != 0xFFFFFFFFu && rid0 - rbase < MIC_RMAX, v1 = s1_ != 0xFFFFFFFFu && rid1 - rbase < MIC_RMAX;
               const uint4* sp0 = stage + (v0 ? rid0 - rbase : 0) * MIC_MSTRIDE;
               const uint4* sp1 = stage + (v1 ? rid1 - rbase : 0) * MIC_MSTRIDE;
               const unsigned long long* k0 = (const unsigned long long*)sp0;
               const unsigned long long* k1 = (const unsigned long long*)sp1;
-              const uint64_t c0 = c[0], c1 = c[1];
+              const uint64_t c0 = k0_, c1 = k1_;
               const uint32_t mz0 = sp0[7].z, mz1 = sp1[7].z;
               uint32_t pos0 = 0, pos1 = 0; bool eq0 = false, eq1 = false;
               { const uint64_t x = k0[7], y = k1[7];
@@ -548,19 +564,87 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
               const uint32_t p0 = pos0 ? pos0 - 1 : 0, p1 = pos1 ? pos1 - 1 : 0;
               const uint32_t w0 = ((const uint32_t*)sp0)[24 + (leaf0 ? p0 >> 1 : 0)], w1 = ((const uint32_t*)sp1)[24 + (leaf1 ? p1 >> 1 : 0)];
               if (v0) {
-                res0 = 0; nx0 = 0xFFFFFFFFu;
-                if (pos0) { if (leaf0) { if (eq0) res0 = ((p0 & 1) ? w0 >> 16 : w0 & 0xFFFFu) + 1; } else nx0 = w0 + p0; }
+                o0_ = 0; y0_ = 0xFFFFFFFFu;
+                if (pos0) { if (leaf0) { if (eq0) o0_ = ((p0 & 1) ? w0 >> 16 : w0 & 0xFFFFu) + 1; } else y0_ = w0 + p0; }
               }
               if (v1) {
-                res1 = 0; nx1 = 0xFFFFFFFFu;
-                if (pos1) { if (leaf1) { if (eq1) res1 = ((p1 & 1) ? w1 >> 16 : w1 & 0xFFFFu) + 1; } else nx1 = w1 + p1; }
+                o1_ = 0; y1_ = 0xFFFFFFFFu;
+                if (pos1) { if (leaf1) { if (eq1) o1_ = ((p1 & 1) ? w1 >> 16 : w1 & 0xFFFFu) + 1; } else y1_ = w1 + p1; }
               }
             }
           }
+        };
+        if (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {
+          uint32_t nx0, nx1;
+          level(sl0, sl1, c[0], c[1], res0, res1, nx0, nx1);
           PH(3)
+          tally2(res0, res1, acc, n_ent, overflow, total, lane);
           sl0 = nx0; sl1 = nx1;
+          // ---- deeper levels of the bucket trees.  Nearly every chunk has k-mers in buckets of more than 12 entries (two
+          // super-k-mers sharing a slot are enough), but only ~40 % of its k-mers: instead of a second full round over
+          // two sparse 64-lane passes (240 VALU per read, measured by ablation), the k-mers that descend are packed into
+          // ONE array in k-mer order (equal child slots stay adjacent) and levels 2, 3, ... run on that.  The stage area
+          // is free between levels and serves as the scratch for the packing.
+          const uint64_t mm0 = __ballot(sl0 != 0xFFFFFFFFu), mm1 = __ballot(sl1 != 0xFFFFFFFFu);
+          const uint32_t n0 = __popcll(mm0), n2 = n0 + __popcll(mm1);
+          if (n2 > 64) {               // more than one array holds (rare): level by level on both passes
+            while (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {
+              uint32_t r0 = 0, r1 = 0, y0, y1;
+              level(sl0, sl1, c[0], c[1], r0, r1, y0, y1);
+              tally2(r0, r1, acc, n_ent, overflow, total, lane);
+              sl0 = y0; sl1 = y1;
+            }
+          } else if (n2) {
+            unsigned long long* ck = (unsigned long long*)stage;          // 64 keys
+            uint32_t* cs = (uint32_t*)(stage + 32);                        // 64 slots, behind the keys
+            __builtin_amdgcn_wave_barrier();
+            if ((mm0 >> lane) & 1) { const uint32_t d = below(mm0); ck[d] = c[0]; cs[d] = sl0; }
+            if ((mm1 >> lane) & 1) { const uint32_t d = n0 + below(mm1); ck[d] = c[1]; cs[d] = sl1; }
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t c2 = ck[lane];
+            uint32_t s2 = (uint32_t)lane < n2 ? cs[lane] : 0xFFFFFFFFu;
+            __builtin_amdgcn_wave_barrier();
+            while (__ballot(s2 != 0xFFFFFFFFu)) {
+              const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)s2, 0x138, 0xF, 0xF, false);   // wave_shr:1
+              const bool f2 = s2 != 0xFFFFFFFFu && s2 != pv;
+              const uint64_t b2 = __ballot(f2);
+              const uint32_t R2 = __popcll(b2), rid2 = below(b2) + (f2 ? 1u : 0u) - 1;
+              uint32_t y2 = 0xFFFFFFFFu;
+              for (uint32_t rbase = 0; rbase < R2; rbase += MIC_RMAX) {
+                __builtin_amdgcn_wave_barrier();
+                if (f2 && rid2 - rbase < MIC_RMAX) runslot[rid2 - rbase] = s2;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t nrun = R2 - rbase < MIC_RMAX ? R2 - rbase : MIC_RMAX;
+                uint32_t sidx[MIC_RMAX / 8];
+#pragma unroll
+                for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = runslot[8 * i + (lane >> 3)];
+#pragma unroll
+                for (int i = 0; i < MIC_RMAX / 8; ++i) {
+                  if (8u * i + (lane >> 3) < nrun)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
+                                                     (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const bool v2 = s2 != 0xFFFFFFFFu && rid2 - rbase < MIC_RMAX;
+                const uint4* sp = stage + (v2 ? rid2 - rbase : 0) * MIC_MSTRIDE;
+                const unsigned long long* kk = (const unsigned long long*)sp;
+                const uint32_t mz = sp[7].z;
+                uint32_t pos = 0; bool eq;
+                { const uint64_t x = kk[7]; if (x <= c2) pos = 8; eq = x == c2; }
+                { const uint64_t x = kk[pos + 3]; if (x <= c2) pos += 4; eq = eq || x == c2; }
+                { const uint32_t i = pos + 1; const uint64_t x = kk[i < 11 ? i : 11]; if (i < 12 && x <= c2) pos += 2; eq = eq || x == c2; }
+                { const uint32_t i = pos; const uint64_t x = kk[i < 11 ? i : 11]; if (i < 12 && x <= c2) pos += 1; eq = eq || x == c2; }
+                const bool leaf = !(mz & MIC_M_DIR);
+                const uint32_t pp2 = pos ? pos - 1 : 0;
+                const uint32_t wv2 = ((const uint32_t*)sp)[24 + (leaf ? pp2 >> 1 : 0)];
+                if (v2 && pos) { if (leaf) { if (eq) res2 = ((pp2 & 1) ? wv2 >> 16 : wv2 & 0xFFFFu) + 1; } else y2 = wv2 + pp2; }
+              }
+              s2 = y2;
+            }
+            tally2(res2, 0, acc, n_ent, overflow, total, lane);
+          }
         }
-        tally2(res0, res1, acc, n_ent, overflow, total, lane);
         PH(4)
       }
     }
