@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
             for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = runslot[8 * i + (lane >> 3)];
 #pragma unroll
             for (int i = 0; i < MIC_RMAX / 8; ++i) {
+              if (8u * i >= nrun) break;                 // wave-uniform: no address arithmetic for unused groups
               if (8u * i + (lane >> 3) < nrun)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
                                                  (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
@@ -578,7 +579,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
           uint32_t nx0, nx1;
           level(sl0, sl1, c[0], c[1], res0, res1, nx0, nx1);
           PH(3)
-          tally2(res0, res1, acc, n_ent, overflow, total, lane);
           sl0 = nx0; sl1 = nx1;
           // ---- deeper levels of the bucket trees.  Nearly every chunk has k-mers in buckets of more than 12 entries (two
           // super-k-mers sharing a slot are enough), but only ~40 % of its k-mers: instead of a second full round over
@@ -589,9 +589,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
           const uint32_t n0 = __popcll(mm0), n2 = n0 + __popcll(mm1);
           if (n2 > 64) {               // more than one array holds (rare): level by level on both passes
             while (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {
-              uint32_t r0 = 0, r1 = 0, y0, y1;
-              level(sl0, sl1, c[0], c[1], r0, r1, y0, y1);
-              tally2(r0, r1, acc, n_ent, overflow, total, lane);
+              uint32_t y0, y1;
+              level(sl0, sl1, c[0], c[1], res0, res1, y0, y1);   // a k-mer that descends had no hit yet: res0/res1 are free
               sl0 = y0; sl1 = y1;
             }
           } else if (n2) {
@@ -620,6 +619,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
                 for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = runslot[8 * i + (lane >> 3)];
 #pragma unroll
                 for (int i = 0; i < MIC_RMAX / 8; ++i) {
+                  if (8u * i >= nrun) break;
                   if (8u * i + (lane >> 3) < nrun)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
                                                      (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
@@ -642,9 +642,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
               }
               s2 = y2;
             }
-            tally2(res2, 0, acc, n_ent, overflow, total, lane);
           }
         }
+        tally3(res0, res1, res2, acc, n_ent, overflow, total, lane);
         PH(4)
       }
     }
