@@ -176,6 +176,7 @@ int main(int argc, char** argv) {
   }
   o.k = k; o.min_count_t = minT; o.threads = cpu; o.batches = batches; o.devices = devices; o.sampling = sfactor; o.gap = gap;
   o.tsk = tsk; o.extended = ext; o.light = light; o.db_sharded = db_sharded;
+  if (tsk) std::cerr << "Note: --tsk is accepted for compatibility; the per-target .ht text files (k-mer, count) are not written." << std::endl;
   o.htsize = htsize_override ? htsize_override : (light ? HTSIZE_LIGHT : HTSIZE_FULL);
   o.targets = argv[i_targets];
   o.folder = argv[i_folder];
