@@ -346,6 +346,30 @@ __device__ __forceinline__ void sliding_min3(uint32_t& a0, uint32_t& a1, uint32_
   if (cover < w) step(w - cover);
 }
 
+// Two-array form: the m-mers past position 127 are not a third array but arrive as `tail` (see the kernel).
+__device__ __forceinline__ void sliding_min2(uint32_t& a0, uint32_t& a1, int w, int lane) {
+  auto step = [&](int s) {
+    const int src = (lane + s) & 63;
+    const bool wrap = lane + s >= 64;
+    uint32_t x0 = bperm(src, a0), x1 = bperm(src, a1);
+    uint32_t n0 = wrap ? x1 : x0, n1 = wrap ? 0xFFFFFFFFu : x1;
+    a0 = n0 < a0 ? n0 : a0; a1 = n1 < a1 ? n1 : a1;
+  };
+  int cover = 1;
+  while (2 * cover <= w) { step(cover); cover *= 2; }
+  if (cover < w) step(w - cover);
+}
+
+// inclusive prefix minimum within each row of 16 lanes (four DPP row_shr steps, no LDS)
+__device__ __forceinline__ uint32_t row_prefix_min(uint32_t t) {
+  uint32_t x;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)t, 0x111, 0xF, 0xF, false); t = x < t ? x : t;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)t, 0x112, 0xF, 0xF, false); t = x < t ? x : t;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)t, 0x114, 0xF, 0xF, false); t = x < t ? x : t;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)t, 0x118, 0xF, 0xF, false); t = x < t ? x : t;
+  return t;
+}
+
 // -DMIC_PHASE_TIMING: per-phase cycle sums of query_kernel_m (s_memtime around each phase, one atomicAdd per wave),
 // printed by the launcher.  A measuring build only: the counter reads themselves cost ~5 %.
 // -DMIC_PERTURB: sensitivity analysis.  MIC_PERTURB_VALU / _LDS / _SALU = number of 8-instruction groups of dummy
@@ -383,9 +407,18 @@ __device__ unsigned long long g_phase[8];
 #define PH(i)
 #define PH_END
 #endif
+#ifndef MIC_TAIL_KEYS
+#define MIC_TAIL_KEYS 1
+#endif
+#ifndef MIC_SPEC
+#define MIC_SPEC 1
+#endif
 #ifndef MIC_M_WPB
 #define MIC_M_WPB 4        // waves per block of query_kernel_m (measured: 1: 778, 2: 757, 4: 824-834 Mreads/s; tools/wpb_sweep.sh)
 #endif
+// KK / MM: k and the minimizer length as compile-time constants (0 = take them from the table): the launcher picks the
+// instantiation for cuCLARK's k = 31 and cuCLARK-l's k = 27 with m = 20; shift counts, masks and the window loop fold.
+template <int KK, int MM>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m(const MicQueryArgs a PERTURB_PARAMS) {
   __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE];
   __shared__ uint32_t s_run[MIC_M_WPB][MIC_RMAX];
@@ -397,7 +430,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * MIC_M_WPB + wv);
   const uint32_t n_waves = gridDim.x * MIC_M_WPB;
   const MicTable& t = a.t;
-  const int k = t.k, m = t.m, w = k - m + 1;
+  const int k = KK ? KK : t.k, m = MM ? MM : t.m, w = k - m + 1;
   const uint4* __restrict__ slots = t.slots;
   const uint16_t* __restrict__ cont = a.cont;
   // number of set bits of a 64-bit lane mask below this lane (v_mbcnt_lo/hi: no mask register to keep alive)
@@ -416,7 +449,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
     const uint64_t abase = ((uint64_t)(cont + pp_w)) & ~3ULL;
     const uint32_t rr = r_ptr < a.n_reads ? r_ptr : a.n_reads - 1;
     const uint64_t pbase = (uint64_t)(a.reads_ptr + rr) - 48;
-    const uint32_t li = lane < 14 ? (uint32_t)lane : 0u;
+    uint32_t lv = (uint32_t)lane;
+    asm volatile("" : "+v"(lv));      // recomputed per read (3 VALU) instead of a 64-bit offset kept live in VGPRs
+    const uint32_t li = lv < 14 ? lv : 0u;
     const uint64_t addr = (li < 12 ? abase : pbase) + 4 * li;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
                                      (__attribute__((address_space(3))) void*)entry, 4, 0, 0);
@@ -466,6 +501,13 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
         const uint32_t wd = window_word_w(cont, first, cend, base, lane, ahead_ok && base == 0, cur_w);
         // k-mers of the two passes and the order keys of the m-mers at positions base+64h+lane, h = 0..2
         uint64_t c[2]; bool act[2]; uint32_t hk0, hk1, hk2;
+        // The windows of the chunk's last k-mers reach m-mers at positions base+128 .. base+128+w-2.  m-mer 128+j is the
+        // LAST m-mer of k-mer 64 + (65-w+j) of pass 1, so for w <= 16 its order key comes out of that lane's k-mer and
+        // reverse complement (no third assembly pass) and the minimum over positions 128 .. 64+lane+w-1 is a prefix
+        // minimum inside the last DPP row.  A chunk of at most 129-w k-mers (every 100/125-bp read) needs neither.
+        const bool past = nk - base > (uint32_t)(129 - w);
+        const bool tail_path = MIC_TAIL_KEYS && w <= 16;
+        uint32_t tail = 0xFFFFFFFFu;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int idx = 4 * h + (lane >> 4);
@@ -488,17 +530,26 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
           const uint64_t mf = kmer >> (2 * (k - m)), mr = rck & ((1ULL << (2 * m)) - 1);
           uint32_t key = mmer_order_key_canon(mf < mr ? mf : mr);
           if (h == 0) hk0 = key; else hk1 = key;
+          if (h == 1 && tail_path && past) {
+            // last m-mer of the k-mer = its last m nt; reverse complement = first m nt of rc(k-mer)
+            const uint64_t tf = kmer & ((1ULL << (2 * m)) - 1), tr = rck >> (2 * (k - m));
+            const uint32_t tk = mmer_order_key_canon(tf < tr ? tf : tr);
+            tail = row_prefix_min(lane >= 65 - w ? tk : 0xFFFFFFFFu);
+          }
         }
-        // m-mers at positions base+128 .. base+128+w-2 end the windows of the chunk's last k-mers; a chunk of at most
-        // 129-w k-mers (every 100/125-bp read) never looks past position 127 and skips this third pass
-        hk2 = 0xFFFFFFFFu;
-        if (nk - base > (uint32_t)(129 - w)) {
-          const int idx = 8 + (lane >> 4);
-          uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
-          uint64_t mm = kmer_from_dwords(d0, d1, d2, lane & 15, m);
-          hk2 = lane < w - 1 ? mmer_order_key(mm, m) : 0xFFFFFFFFu;
+        if (tail_path) {
+          sliding_min2(hk0, hk1, w, lane);
+          hk1 = tail < hk1 ? tail : hk1;
+        } else {
+          hk2 = 0xFFFFFFFFu;
+          if (past) {
+            const int idx = 8 + (lane >> 4);
+            uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
+            uint64_t mm = kmer_from_dwords(d0, d1, d2, lane & 15, m);
+            hk2 = lane < w - 1 ? mmer_order_key(mm, m) : 0xFFFFFFFFu;
+          }
+          sliding_min3(hk0, hk1, hk2, w, lane);
         }
-        sliding_min3(hk0, hk1, hk2, w, lane);
         uint32_t sl0 = act[0] ? mslot_of_key(hk0, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         uint32_t sl1 = act[1] ? mslot_of_key(hk1, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         uint32_t res0 = 0, res1 = 0, res2 = 0;   // label + 1 of the hit: passes 0, 1 and the compacted deeper levels
@@ -947,10 +998,15 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
       if ((e = getenv("MIC_PERTURB_VALU"))) pv[0] = atoi(e);
       if ((e = getenv("MIC_PERTURB_LDS"))) pv[1] = atoi(e);
       if ((e = getenv("MIC_PERTURB_SALU"))) pv[2] = atoi(e);
-      query_kernel_m<<<(blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, 64 * MIC_M_WPB, 0, s>>>(a, pv[0], pv[1], pv[2]);
+      query_kernel_m<0, 0><<<(blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, 64 * MIC_M_WPB, 0, s>>>(a, pv[0], pv[1], pv[2]);
     }
 #else
-    query_kernel_m<<<(blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, 64 * MIC_M_WPB, 0, s>>>(a);
+    {
+      const unsigned g = (blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, b = 64 * MIC_M_WPB;
+      if (MIC_SPEC && a.t.k == 31 && a.t.m == 20) query_kernel_m<31, 20><<<g, b, 0, s>>>(a);        // cuCLARK
+      else if (MIC_SPEC && a.t.k == 27 && a.t.m == 20) query_kernel_m<27, 20><<<g, b, 0, s>>>(a);   // cuCLARK-l
+      else query_kernel_m<0, 0><<<g, b, 0, s>>>(a);
+    }
 #endif
 #ifdef MIC_PHASE_TIMING
     unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
