@@ -36,8 +36,19 @@ __device__ __forceinline__ uint64_t canonical(uint64_t kmer, int k) {
 // order key of an m-mer (m <= 31): 32-bit mix of its canonical value.  The slot of a k-mer is a function
 // of the MINIMUM order key over its w = k-m+1 m-mers only, so a k-mer and its reverse complement (same canonical
 // m-mers) agree, and ties between different m-mers are harmless.
+#ifndef MIC_CHEAP_HASH
+#define MIC_CHEAP_HASH 1
+#endif
 __device__ __forceinline__ uint32_t mmer_order_key_canon(uint64_t u) {   // u = canonical m-mer value
+#if MIC_CHEAP_HASH
+  // 32-bit multiplies issue at half the rate of plain integer ops (tools/valu_rate_bench.hip): the high word (8 bits
+  // for m = 20) goes through one full-rate 24-bit multiply-add; bits 56+ of a 29..31-mer only reach the key through
+  // the fold.  The order only has to look random and be the same function in the table build and the query.
+  const uint32_t hi = (uint32_t)(u >> 32);
+  uint32_t h = (uint32_t)u * 0x9E3779B1u ^ (__umul24(hi ^ (hi >> 24), 0xEBCA77u) + 0x27D4EB2Fu);
+#else
   uint32_t h = (uint32_t)u * 0x9E3779B1u ^ ((uint32_t)(u >> 32) * 0x85EBCA77u + 0x27D4EB2Fu);
+#endif
   h ^= h >> 15; h *= 0x2C1B3C6Du;      // one multiply-xorshift round: the order only has to look random
   return h;
 }
@@ -45,10 +56,15 @@ __device__ __forceinline__ uint32_t mmer_order_key_canon(uint64_t u) {   // u = 
 __device__ __forceinline__ uint32_t mmer_order_key(uint64_t x, int m) { return mmer_order_key_canon(canonical(x, m)); }
 
 __device__ __forceinline__ uint32_t mslot_of_key(uint32_t min_key, uint32_t n_slots) {
+#if MIC_CHEAP_HASH
+  // the minimum of w hashes is small but its low bits are uniform: one odd multiply carries them into the high bits
+  return __umulhi(min_key * 0xC2B2AE3Du, n_slots);
+#else
   // the minimum of w hashes is small: remix before taking the high bits
   uint32_t z = min_key * 0xC2B2AE3Du;
   z ^= z >> 15; z *= 0x165667B1u;
   return __umulhi(z, n_slots);
+#endif
 }
 
 // sequential form (table build, dense fallback, statistics)

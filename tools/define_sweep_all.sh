@@ -1,0 +1,11 @@
+#!/bin/bash
+# Rebuild the whole library on the GPU box with each given option set (options that change the table as well as the
+# kernels) and run the headline bench: tools/define_sweep_all.sh "-DA=1" "-DA=0" ...   The last set stays built.
+cd $GRAFT_REPO_ROOT/cuclark_amd/csrc
+for d in "$@"; do
+  rm -f obj/mic_kernels.o obj/mic_build.o obj/mic_engine.o obj/mic_synth.o obj/mic_dbbuild.o
+  make -j8 all EXTRA="$d" 2>&1 | grep -E "error" -A3
+  for i in 1 2; do
+    python $GRAFT_REPO_ROOT/bench.py --no-cpu --steps 10 --warmup 2 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); t=d['config']['table']; print('$d', d['value'], d['ms_per_step'], 'overflow', t['overflow_slots'], 'largest', t['largest_minimizer_bucket'], 'GB', t['hbm_GB'])"
+  done
+done
