@@ -225,7 +225,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": round(traffic, 1) if traffic else None,
                 "traffic_source": traffic_src,
-                "kernel": "query_kernel_m" if info["layout"] == 2 else "query_kernel", "kernel_ms": round(kern_s * 1e3, 3),
+                "kernel": {1: "query_kernel", 2: "query_kernel_m", 3: "query_kernel_s"}[info["layout"]], "kernel_ms": round(kern_s * 1e3, 3),
                 "algorithmic_bytes_per_kmer": round(bytes_per_kmer, 2), "kmers_per_launch": st["kmers"],
                 "probes_per_launch": st["probed"], "hit_rate": round(h, 4), "mean_probed_bucket_len": round(lam_q, 3),
                 "probes_per_s_G": round(st["probed"] / kern_s / 1e9, 2),
@@ -356,7 +356,7 @@ def main():
                        "mode": ("table-sharded by bucket range + all_to_all of sparse rows" if db_mode else
                                 ("read-sharded, table replicated" if world > 1 else "single GPU, table resident")),
                        "table": {"htsize": info["htsize"], "kmers": info["n_elems"], "slot_class": info["slot_class"],
-                                 "layout": {1: "direct: one 64-B slot per on-disk bucket", 2: "minimizer-keyed 128-B slots"}[info["layout"]],
+                                 "layout": {1: "direct: one 64-B slot per on-disk bucket", 2: "minimizer-keyed 128-B slots", 3: "super-k-mer 128-B slots"}[info["layout"]],
                                  "minimizer_len": info["minimizer_len"], "largest_minimizer_bucket": info["max_chain"],
                                  "hbm_GB": round(info["hbm_bytes"] / 1e9, 2), "overflow_slots": info["n_overflow"],
                                  "max_bucket": info["max_bucket"], "on_disk_equiv_GB": round((info["htsize"] + n_el * (key_b + 2)) / 1e9, 2)},

@@ -16,7 +16,7 @@ MIC_RESULT_WORDS = 8
 MIC_FLAG_ROW_OVERFLOW = 1
 MIC_FLAG_DENSE_PATH = 2
 MIC_ROW_INVALID = 0xFFFFFFFF
-MIC_LAYOUT_AUTO, MIC_LAYOUT_DIRECT, MIC_LAYOUT_MINIMIZER = 0, 1, 2
+MIC_LAYOUT_AUTO, MIC_LAYOUT_DIRECT, MIC_LAYOUT_MINIMIZER, MIC_LAYOUT_SUPER = 0, 1, 2, 3
 
 
 class MicError(RuntimeError):

@@ -13,6 +13,9 @@
 #include <stdlib.h>
 #include <time.h>
 #include <vector>
+#include <math.h>
+
+#include <hipcub/hipcub.hpp>
 
 #define TILE 256
 
@@ -552,6 +555,153 @@ __global__ void __launch_bounds__(256) m_sort_kernel(const uint32_t* __restrict_
   }
 }
 
+
+// =====================================================================================================================
+// Super-k-mer table (layout 3, mic_device.h): candidates -> per-slot staging -> merge into entries -> slots.
+//   S1  per bucket: reachable k-mers -> candidates (oriented k-mer, minimizer position, x) -> count[slot(x)]++
+//   S2  exclusive scan of the counts (hipcub) -> staging offsets; S3 scatter of (k-mer, position | label << 8)
+//   S4  per slot, one thread: sort the staged candidates by (low 32 bits of x, x, position), merge the ones whose
+//       nucleotides agree where they overlap (same x, same label) into entries; first run counts the entries (-> chain
+//       slots, second scan), second run writes the slots.
+// =====================================================================================================================
+typedef unsigned __int128 u128;
+
+template <typename RAW>
+__global__ void __launch_bounds__(TILE) s_count_kernel(MBuildArgs a, uint32_t* __restrict__ cnt,
+                                                       unsigned long long* __restrict__ kept) {
+  unsigned long long mine = 0;
+  for_reachable<RAW>(a, [&](uint64_t c, uint16_t) {
+    s_candidates(c, a.k, a.m, [&](uint64_t, int, uint64_t x) { atomicAdd(&cnt[sslot_of_x(x, (uint32_t)a.n_mslots)], 1u); });
+    ++mine;
+  });
+  if (mine) atomicAdd(kept, mine);
+}
+
+template <typename RAW>
+__global__ void __launch_bounds__(TILE) s_scatter_kernel(MBuildArgs a, const unsigned long long* __restrict__ off,
+                                                         uint32_t* __restrict__ cursor, unsigned long long* __restrict__ cand_k,
+                                                         uint32_t* __restrict__ cand_m) {
+  for_reachable<RAW>(a, [&](uint64_t c, uint16_t lb) {
+    s_candidates(c, a.k, a.m, [&](uint64_t K, int j, uint64_t x) {
+      const uint32_t s = sslot_of_x(x, (uint32_t)a.n_mslots);
+      const unsigned long long pos = off[s] + atomicAdd(&cursor[s], 1u);
+      cand_k[pos] = K; cand_m[pos] = (uint32_t)j | ((uint32_t)lb << 8);
+    });
+  });
+}
+
+__global__ void s_nonzero_kernel(const uint32_t* __restrict__ cnt, uint64_t n, unsigned long long* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long b = __ballot(i < n && cnt[i] != 0);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
+}
+
+struct SOpen { u128 S, known; uint32_t pmask, label; };
+
+__device__ inline uint64_t s_x_of(unsigned long long K, uint32_t j, int k, int m) {
+  return (K >> (2 * (k - m - (int)j))) & ((1ULL << (2 * m)) - 1);
+}
+// order of the staged candidates: (low 32 bits of x, high bits of x, minimizer position)
+__device__ inline bool s_less(unsigned long long Ka, uint32_t ma, unsigned long long Kb, uint32_t mb, int k, int m) {
+  const uint64_t xa = s_x_of(Ka, ma & 0xFF, k, m), xb = s_x_of(Kb, mb & 0xFF, k, m);
+  if ((uint32_t)xa != (uint32_t)xb) return (uint32_t)xa < (uint32_t)xb;
+  if (xa != xb) return xa < xb;
+  return (ma & 0xFF) < (mb & 0xFF);
+}
+
+struct SWriter {   // where the entries of one slot go: the main slot, then its contiguous continuation slots
+  uint32_t* slots; uint64_t main, chain; uint32_t n_total, n_out;
+  __device__ uint32_t* slot_of(uint32_t idx) const {
+    return slots + (idx < MIC_S_CAP ? main : chain + (idx - MIC_S_CAP) / MIC_S_CAP) * 32;
+  }
+};
+
+template <bool WRITE>
+__device__ inline void s_emit(const SOpen& o, uint64_t x, int L, SWriter& wr) {
+  if (WRITE) {
+    uint32_t* q = wr.slot_of(wr.n_out);
+    const uint32_t e = wr.n_out % MIC_S_CAP;
+    const u128 v = o.S << (96 - 2 * L);
+    q[e] = (uint32_t)x;
+    q[6 + 3 * e] = (uint32_t)(v >> 64); q[7 + 3 * e] = (uint32_t)(v >> 32); q[8 + 3 * e] = (uint32_t)v;
+    q[24 + e] = (o.pmask << 16) | o.label;
+  }
+  ++wr.n_out;
+}
+
+#define S_MAXOPEN 4
+template <bool WRITE>
+__global__ void __launch_bounds__(256) s_merge_kernel(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ cnt,
+                                                      uint64_t n_slots, unsigned long long* __restrict__ cand_k,
+                                                      uint32_t* __restrict__ cand_m, int k, int m,
+                                                      uint32_t* __restrict__ n_ent, const unsigned long long* __restrict__ chain_off,
+                                                      uint32_t* __restrict__ slots, uint32_t* __restrict__ max_ent) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const uint32_t n = cnt[s];
+  unsigned long long* K = cand_k + off[s];
+  uint32_t* M = cand_m + off[s];
+  const int w = k - m + 1, L = k + w - 1;
+  SWriter wr; wr.slots = slots; wr.main = s; wr.chain = 0; wr.n_total = 0; wr.n_out = 0;
+  if (WRITE) {
+    wr.n_total = n_ent[s];
+    const uint32_t n_chain = wr.n_total > MIC_S_CAP ? (wr.n_total - 1) / MIC_S_CAP : 0;
+    wr.chain = n_slots + chain_off[s];
+    for (uint32_t c = 0; c <= n_chain; ++c) {               // headers and empty entries of every slot of this bucket
+      uint32_t* q = slots + (c == 0 ? s : wr.chain + c - 1) * 32;
+      for (int e = 0; e < 6; ++e) q[e] = 0xFFFFFFFFu;
+      for (int e = 6; e < 30; ++e) q[e] = 0;
+      const uint32_t here = wr.n_total - c * MIC_S_CAP > MIC_S_CAP ? MIC_S_CAP : wr.n_total - c * MIC_S_CAP;
+      q[30] = (wr.n_total ? here : 0) | (c < n_chain ? MIC_S_NEXT : 0);
+      q[31] = c < n_chain ? (uint32_t)(wr.chain + c) : 0;
+    }
+  } else {
+    // shell sort of the staged candidates (in place; the second run finds them sorted)
+    const uint32_t gaps[] = {701, 301, 132, 57, 23, 10, 4, 1};
+    for (int g = 0; g < 8; ++g) {
+      const uint32_t gap = gaps[g];
+      if (gap >= n) continue;
+      for (uint32_t i = gap; i < n; ++i) {
+        const unsigned long long kv = K[i]; const uint32_t mv = M[i];
+        uint32_t j = i;
+        while (j >= gap && s_less(kv, mv, K[j - gap], M[j - gap], k, m)) { K[j] = K[j - gap]; M[j] = M[j - gap]; j -= gap; }
+        K[j] = kv; M[j] = mv;
+      }
+    }
+  }
+  SOpen open[S_MAXOPEN]; int n_open = 0; uint64_t cur_x = 0;
+  const u128 kmask = (((u128)1) << (2 * k)) - 1;
+  for (uint32_t i = 0; i < n; ++i) {
+    const unsigned long long kv = K[i]; const uint32_t mv = M[i];
+    const uint32_t j = mv & 0xFF, lb = mv >> 8;
+    const uint64_t x = s_x_of(kv, j, k, m);
+    if (n_open && x != cur_x) { for (int o = 0; o < n_open; ++o) s_emit<WRITE>(open[o], cur_x, L, wr); n_open = 0; }
+    cur_x = x;
+    const u128 SK = (u128)kv << (2 * j), MK = kmask << (2 * j);
+    bool done = false;
+    for (int o = 0; o < n_open && !done; ++o) {
+      if (open[o].label == lb && !((open[o].pmask >> j) & 1) && ((open[o].S ^ SK) & open[o].known & MK) == 0) {
+        open[o].S |= SK; open[o].known |= MK; open[o].pmask |= 1u << j; done = true;
+      }
+    }
+    if (!done) {
+      if (n_open == S_MAXOPEN) {                              // keep the most recent contexts open
+        s_emit<WRITE>(open[0], cur_x, L, wr);
+        for (int o = 1; o < S_MAXOPEN; ++o) open[o - 1] = open[o];
+        --n_open;
+      }
+      open[n_open].S = SK; open[n_open].known = MK; open[n_open].pmask = 1u << j; open[n_open].label = lb; ++n_open;
+    }
+  }
+  for (int o = 0; o < n_open; ++o) s_emit<WRITE>(open[o], cur_x, L, wr);
+  if (!WRITE) { n_ent[s] = wr.n_out; if (wr.n_out > MIC_S_CAP) atomicMax(max_ent, wr.n_out); }
+}
+
+__global__ void s_chain_demand_kernel(const uint32_t* __restrict__ n_ent, uint64_t n, uint32_t* __restrict__ demand) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const uint32_t e = n_ent[i]; demand[i] = e > MIC_S_CAP ? (e - 1) / MIC_S_CAP : 0; }
+}
+
 }  // namespace
 
 int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
@@ -682,6 +832,160 @@ done:
   if (d_tile) hipFree(d_tile);
   if (d_kept) hipFree(d_kept);
   if (d_max) hipFree(d_max);
+  if (slots) hipFree(slots);
+  return rc;
+}
+
+struct CastU64 { __host__ __device__ unsigned long long operator()(const uint32_t& v) const { return (unsigned long long)v; } };
+
+static hipError_t scan_u32_to_u64(const uint32_t* in, unsigned long long* out, uint64_t n, hipStream_t s) {
+  hipcub::TransformInputIterator<unsigned long long, CastU64, const uint32_t*> it(in, CastU64());
+  size_t tb = 0; void* tmp = nullptr;
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, out, (int)n, s);
+  if (e != hipSuccess) return e;
+  if ((e = hipMalloc(&tmp, tb ? tb : 16)) != hipSuccess) return e;
+  e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, it, out, (int)n, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  hipFree(tmp);
+  return e != hipSuccess ? e : e2;
+}
+
+int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
+                     int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
+                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap) {
+  int rc = 0;
+  const unsigned n_tiles = (unsigned)((n_buckets + TILE - 1) / TILE);
+  TileA* d_a = nullptr; uint32_t* d_cnt = nullptr; uint32_t* d_cur = nullptr; unsigned long long* d_off = nullptr;
+  unsigned long long* d_coff = nullptr; unsigned long long* d_scal = nullptr; uint32_t* d_max = nullptr;
+  unsigned long long* d_ck = nullptr; uint32_t* d_cm = nullptr; uint32_t* slots = nullptr;
+  std::vector<TileA> h_a(n_tiles);
+  uint64_t tot_elems = 0, tot_nz = 0, n_slots = 0, n_cand = 0, n_chain = 0;
+  unsigned long long h_scal[2] = {0, 0}; uint32_t h_max = 0;
+  MBuildArgs a;
+  const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
+  struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    hipStreamSynchronize(s);
+    struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    fprintf(stderr, "[load]   %s: %.3f s\n", what, (t.tv_sec - t_prev.tv_sec) + (t.tv_nsec - t_prev.tv_nsec) / 1e9);
+    t_prev = t;
+  };
+#define BY_RAW(KERN, ...) do { if (key_bytes == 8) KERN<uint64_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); \
+    else if (key_bytes == 4) KERN<uint32_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); \
+    else KERN<uint16_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); } while (0)
+  HIPCK(hipMalloc(&d_a, sizeof(TileA) * n_tiles));
+  HIPCK(hipMalloc(&d_scal, 16));
+  HIPCK(hipMalloc(&d_max, 4));
+  tile_a_kernel<<<n_tiles, TILE, 0, s>>>(d_sizes, n_buckets, d_a);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(h_a.data(), d_a, sizeof(TileA) * n_tiles, hipMemcpyDeviceToHost, s));
+  HIPCK(hipStreamSynchronize(s));
+  for (unsigned t = 0; t < n_tiles; ++t) {
+    uint64_t e = h_a[t].elems, z = h_a[t].nonzero;
+    h_a[t].elems = tot_elems; h_a[t].nonzero = tot_nz; tot_elems += e; tot_nz += z;
+  }
+  HIPCK(hipMemcpyAsync(d_a, h_a.data(), sizeof(TileA) * n_tiles, hipMemcpyHostToDevice, s));
+  a.sizes = d_sizes; a.n_buckets = n_buckets; a.bucket0 = bucket0; a.htsize = htsize; a.keys = d_keys; a.labels = d_labels;
+  a.base_a = d_a; a.sampling = sampling; a.rank_base = rank_base; a.k = k; a.m = m;
+  // Sizing: the number of entries is about the number of distinct minimizers D among the stored k-mers.  A first
+  // counting pass over G provisional slots leaves N non-empty ones, so D ~ -G ln(1 - N/G); the table then gets
+  // D / 1.5 slots (6 entries each: P(overflow) ~ 2e-4 for Poisson(1.5)).  MIC_SSLOT_LOAD overrides the 1.5.
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 0) n_slots = tot_elems / (sampling > 1 ? 4ull * sampling : 4ull) + 64;
+    if (n_slots > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many S-slots"); rc = -1; goto done; }
+    if (d_cnt) { hipFree(d_cnt); d_cnt = nullptr; }
+    HIPCK(hipMalloc(&d_cnt, n_slots * 4));
+    HIPCK(hipMemsetAsync(d_cnt, 0, n_slots * 4, s));
+    HIPCK(hipMemsetAsync(d_scal, 0, 16, s));
+    a.n_mslots = n_slots;
+    BY_RAW(s_count_kernel, a, d_cnt, d_scal);
+    HIPCK(hipGetLastError());
+    if (pass == 0) {
+      s_nonzero_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_cnt, n_slots, d_scal + 1);
+      HIPCK(hipGetLastError());
+      HIPCK(hipMemcpyAsync(h_scal, d_scal, 16, hipMemcpyDeviceToHost, s));
+      HIPCK(hipStreamSynchronize(s));
+      const double G = (double)n_slots, N = (double)h_scal[1];
+      double D = N >= G ? 8.0 * G : -G * log(1.0 - N / G);
+      double load = 1.5;
+      if (const char* env = getenv("MIC_SSLOT_LOAD")) { double v = atof(env); if (v > 0.05 && v < 6) load = v; }
+      n_slots = (uint64_t)(D / load) + 64;
+    }
+  }
+  HIPCK(hipMemcpyAsync(h_scal, d_scal, 8, hipMemcpyDeviceToHost, s));
+  HIPCK(hipStreamSynchronize(s));
+  lap("bucket sums + slot counts (sizing)");
+  HIPCK(hipMalloc(&d_off, (n_slots + 1) * 8));
+  HIPCK(scan_u32_to_u64(d_cnt, d_off, n_slots, s));
+  {
+    unsigned long long last_off = 0; uint32_t last_cnt = 0;
+    HIPCK(hipMemcpy(&last_off, d_off + n_slots - 1, 8, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(&last_cnt, d_cnt + n_slots - 1, 4, hipMemcpyDeviceToHost));
+    n_cand = last_off + last_cnt;
+  }
+  {
+    hipError_t e1 = hipMalloc(&d_ck, (n_cand + 1) * 8), e2 = hipMalloc(&d_cm, (n_cand + 1) * 4);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      (void)hipGetLastError();
+      snprintf(err, err_cap, "the super-k-mer build needs %.2f GB of staging", (double)n_cand * 12 / 1e9); rc = -3; goto done;
+    }
+  }
+  HIPCK(hipMalloc(&d_cur, n_slots * 4));
+  HIPCK(hipMemsetAsync(d_cur, 0, n_slots * 4, s));
+  BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm);
+  HIPCK(hipGetLastError());
+  lap("scatter of the candidates");
+  HIPCK(hipMemsetAsync(d_max, 0, 4, s));
+  s_merge_kernel<false><<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_cur, nullptr,
+                                                                         nullptr, d_max);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
+  lap("sort + merge (count)");
+  {
+    // chain slots: demand per slot into a scratch u32 array (the candidate offsets stay), scanned to 64-bit bases
+    uint32_t* d_dem = nullptr;
+    HIPCK(hipMalloc(&d_dem, n_slots * 4));
+    s_chain_demand_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_cur, n_slots, d_dem);
+    HIPCK(hipMalloc(&d_coff, (n_slots + 1) * 8));
+    hipError_t e = scan_u32_to_u64(d_dem, d_coff, n_slots, s);
+    unsigned long long last_off = 0; uint32_t last_dem = 0;
+    if (e == hipSuccess) e = hipMemcpy(&last_off, d_coff + n_slots - 1, 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&last_dem, d_dem + n_slots - 1, 4, hipMemcpyDeviceToHost);
+    hipFree(d_dem);
+    HIPCK(e);
+    n_chain = last_off + last_dem;
+  }
+  if (n_slots + n_chain > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many S-slots"); rc = -1; goto done; }
+  {
+    hipError_t e_ = hipMalloc(&slots, (size_t)(n_slots + n_chain + 1) * 128);
+    if (e_ != hipSuccess) {
+      (void)hipGetLastError();
+      snprintf(err, err_cap, "hipMalloc of %.2f GB for the super-k-mer table failed: %s",
+               (double)(n_slots + n_chain + 1) * 128 / 1e9, hipGetErrorString(e_));
+      rc = -3; goto done;
+    }
+  }
+  s_merge_kernel<true><<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_cur, d_coff,
+                                                                        slots, d_max);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemsetAsync(slots + (size_t)(n_slots + n_chain) * 32, 0xFF, 128, s));   // the spare slot after the table: empty
+  HIPCK(hipStreamSynchronize(s));
+  lap("merge (write)");
+#undef BY_RAW
+  out->slots = (uint4*)slots; slots = nullptr;
+  out->n_main = n_slots; out->n_overflow = n_chain; out->n_elems = h_scal[0]; out->n_elems_file = tot_elems;
+  out->max_bucket = 0; out->max_chain = h_max;
+done:
+  if (d_a) hipFree(d_a);
+  if (d_cnt) hipFree(d_cnt);
+  if (d_cur) hipFree(d_cur);
+  if (d_off) hipFree(d_off);
+  if (d_coff) hipFree(d_coff);
+  if (d_scal) hipFree(d_scal);
+  if (d_max) hipFree(d_max);
+  if (d_ck) hipFree(d_ck);
+  if (d_cm) hipFree(d_cm);
   if (slots) hipFree(slots);
   return rc;
 }

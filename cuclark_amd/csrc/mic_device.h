@@ -78,6 +78,79 @@ __device__ __forceinline__ uint32_t mslot_of_kmer(uint64_t kmer, int k, int m, u
   return mslot_of_key(best, n_slots);
 }
 
+// ---- super-k-mer table ("S-table", layout 3) --------------------------------------------------------------------
+// The k-mers of the database that share a minimizer OCCURRENCE overlap by k-1 nucleotides: they are stored as one
+// entry, the super-k-mer S of k+w-1 nucleotides with the minimizer at the fixed position w-1, plus a w-bit presence
+// mask (bit j: the k-mer whose minimizer sits at its position j, i.e. S[w-1-j, w-1-j+k), is in the database) and one
+// label.  ~6.5 k-mers per 16-byte entry instead of 10 bytes each, so a 128-byte slot (6 entries) practically never
+// overflows and a lookup is ONE slot.  Everything is exact: the k-mer is compared in full against the entry.
+//   orientation: the k-mer is taken in the strand where the minimizer reads as its canonical m-mer value x;
+//   order of m-mers: the top 27 bits of mmer_order_key_canon(x); the low 5 bits of the query's sliding-minimum key carry
+//   the strand and the position, so positions that tie on the 27 bits are resolved arbitrarily by the query - the
+//   build stores a k-mer under EVERY tied position (and under both strands of a palindromic minimizer);
+//   slot = hash of the full x (not of the 32-bit order key: distinct minimizers no longer collide in key space).
+// 128-byte slot, 32 words: [0..5] sort keys = low 32 bits of x, ascending, unused = ~0 | [6..23] S as 3 words per
+// entry, nucleotide 0 in the top bits of word 0 | [24..29] presence mask << 16 | label | [30] entries | HAS_NEXT << 8
+// | [31] index of the continuation slot (same format) when more than 6 entries hash here.
+#define MIC_S_CAP 6
+#define MIC_S_NEXT 0x100u
+
+__device__ __forceinline__ uint32_t s_order27(uint64_t x) { return mmer_order_key_canon(x) >> 5; }
+
+__device__ __forceinline__ uint32_t sslot_of_x(uint64_t x, uint32_t n_slots) {
+  const uint32_t hi = (uint32_t)(x >> 32);
+  uint32_t h = (uint32_t)x * 0x85EBCA77u + __umul24(hi ^ (hi >> 24), 0xC2B2AFu);
+  h ^= h >> 15; h *= 0x165667B1u;
+  return __umulhi(h, n_slots);
+}
+
+// k-mer at nucleotide offset a (0..15) of a super-k-mer stored as three words
+__device__ __forceinline__ uint64_t s_extract(uint32_t w0, uint32_t w1, uint32_t w2, int a, int k) {
+  const int s = 2 * a;
+  const uint64_t hi = ((uint64_t)w0 << 32) | w1;
+  const uint64_t x = s ? ((hi << s) | (uint64_t)(w2 >> (32 - s))) : hi;
+  return x >> (64 - 2 * k);
+}
+
+// every (oriented k-mer, minimizer position, minimizer value) under which the query may look canonical k-mer c up
+template <typename F>
+__device__ __forceinline__ void s_candidates(uint64_t c, int k, int m, F&& f) {
+  const int w = k - m + 1;
+  const uint64_t mask = (1ULL << (2 * m)) - 1;
+  const uint64_t rc = revcomp_bits(c, k);
+  uint32_t hmin = 0xFFFFFFFFu;
+  for (int i = 0; i < w; ++i) {
+    const uint64_t mf = (c >> (2 * (k - m - i))) & mask, mr = revcomp_bits(mf, m);
+    const uint32_t h = s_order27(mf < mr ? mf : mr);
+    hmin = h < hmin ? h : hmin;
+  }
+  for (int i = 0; i < w; ++i) {
+    const uint64_t mf = (c >> (2 * (k - m - i))) & mask, mr = revcomp_bits(mf, m);
+    if (s_order27(mf < mr ? mf : mr) != hmin) continue;
+    if (mf <= mr) f(c, i, mf);
+    if (mf >= mr) f(rc, w - 1 - i, mr);
+  }
+}
+
+// sequential lookup (dense fallback, statistics, tests of the build): label + 1 or 0
+__device__ inline uint32_t s_probe(const uint4* __restrict__ slots, uint32_t n_slots, uint64_t c, int k, int m) {
+  uint64_t K = 0, x = 0; int j = -1;
+  s_candidates(c, k, m, [&](uint64_t kk, int jj, uint64_t xx) { if (j < 0) { K = kk; j = jj; x = xx; } });
+  const int w = k - m + 1;
+  uint64_t slot = sslot_of_x(x, n_slots);
+  for (;;) {
+    const uint32_t* q = (const uint32_t*)(slots + slot * 8);
+    for (int e = 0; e < MIC_S_CAP; ++e) {
+      if (q[e] != (uint32_t)x) continue;
+      const uint32_t pl = q[24 + e];
+      if (!((pl >> (16 + j)) & 1)) continue;
+      if (s_extract(q[6 + 3 * e], q[7 + 3 * e], q[8 + 3 * e], w - 1 - j, k) == K) return (pl & 0xFFFFu) + 1;
+    }
+    if (!(q[30] & MIC_S_NEXT)) return 0;
+    slot = q[31];
+  }
+}
+
 // M-slot words (uint4 q[8]): q[0..5] = 12 keys (u64, ascending, unused = ~0); q[6], q[7].xy = 12 labels (u16) in a
 // LEAF, or q[6].x = index of the first child slot in a DIRECTORY; q[7].z = meta (bits 0..7 = entries / children).
 #define MIC_M_N(meta) ((meta) & 0xFFu)

@@ -89,7 +89,7 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   e->table.shard_end = s1;
   e->table.div = mic_make_div(htsize);
   e->table.k = e->cfg.k;
-  e->table.layout = layout == MIC_LAYOUT_MINIMIZER ? 1 : 0;
+  e->table.layout = layout == MIC_LAYOUT_MINIMIZER ? 1 : layout == MIC_LAYOUT_SUPER ? 2 : 0;
   e->table.m = m;
   e->table.sharded = (s0 != 0 || s1 != htsize) ? 1 : 0;
   e->table.sizes = e->d_sizes;
@@ -97,10 +97,10 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   i.htsize = htsize; i.shard_start = s0; i.shard_end = s1;
   i.n_elems = b.n_elems; i.n_elems_file = b.n_elems_file;
   i.n_slots = b.n_main + b.n_overflow; i.n_overflow = b.n_overflow;
-  i.hbm_bytes = (b.n_main + b.n_overflow + 1) * (uint64_t)(layout == MIC_LAYOUT_MINIMIZER ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
-  i.key_bytes = key_bytes; i.slot_class = layout == MIC_LAYOUT_MINIMIZER ? 128 : e->slot_class; i.max_bucket = b.max_bucket;
-  i.sampling = sampling; i.layout = layout; i.minimizer_len = layout == MIC_LAYOUT_MINIMIZER ? m : 0;
-  i.max_chain = layout == MIC_LAYOUT_MINIMIZER ? b.max_chain : 0; i.reserved = 0;
+  i.hbm_bytes = (b.n_main + b.n_overflow + 1) * (uint64_t)(layout != MIC_LAYOUT_DIRECT ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
+  i.key_bytes = key_bytes; i.slot_class = layout != MIC_LAYOUT_DIRECT ? 128 : e->slot_class; i.max_bucket = b.max_bucket;
+  i.sampling = sampling; i.layout = layout; i.minimizer_len = layout != MIC_LAYOUT_DIRECT ? m : 0;
+  i.max_chain = layout != MIC_LAYOUT_DIRECT ? b.max_chain : 0; i.reserved = 0;
   e->db_loaded = true;
 }
 
@@ -173,6 +173,7 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
     const char* env = getenv("MIC_LAYOUT");
     if (env && !strcmp(env, "direct")) layout = MIC_LAYOUT_DIRECT;
     else if (env && !strcmp(env, "minimizer")) layout = MIC_LAYOUT_MINIMIZER;
+    else if (env && !strcmp(env, "super")) layout = MIC_LAYOUT_SUPER;
     else { layout = e->cfg.k >= 24 ? MIC_LAYOUT_MINIMIZER : MIC_LAYOUT_DIRECT; by_default = true; }  // measured: DESIGN.md §3.2
   }
   int m = 20;   // measured best for k = 31: minimizers long enough to be nearly unique in the table
@@ -180,6 +181,10 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   if (m > e->cfg.k - 4) m = e->cfg.k - 4;   // window w = k-m+1 >= 5
   if (m > 31) m = 31;
   if (layout == MIC_LAYOUT_MINIMIZER && (m < 8 || e->cfg.k - m + 1 > 64)) layout = MIC_LAYOUT_DIRECT;
+  if (layout == MIC_LAYOUT_SUPER) {          // the super-k-mer entries hold windows of at most 16 m-mers
+    if (m < e->cfg.k - 15) m = e->cfg.k - 15;
+    if (m < 8 || m > 31 || e->cfg.k - m + 1 < 2) layout = MIC_LAYOUT_DIRECT;
+  }
   if (e->d_sizes) { hipFree(e->d_sizes); e->d_sizes = nullptr; }
   if (hipMalloc(&e->d_sizes, s1 - s0) == hipSuccess)
     hipMemcpyAsync(e->d_sizes, d_sizes_shard, s1 - s0, hipMemcpyDeviceToDevice, e->stream);
@@ -190,7 +195,10 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
     // -3: even the densest minimizer table exceeds the free HBM; the direct layout is ~40 % smaller (64 B per bucket)
     if (rc == -3 && by_default) { layout = MIC_LAYOUT_DIRECT; memset(&b, 0, sizeof(b)); }
   }
-  if (layout != MIC_LAYOUT_MINIMIZER)
+  if (layout == MIC_LAYOUT_SUPER)
+    rc = mic_build_stable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
+                          e->cfg.k, m, e->stream, &b, err, sizeof(err));
+  else if (layout != MIC_LAYOUT_MINIMIZER)
     rc = mic_build_table(d_sizes_shard, s1 - s0, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
                          e->slot_class, e->stream, &b, err, sizeof(err));
   if (rc != 0) return fail(rc, "table build: %s", err);
@@ -264,7 +272,7 @@ int mic_create(const mic_config* cfg, mic_engine** out) {
   if (!cfg || !out) return fail(MIC_E_INVALID, "null argument");
   if (cfg->k < 2 || cfg->k > 32) return fail(MIC_E_INVALID, "The k-mer length should be in [2,32].");
   if (cfg->num_targets > 65535) return fail(MIC_E_INVALID, "too many targets (%u > 65535)", cfg->num_targets);
-  if (cfg->layout > MIC_LAYOUT_MINIMIZER) return fail(MIC_E_INVALID, "unknown table layout %u", cfg->layout);
+  if (cfg->layout > MIC_LAYOUT_SUPER) return fail(MIC_E_INVALID, "unknown table layout %u", cfg->layout);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
     return fail(MIC_E_NODEVICE, "no HIP device available: the MI355X engine cannot run (there is no CPU fallback)");

@@ -77,6 +77,9 @@ static inline __host__ __device__ uint64_t mic_div(uint64_t n, const MicDiv& dv)
 #define MIC_LAYOUT_DIRECT 1
 #define MIC_LAYOUT_MINIMIZER 2
 #endif
+#ifndef MIC_LAYOUT_SUPER
+#define MIC_LAYOUT_SUPER 3
+#endif
 
 struct MicTable {
   const uint4* slots;    // layout 0: 4 x uint4 per slot; layout 1: 8 x uint4 per slot
@@ -85,7 +88,7 @@ struct MicTable {
   uint64_t shard_end;
   MicDiv div;            // division by htsize
   int k;
-  int layout;            // 0 = direct slots, 1 = minimizer-keyed slots
+  int layout;            // 0 = direct slots, 1 = minimizer-keyed slots, 2 = super-k-mer slots
   int m;                 // minimizer length (layout 1)
   int sharded;           // 1 if [shard_start, shard_end) is a strict subset of the table
   const uint8_t* sizes;  // kept copy of the shard's on-disk bucket sizes (statistics only)
@@ -132,6 +135,10 @@ int mic_build_table(const uint8_t* d_sizes, uint64_t n_buckets, const void* d_ke
                     MicBuildOut* out, char* err, size_t err_cap);
 // Minimizer-keyed table from the same inputs.  bucket0 = index of the shard's first bucket in the whole table.
 int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
+                     int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
+                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap);
+// Super-k-mer table (layout 3, mic_device.h) from the same inputs.
+int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
                      int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
                      hipStream_t s, MicBuildOut* out, char* err, size_t err_cap);
 // sums over d_sizes[0..n): total elements and non-empty buckets

@@ -725,6 +725,256 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
   PH_END
 }
 
+// =====================================================================================================================
+// query_kernel_s - super-k-mer table (layout 2 internally, MIC_LAYOUT_SUPER; format and rules in mic_device.h).  Same
+// work mapping, k-mer assembly, run detection, LDS-DMA staging, tally and result code as query_kernel_m.  Differences:
+// the sliding-minimum keys carry the strand and position of their m-mer in the low 5 bits, so every k-mer knows WHERE its
+// minimizer sits: it orients itself by the minimizer's strand, takes the slot from the full minimizer value, finds the
+// entries with that value by a 3-step search over the slot's six sort keys and compares itself with the super-k-mer at
+// its alignment.  A slot holds ~1.5 entries on average: continuation slots are rare and there is no second level.
+// =====================================================================================================================
+template <int KK, int MM>
+__global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s(const MicQueryArgs a) {
+  __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE];
+  __shared__ uint32_t s_run[MIC_M_WPB][MIC_RMAX];
+  __shared__ uint32_t s_ahead[MIC_M_WPB][2][64];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: LDS bases stay in SGPRs
+  uint4* stage = s_stage[wv];
+  uint32_t* runslot = s_run[wv];
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * MIC_M_WPB + wv);
+  const uint32_t n_waves = gridDim.x * MIC_M_WPB;
+  const MicTable& t = a.t;
+  const int k = KK ? KK : t.k, m = MM ? MM : t.m, w = k - m + 1;
+  const uint4* __restrict__ slots = t.slots;
+  const uint16_t* __restrict__ cont = a.cont;
+  // number of set bits of a 64-bit lane mask below this lane (v_mbcnt_lo/hi: no mask register to keep alive)
+  auto below = [](uint64_t mask) { return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
+
+  PH_DECL
+  // Read-ahead through LDS (global_load_lds_dword): no VGPR lives across a read and no load result is touched near its
+  // issue, so nothing waits for it.  One DMA instruction per read fetches {header + first window of read j+2 (lanes
+  // 0..11, aligned dwords), reads_ptr of read j+3 (lanes 12, 13)}; it is taken one read later, before the result stores
+  // of finish_read (stores count in vmcnt too - waiting for the entry after them would wait for their acknowledgement).
+  uint32_t* ahead0 = s_ahead[wv][0];
+  uint32_t* ahead1 = s_ahead[wv][1];
+  auto ahead_issue = [&](uint32_t* entry, uint32_t pp_w, uint32_t r_ptr) {
+    // lanes 0..11: aligned dwords of the window; lanes 12, 13: reads_ptr[rr], reads_ptr[rr + 1]; the rest repeat lane 0.
+    // One select between two wave-uniform bases, then base + 4 * lane (the pointer base is pre-biased by -48).
+    const uint64_t abase = ((uint64_t)(cont + pp_w)) & ~3ULL;
+    const uint32_t rr = r_ptr < a.n_reads ? r_ptr : a.n_reads - 1;
+    const uint64_t pbase = (uint64_t)(a.reads_ptr + rr) - 48;
+    uint32_t lv = (uint32_t)lane;
+    asm volatile("" : "+v"(lv));      // recomputed per read (3 VALU) instead of a 64-bit offset kept live in VGPRs
+    const uint32_t li = lv < 14 ? lv : 0u;
+    const uint64_t addr = (li < 12 ? abase : pbase) + 4 * li;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
+                                     (__attribute__((address_space(3))) void*)entry, 4, 0, 0);
+  };
+  auto ahead_take = [&](const uint32_t* entry, uint32_t pp_w, uint32_t& hdr, uint32_t& wword, uint32_t& npp, uint32_t& npe) {
+    const uint32_t raw = entry[lane];
+    npp = __builtin_amdgcn_readlane(raw, 12); npe = __builtin_amdgcn_readlane(raw, 13);
+    const bool odd = (((uint64_t)(cont + pp_w)) >> 1) & 1;      // is container pp_w the high half of its dword?
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw, 0x101, 0xF, 0xF, true);   // row_shl:1 = lane+1
+    const uint32_t first = __builtin_amdgcn_readfirstlane(raw);
+    hdr = odd ? first >> 16 : first & 0xFFFFu;
+    // window word of lane L = (container pp+1+2L) << 16 | container pp+2+2L
+    wword = odd ? ((up << 16) | (up >> 16)) : ((raw & 0xFFFF0000u) | (up & 0xFFFFu));
+  };
+  uint32_t cur_pp, cur_pe, cur_hdr, cur_w;   // read r: pointers, first part header, first window
+  uint32_t n_pp, n_pe;                       // pointers of read r + n_waves
+  uint32_t ahead_sel;
+  {
+    const uint32_t r0 = wave0 < a.n_reads ? wave0 : a.n_reads - 1;
+    cur_pp = __builtin_amdgcn_readfirstlane(a.reads_ptr[r0]); cur_pe = __builtin_amdgcn_readfirstlane(a.reads_ptr[r0 + 1]);
+    ahead_issue(ahead0, cur_pp, wave0 + n_waves);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    ahead_take(ahead0, cur_pp, cur_hdr, cur_w, n_pp, n_pe);
+    ahead_issue(ahead1, n_pp, wave0 + 2 * n_waves);
+    ahead_sel = 1;
+  }
+  for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
+    PH(6)
+    uint32_t pp = cur_pp;
+    const uint32_t pe = cur_pe;
+    RowAcc acc; acc.label1 = 0; acc.count = 0;
+    uint32_t n_ent = 0, overflow = 0, total = 0;
+    bool first_part = true;
+
+    while (pp < pe) {
+      const uint32_t plen = __builtin_amdgcn_readfirstlane(first_part ? cur_hdr : (uint32_t)cont[pp]);
+      const bool ahead_ok = first_part;
+      first_part = false;
+      if (plen == 0) break;
+      const uint32_t first = pp + 1;
+      pp = first + (plen + 7) / 8;
+      if (plen < (uint32_t)k) continue;
+      const uint32_t nk = plen - k + 1;
+      const uint32_t cend = pp;
+      for (uint32_t base = 0; base < nk; base += 128) {
+        const uint32_t wd = window_word_w(cont, first, cend, base, lane, ahead_ok && base == 0, cur_w);
+        // k-mers of the two passes and the keys of the m-mers at positions base+64h+lane: order (27 bits) | strand | pos & 15
+        uint64_t km[2], rk[2]; bool act[2]; uint32_t hk0, hk1;
+        const bool past = nk - base > (uint32_t)(129 - w);     // see query_kernel_m: the tail keys come out of pass 1
+        uint32_t tail = 0xFFFFFFFFu;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int idx = 4 * h + (lane >> 4);
+          uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
+          uint64_t kmer = kmer_from_dwords(d0, d1, d2, lane & 15, k);
+          const uint64_t rck = revcomp_bits(kmer, k);
+          km[h] = kmer; rk[h] = rck;
+          act[h] = base + 64 * h + lane < nk;
+          if (t.sharded) {   // table-sharded mode only: divisor and bounds are re-read from the kernarg segment (see finish)
+            uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+            MicDiv dv; dv.d = kc->t.div.d; dv.magic = kc->t.div.magic; dv.shift = kc->t.div.shift; dv.add = kc->t.div.add;
+            const uint64_t s_lo = kc->t.shard_start, s_hi = kc->t.shard_end;
+            const uint64_t cc = kmer < rck ? kmer : rck;
+            uint64_t q = mic_div(cc, dv);
+            uint64_t rem = cc - q * dv.d;
+            act[h] = act[h] && rem >= s_lo && rem < s_hi;
+          }
+          // m-mer at this position = first m nt of the k-mer; its reverse complement = last m nt of rc(k-mer)
+          const uint64_t mf = kmer >> (2 * (k - m)), mr = rck & ((1ULL << (2 * m)) - 1);
+          const bool fw = mf < mr;
+          uint32_t key = (mmer_order_key_canon(fw ? mf : mr) & ~31u) | (fw ? 0u : 16u) | (uint32_t)(lane & 15);
+          if (h == 0) hk0 = key; else hk1 = key;
+          if (h == 1 && past) {
+            // last m-mer of the k-mer (position 64 + lane + w - 1) = its last m nt; reverse complement = first m nt of rc(k-mer)
+            const uint64_t tf = kmer & ((1ULL << (2 * m)) - 1), tr = rck >> (2 * (k - m));
+            const bool tfw = tf < tr;
+            const uint32_t tk = (mmer_order_key_canon(tfw ? tf : tr) & ~31u) | (tfw ? 0u : 16u) | (uint32_t)((lane + w - 1) & 15);
+            tail = row_prefix_min(lane >= 65 - w ? tk : 0xFFFFFFFFu);
+          }
+        }
+        sliding_min2(hk0, hk1, w, lane);
+        hk1 = tail < hk1 ? tail : hk1;
+        // every k-mer now knows its minimizer: strand and position -> oriented k-mer, nucleotide offset in the entry,
+        // minimizer value x -> slot and sort key
+        uint64_t ko[2]; uint32_t ao[2], tk32[2], sl[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t mk = h == 0 ? hk0 : hk1;
+          const uint32_t j = (mk - (uint32_t)lane) & 15;
+          const bool rev = (mk & 16u) != 0;
+          ko[h] = rev ? rk[h] : km[h];
+          const uint32_t jo = rev ? (uint32_t)(w - 1) - j : j;     // minimizer position in the oriented k-mer
+          ao[h] = (uint32_t)(w - 1) - jo;                           // offset of the k-mer in the super-k-mer
+          const uint64_t x = (ko[h] >> (2 * ((uint32_t)(k - m) - jo))) & ((1ULL << (2 * m)) - 1);
+          tk32[h] = (uint32_t)x;
+          sl[h] = act[h] ? sslot_of_x(x, (uint32_t)t.n_main) : 0xFFFFFFFFu;
+        }
+        uint32_t sl0 = sl[0], sl1 = sl[1];
+        uint32_t res0 = 0, res1 = 0;   // label + 1 of the hit
+        PH(0)
+
+        // one level of the table on both passes: runs of equal slots, LDS-DMA of the distinct slots, lockstep search
+        auto level = [&](uint32_t s0_, uint32_t s1_, uint32_t& o0_, uint32_t& o1_, uint32_t& y0_, uint32_t& y1_) {
+          // runs of equal slots over the 128 positions
+          uint32_t p0 = bperm((lane + 63) & 63, s0_), p1 = bperm((lane + 63) & 63, s1_);
+          uint32_t last0 = bperm(63, s0_);
+          if (lane == 0) { p0 = 0xFFFFFFFFu; p1 = last0; }
+          const bool f0 = s0_ != 0xFFFFFFFFu && s0_ != p0, f1 = s1_ != 0xFFFFFFFFu && s1_ != p1;
+          const uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
+          const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1);
+          const uint32_t rid0 = below(b0) + (f0 ? 1u : 0u) - 1, rid1 = R0 + below(b1) + (f1 ? 1u : 0u) - 1;
+          y0_ = 0xFFFFFFFFu; y1_ = 0xFFFFFFFFu;   // slots to probe at the next level
+          for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
+            __builtin_amdgcn_wave_barrier();
+            if (f0 && rid0 - rbase < MIC_RMAX) runslot[rid0 - rbase] = s0_;
+            if (f1 && rid1 - rbase < MIC_RMAX) runslot[rid1 - rbase] = s1_;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t nrun = R - rbase < MIC_RMAX ? R - rbase : MIC_RMAX;
+            // every distinct slot goes HBM -> LDS directly (global_load_lds_dwordx4: lane L lands at base + 16*L, no
+            // VGPRs): all staging loads of the round are in flight together and are awaited once.  (Staging through
+            // registers put each load in its own basic block: load, wait, ds_write, next load - up to four serialized
+            // HBM latencies per round; rotating the quarters to dodge LDS bank conflicts measured slower.)
+            uint32_t sidx[MIC_RMAX / 8];
+#pragma unroll
+            for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = runslot[8 * i + (lane >> 3)];
+#pragma unroll
+            for (int i = 0; i < MIC_RMAX / 8; ++i) {
+              if (8u * i >= nrun) break;                 // wave-uniform: no address arithmetic for unused groups
+              if (8u * i + (lane >> 3) < nrun)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
+                                                 (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // Both k-mers of the lane look in their staged slot in lockstep: lower bound of the sort key among the six
+            // (three reads), then the entry: key, super-k-mer, mask | label.  Lanes without a search read slot 0 and discard.
+            {
+              const bool v0 = s0_ != 0xFFFFFFFFu && rid0 - rbase < MIC_RMAX, v1 = s1_ != 0xFFFFFFFFu && rid1 - rbase < MIC_RMAX;
+              const uint32_t* q0 = (const uint32_t*)(stage + (v0 ? rid0 - rbase : 0) * MIC_MSTRIDE);
+              const uint32_t* q1 = (const uint32_t*)(stage + (v1 ? rid1 - rbase : 0) * MIC_MSTRIDE);
+              const uint32_t t0 = tk32[0], t1 = tk32[1];
+              uint32_t e0 = q0[3] < t0 ? 4u : 0u, e1 = q1[3] < t1 ? 4u : 0u;
+              e0 += q0[e0 + 1] < t0 ? 2u : 0u; e1 += q1[e1 + 1] < t1 ? 2u : 0u;                    // index <= 5
+              e0 += q0[e0 < 5 ? e0 : 5] < t0 ? 1u : 0u; e1 += q1[e1 < 5 ? e1 : 5] < t1 ? 1u : 0u;
+              const uint2 mz0 = *(const uint2*)(q0 + 30), mz1 = *(const uint2*)(q1 + 30);      // entries | NEXT, next slot
+              const uint32_t last0 = q0[5], last1 = q1[5];
+              bool more0 = v0 && e0 < 6, more1 = v1 && e1 < 6;
+              uint32_t hit0 = 0, hit1 = 0;
+              e0 = e0 < 5 ? e0 : 5; e1 = e1 < 5 ? e1 : 5;
+              for (;;) {
+                const uint32_t g0 = q0[e0], g1 = q1[e1];
+                const uint32_t a0 = q0[6 + 3 * e0], b0 = q0[7 + 3 * e0], c0 = q0[8 + 3 * e0], p0 = q0[24 + e0];
+                const uint32_t a1 = q1[6 + 3 * e1], b1 = q1[7 + 3 * e1], c1 = q1[8 + 3 * e1], p1 = q1[24 + e1];
+                const bool same0 = more0 && g0 == t0, same1 = more1 && g1 == t1;
+                const bool m0 = same0 && ((p0 >> (16 + (w - 1) - ao[0])) & 1) && s_extract(a0, b0, c0, (int)ao[0], k) == ko[0];
+                const bool m1 = same1 && ((p1 >> (16 + (w - 1) - ao[1])) & 1) && s_extract(a1, b1, c1, (int)ao[1], k) == ko[1];
+                if (m0) hit0 = (p0 & 0xFFFFu) + 1;
+                if (m1) hit1 = (p1 & 0xFFFFu) + 1;
+                more0 = same0 && !m0 && e0 < 5; more1 = same1 && !m1 && e1 < 5;     // another entry of the same minimizer?
+                e0 += more0 ? 1u : 0u; e1 += more1 ? 1u : 0u;
+                if (!(__ballot(more0) | __ballot(more1))) break;
+              }
+              // continuation slot: only if the entries there can carry this key (they are sorted across the chain)
+              if (v0) { o0_ = hit0; y0_ = (!hit0 && (mz0.x & MIC_S_NEXT) && last0 <= t0) ? mz0.y : 0xFFFFFFFFu; }
+              if (v1) { o1_ = hit1; y1_ = (!hit1 && (mz1.x & MIC_S_NEXT) && last1 <= t1) ? mz1.y : 0xFFFFFFFFu; }
+            }
+          }
+        };
+        while (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {   // second and later rounds: continuation slots (rare)
+          uint32_t nx0, nx1;
+          level(sl0, sl1, res0, res1, nx0, nx1);
+          PH(3)
+          sl0 = nx0; sl1 = nx1;
+        }
+        tally2(res0, res1, acc, n_ent, overflow, total, lane);
+        PH(4)
+      }
+    }
+    // next read's header/window and the pointers of the one after it: take before the stores below, issue after
+    uint32_t t_hdr, t_w, t_pp, t_pe;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_w, t_pp, t_pe);
+    __builtin_amdgcn_wave_barrier();
+    PH(4)
+    {
+      // The output pointers are needed once per read: they are re-read from the kernarg segment here (scalar loads
+      // that hit the scalar cache) instead of living in SGPRs for the whole kernel - the kernel was spilling 35 SGPRs
+      // into VGPR lanes, ~58 v_readlane/v_writelane per read.  The asm keeps the loads from being hoisted.
+      uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));
+      const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+      struct { uint32_t* results; uint32_t* rows; uint32_t* flagged; uint32_t row_words, flagged_cap; } fa;
+      fa.results = kc->results; fa.rows = kc->rows; fa.flagged = kc->flagged; fa.row_words = kc->row_words; fa.flagged_cap = kc->flagged_cap;
+      finish_read(acc, n_ent, total, overflow, r, fa, lane);
+    }
+    ahead_issue(ahead_sel ? ahead0 : ahead1, t_pp, r + 3 * n_waves);
+    ahead_sel ^= 1;
+    cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; cur_w = t_w; n_pp = t_pp; n_pe = t_pe;
+    PH(5)
+  }
+  PH_END
+}
+
+
 // ---- merge / result on sparse rows ----------------------------------------------------------------
 // mergeKernel (CuClarkDB.cu:1321-1415): one thread per read, two-pointer merge by ascending target.
 __global__ void merge_rows_kernel(const uint32_t* __restrict__ ra, const uint32_t* __restrict__ rb,
@@ -833,6 +1083,14 @@ __device__ inline uint32_t probe_scalar_m(const MicTable& t, uint64_t kmer) {
 
 template <bool KEY64>
 __device__ inline uint32_t probe_any(const MicTable& t, uint64_t kmer) {
+  if (t.layout == 2) {
+    const uint64_t c = canonical(kmer, t.k);
+    if (t.sharded) {
+      const uint64_t q = mic_div(c, t.div), rem = c - q * t.div.d;
+      if (rem < t.shard_start || rem >= t.shard_end) return 0;
+    }
+    return s_probe(t.slots, (uint32_t)t.n_main, c, t.k, t.m);
+  }
   return t.layout ? probe_scalar_m(t, kmer) : probe_scalar<KEY64>(t, kmer);
 }
 
@@ -990,7 +1248,13 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     unsigned want = by_work > fill ? by_work : fill;
     if (blocks > want) blocks = want;
   }
-  if (a.t.layout) {
+  if (a.t.layout == 2) {
+    const unsigned g = (blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, b = 64 * MIC_M_WPB;
+    if (a.t.k == 31 && a.t.m == 20) query_kernel_s<31, 20><<<g, b, 0, s>>>(a);
+    else if (a.t.k == 27 && a.t.m == 20) query_kernel_s<27, 20><<<g, b, 0, s>>>(a);
+    else query_kernel_s<0, 0><<<g, b, 0, s>>>(a);
+  }
+  else if (a.t.layout) {
 #ifdef MIC_PERTURB
     {
       int pv[4] = {0, 0, 0, 0};

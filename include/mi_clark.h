@@ -59,9 +59,10 @@ typedef struct mic_config {
   uint32_t layout;      /* resident table layout: MIC_LAYOUT_AUTO / _DIRECT / _MINIMIZER */
 } mic_config;
 
-#define MIC_LAYOUT_AUTO 0      /* minimizer table for k >= 24, else direct; env MIC_LAYOUT=direct|minimizer overrides */
+#define MIC_LAYOUT_AUTO 0      /* minimizer table for k >= 24, else direct; env MIC_LAYOUT=direct|minimizer|super overrides */
 #define MIC_LAYOUT_DIRECT 1    /* one 64-byte slot per on-disk bucket (one HBM request per k-mer) */
 #define MIC_LAYOUT_MINIMIZER 2 /* 128-byte slots keyed by the k-mer's minimizer (one HBM request per ~7 k-mers) */
+#define MIC_LAYOUT_SUPER 3     /* 128-byte slots of super-k-mers: the k-mers sharing a minimizer occurrence as one entry (experimental; env MIC_LAYOUT=super) */
 
 typedef struct mic_db_info {
   uint64_t htsize;         /* buckets in the whole table (= size of .sz)               */

@@ -10,10 +10,10 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["direct", "minimizer"])
+@pytest.fixture(autouse=True, params=["direct", "minimizer", "super"])
 def table_layout(request, monkeypatch):
-    """Every test runs against both resident layouts: one 64-byte slot per on-disk bucket, and the
-    minimizer-keyed 128-byte slots.  The engine reads MIC_LAYOUT when a table is built."""
+    """Every test runs against the resident layouts: one 64-byte slot per on-disk bucket, the
+    minimizer-keyed 128-byte slots, and the super-k-mer slots.  The engine reads MIC_LAYOUT when a table is built."""
     monkeypatch.setenv("MIC_LAYOUT", request.param)
     return request.param
 
@@ -59,7 +59,7 @@ def test_golden_queries_from_files(name, db_dir):
         info = e.info()
         assert info["htsize"] == meta["htsize"] and info["key_bytes"] == meta["key_bytes"]
         assert info["n_elems"] == meta["ky"].size
-        assert info["layout"] == {"direct": 1, "minimizer": 2}[os.environ["MIC_LAYOUT"]]
+        assert info["layout"] == {"direct": 1, "minimizer": 2, "super": 3}[os.environ["MIC_LAYOUT"]]
         rp, cont = _kmer_reads(q["kmers"], k)
         res = e.classify_packed(rp, cont)
     found = res[:, 0] == 1
