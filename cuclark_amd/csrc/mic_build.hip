@@ -860,7 +860,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   unsigned long long* d_ck = nullptr; uint32_t* d_cm = nullptr; uint32_t* slots = nullptr;
   std::vector<TileA> h_a(n_tiles);
   uint64_t tot_elems = 0, tot_nz = 0, n_slots = 0, n_cand = 0, n_chain = 0;
-  unsigned long long h_scal[2] = {0, 0}; uint32_t h_max = 0;
+  unsigned long long h_scal[2] = {0, 0}; uint32_t h_max = 0; double avail_b = 0;
   MBuildArgs a;
   const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
   struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
@@ -925,6 +925,22 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     n_cand = last_off + last_cnt;
   }
   {
+    // staging (12 B per candidate) + per-slot arrays + at least the main slots must fit next to what is resident already
+    size_t free_b = 0, total_b = 0;
+    HIPCK(hipMemGetInfo(&free_b, &total_b));
+    avail_b = (double)free_b - 1.5e9;
+    if (const char* env = getenv("MIC_HBM_LIMIT_GB")) {   // test hook: pretend only this much is available
+      const double lim = atof(env) * 1e9;
+      if (lim > 0 && avail_b > lim) avail_b = lim;
+    }
+    const double need = (double)n_cand * 12 + (double)n_slots * (16 + 128);
+    if (need > avail_b) {
+      snprintf(err, err_cap, "the super-k-mer table and its build need at least %.3f GB, %.3f GB of HBM are available", need / 1e9,
+               avail_b / 1e9);
+      rc = -3; goto done;
+    }
+  }
+  {
     hipError_t e1 = hipMalloc(&d_ck, (n_cand + 1) * 8), e2 = hipMalloc(&d_cm, (n_cand + 1) * 4);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       (void)hipGetLastError();
@@ -957,6 +973,11 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     n_chain = last_off + last_dem;
   }
   if (n_slots + n_chain > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many S-slots"); rc = -1; goto done; }
+  if ((double)(n_slots + n_chain + 1) * 128 + (double)n_cand * 12 > avail_b) {
+    snprintf(err, err_cap, "the super-k-mer table and its build need at least %.3f GB, %.3f GB of HBM are available",
+             ((double)(n_slots + n_chain + 1) * 128 + (double)n_cand * 12) / 1e9, avail_b / 1e9);
+    rc = -3; goto done;
+  }
   {
     hipError_t e_ = hipMalloc(&slots, (size_t)(n_slots + n_chain + 1) * 128);
     if (e_ != hipSuccess) {

@@ -174,13 +174,14 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
     if (env && !strcmp(env, "direct")) layout = MIC_LAYOUT_DIRECT;
     else if (env && !strcmp(env, "minimizer")) layout = MIC_LAYOUT_MINIMIZER;
     else if (env && !strcmp(env, "super")) layout = MIC_LAYOUT_SUPER;
-    else { layout = e->cfg.k >= 24 ? MIC_LAYOUT_MINIMIZER : MIC_LAYOUT_DIRECT; by_default = true; }  // measured: DESIGN.md §3.2
+    else { layout = e->cfg.k >= 24 ? MIC_LAYOUT_SUPER : MIC_LAYOUT_DIRECT; by_default = true; }  // measured: DESIGN.md §3
   }
   int m = 20;   // measured best for k = 31: minimizers long enough to be nearly unique in the table
   if (const char* env = getenv("MIC_MINIMIZER_LEN")) m = atoi(env);
   if (m > e->cfg.k - 4) m = e->cfg.k - 4;   // window w = k-m+1 >= 5
   if (m > 31) m = 31;
   if (layout == MIC_LAYOUT_MINIMIZER && (m < 8 || e->cfg.k - m + 1 > 64)) layout = MIC_LAYOUT_DIRECT;
+  const int m0 = m;
   if (layout == MIC_LAYOUT_SUPER) {          // the super-k-mer entries hold windows of at most 16 m-mers
     if (m < e->cfg.k - 15) m = e->cfg.k - 15;
     if (m < 8 || m > 31 || e->cfg.k - m + 1 < 2) layout = MIC_LAYOUT_DIRECT;
@@ -189,16 +190,20 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   if (hipMalloc(&e->d_sizes, s1 - s0) == hipSuccess)
     hipMemcpyAsync(e->d_sizes, d_sizes_shard, s1 - s0, hipMemcpyDeviceToDevice, e->stream);
   int rc = 0;
+  // By default: super-k-mer slots; if their build does not fit in the free HBM, the minimizer-keyed slots (no staging
+  // area), then the direct layout (64 B per bucket).  An explicitly requested layout fails with the sizes in the message.
+  if (layout == MIC_LAYOUT_SUPER) {
+    rc = mic_build_stable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
+                          e->cfg.k, m, e->stream, &b, err, sizeof(err));
+    if (rc == -3 && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; }
+  }
   if (layout == MIC_LAYOUT_MINIMIZER) {
     rc = mic_build_mtable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
                           e->cfg.k, m, e->stream, &b, err, sizeof(err));
     // -3: even the densest minimizer table exceeds the free HBM; the direct layout is ~40 % smaller (64 B per bucket)
     if (rc == -3 && by_default) { layout = MIC_LAYOUT_DIRECT; memset(&b, 0, sizeof(b)); }
   }
-  if (layout == MIC_LAYOUT_SUPER)
-    rc = mic_build_stable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
-                          e->cfg.k, m, e->stream, &b, err, sizeof(err));
-  else if (layout != MIC_LAYOUT_MINIMIZER)
+  if (layout == MIC_LAYOUT_DIRECT)
     rc = mic_build_table(d_sizes_shard, s1 - s0, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
                          e->slot_class, e->stream, &b, err, sizeof(err));
   if (rc != 0) return fail(rc, "table build: %s", err);

@@ -816,13 +816,15 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
         const uint32_t wd = window_word_w(cont, first, cend, base, lane, ahead_ok && base == 0, cur_w);
         // k-mers of the two passes and the keys of the m-mers at positions base+64h+lane: order (27 bits) | strand | pos & 15
         uint64_t km[2], rk[2]; bool act[2]; uint32_t hk0, hk1;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // lane-derived shift counts and positions are recomputed per chunk, not kept in VGPRs
         const bool past = nk - base > (uint32_t)(129 - w);     // see query_kernel_m: the tail keys come out of pass 1
         uint32_t tail = 0xFFFFFFFFu;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int idx = 4 * h + (lane >> 4);
           uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
-          uint64_t kmer = kmer_from_dwords(d0, d1, d2, lane & 15, k);
+          uint64_t kmer = kmer_from_dwords(d0, d1, d2, ln & 15, k);
           const uint64_t rck = revcomp_bits(kmer, k);
           km[h] = kmer; rk[h] = rck;
           act[h] = base + 64 * h + lane < nk;
@@ -840,14 +842,14 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
           // m-mer at this position = first m nt of the k-mer; its reverse complement = last m nt of rc(k-mer)
           const uint64_t mf = kmer >> (2 * (k - m)), mr = rck & ((1ULL << (2 * m)) - 1);
           const bool fw = mf < mr;
-          uint32_t key = (mmer_order_key_canon(fw ? mf : mr) & ~31u) | (fw ? 0u : 16u) | (uint32_t)(lane & 15);
+          uint32_t key = (mmer_order_key_canon(fw ? mf : mr) & ~31u) | (fw ? 0u : 16u) | (uint32_t)(ln & 15);
           if (h == 0) hk0 = key; else hk1 = key;
           if (h == 1 && past) {
             // last m-mer of the k-mer (position 64 + lane + w - 1) = its last m nt; reverse complement = first m nt of rc(k-mer)
             const uint64_t tf = kmer & ((1ULL << (2 * m)) - 1), tr = rck >> (2 * (k - m));
             const bool tfw = tf < tr;
-            const uint32_t tk = (mmer_order_key_canon(tfw ? tf : tr) & ~31u) | (tfw ? 0u : 16u) | (uint32_t)((lane + w - 1) & 15);
-            tail = row_prefix_min(lane >= 65 - w ? tk : 0xFFFFFFFFu);
+            const uint32_t tk = (mmer_order_key_canon(tfw ? tf : tr) & ~31u) | (tfw ? 0u : 16u) | (uint32_t)((ln + w - 1) & 15);
+            tail = row_prefix_min(ln >= 65 - w ? tk : 0xFFFFFFFFu);
           }
         }
         sliding_min2(hk0, hk1, w, lane);
@@ -858,7 +860,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const uint32_t mk = h == 0 ? hk0 : hk1;
-          const uint32_t j = (mk - (uint32_t)lane) & 15;
+          const uint32_t j = (mk - (uint32_t)ln) & 15;
           const bool rev = (mk & 16u) != 0;
           ko[h] = rev ? rk[h] : km[h];
           const uint32_t jo = rev ? (uint32_t)(w - 1) - j : j;     // minimizer position in the oriented k-mer
@@ -1250,8 +1252,9 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   }
   if (a.t.layout == 2) {
     const unsigned g = (blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, b = 64 * MIC_M_WPB;
-    if (a.t.k == 31 && a.t.m == 20) query_kernel_s<31, 20><<<g, b, 0, s>>>(a);
-    else if (a.t.k == 27 && a.t.m == 20) query_kernel_s<27, 20><<<g, b, 0, s>>>(a);
+    static const bool generic = getenv("MIC_S_GENERIC") != nullptr;
+    if (!generic && a.t.k == 31 && a.t.m == 20) query_kernel_s<31, 20><<<g, b, 0, s>>>(a);
+    else if (!generic && a.t.k == 27 && a.t.m == 20) query_kernel_s<27, 20><<<g, b, 0, s>>>(a);
     else query_kernel_s<0, 0><<<g, b, 0, s>>>(a);
   }
   else if (a.t.layout) {

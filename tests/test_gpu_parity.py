@@ -533,9 +533,14 @@ def test_properties_at_scale():
             return res, rows, e
     res_m, rows_m, _ = run(2)
     res_d, rows_d, _ = run(1)
+    res_s, rows_s, _ = run(3)
     assert torch.equal(res_m[:, :6], res_d[:, :6])              # words 0..5: sum, best/second, targets hit
+    assert torch.equal(res_s[:, :6], res_d[:, :6])
     valid = (rows_m[:, 0] != -1) & (rows_d[:, 0] != -1)
     assert valid.float().mean() > 0.999 and torch.equal(rows_m[valid], rows_d[valid])
+    assert torch.equal(rows_s[valid], rows_d[valid])
+    _, rows_sa, _ = run(3, (0, htsize // 3))                    # the super-k-mer table sharded by on-disk bucket range
+    _, rows_sb, _ = run(3, (htsize // 3, htsize))
     # two shards merged on the device == the whole table
     half = htsize // 2
     _, rows_a, _ = run(2, (0, half))
@@ -548,6 +553,14 @@ def test_properties_at_scale():
         e.merge_rows_device(rows_a.data_ptr(), rows_b.data_ptr(), merged.data_ptr(), n_reads)
         e.result_from_rows_device(merged.data_ptr(), res2.data_ptr(), n_reads)
         e.sync()
+    with MiClarkDB(k, T) as e:
+        e.read_device(d_sizes.data_ptr(), htsize, d_keys.data_ptr(), 8, d_labels.data_ptr(), shard=(0, 1000))
+        merged_s = torch.zeros_like(rows_sa)
+        torch.cuda.synchronize()
+        e.merge_rows_device(rows_sa.data_ptr(), rows_sb.data_ptr(), merged_s.data_ptr(), n_reads)
+        e.sync()
+    ok_s = (merged_s[:, 0] != -1) & valid
+    assert ok_s.float().mean() > 0.999 and torch.equal(merged_s[ok_s], rows_m[ok_s])
     ok_rows = (merged[:, 0] != -1) & valid
     assert ok_rows.float().mean() > 0.999
     assert torch.equal(merged[ok_rows], rows_m[ok_rows]) and torch.equal(res2[ok_rows][:, :5], res_m[ok_rows][:, :5])
