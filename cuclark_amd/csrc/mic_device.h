@@ -108,7 +108,7 @@ __device__ __forceinline__ uint32_t sslot_of_x(uint64_t x, uint32_t n_slots) {
 __device__ __forceinline__ uint64_t s_extract(uint32_t w0, uint32_t w1, uint32_t w2, int a, int k) {
   const int s = 2 * a;
   const uint64_t hi = ((uint64_t)w0 << 32) | w1;
-  const uint64_t x = s ? ((hi << s) | (uint64_t)(w2 >> (32 - s))) : hi;
+  const uint64_t x = (hi << s) | ((uint64_t)w2 >> (32 - s));     // s = 0: the 64-bit shift by 32 yields 0
   return x >> (64 - 2 * k);
 }
 

@@ -16,6 +16,13 @@
 
 #include <stdlib.h>
 
+#ifndef MIC_FUNNEL64
+#define MIC_FUNNEL64 1
+#endif
+#ifndef MIC_S_LINEAR
+#define MIC_S_LINEAR 0
+#endif
+
 namespace {
 
 // Slot loads have no reuse (one random 64-byte request per probe): nontemporal loads keep them from displacing
@@ -31,7 +38,11 @@ __device__ __forceinline__ uint4 load_slot_quarter(const uint4* p) {
 __device__ __forceinline__ uint64_t kmer_from_dwords(uint32_t d0, uint32_t d1, uint32_t d2, int nt_in_dword, int k) {
   const int s = 2 * nt_in_dword;  // 0..30
   uint64_t a = ((uint64_t)d0 << 32) | d1;
+#if MIC_FUNNEL64
+  uint64_t x = (a << s) | ((uint64_t)d2 >> (32 - s));      // the 64-bit shift by 32 (s = 0) yields 0: no select
+#else
   uint64_t x = s ? ((a << s) | (uint64_t)(d2 >> (32 - s))) : a;
+#endif
   return x >> (64 - 2 * k);
 }
 
@@ -771,17 +782,23 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
                                      (__attribute__((address_space(3))) void*)entry, 4, 0, 0);
   };
-  auto ahead_take = [&](const uint32_t* entry, uint32_t pp_w, uint32_t& hdr, uint32_t& wword, uint32_t& npp, uint32_t& npe) {
+  auto ahead_take = [&](const uint32_t* entry, uint32_t pp_w, uint32_t& hdr, uint32_t& npp, uint32_t& npe) {
     const uint32_t raw = entry[lane];
     npp = __builtin_amdgcn_readlane(raw, 12); npe = __builtin_amdgcn_readlane(raw, 13);
     const bool odd = (((uint64_t)(cont + pp_w)) >> 1) & 1;      // is container pp_w the high half of its dword?
-    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw, 0x101, 0xF, 0xF, true);   // row_shl:1 = lane+1
     const uint32_t first = __builtin_amdgcn_readfirstlane(raw);
     hdr = odd ? first >> 16 : first & 0xFFFFu;
-    // window word of lane L = (container pp+1+2L) << 16 | container pp+2+2L
-    wword = odd ? ((up << 16) | (up >> 16)) : ((raw & 0xFFFF0000u) | (up & 0xFFFFu));
   };
-  uint32_t cur_pp, cur_pe, cur_hdr, cur_w;   // read r: pointers, first part header, first window
+  // the first window of the read comes out of the same LDS entry when its first chunk starts (the entry is not written
+  // again before the end of that read): no VGPR carries it across finish_read
+  auto ahead_word = [&](const uint32_t* entry, uint32_t pp_w) {
+    const uint32_t raw = entry[lane];
+    const bool odd = (((uint64_t)(cont + pp_w)) >> 1) & 1;
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw, 0x101, 0xF, 0xF, true);   // row_shl:1 = lane+1
+    // window word of lane L = (container pp+1+2L) << 16 | container pp+2+2L
+    return odd ? ((up << 16) | (up >> 16)) : ((raw & 0xFFFF0000u) | (up & 0xFFFFu));
+  };
+  uint32_t cur_pp, cur_pe, cur_hdr;   // read r: pointers, first part header
   uint32_t n_pp, n_pe;                       // pointers of read r + n_waves
   uint32_t ahead_sel;
   {
@@ -790,7 +807,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
     ahead_issue(ahead0, cur_pp, wave0 + n_waves);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    ahead_take(ahead0, cur_pp, cur_hdr, cur_w, n_pp, n_pe);
+    ahead_take(ahead0, cur_pp, cur_hdr, n_pp, n_pe);
     ahead_issue(ahead1, n_pp, wave0 + 2 * n_waves);
     ahead_sel = 1;
   }
@@ -813,7 +830,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
       const uint32_t nk = plen - k + 1;
       const uint32_t cend = pp;
       for (uint32_t base = 0; base < nk; base += 128) {
-        const uint32_t wd = window_word_w(cont, first, cend, base, lane, ahead_ok && base == 0, cur_w);
+        const bool use_ahead = ahead_ok && base == 0;
+        const uint32_t wd = window_word_w(cont, first, cend, base, lane, use_ahead,
+                                          use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp) : 0u);
         // k-mers of the two passes and the keys of the m-mers at positions base+64h+lane: order (27 bits) | strand | pos & 15
         uint64_t km[2], rk[2]; bool act[2]; uint32_t hk0, hk1;
         int ln = lane;
@@ -913,11 +932,18 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
               const uint32_t* q0 = (const uint32_t*)(stage + (v0 ? rid0 - rbase : 0) * MIC_MSTRIDE);
               const uint32_t* q1 = (const uint32_t*)(stage + (v1 ? rid1 - rbase : 0) * MIC_MSTRIDE);
               const uint32_t t0 = tk32[0], t1 = tk32[1];
+#if MIC_S_LINEAR
+              // all six sort keys in one LDS round trip; rank = number of keys below t
+              const uint4 ka0 = *(const uint4*)q0, ka1 = *(const uint4*)q1;
+              const uint2 kb0 = *(const uint2*)(q0 + 4), kb1 = *(const uint2*)(q1 + 4);
+              uint32_t e0 = (ka0.x < t0) + (ka0.y < t0) + (ka0.z < t0) + (ka0.w < t0) + (kb0.x < t0) + (kb0.y < t0);
+              uint32_t e1 = (ka1.x < t1) + (ka1.y < t1) + (ka1.z < t1) + (ka1.w < t1) + (kb1.x < t1) + (kb1.y < t1);
+#else
               uint32_t e0 = q0[3] < t0 ? 4u : 0u, e1 = q1[3] < t1 ? 4u : 0u;
               e0 += q0[e0 + 1] < t0 ? 2u : 0u; e1 += q1[e1 + 1] < t1 ? 2u : 0u;                    // index <= 5
               e0 += q0[e0 < 5 ? e0 : 5] < t0 ? 1u : 0u; e1 += q1[e1 < 5 ? e1 : 5] < t1 ? 1u : 0u;
-              const uint2 mz0 = *(const uint2*)(q0 + 30), mz1 = *(const uint2*)(q1 + 30);      // entries | NEXT, next slot
-              const uint32_t last0 = q0[5], last1 = q1[5];
+#endif
+              const uint32_t mz0 = q0[30], mz1 = q1[30];      // entries | NEXT
               bool more0 = v0 && e0 < 6, more1 = v1 && e1 < 6;
               uint32_t hit0 = 0, hit1 = 0;
               e0 = e0 < 5 ? e0 : 5; e1 = e1 < 5 ? e1 : 5;
@@ -934,9 +960,15 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
                 e0 += more0 ? 1u : 0u; e1 += more1 ? 1u : 0u;
                 if (!(__ballot(more0) | __ballot(more1))) break;
               }
-              // continuation slot: only if the entries there can carry this key (they are sorted across the chain)
-              if (v0) { o0_ = hit0; y0_ = (!hit0 && (mz0.x & MIC_S_NEXT) && last0 <= t0) ? mz0.y : 0xFFFFFFFFu; }
-              if (v1) { o1_ = hit1; y1_ = (!hit1 && (mz1.x & MIC_S_NEXT) && last1 <= t1) ? mz1.y : 0xFFFFFFFFu; }
+              if (v0) { o0_ = hit0; y0_ = 0xFFFFFFFFu; }
+              if (v1) { o1_ = hit1; y1_ = 0xFFFFFFFFu; }
+              // continuation slot (rare, wave-uniform test): only if the entries there can carry this key - they are sorted
+              // across the chain, so the last key of this slot must not be above it
+              const bool n0 = v0 && !hit0 && (mz0 & MIC_S_NEXT), n1 = v1 && !hit1 && (mz1 & MIC_S_NEXT);
+              if (__ballot(n0) | __ballot(n1)) {
+                if (n0 && q0[5] <= t0) y0_ = q0[31];
+                if (n1 && q1[5] <= t1) y1_ = q1[31];
+              }
             }
           }
         };
@@ -951,10 +983,10 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
       }
     }
     // next read's header/window and the pointers of the one after it: take before the stores below, issue after
-    uint32_t t_hdr, t_w, t_pp, t_pe;
+    uint32_t t_hdr, t_pp, t_pe;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_w, t_pp, t_pe);
+    ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_pp, t_pe);
     __builtin_amdgcn_wave_barrier();
     PH(4)
     {
@@ -970,7 +1002,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
     }
     ahead_issue(ahead_sel ? ahead0 : ahead1, t_pp, r + 3 * n_waves);
     ahead_sel ^= 1;
-    cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; cur_w = t_w; n_pp = t_pp; n_pe = t_pe;
+    cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; n_pp = t_pp; n_pe = t_pe;
     PH(5)
   }
   PH_END

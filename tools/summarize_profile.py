@@ -49,7 +49,7 @@ q = [r for r in rows if "query_kernel" in r["Name"]][0]
 slots_cal = 256 * 8 * 256 // 4 * 16 * 4  # quads x iters x unroll of gather_coop64_kernel<4>
 out = {
     "tag": tag, "workload": bench["config"]["workload"], "reads_per_launch": bench["config"]["reads_per_gpu"],
-    "layout": 2 if bench["config"]["table"]["slot_class"] == 128 else 1,
+    "layout": 3 if "super" in bench["config"]["table"]["layout"] else 2 if "minimizer" in bench["config"]["table"]["layout"] else 1,
     "kernel": q["Name"], "rocprof_calls": int(q["Calls"]), "rocprof_avg_ms": float(q["AverageNs"]) / 1e6,
     "bench_hip_event_ms": bench["roofline"]["kernel_ms"],
     "pmc_per_launch": pmc,
