@@ -591,9 +591,10 @@ __global__ void __launch_bounds__(TILE) s_scatter_kernel(MBuildArgs a, const uns
 }
 
 __global__ void s_nonzero_kernel(const uint32_t* __restrict__ cnt, uint64_t n, unsigned long long* __restrict__ out) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long b = __ballot(i < n && cnt[i] != 0);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
+  unsigned long long mine = 0;     // grid-stride: one atomic per wave of a small grid, not one per 64 slots
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mine += cnt[i] != 0;
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
 }
 
 struct SOpen { u128 S, known; uint32_t pmask, label; };
@@ -902,7 +903,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     BY_RAW(s_count_kernel, a, d_cnt, d_scal);
     HIPCK(hipGetLastError());
     if (pass == 0) {
-      s_nonzero_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_cnt, n_slots, d_scal + 1);
+      s_nonzero_kernel<<<4096, 256, 0, s>>>(d_cnt, n_slots, d_scal + 1);
       HIPCK(hipGetLastError());
       HIPCK(hipMemcpyAsync(h_scal, d_scal, 16, hipMemcpyDeviceToHost, s));
       HIPCK(hipStreamSynchronize(s));

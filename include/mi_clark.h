@@ -59,10 +59,10 @@ typedef struct mic_config {
   uint32_t layout;      /* resident table layout: MIC_LAYOUT_AUTO / _DIRECT / _MINIMIZER */
 } mic_config;
 
-#define MIC_LAYOUT_AUTO 0      /* minimizer table for k >= 24, else direct; env MIC_LAYOUT=direct|minimizer|super overrides */
+#define MIC_LAYOUT_AUTO 0      /* super-k-mer table for k >= 24 (minimizer, then direct if it does not fit), else direct; env MIC_LAYOUT=direct|minimizer|super overrides */
 #define MIC_LAYOUT_DIRECT 1    /* one 64-byte slot per on-disk bucket (one HBM request per k-mer) */
 #define MIC_LAYOUT_MINIMIZER 2 /* 128-byte slots keyed by the k-mer's minimizer (one HBM request per ~7 k-mers) */
-#define MIC_LAYOUT_SUPER 3     /* 128-byte slots of super-k-mers: the k-mers sharing a minimizer occurrence as one entry (experimental; env MIC_LAYOUT=super) */
+#define MIC_LAYOUT_SUPER 3     /* 128-byte slots of super-k-mers: the k-mers sharing a minimizer occurrence are one entry; one slot per lookup */
 
 typedef struct mic_db_info {
   uint64_t htsize;         /* buckets in the whole table (= size of .sz)               */
@@ -74,12 +74,12 @@ typedef struct mic_db_info {
   uint64_t n_overflow;     /* overflow slots                                            */
   uint64_t hbm_bytes;      /* bytes of HBM held by the table                            */
   int32_t key_bytes;       /* width of the keys on disk: 2, 4 or 8                      */
-  int32_t slot_class;      /* 32: 8 entries/slot (u32 quotients); 64: 4 entries/slot; 128: minimizer table */
+  int32_t slot_class;      /* 32: 8 entries/slot (u32 quotients); 64: 4 entries/slot; 128: minimizer / super-k-mer table */
   uint32_t max_bucket;     /* largest kept bucket                                       */
   uint32_t sampling;
-  int32_t layout;          /* MIC_LAYOUT_DIRECT or MIC_LAYOUT_MINIMIZER                 */
-  int32_t minimizer_len;   /* m (layout MINIMIZER), else 0                              */
-  uint32_t max_chain;      /* entries in the fullest slot chain (layout MINIMIZER)      */
+  int32_t layout;          /* MIC_LAYOUT_DIRECT, _MINIMIZER or _SUPER                   */
+  int32_t minimizer_len;   /* m (layouts MINIMIZER, SUPER), else 0                      */
+  uint32_t max_chain;      /* entries in the fullest slot chain (MINIMIZER, SUPER)      */
   uint32_t reserved;
 } mic_db_info;
 

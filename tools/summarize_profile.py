@@ -45,23 +45,46 @@ for name in ("cal_fetch", "cal_rdreq"):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for c, v in agg.items():
             cal[c] = v[-1]  # last launch = 8 GiB table
+cal128 = {}
+for name in ("cal128_fetch", "cal128_rdreq"):
+    for f in newest(os.path.join(src, name, "*", "*_counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "runs_kernel<128, 1, 0>" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for c, v in agg.items():
+            cal128[c] = v[-1]
 q = [r for r in rows if "query_kernel" in r["Name"]][0]
+slots_cal128 = 256 * 64 * 4 * 8 * 128   # blocks (64 per CU) x waves x reads per wave x 128 one-slot probes of runs_kernel<128, 1, 0>
+layout_id = 3 if "super" in bench["config"]["table"]["layout"] else 2 if "minimizer" in bench["config"]["table"]["layout"] else 1
+# bytes per tallied FETCH_SIZE byte in this layout's access shape: measured on the known slot count when present
+fetch_scale = 1.0
+if layout_id >= 2 and cal128.get("FETCH_SIZE"):
+    fetch_scale = slots_cal128 * 128 / (cal128["FETCH_SIZE"] * 1024)
 slots_cal = 256 * 8 * 256 // 4 * 16 * 4  # quads x iters x unroll of gather_coop64_kernel<4>
 out = {
     "tag": tag, "workload": bench["config"]["workload"], "reads_per_launch": bench["config"]["reads_per_gpu"],
-    "layout": 3 if "super" in bench["config"]["table"]["layout"] else 2 if "minimizer" in bench["config"]["table"]["layout"] else 1,
+    "layout": layout_id,
     "kernel": q["Name"], "rocprof_calls": int(q["Calls"]), "rocprof_avg_ms": float(q["AverageNs"]) / 1e6,
     "bench_hip_event_ms": bench["roofline"]["kernel_ms"],
     "pmc_per_launch": pmc,
-    "fetch_bytes_per_launch": pmc.get("FETCH_SIZE", 0) * 1024,
+    "fetch_bytes_per_launch": pmc.get("FETCH_SIZE", 0) * 1024 * fetch_scale,
+    "fetch_size_scale": fetch_scale,
     "write_bytes_per_launch": pmc.get("WRITE_SIZE", 0) * 1024,
     "rdreq_per_probe": pmc.get("TCC_EA0_RDREQ_sum", 0) / bench["roofline"]["probes_per_launch"],
     "rdreq_per_read": pmc.get("TCC_EA0_RDREQ_sum", 0) / bench["config"]["reads_per_gpu"],
     "calibration": {"kernel": "gather_coop64_kernel<4> (tools/gather_bench.hip), 8 GiB table: 4 lanes x 16 B per random 64-B slot",
                     "slots_loaded": slots_cal, "FETCH_SIZE_KB": cal.get("FETCH_SIZE"), "TCC_EA0_RDREQ_sum": cal.get("TCC_EA0_RDREQ_sum"),
                     "bytes_per_slot_by_FETCH_SIZE": cal.get("FETCH_SIZE", 0) * 1024 / slots_cal,
-                    "note": "FETCH_SIZE*1024 equals 64 B x slots in this access shape (64-B requests, RDREQ_32B = 0): no x2 "
-                            "correction applies; the x2 of the guide is for 128-B streaming requests"},
+                    "slots128": {"kernel": "runs_kernel<128, 1, 0> (tools/gather_runs_bench.hip), 16 GiB table: 8 lanes x 16 B per random 128-B slot",
+                                 "slots_loaded": slots_cal128, "FETCH_SIZE_KB": cal128.get("FETCH_SIZE"),
+                                 "TCC_EA0_RDREQ_sum": cal128.get("TCC_EA0_RDREQ_sum"),
+                                 "bytes_per_slot_by_FETCH_SIZE": cal128.get("FETCH_SIZE", 0) * 1024 / slots_cal128,
+                                 "requests_per_slot": cal128.get("TCC_EA0_RDREQ_sum", 0) / slots_cal128},
+                    "note": "64-byte slots (direct layout): FETCH_SIZE*1024 equals 64 B x slots, one request per slot, no correction. "
+                            "128-byte slots (minimizer and super-k-mer layouts): ONE request per slot, tallied at 64 B (the guide's gfx950 "
+                            "rule for 128-B requests, confirmed on a known slot count): fetch_bytes_per_launch = FETCH_SIZE*1024 x "
+                            "fetch_size_scale, and TCC_EA0_RDREQ counts slot requests, not 64-byte sectors"},
 }
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_query_kernel.json"), "w"), indent=1)
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w"), indent=1)
