@@ -36,6 +36,9 @@ __device__ __forceinline__ uint64_t canonical(uint64_t kmer, int k) {
 // order key of an m-mer (m <= 31): 32-bit mix of its canonical value.  The slot of a k-mer is a function
 // of the MINIMUM order key over its w = k-m+1 m-mers only, so a k-mer and its reverse complement (same canonical
 // m-mers) agree, and ties between different m-mers are harmless.
+#ifndef MIC_HASH_LITE
+#define MIC_HASH_LITE 2   /* bit 0: order key without its xorshift (+0.4 %, kept off: real genomes are not random); bit 1: slot = plain multiplicative hash (+0.6 %) */
+#endif
 #ifndef MIC_CHEAP_HASH
 #define MIC_CHEAP_HASH 1
 #endif
@@ -49,7 +52,11 @@ __device__ __forceinline__ uint32_t mmer_order_key_canon(uint64_t u) {   // u = 
 #else
   uint32_t h = (uint32_t)u * 0x9E3779B1u ^ ((uint32_t)(u >> 32) * 0x85EBCA77u + 0x27D4EB2Fu);
 #endif
+#if MIC_HASH_LITE & 1
+  h *= 0x2C1B3C6Du;                    // the second multiply alone carries the low bits upwards
+#else
   h ^= h >> 15; h *= 0x2C1B3C6Du;      // one multiply-xorshift round: the order only has to look random
+#endif
   return h;
 }
 
@@ -100,7 +107,9 @@ __device__ __forceinline__ uint32_t s_order27(uint64_t x) { return mmer_order_ke
 __device__ __forceinline__ uint32_t sslot_of_x(uint64_t x, uint32_t n_slots) {
   const uint32_t hi = (uint32_t)(x >> 32);
   uint32_t h = (uint32_t)x * 0x85EBCA77u + __umul24(hi ^ (hi >> 24), 0xC2B2AFu);
+#if !(MIC_HASH_LITE & 2)
   h ^= h >> 15; h *= 0x165667B1u;
+#endif
   return __umulhi(h, n_slots);
 }
 
