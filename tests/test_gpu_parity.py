@@ -446,9 +446,53 @@ def test_skewed_minimizer_bucket():
         res = e.classify_packed(rp, cont)
     if info["layout"] == 2:
         assert info["max_chain"] > 500           # one bucket holds a large share of the 4096 core k-mers (3-level tree)
+    if info["layout"] == 3:
+        assert info["max_chain"] > 300           # random labels keep the k-mers of a minimizer apart: a long slot chain
     assert ((res[:, 0] == 1) == (f == 1)).all()
     assert (res[f == 1, 1] == l[f == 1].astype(np.uint32) + 1).all()
     assert f[:4096].all()
+
+
+def test_super_table_with_crowded_slots(monkeypatch):
+    """The super-k-mer table at 5.9 entries per 6-entry slot instead of 1.5 (MIC_SSLOT_LOAD): most slots continue in a
+    chain of further slots; unrelated k-mers (one entry each) and k-mers cut from genomes (shared entries); answers equal
+    the sparse table's and the oracle's."""
+    if os.environ["MIC_LAYOUT"] != "super":
+        pytest.skip("sizing of the super-k-mer table")
+    rng = np.random.default_rng(29)
+    k, T, htsize = 31, 9, 2000003
+    o = gu.oracle()
+    genome = rng.integers(0, 4, 60000)
+    gk = set()
+    v = 0
+    for i, nt in enumerate(genome):
+        v = ((v << 2) | int(nt)) & ((1 << 62) - 1)
+        if i >= k - 1 and (i // 97) % 3:           # runs of present k-mers with gaps (presence masks with holes)
+            gk.add(o.canonical(v, k))
+    sizes, keys, labels, canon = gu.random_db(rng, htsize, 60000, k, 8, T)
+    allk = sorted(set(int(c) for c in canon) | gk, key=lambda c: (c % htsize, c // htsize))
+    sizes = np.zeros(htsize, np.int64)
+    for c in allk:
+        sizes[c % htsize] += 1
+    keys = np.array([c // htsize for c in allk], dtype=np.uint64)
+    labels = np.array([(c >> 7) % T for c in allk], dtype=np.uint16)
+    odb = o.db_from_arrays(sizes.astype(np.uint8), keys, labels)
+    q = np.array(allk[::3] + [o.revcomp(c, k) for c in allk[1::11]] + [c ^ 3 for c in allk[::13]], dtype=np.uint64)
+    q = np.concatenate([q, rng.integers(0, 1 << 62, 3000, dtype=np.uint64)])
+    rp, cont = _kmer_reads(q, k)
+    f, l = odb.find_many(q, k)
+
+    def run():
+        with _engine(k, T) as e:
+            e.read_arrays(sizes.astype(np.uint8), keys, labels)
+            return e.info(), e.classify_packed(rp, cont)
+    base_info, base = run()
+    monkeypatch.setenv("MIC_SSLOT_LOAD", "5.9")
+    info, res = run()
+    assert info["layout"] == 3 and info["n_slots"] < base_info["n_slots"] / 2 and info["n_overflow"] > base_info["n_overflow"]
+    assert (res == base).all()
+    assert ((res[:, 0] == 1) == (f == 1)).all()
+    assert (res[f == 1, 1] == l[f == 1].astype(np.uint32) + 1).all()
 
 
 def test_table_adapts_to_the_free_hbm(monkeypatch):
