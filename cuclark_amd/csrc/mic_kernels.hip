@@ -16,6 +16,9 @@
 
 #include <stdlib.h>
 
+#ifndef MIC_S_ABLATE
+#define MIC_S_ABLATE 0   /* timing-only builds: 1 no tally, 2 no wait before the read-ahead take, 3 no finish_read */
+#endif
 #ifndef MIC_FUNNEL64
 #define MIC_FUNNEL64 1
 #endif
@@ -923,8 +926,10 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
                                                  (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
             }
+            PH(1)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            PH(2)
             // Both k-mers of the lane look in their staged slot in lockstep: lower bound of the sort key among the six
             // (three reads), then the entry: key, super-k-mer, mask | label.  Lanes without a search read slot 0 and discard.
             {
@@ -978,17 +983,26 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
           PH(3)
           sl0 = nx0; sl1 = nx1;
         }
+#if MIC_S_ABLATE != 1
         tally2(res0, res1, acc, n_ent, overflow, total, lane);
+#else
+        total += __popcll(__ballot(res0 != 0)) + __popcll(__ballot(res1 != 0));
+#endif
         PH(4)
       }
     }
     // next read's header/window and the pointers of the one after it: take before the stores below, issue after
     uint32_t t_hdr, t_pp, t_pe;
+#if MIC_S_ABLATE != 2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_wave_barrier();
+#ifdef MIC_PHASE_SPLIT_TAKE
+    PH(5)
+#endif
     ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_pp, t_pe);
     __builtin_amdgcn_wave_barrier();
-    PH(4)
+    PH(6)
     {
       // The output pointers are needed once per read: they are re-read from the kernarg segment here (scalar loads
       // that hit the scalar cache) instead of living in SGPRs for the whole kernel - the kernel was spilling 35 SGPRs
@@ -998,7 +1012,11 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
       const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
       struct { uint32_t* results; uint32_t* rows; uint32_t* flagged; uint32_t row_words, flagged_cap; } fa;
       fa.results = kc->results; fa.rows = kc->rows; fa.flagged = kc->flagged; fa.row_words = kc->row_words; fa.flagged_cap = kc->flagged_cap;
+#if MIC_S_ABLATE != 3
       finish_read(acc, n_ent, total, overflow, r, fa, lane);
+#else
+      if (total == 0x7FFFFFFFu && lane == 0) fa.results[r * 8] = acc.count;
+#endif
     }
     ahead_issue(ahead_sel ? ahead0 : ahead1, t_pp, r + 3 * n_waves);
     ahead_sel ^= 1;
@@ -1288,6 +1306,16 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     if (!generic && a.t.k == 31 && a.t.m == 20) query_kernel_s<31, 20><<<g, b, 0, s>>>(a);
     else if (!generic && a.t.k == 27 && a.t.m == 20) query_kernel_s<27, 20><<<g, b, 0, s>>>(a);
     else query_kernel_s<0, 0><<<g, b, 0, s>>>(a);
+#ifdef MIC_PHASE_TIMING
+    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipStreamSynchronize(s);
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+    fprintf(stderr, "[phase cycles, %% of wave time] reads=%zu:", (size_t)a.n_reads);
+    const char* nm[8] = {"kmers+minimizers+slots", "runs+dma issue", "wait hbm", "slot search", "tally", "finish", "read setup + take of the read-ahead", "total"};
+    for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * h[i] / (double)h[7]);
+    fprintf(stderr, " | cycles/read/wave %.0f\n", (double)h[7] / (double)a.n_reads);
+#endif
   }
   else if (a.t.layout) {
 #ifdef MIC_PERTURB
@@ -1313,7 +1341,7 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h));
     hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
     fprintf(stderr, "[phase cycles, %% of wave time] reads=%zu waves=%u:", (size_t)a.n_reads, blocks * 4);
-    const char* nm[8] = {"kmers+minimizers", "runs+dma issue", "wait hbm", "slot search", "tally+take", "finish", "read setup", "total"};
+    const char* nm[8] = {"kmers+minimizers", "runs+dma issue", "wait hbm", "slot search", "tally", "finish", "read setup + take of the read-ahead", "total"};
     for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * h[i] / (double)h[7]);
     fprintf(stderr, " | cycles/read/wave %.0f\n", (double)h[7] / (double)a.n_reads);
 #endif
