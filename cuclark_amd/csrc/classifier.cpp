@@ -16,7 +16,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <fstream>
 #include <iostream>
 #include <mutex>
@@ -234,14 +236,158 @@ class MmapSource : public Classifier::SegmentSource {
   int fd_ = -1; const uint8_t* map_ = nullptr; size_t nb_ = 0, pos_ = 0, seg_;
 };
 
+// Decompressed bytes of a gzip (or plain) file, produced on a background thread so that inflating overlaps whatever
+// the consumer does with the bytes (record splitting, the paired-end merge, the other file of a pair).  Block-gzip
+// files (BGZF: every member carries its compressed size in a 'BC' extra field, as bgzip / samtools write them) are
+// inflated block-parallel by a few threads; ordinary gzip is one zlib stream (~0.45 GB/s), plain files pass through.
+// The reference leaves this to `gunzip` in classify_metagenome.sh:116-142.
+class InflateStream {
+ public:
+  explicit InflateStream(const std::string& path, unsigned threads = 0) {
+    unsigned hw = std::thread::hardware_concurrency();
+    threads_ = threads ? threads : std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
+    if (const char* env = getenv("MIC_INFLATE_THREADS")) { long v = atol(env); if (v >= 1 && v <= 64) threads_ = (unsigned)v; }
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return;
+    unsigned char h[18];
+    size_t n = fread(h, 1, sizeof(h), f);
+    bgzf_ = n == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' &&
+            h[13] == 'C' && h[14] == 2 && h[15] == 0;
+    if (bgzf_) { rewind(f); raw_ = f; }
+    else {
+      fclose(f);
+      gz_ = gzopen(path.c_str(), "rb");
+      if (!gz_) return;
+      gzbuffer(gz_, 1 << 20);
+    }
+    ok_ = true;
+    producer_ = std::thread([this] { bgzf_ ? produce_bgzf() : produce_gz(); });
+  }
+  ~InflateStream() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+    cv_space_.notify_all();
+    if (producer_.joinable()) producer_.join();
+    if (gz_) gzclose(gz_);
+    if (raw_) fclose(raw_);
+  }
+  InflateStream(const InflateStream&) = delete;
+  InflateStream& operator=(const InflateStream&) = delete;
+  bool ok() const { return ok_; }
+  bool block_gzip() const { return bgzf_; }
+  // like gzread: up to n bytes, 0 at the end of the data, -1 on a corrupt file
+  long read(void* dst, size_t n) {
+    size_t got = 0;
+    char* d = (char*)dst;
+    while (got < n) {
+      if (pos_ == cur_.size()) {
+        std::unique_lock<std::mutex> g(m_);
+        cv_data_.wait(g, [&] { return !q_.empty() || done_; });
+        if (q_.empty()) { if (failed_) return -1; break; }
+        cur_.swap(q_.front()); q_.pop_front(); pos_ = 0;
+        g.unlock();
+        cv_space_.notify_one();
+        continue;
+      }
+      const size_t take = std::min(n - got, cur_.size() - pos_);
+      memcpy(d + got, cur_.data() + pos_, take);
+      got += take; pos_ += take;
+    }
+    return (long)got;
+  }
+
+ private:
+  bool push(std::vector<char>& chunk) {           // false: the consumer went away
+    std::unique_lock<std::mutex> g(m_);
+    cv_space_.wait(g, [&] { return q_.size() < 4 || stop_; });
+    if (stop_) return false;
+    q_.emplace_back(); q_.back().swap(chunk);
+    g.unlock();
+    cv_data_.notify_one();
+    return true;
+  }
+  void finish(bool failed) {
+    { std::lock_guard<std::mutex> g(m_); done_ = true; failed_ = failed; }
+    cv_data_.notify_all();
+  }
+  void produce_gz() {
+    for (;;) {
+      std::vector<char> chunk(8u << 20);
+      int n = gzread(gz_, chunk.data(), (unsigned)chunk.size());
+      if (n <= 0) { finish(n < 0); return; }
+      chunk.resize((size_t)n);
+      if (!push(chunk)) return;
+    }
+  }
+  void produce_bgzf() {
+    struct Blk { size_t off, csize, isize, out; };
+    std::vector<unsigned char> in;
+    for (;;) {
+      in.clear();
+      std::vector<Blk> blks;
+      size_t out_total = 0;
+      while (blks.size() < 512) {                  // <= 32 MB of output per batch
+        unsigned char h[18];
+        size_t n = fread(h, 1, 18, raw_);
+        if (n == 0) break;
+        if (n != 18 || h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C') { finish(true); return; }
+        const size_t bsize = (size_t)(h[16] | (h[17] << 8)) + 1;
+        if (bsize < 26) { finish(true); return; }
+        const size_t off = in.size();
+        in.resize(off + bsize);
+        memcpy(in.data() + off, h, 18);
+        if (fread(in.data() + off + 18, 1, bsize - 18, raw_) != bsize - 18) { finish(true); return; }
+        const unsigned char* t = in.data() + off + bsize - 4;
+        const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+        if (isize > 65536) { finish(true); return; }
+        blks.push_back({off, bsize, isize, out_total});
+        out_total += isize;
+      }
+      if (blks.empty()) { finish(false); return; }
+      std::vector<char> chunk(out_total);
+      std::atomic<bool> bad{false};
+      auto work = [&](unsigned t0) {
+        for (size_t b = t0; b < blks.size(); b += threads_) {
+          const Blk& k = blks[b];
+          if (k.isize == 0) continue;
+          z_stream zs; memset(&zs, 0, sizeof(zs));
+          if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
+          zs.next_in = in.data() + k.off + 18; zs.avail_in = (uInt)(k.csize - 18 - 8);
+          zs.next_out = (Bytef*)chunk.data() + k.out; zs.avail_out = (uInt)k.isize;
+          const int rc = inflate(&zs, Z_FINISH);
+          if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
+          inflateEnd(&zs);
+          const unsigned char* c = in.data() + k.off + k.csize - 8;
+          const uLong want = (uLong)c[0] | ((uLong)c[1] << 8) | ((uLong)c[2] << 16) | ((uLong)c[3] << 24);
+          if (crc32(crc32(0L, Z_NULL, 0), (const Bytef*)chunk.data() + k.out, (uInt)k.isize) != want) bad = true;
+        }
+      };
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < threads_ && t < blks.size(); ++t) pool.emplace_back(work, t);
+      work(0);
+      for (auto& th : pool) th.join();
+      if (bad) { finish(true); return; }
+      if (!chunk.empty() && !push(chunk)) return;
+    }
+  }
+
+  bool ok_ = false, bgzf_ = false;
+  unsigned threads_ = 1;
+  gzFile gz_ = nullptr; FILE* raw_ = nullptr;
+  std::thread producer_;
+  std::mutex m_; std::condition_variable cv_data_, cv_space_;
+  std::deque<std::vector<char>> q_;
+  bool done_ = false, failed_ = false, stop_ = false;
+  std::vector<char> cur_; size_t pos_ = 0;
+};
+
+
 // gzip (or plain) file through zlib: inflate ~seg bytes, keep the incomplete last record for the next segment
 class GzSource : public Classifier::SegmentSource {
  public:
-  GzSource(const std::string& path, size_t seg) : seg_(seg) { g_ = gzopen(path.c_str(), "rb"); if (g_) gzbuffer(g_, 1 << 20); }
-  ~GzSource() override { if (g_) gzclose(g_); }
-  bool ok() const { return g_ != nullptr; }
+  GzSource(const std::string& path, size_t seg) : in_(path), seg_(seg) {}
+  bool ok() const { return in_.ok(); }
   bool next(Classifier::Segment& s) override {
-    if (!g_ || (eof_ && carry_.empty())) return false;
+    if (!in_.ok() || (eof_ && carry_.empty())) return false;
     std::string buf;
     buf.swap(carry_);
     size_t want = seg_;
@@ -249,8 +395,9 @@ class GzSource : public Classifier::SegmentSource {
       while (!eof_ && buf.size() < want) {
         size_t old = buf.size();
         buf.resize(old + (8u << 20));
-        int n = gzread(g_, &buf[old], 8u << 20);
+        long n = in_.read(&buf[old], 8u << 20);
         buf.resize(old + (n > 0 ? (size_t)n : 0));
+        if (n < 0) die("Failed to uncompress input objects.");
         if (n <= 0) eof_ = true;
       }
       if (eof_) break;
@@ -272,21 +419,21 @@ class GzSource : public Classifier::SegmentSource {
     return true;
   }
  private:
-  gzFile g_ = nullptr; std::string carry_; bool eof_ = false; size_t seg_;
+  InflateStream in_; std::string carry_; bool eof_ = false; size_t seg_;
 };
 
 // line reader over zlib (plain files are read transparently)
 class GzLines {
  public:
-  explicit GzLines(const std::string& path) : buf_(1 << 20) { g_ = gzopen(path.c_str(), "rb"); if (g_) gzbuffer(g_, 1 << 20); }
-  ~GzLines() { if (g_) gzclose(g_); }
-  bool ok() const { return g_ != nullptr; }
+  explicit GzLines(const std::string& path) : in_(path), buf_(1 << 20) {}
+  bool ok() const { return in_.ok(); }
   bool line(std::string& out) {   // getLineFromFile semantics: strip one trailing '\n' (file.cc:124-141)
     out.clear();
     for (;;) {
       if (pos_ == len_) {
-        if (!g_) return !out.empty();
-        int n = gzread(g_, buf_.data(), (unsigned)buf_.size());
+        if (!in_.ok()) return !out.empty();
+        long n = in_.read(buf_.data(), buf_.size());
+        if (n < 0) die("Failed to uncompress input objects.");
         if (n <= 0) return !out.empty() || false;
         pos_ = 0; len_ = (size_t)n;
       }
@@ -297,7 +444,7 @@ class GzLines {
     }
   }
  private:
-  gzFile g_ = nullptr; std::vector<char> buf_; size_t pos_ = 0, len_ = 0;
+  InflateStream in_; std::vector<char> buf_; size_t pos_ = 0, len_ = 0;
 };
 
 // paired-end FASTQ -> segments of the merged FASTA text ">id\nseq1Nseq2\n" (file.cc:205-268)

@@ -154,6 +154,59 @@ def test_streaming_segments_give_identical_csv(tmp_path):
             assert "(131 objects)" in r.stdout or "(80 objects)" in r.stdout or "(40 objects)" in r.stdout
 
 
+def _write_bgzf(src, dst, block=700):
+    """Block-gzip (BGZF, what bgzip / samtools write): one gzip member per block with a 'BC' extra field holding its size."""
+    import struct
+    import zlib
+    data = open(src, "rb").read()
+    with open(dst, "wb") as fo:
+        for off in list(range(0, len(data), block)) + [len(data)]:      # the last, empty block is the EOF marker
+            raw = data[off:off + block] if off < len(data) else b""
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = co.compress(raw) + co.flush()
+            bsize = 18 + len(body) + 8
+            fo.write(b"\x1f\x8b\x08\x04" + struct.pack("<IBBH", 0, 0, 255, 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+            fo.write(body + struct.pack("<II", zlib.crc32(raw) & 0xFFFFFFFF, len(raw)))
+
+
+@pytest.mark.gpu
+def test_block_gzip_and_multi_member_gzip_inputs(tmp_path):
+    """Block-gzip input is inflated block-parallel, concatenated gzip members by zlib, both on a side thread; paired files
+    are inflated concurrently.  The CSV must not change by a byte; a damaged block is reported, not classified."""
+    import gzip
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "light_k27_u32", light=True)
+    t = _targets_file(tmp)
+    fq = os.path.join(gu.GOLDEN, "reads_k27.fq")
+    bg = os.path.join(tmp, "reads.fq.bgz")
+    _write_bgzf(fq, bg)
+    import zlib
+    assert zlib.decompressobj(31).decompress(open(bg, "rb").read())[:20] == open(fq, "rb").read()[:20]   # a valid gzip file
+    mm = os.path.join(tmp, "reads_mm.fq.gz")
+    data = open(fq, "rb").read()
+    cut = data.index(b"\n@", len(data) // 2) + 1
+    with open(mm, "wb") as fo:
+        fo.write(gzip.compress(data[:cut]) + gzip.compress(data[cut:]))
+    p1, p2 = os.path.join(tmp, "p1.fq.bgz"), os.path.join(tmp, "p2.fq.gz")
+    _write_bgzf(os.path.join(gu.GOLDEN, "pairs_k27_1.fq"), p1, block=333)
+    with open(os.path.join(gu.GOLDEN, "pairs_k27_2.fq"), "rb") as fi, gzip.open(p2, "wb") as fo:
+        fo.write(fi.read())
+    cases = [(["-O", bg], "expected_k27_fq.csv"), (["-O", mm], "expected_k27_fq.csv"), (["-P", p1, p2], "expected_k27_pairs.csv")]
+    for threads in ("1", "5"):
+        for src, exp in cases:
+            out = os.path.join(tmp, f"t{threads}_{exp}")
+            r = _run([EXE_L, "-T", t, "-D", d, *src, "-R", out, "-n", "2", "-b", "3"],
+                     env=dict(os.environ, MIC_SEGMENT_KB="2", MIC_INFLATE_THREADS=threads))
+            assert r.returncode == 0, r.stderr
+            assert open(out + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, exp), "rb").read(), (threads, exp)
+    broken = bytearray(open(bg, "rb").read())
+    broken[len(broken) // 2] ^= 0x5A
+    bad = os.path.join(tmp, "broken.fq.bgz")
+    open(bad, "wb").write(bytes(broken))
+    r = _run([EXE_L, "-T", t, "-D", d, "-O", bad, "-R", os.path.join(tmp, "broken")])
+    assert r.returncode != 0 and "uncompress" in (r.stderr + r.stdout)
+
+
 @pytest.mark.gpu
 def test_set_targets_then_classify_end_to_end(tmp_path):
     """The reference's user flow on a fresh directory: set_targets.sh <dir> custom (taxonomy already downloaded), then
