@@ -885,9 +885,10 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
           const uint32_t j = (mk - (uint32_t)ln) & 15;
           const bool rev = (mk & 16u) != 0;
           ko[h] = rev ? rk[h] : km[h];
-          const uint32_t jo = rev ? (uint32_t)(w - 1) - j : j;     // minimizer position in the oriented k-mer
-          ao[h] = (uint32_t)(w - 1) - jo;                           // offset of the k-mer in the super-k-mer
-          const uint64_t x = (ko[h] >> (2 * ((uint32_t)(k - m) - jo))) & ((1ULL << (2 * m)) - 1);
+          // minimizer position in the oriented k-mer: jo = rev ? w-1-j : j; offset of the k-mer in the super-k-mer:
+          // w-1-jo; and because k-m = w-1 that offset is also the number of nucleotides to the right of the minimizer
+          ao[h] = rev ? j : (uint32_t)(w - 1) - j;
+          const uint64_t x = (ko[h] >> (2 * ao[h])) & ((1ULL << (2 * m)) - 1);
           tk32[h] = (uint32_t)x;
           sl[h] = act[h] ? sslot_of_x(x, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         }
