@@ -9,7 +9,7 @@ per-target hit counts + best/second) over one batch of synthetic reads that is a
 Workloads, all synthetic, generated in HBM by libmi_clark.so's generators:
   full   config 3: 10 M x 150 bp reads (80 % sampled from the genomes with 1 % substitutions and 0.1 % N, 20 % random)
          vs. a 36 GB-on-disk-equivalent k=31 table: HTSIZE 1610612741, u32 keys, ~5.7e9 k-mers, 4096 targets,
-         resident as 103 GB of 64-byte slots.                                  [default]
+         resident as 75 GB of 128-byte super-k-mer slots (MIC_LAYOUT=minimizer|direct for the other layouts).  [default]
   light  config 2: same reads vs. the CuCLARK-l-scale table: HTSIZE 57777779, k=31 (u64 keys), ~54 M k-mers.
   tiny   plumbing-size case for quick checks.
 Multi-GPU (one process per GPU, launched with torch.distributed.run):
