@@ -894,7 +894,8 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   // D / 1.5 slots (6 entries each: P(overflow) ~ 2e-4 for Poisson(1.5)).  MIC_SSLOT_LOAD overrides the 1.5.
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 0) n_slots = tot_elems / (sampling > 1 ? 4ull * sampling : 4ull) + 64;
-    if (n_slots > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many S-slots"); rc = -1; goto done; }
+    // the scans below take an int item count; a table this large (> 2^31 slots = 275 GB) does not fit one GPU anyway
+    if (n_slots > 0x7FFFFF00ull) { snprintf(err, err_cap, "the super-k-mer table would need %llu slots", (unsigned long long)n_slots); rc = -3; goto done; }
     if (d_cnt) { hipFree(d_cnt); d_cnt = nullptr; }
     HIPCK(hipMalloc(&d_cnt, n_slots * 4));
     HIPCK(hipMemsetAsync(d_cnt, 0, n_slots * 4, s));
