@@ -453,6 +453,56 @@ def test_skewed_minimizer_bucket():
     assert f[:4096].all()
 
 
+def test_low_complexity_and_palindromic_minimizers():
+    """k-mers whose m-mers repeat (poly-A, dinucleotide and trinucleotide repeats: every window position ties) or whose
+    minimizer is its own reverse complement ((ACGT)n): the minimizer-keyed layouts must find them from either strand of a
+    read, and must not find their one-nucleotide neighbours."""
+    rng = np.random.default_rng(31)
+    k, T, htsize = 31, 5, 100003
+    o = gu.oracle()
+    enc = lambda seq: int("".join(str("TGCA".index(ch)) for ch in seq), 4)
+    seqs = ["A" * 31, "C" * 31, "AC" * 15 + "A", "ACG" * 10 + "A", "AAT" * 10 + "T", "ACGT" * 7 + "ACG", "TTGCAA" * 5 + "T"]
+    for _ in range(40):                       # palindromic 20-mers inside random flanks, at every offset
+        off = int(rng.integers(0, 12))
+        fl = "".join(rng.choice(list("ACGT"), 31))
+        seqs.append(fl[:off] + "ACGT" * 5 + fl[off + 20:])
+        seqs.append(fl[:off] + "GAATTC" * 3 + "GA" + fl[off + 20:])
+    kmers = [enc(q) for q in seqs]
+    extra = [int(v) for v in rng.integers(0, 1 << 62, 500, dtype=np.uint64)]
+    canon = sorted({o.canonical(v, k) for v in kmers + extra}, key=lambda c: (c % htsize, c // htsize))
+    sizes = np.zeros(htsize, np.int64)
+    for c in canon:
+        sizes[c % htsize] += 1
+    keys = np.array([c // htsize for c in canon], dtype=np.uint64)
+    labels = np.array([(c >> 3) % T for c in canon], dtype=np.uint16)
+    odb = o.db_from_arrays(sizes.astype(np.uint8), keys, labels)
+    q = np.array(kmers + [o.revcomp(v, k) for v in kmers] + [v ^ 1 for v in kmers] + [v ^ (3 << 40) for v in kmers] + extra[:50],
+                 dtype=np.uint64)
+    rp, cont = _kmer_reads(q, k)
+    f, l = odb.find_many(q, k)
+    assert f[:2 * len(kmers)].all()
+    with _engine(k, T) as e:
+        e.read_arrays(sizes.astype(np.uint8), keys, labels)
+        res = e.classify_packed(rp, cont)
+    assert ((res[:, 0] == 1) == (f == 1)).all()
+    assert (res[f == 1, 1] == l[f == 1].astype(np.uint32) + 1).all()
+    # the same k-mers inside longer reads (the sliding window sees them next to unrelated m-mers), both strands
+    reads = []
+    for sq in seqs[:20]:
+        fl = "".join(rng.choice(list("ACGT"), 40))
+        reads.append(fl[:20] + sq + fl[20:])
+        reads.append("".join({"A": "T", "C": "G", "G": "C", "T": "A"}[ch] for ch in reversed(reads[-1])))
+    from cuclark_amd import host
+    data = "".join(f">r{i}\n{sq}\n" for i, sq in enumerate(reads)).encode()
+    idx = host.index_reads(data)
+    rp2, cont2 = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    counts, expect = _oracle_results(odb, k, rp2, cont2, T)
+    with _engine(k, T) as e:
+        e.read_arrays(sizes.astype(np.uint8), keys, labels)
+        res2 = e.classify_packed(rp2, cont2)
+    assert (res2[:, :5] == expect).all() and (expect[:, 0] >= 1).all()
+
+
 def test_super_table_with_crowded_slots(monkeypatch):
     """The super-k-mer table at 5.9 entries per 6-entry slot instead of 1.5 (MIC_SSLOT_LOAD): most slots continue in a
     chain of further slots; unrelated k-mers (one entry each) and k-mers cut from genomes (shared entries); answers equal
