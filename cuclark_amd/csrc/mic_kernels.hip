@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
 // entries with that value by a 3-step search over the slot's six sort keys and compares itself with the super-k-mer at
 // its alignment.  A slot holds ~1.5 entries on average: continuation slots are rare and there is no second level.
 // =====================================================================================================================
-template <int KK, int MM>
+template <int KK, int MM, bool SHARDED>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s(const MicQueryArgs a) {
   __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE];
   __shared__ uint32_t s_run[MIC_M_WPB][MIC_RMAX];
@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
           const uint64_t rck = revcomp_bits(kmer, k);
           km[h] = kmer; rk[h] = rck;
           act[h] = base + 64 * h + lane < nk;
-          if (t.sharded) {   // table-sharded mode only: divisor and bounds are re-read from the kernarg segment (see finish)
+          if (SHARDED) {   // table-sharded mode only (its own instantiation: the unsharded kernel carries none of this): divisor and bounds are re-read from the kernarg segment (see finish)
             uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kp));
             const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
@@ -1304,9 +1304,11 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   if (a.t.layout == 2) {
     const unsigned g = (blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, b = 64 * MIC_M_WPB;
     static const bool generic = getenv("MIC_S_GENERIC") != nullptr;
-    if (!generic && a.t.k == 31 && a.t.m == 20) query_kernel_s<31, 20><<<g, b, 0, s>>>(a);
-    else if (!generic && a.t.k == 27 && a.t.m == 20) query_kernel_s<27, 20><<<g, b, 0, s>>>(a);
-    else query_kernel_s<0, 0><<<g, b, 0, s>>>(a);
+    const bool sh = a.t.sharded != 0;
+    if (!generic && a.t.k == 31 && a.t.m == 20) { if (sh) query_kernel_s<31, 20, true><<<g, b, 0, s>>>(a); else query_kernel_s<31, 20, false><<<g, b, 0, s>>>(a); }
+    else if (!generic && a.t.k == 27 && a.t.m == 20) { if (sh) query_kernel_s<27, 20, true><<<g, b, 0, s>>>(a); else query_kernel_s<27, 20, false><<<g, b, 0, s>>>(a); }
+    else if (sh) query_kernel_s<0, 0, true><<<g, b, 0, s>>>(a);
+    else query_kernel_s<0, 0, false><<<g, b, 0, s>>>(a);
 #ifdef MIC_PHASE_TIMING
     unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipStreamSynchronize(s);
