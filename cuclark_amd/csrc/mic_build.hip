@@ -858,7 +858,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   const unsigned n_tiles = (unsigned)((n_buckets + TILE - 1) / TILE);
   TileA* d_a = nullptr; uint32_t* d_cnt = nullptr; uint32_t* d_cur = nullptr; unsigned long long* d_off = nullptr;
   unsigned long long* d_coff = nullptr; unsigned long long* d_scal = nullptr; uint32_t* d_max = nullptr;
-  unsigned long long* d_ck = nullptr; uint32_t* d_cm = nullptr; uint32_t* slots = nullptr;
+  unsigned long long* d_ck = nullptr; uint32_t* d_cm = nullptr; uint32_t* slots = nullptr; uint32_t* d_dem = nullptr;
   std::vector<TileA> h_a(n_tiles);
   uint64_t tot_elems = 0, tot_nz = 0, n_slots = 0, n_cand = 0, n_chain = 0;
   unsigned long long h_scal[2] = {0, 0}; uint32_t h_max = 0; double avail_b = 0;
@@ -962,7 +962,6 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   lap("sort + merge (count)");
   {
     // chain slots: demand per slot into a scratch u32 array (the candidate offsets stay), scanned to 64-bit bases
-    uint32_t* d_dem = nullptr;
     HIPCK(hipMalloc(&d_dem, n_slots * 4));
     s_chain_demand_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_cur, n_slots, d_dem);
     HIPCK(hipMalloc(&d_coff, (n_slots + 1) * 8));
@@ -970,7 +969,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     unsigned long long last_off = 0; uint32_t last_dem = 0;
     if (e == hipSuccess) e = hipMemcpy(&last_off, d_coff + n_slots - 1, 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(&last_dem, d_dem + n_slots - 1, 4, hipMemcpyDeviceToHost);
-    hipFree(d_dem);
+    hipFree(d_dem); d_dem = nullptr;
     HIPCK(e);
     n_chain = last_off + last_dem;
   }
@@ -1009,6 +1008,7 @@ done:
   if (d_max) hipFree(d_max);
   if (d_ck) hipFree(d_ck);
   if (d_cm) hipFree(d_cm);
+  if (d_dem) hipFree(d_dem);
   if (slots) hipFree(slots);
   return rc;
 }
