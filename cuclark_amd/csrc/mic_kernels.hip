@@ -1307,6 +1307,7 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     const bool sh = a.t.sharded != 0;
     if (!generic && a.t.k == 31 && a.t.m == 20) { if (sh) query_kernel_s<31, 20, true><<<g, b, 0, s>>>(a); else query_kernel_s<31, 20, false><<<g, b, 0, s>>>(a); }
     else if (!generic && a.t.k == 27 && a.t.m == 20) { if (sh) query_kernel_s<27, 20, true><<<g, b, 0, s>>>(a); else query_kernel_s<27, 20, false><<<g, b, 0, s>>>(a); }
+    else if (!generic && a.t.k == 32 && a.t.m == 20) { if (sh) query_kernel_s<32, 20, true><<<g, b, 0, s>>>(a); else query_kernel_s<32, 20, false><<<g, b, 0, s>>>(a); }
     else if (sh) query_kernel_s<0, 0, true><<<g, b, 0, s>>>(a);
     else query_kernel_s<0, 0, false><<<g, b, 0, s>>>(a);
 #ifdef MIC_PHASE_TIMING
