@@ -43,6 +43,14 @@ class MicSynthSpec(C.Structure):
                 ("n_genomes", C.c_uint32), ("k", C.c_int32), ("key_bytes", C.c_int32)]
 
 
+class MicIngestResult(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("csv_bytes", C.c_uint64), ("csv", C.c_void_p), ("results", C.c_void_p),
+                ("status", C.c_uint32), ("n_lines", C.c_uint32)]
+
+
+MIC_INGEST_OK, MIC_INGEST_FALLBACK, MIC_INGEST_ODD_RECORD, MIC_INGEST_TRUNCATED = 0, 1, 2, 4
+MIC_INGEST_LONG_READ, MIC_INGEST_TOO_MANY, MIC_INGEST_DENSE = 8, 16, 32
+
 # every symbol include/mi_clark.h declares: (name, restype, argtypes)
 _VP, _SZ, _U32P, _U16P, _U64P = C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p
 SYMBOLS = [
@@ -72,6 +80,11 @@ SYMBOLS = [
     ("mic_count_dense_device", C.c_int, [_VP, _VP, _VP, _VP, _SZ, _VP, _VP]),
     ("mic_probe_stats_device", C.c_int, [_VP, _VP, _VP, _SZ, C.POINTER(C.c_uint64)]),
     ("mic_last_query_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
+    ("mic_ingest_alloc", C.c_int, [_VP, _SZ, _SZ, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.POINTER(_VP)]),
+    ("mic_ingest_classify", C.c_int, [_VP, _SZ, _SZ, C.c_int, C.POINTER(MicIngestResult)]),
+    ("mic_ingest_fetch_packed", C.c_int, [_VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("mic_ingest_free", C.c_int, [_VP]),
+    ("mic_format_ratio_g", C.c_int, [C.c_uint32, C.c_uint32, C.c_char_p]),
     ("mic_key_bytes_rule", C.c_int, [C.c_uint64, C.c_int]),
     ("mic_index_reads", C.c_long, [_VP, _SZ, _SZ, _U64P, _U64P, _U64P, _U64P, _U64P]),
     ("mic_index_reads_parallel", C.c_long, [_VP, _SZ, C.c_int, _SZ, _U64P, _U64P, _U64P, _U64P, _U64P]),

@@ -69,6 +69,7 @@ struct mic_engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   size_t last_n_reads = 0;
+  void* ingest = nullptr;      // device-side ingest state (mic_ingest.hip)
 };
 
 namespace {
@@ -261,6 +262,25 @@ int run_dense(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, const
 
 }  // namespace
 
+// ---- what mic_ingest.hip needs from the engine ------------------------------------------------------------------------
+int mic_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int mic_engine_table(mic_engine* e, MicTable* t, int* slot_class, int* n_cu, int* device, int* k, uint32_t* n_targets) {
+  if (!e) return fail(MIC_E_INVALID, "null engine");
+  *t = e->table;
+  if (!e->db_loaded) t->slots = nullptr;
+  *slot_class = e->slot_class; *n_cu = e->n_cu; *device = e->device; *k = e->cfg.k; *n_targets = e->cfg.num_targets;
+  return MIC_OK;
+}
+
+void** mic_engine_ingest_slot(mic_engine* e) { return &e->ingest; }
+
 extern "C" {
 
 const char* mic_last_error(void) { return g_err; }
@@ -313,6 +333,7 @@ int mic_destroy(mic_engine* e) {
   if (!e) return MIC_OK;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
+  mic_ingest_free(e);
   free_batches(e);
   if (e->slots) hipFree(e->slots);
   if (e->d_sizes) hipFree(e->d_sizes);

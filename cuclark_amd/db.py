@@ -151,6 +151,39 @@ class MiClarkDB:
         self.freeBatchMemory()
         return (res, rows) if extended else res
 
+    # -- device-side ingest: raw FASTA/FASTQ bytes -> CSV text (mic_ingest_*)
+    def ingest_alloc(self, n_slots, max_bytes, target_names, want_results=False):
+        names = (C.c_char_p * len(target_names))(*[t.encode() for t in target_names])
+        raw = (C.c_void_p * n_slots)()
+        check(self.L.mic_ingest_alloc(self.h, n_slots, max_bytes, names, len(target_names), int(bool(want_results)), raw))
+        self._ingest = dict(raw=[_as_np(raw[i], (max_bytes,), np.uint8) for i in range(n_slots)], max_bytes=max_bytes)
+        return self._ingest["raw"]
+
+    def ingest_classify(self, slot, data, paired=False):
+        """data: bytes of whole records.  Returns dict(status, n_reads, csv (bytes), results (u32[n,8] or None))."""
+        buf = np.frombuffer(data, np.uint8)
+        self._ingest["raw"][slot][: buf.size] = buf
+        out = _lib.MicIngestResult()
+        check(self.L.mic_ingest_classify(self.h, slot, buf.size, int(bool(paired)), C.byref(out)))
+        r = dict(status=int(out.status), n_reads=int(out.n_reads), n_lines=int(out.n_lines), csv=None, results=None)
+        if out.status == 0:
+            r["csv"] = C.string_at(out.csv, out.csv_bytes) if out.csv_bytes else b""
+            if out.results:
+                r["results"] = _as_np(out.results, (int(out.n_reads), MIC_RESULT_WORDS), np.uint32).copy()
+        return r
+
+    def ingest_fetch_packed(self, slot):
+        n, m = C.c_uint64(0), C.c_uint64(0)
+        check(self.L.mic_ingest_fetch_packed(self.h, slot, None, 0, None, 0, C.byref(n), C.byref(m)))
+        rp = np.zeros(n.value + 1, np.uint32)
+        ct = np.zeros(max(m.value, 1), np.uint16)
+        check(self.L.mic_ingest_fetch_packed(self.h, slot, rp.ctypes.data, rp.size, ct.ctypes.data, ct.size, None, None))
+        return rp, ct[: m.value]
+
+    def ingest_free(self):
+        self._ingest = None
+        check(self.L.mic_ingest_free(self.h))
+
     # -- device-resident entry points (pointers are raw device addresses, e.g. torch.Tensor.data_ptr())
     def query_device(self, d_reads_pointer, d_containers, n_reads, d_results, d_rows=0, stream=0):
         check(self.L.mic_query_device(self.h, d_reads_pointer, d_containers, n_reads, d_results, d_rows or None,

@@ -178,6 +178,52 @@ int mic_probe_stats_device(mic_engine* e, const uint32_t* d_reads_pointer, const
  * stream it ran on (blocks until it finished). */
 int mic_last_query_ms(mic_engine* e, float* ms);
 
+/* ---- device-side ingest: raw FASTA / FASTQ bytes in, result-CSV text out ----------------------------------------
+ * The reference does the read indexing (CuCLARK_hh.hh:1339-1534), the 2-bit packing with its N-splitting
+ * (CuCLARK_hh.hh:1616-1716) and the CSV lines (printExtendedResultsSynced, CuCLARK_hh.hh:1951-2139) on host threads
+ * around queryBatch; at MI355X kernel rates those loops are the bottleneck by two orders of magnitude.  Here a batch
+ * of WHOLE records is handed over as the bytes of the file and comes back as the bytes of the CSV (no header line,
+ * non-extended format): line index, record index, packer, query kernel and CSV formatter all run on the device,
+ * the host only moves bytes.  Output is byte-identical to mic_index_reads + mic_pack_reads + mic_batch_query +
+ * mic_csv_line on the same bytes.
+ *
+ * mic_ingest_alloc    engine-owned pinned input buffers (raw[i], max_bytes each) lent to the caller, as
+ *                     CuClarkDB::malloc lends its batch buffers (CuClarkDB.cu:355-360); target_names as in mic_csv_line.
+ * mic_ingest_classify blocking; slot-private stream: call it from one host thread per slot to keep the device busy.
+ *                     The slot's first byte must be '>' (FASTA, also the merged paired-end text of file.cc:205-268;
+ *                     paired != 0 then subtracts the separator from the Length column, CuCLARK_hh.hh:2119) or '@' (FASTQ).
+ *                     out->status == MIC_INGEST_OK: out->csv / csv_bytes / n_reads are valid until the slot's next call.
+ *                     out->status & MIC_INGEST_FALLBACK: the batch holds something the device path does not
+ *                     reproduce (the other bits say what); nothing was produced and the caller runs the host path
+ *                     (mic_index_reads ... mic_csv_line) on these bytes.
+ * mic_ingest_fetch_packed  test hook: the packed reads of the slot's last batch as the query kernel saw them. */
+#define MIC_INGEST_OK 0u
+#define MIC_INGEST_FALLBACK 1u     /* run the host path on this batch                                        */
+#define MIC_INGEST_ODD_RECORD 2u   /* empty read name, FASTA record without a sequence line, unknown format   */
+#define MIC_INGEST_TRUNCATED 4u    /* FASTQ line count not a multiple of four                                 */
+#define MIC_INGEST_LONG_READ 8u    /* a sequence of more than MIC_MAX_PART bytes                              */
+#define MIC_INGEST_TOO_MANY 16u    /* more lines / reads / containers / CSV bytes than the slot was sized for */
+#define MIC_INGEST_DENSE 32u       /* a read needs the dense fallback (more than 64 targets hit)              */
+
+typedef struct mic_ingest_result {
+  uint64_t n_reads;
+  uint64_t csv_bytes;
+  const char* csv;           /* pinned host memory of the slot                                    */
+  const uint32_t* results;   /* MIC_RESULT_WORDS per read when want_results was set, else NULL    */
+  uint32_t status;
+  uint32_t n_lines;
+} mic_ingest_result;
+
+int mic_ingest_alloc(mic_engine* e, size_t n_slots, size_t max_bytes, const char* const* target_names, uint32_t n_targets,
+                     int want_results, uint8_t** raw /*[n_slots]*/);
+int mic_ingest_classify(mic_engine* e, size_t slot, size_t n_bytes, int paired, mic_ingest_result* out);
+int mic_ingest_fetch_packed(mic_engine* e, size_t slot, uint32_t* reads_pointer, size_t rp_cap, uint16_t* containers,
+                            size_t cont_cap, uint64_t* n_reads, uint64_t* n_containers);
+int mic_ingest_free(mic_engine* e);
+/* "%g" of (double)num / den for 0 < num <= den, by the integer-only formatter the device CSV kernel uses
+ * (csrc/mic_fmt.h); writes at most 14 characters and a terminator, returns the length. */
+int mic_format_ratio_g(uint32_t num, uint32_t den, char* out16);
+
 /* ---- host-side pieces of the path (pure CPU, no device needed) -------------------------------- */
 /* Key width rule, main.cc:274-316. */
 int mic_key_bytes_rule(uint64_t htsize, int k);
