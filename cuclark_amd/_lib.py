@@ -89,6 +89,7 @@ SYMBOLS = [
     ("mic_index_reads", C.c_long, [_VP, _SZ, _SZ, _U64P, _U64P, _U64P, _U64P, _U64P]),
     ("mic_index_reads_parallel", C.c_long, [_VP, _SZ, C.c_int, _SZ, _U64P, _U64P, _U64P, _U64P, _U64P]),
     ("mic_find_record_start", _SZ, [_VP, _SZ, _SZ]),
+    ("mic_find_record_start_in", _SZ, [_VP, _SZ, C.c_int, _SZ]),
     ("mic_pack_bound", _SZ, [_U64P, _U64P, _SZ, C.c_int]),
     ("mic_pack_reads", _SZ, [_VP, _U64P, _U64P, _U64P, _SZ, C.c_int, _U32P, _U16P, _SZ]),
     ("mic_csv_header", C.c_int, [C.c_char_p, _SZ, C.c_int, C.POINTER(C.c_char_p), C.c_uint32]),

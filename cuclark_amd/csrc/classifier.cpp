@@ -159,6 +159,7 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
 }
 
 Classifier::~Classifier() {
+  release_ingest();
   for (mic_engine* e : engines_) mic_destroy(e);
 }
 
@@ -491,6 +492,93 @@ class OneBuffer : public Classifier::SegmentSource {
 
 }  // namespace
 
+// ---- feeders of the device-ingest streaming path (Classifier::run_stream) ------------------------------------------
+namespace {
+
+// plain file: ranges are cut at record starts found in small windows read with pread; the bytes of a range go straight
+// from the page cache into the slot's pinned buffer (no mapping, no page faults)
+class FileFeeder : public Classifier::Feeder {
+ public:
+  explicit FileFeeder(const std::string& path) {
+    fd_ = open(path.c_str(), O_RDONLY);
+    struct stat st;
+    if (fd_ == -1 || fstat(fd_, &st) != 0 || st.st_size == 0) return;
+    size_ = (uint64_t)st.st_size;
+    uint8_t c = 0;
+    if (pread(fd_, &c, 1, 0) != 1) return;
+    first_ = c;
+    ok_ = true;
+  }
+  ~FileFeeder() override { if (fd_ != -1) close(fd_); }
+  bool ok() const { return ok_; }
+  uint64_t size() const { return size_; }
+  uint8_t first_byte() const { return first_; }
+  bool assign(size_t want, size_t cap, Classifier::Range& r) override {
+    (void)cap;
+    if (pos_ >= size_) return false;
+    uint64_t end = size_;
+    if (size_ - pos_ > want + want / 8) {
+      // first record start at or after pos_ + want: look in growing windows
+      const bool fasta = first_ == '>';
+      uint64_t from = pos_ + want;
+      size_t win = 1u << 16;
+      for (;;) {
+        const uint64_t w0 = from - 1, w1 = std::min<uint64_t>(size_, w0 + win);
+        buf_.resize((size_t)(w1 - w0));
+        if (pread(fd_, buf_.data(), buf_.size(), (off_t)w0) != (ssize_t)buf_.size()) die("Failed to read the objects file.");
+        const size_t p = mic_find_record_start_in(buf_.data(), buf_.size(), fasta ? 1 : 0, 1);
+        if (p < buf_.size()) { end = w0 + p; break; }
+        if (w1 == size_) { end = size_; break; }
+        win *= 4;
+      }
+    }
+    r.off = pos_; r.len = (size_t)(end - pos_); r.mem = nullptr; r.keep.reset();
+    pos_ = end;
+    return true;
+  }
+  void load(const Classifier::Range& r, uint8_t* dst) override {
+    size_t got = 0;
+    while (got < r.len) {
+      const ssize_t n = pread(fd_, dst + got, r.len - got, (off_t)(r.off + got));
+      if (n <= 0) die("Failed to read the objects file.");
+      got += (size_t)n;
+    }
+  }
+ private:
+  int fd_ = -1; uint64_t size_ = 0, pos_ = 0; uint8_t first_ = 0; bool ok_ = false;
+  std::vector<uint8_t> buf_;
+};
+
+// segments of whole records in memory (inflated gzip, merged paired-end text): ranges are slices of the segments
+class SegmentFeeder : public Classifier::Feeder {
+ public:
+  explicit SegmentFeeder(Classifier::SegmentSource& src) : src_(src) {}
+  bool assign(size_t want, size_t cap, Classifier::Range& r) override {
+    (void)cap;
+    if (!cur_ || pos_ >= cur_->n) {
+      auto s = std::make_shared<Classifier::Segment>();
+      if (!src_.next(*s)) return false;
+      if (!s->own.empty()) s->p = (const uint8_t*)s->own.data();
+      cur_ = s; pos_ = 0;
+    }
+    size_t end = cur_->n;
+    if (cur_->n - pos_ > want + want / 8) {
+      const size_t p = mic_find_record_start_in(cur_->p, cur_->n, cur_->p[0] == '>' ? 1 : 0, pos_ + want);
+      if (p > pos_ && p < cur_->n) end = p;
+    }
+    r.off = pos_; r.len = end - pos_; r.mem = cur_->p + pos_; r.keep = cur_;
+    pos_ = end;
+    return true;
+  }
+  void load(const Classifier::Range& r, uint8_t* dst) override { memcpy(dst, r.mem, r.len); }
+ private:
+  Classifier::SegmentSource& src_;
+  std::shared_ptr<Classifier::Segment> cur_;
+  size_t pos_ = 0;
+};
+
+}  // namespace
+
 std::string merge_paired(const std::string& file1, const std::string& file2) {
   PairedSource src(file1, file2, ~(size_t)0 >> 1);
   if (!src.ok()) die("Error: Found read without sequence");
@@ -505,7 +593,16 @@ void Classifier::run(const std::string& objects, const std::string& results) {
     if (is_gzip(obj)) {
       GzSource src(obj, segment_bytes_);
       if (!src.ok()) { std::cerr << "Failed to uncompress input objects." << std::endl; return; }
-      run_segments(src, res, false);
+      if (device_ingest()) { ensure_ingest(~(size_t)0 >> 1); SegmentFeeder feed(src); run_stream(feed, res, false); }
+      else run_segments(src, res, false);
+      return;
+    }
+    if (device_ingest()) {
+      FileFeeder feed(obj);
+      if (!feed.ok()) { std::cerr << "Failed to open " << obj << std::endl; return; }
+      if (feed.first_byte() != '>' && feed.first_byte() != '@') { std::cerr << "Failed to recognize the format of the file." << std::endl; exit(-1); }
+      ensure_ingest((size_t)feed.size());
+      run_stream(feed, res, false);
       return;
     }
     MmapSource src(obj, segment_bytes_);
@@ -546,7 +643,8 @@ void Classifier::run_paired(const std::string& f1, const std::string& f2, const 
                    << " CPU thread(s)." << std::endl;
     PairedSource src(a, b, segment_bytes_);
     if (!src.ok()) { std::cerr << "Failed to open " << merged_name << std::endl; return; }
-    run_segments(src, res, true);
+    if (device_ingest()) { ensure_ingest(~(size_t)0 >> 1); SegmentFeeder feed(src); run_stream(feed, res, true); }
+    else run_segments(src, res, true);
   };
   bool list_mode = false;
   if (file_exists(results)) {
@@ -620,7 +718,7 @@ void Classifier::run_segments(SegmentSource& src, const std::string& results_bas
     std::thread reader([&] {
       try { have_next = src.next(nxt); } catch (const std::exception& ex) { reader_err = ex.what(); }
     });
-    try { process_segment(cur.p, cur.n, paired, fout); } catch (const std::exception& ex) { if (err.empty()) err = ex.what(); }
+    try { n_objects_ += process_segment(cur.p, cur.n, paired, fout); } catch (const std::exception& ex) { if (err.empty()) err = ex.what(); }
     reader.join();
     if (err.empty() && !reader_err.empty()) err = reader_err;
     if (!err.empty()) break;
@@ -639,7 +737,144 @@ void Classifier::run_segments(SegmentSource& src, const std::string& results_bas
   std::cout << " - Results stored in " << csv << std::endl;
 }
 
-void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FILE* fout) {
+// ---- device-ingest streaming ----------------------------------------------------------------------------------------
+bool Classifier::device_ingest() const {
+  return !opt_.extended && !opt_.db_sharded && getenv("MIC_HOST_INGEST") == nullptr;
+}
+
+void Classifier::release_ingest() {
+  for (mic_engine* e : engines_) mic_ingest_free(e);
+  ingest_raw_.clear();
+  ingest_bytes_ = ingest_workers_ = 0;
+}
+
+void Classifier::ensure_ingest(size_t total_bytes) {
+  // one worker (host thread + slot + stream) moves ~30 Mreads/s; eight saturate the link
+  size_t workers = std::min<size_t>(std::max<size_t>(opt_.threads, 1), 16);
+  size_t bytes = 32u << 20;
+  if (const char* env = getenv("MIC_INGEST_MB")) { long v = atol(env); if (v >= 1 && v <= 1024) bytes = (size_t)v << 20; }
+  if (const char* env = getenv("MIC_INGEST_KB")) { long v = atol(env); if (v >= 4) bytes = (size_t)v << 10; }
+  if (const char* env = getenv("MIC_INGEST_WORKERS")) { long v = atol(env); if (v >= 1 && v <= 64) workers = (size_t)v; }
+  // small inputs: do not pin more than the input needs
+  while (bytes > (1u << 20) && total_bytes / workers < bytes / 2) bytes /= 2;
+  if (total_bytes < bytes) workers = 1;
+  if (!ingest_raw_.empty() && bytes <= ingest_bytes_ && workers <= ingest_workers_) return;
+  release_ingest();
+  const size_t n_eng = engines_.size();
+  std::vector<const char*> nm(names_.size());
+  for (size_t t = 0; t < names_.size(); ++t) nm[t] = names_[t].c_str();
+  ingest_raw_.resize(n_eng);
+  for (size_t d = 0; d < n_eng; ++d) {
+    const size_t slots = (workers + n_eng - 1 - d) / n_eng;
+    if (!slots) continue;
+    ingest_raw_[d].resize(slots);
+    check(mic_ingest_alloc(engines_[d], slots, bytes, nm.data(), (uint32_t)names_.size(), 0, ingest_raw_[d].data()), "ingest slots");
+  }
+  ingest_bytes_ = bytes; ingest_workers_ = workers;
+}
+
+void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool paired) {
+  const std::string csv = results_base + ".csv";  // CuCLARK_hh.hh:539-540
+  const int out_fd = open(csv.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0644);
+  if (out_fd == -1) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return; }
+  struct timeval t0, t1;
+  gettimeofday(&t0, nullptr);
+  n_objects_ = 0;
+  uint64_t out_off = 0;
+  {  // header (CuCLARK_hh.hh:1957-1972)
+    std::vector<const char*> nm(names_.size());
+    for (size_t t = 0; t < names_.size(); ++t) nm[t] = names_[t].c_str();
+    char hb[512];
+    const int w = mic_csv_header(hb, sizeof(hb), 0, nm.data(), (uint32_t)names_.size());
+    if (w > 0 && pwrite(out_fd, hb, (size_t)w, 0) == w) out_off = (uint64_t)w;
+  }
+  const size_t n_eng = engines_.size(), workers = ingest_workers_, cap = ingest_bytes_;
+  const size_t want = cap - cap / 8;                  // leaves room for the record that straddles the target
+  std::mutex feed_mu, out_mu, host_mu;
+  std::condition_variable out_cv;
+  size_t next_id = 0, next_out = 0;
+  bool fed_all = false;
+  std::string err;
+  const bool timing = getenv("MIC_CLI_TIMING") != nullptr;
+  std::atomic<size_t> n_fallback{0}, n_batches{0};
+  auto worker = [&](size_t w) {
+    const size_t d = w % n_eng, slot = w / n_eng;
+    uint8_t* raw = ingest_raw_[d][slot];
+    std::string heap, host_csv;
+    for (;;) {
+      Range r; size_t id;
+      {
+        std::lock_guard<std::mutex> lk(feed_mu);
+        if (!err.empty() || fed_all) return;
+        bool more = false;
+        try { more = feed.assign(want, cap, r); } catch (const std::exception& ex) { err = ex.what(); }
+        if (!more) { fed_all = true; return; }
+        id = next_id++;
+      }
+      const char* text = nullptr; size_t text_n = 0, reads = 0;
+      try {
+        const uint8_t* bytes = raw;
+        bool host = r.len > cap;
+        if (!host) {
+          feed.load(r, raw);
+          mic_ingest_result res;
+          check(mic_ingest_classify(engines_[d], slot, r.len, paired ? 1 : 0, &res), "device ingest");
+          if (res.status == MIC_INGEST_OK) { text = res.csv; text_n = (size_t)res.csv_bytes; reads = (size_t)res.n_reads; }
+          else host = true;
+        } else {
+          heap.resize(r.len);
+          feed.load(r, (uint8_t*)&heap[0]);
+          bytes = (const uint8_t*)heap.data();
+        }
+        r.keep.reset();
+        if (host) {   // the host indexer / packer / CSV writer on this batch (rare: one at a time)
+          std::lock_guard<std::mutex> lk(host_mu);
+          ++n_fallback;
+          host_csv.clear();
+          sink_ = &host_csv;
+          try { reads = process_segment(bytes, r.len, paired, nullptr); } catch (...) { sink_ = nullptr; throw; }
+          sink_ = nullptr;
+          text = host_csv.data(); text_n = host_csv.size();
+        }
+      } catch (const std::exception& ex) {
+        std::lock_guard<std::mutex> lk(feed_mu);
+        if (err.empty()) err = ex.what();
+        text_n = 0; reads = 0;
+      }
+      ++n_batches;
+      uint64_t my_off;
+      {
+        std::unique_lock<std::mutex> lk(out_mu);
+        out_cv.wait(lk, [&] { return next_out == id; });
+        my_off = out_off; out_off += text_n; ++next_out;
+        n_objects_ += reads;
+      }
+      out_cv.notify_all();
+      size_t done = 0;
+      while (done < text_n) {
+        const ssize_t n = pwrite(out_fd, text + done, text_n - done, (off_t)(my_off + done));
+        if (n <= 0) { std::lock_guard<std::mutex> lk(feed_mu); if (err.empty()) err = "Failed to write the results file."; break; }
+        done += (size_t)n;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (size_t w = 1; w < workers; ++w) th.emplace_back(worker, w);
+  worker(0);
+  for (auto& t : th) t.join();
+  close(out_fd);
+  release_batches();
+  if (!err.empty()) die(err);
+  gettimeofday(&t1, nullptr);
+  const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
+  if (timing) std::cerr << "[timing] device ingest: " << n_batches << " batches of <= " << (cap >> 10) << " KB on " << workers
+                        << " worker(s), " << n_fallback << " through the host path" << std::endl;
+  std::cout << " - Assignment time: " << diff << " s. Speed: ";  // CuCLARK_hh.hh:1938-1944
+  std::cout << (size_t)(((double)n_objects_) / (diff) * 60.0) << " objects/min. (" << n_objects_ << " objects)." << std::endl;
+  std::cout << " - Results stored in " << csv << std::endl;
+}
+
+size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FILE* fout) {
   struct timeval t0;
   gettimeofday(&t0, nullptr);
   const bool timing = getenv("MIC_CLI_TIMING") != nullptr;
@@ -667,7 +902,6 @@ void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FIL
     cap = (size_t)n_reads;
   }
   const size_t N = (size_t)n_reads;
-  n_objects_ += N;
   lap("index reads");
   const int k = (int)opt_.k;
   const size_t n_eng = engines_.size();
@@ -787,7 +1021,8 @@ void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FIL
     std::lock_guard<std::mutex> lk(wmu);
     ready[b] = 1;
     while (next_write < nb_total && ready[next_write]) {
-      fwrite(out[next_write].data(), 1, out[next_write].size(), fout);
+      if (sink_) sink_->append(out[next_write]);
+      else fwrite(out[next_write].data(), 1, out[next_write].size(), fout);
       std::string().swap(out[next_write]);
       ++next_write;
     }
@@ -798,6 +1033,7 @@ void Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FIL
     std::cerr << "[timing]   thread-seconds: pack " << t_pack << ", copy+query+wait " << t_query << ", format " << t_format
               << ", ordered write " << t_write << std::endl;
   if (!err.empty()) die(err);
+  return N;
 }
 
 }  // namespace mic

@@ -4,7 +4,10 @@
 #define MIC_CLASSIFIER_HPP
 
 #include <stdint.h>
+#include <stdio.h>
 
+#include <atomic>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -48,12 +51,30 @@ class Classifier {
   class SegmentSource { public: virtual ~SegmentSource() {} virtual bool next(Segment& s) = 0; };
   void run_segments(SegmentSource& src, const std::string& results_base, bool paired);
 
+  // Device-ingest streaming (the default for the non-extended CSV): batches of whole records go to the GPU as the bytes
+  // of the file and come back as the bytes of the CSV (mic_ingest_*); host threads only move bytes.  A batch the device
+  // path hands back (MIC_INGEST_FALLBACK) or that does not fit a slot goes through process_segment instead.
+  struct Range { uint64_t off = 0; size_t len = 0; const uint8_t* mem = nullptr; std::shared_ptr<Segment> keep; };
+  class Feeder {            // assign() is called under a lock and hands out consecutive ranges of whole records
+   public:
+    virtual ~Feeder() {}
+    virtual bool assign(size_t want, size_t cap, Range& r) = 0;
+    virtual void load(const Range& r, uint8_t* dst) = 0;     // any thread, no lock held
+  };
+  void run_stream(Feeder& f, const std::string& results_base, bool paired);
+
   std::string db_name() const;  // getdbName, CuCLARK_hh.hh:580-591
   const std::vector<std::string>& target_names() const { return names_; }
 
  private:
   void parse_targets();  // getTargetsData, CuCLARK_hh.hh:1795-1906
-  void process_segment(const uint8_t* map, size_t nb, bool paired, FILE* fout);
+  size_t process_segment(const uint8_t* map, size_t nb, bool paired, FILE* fout);   // returns the number of objects
+  bool device_ingest() const;                 // is the streaming path usable for this run?
+  void ensure_ingest(size_t total_bytes);     // slots sized for the input at hand
+  void release_ingest();
+  std::vector<std::vector<uint8_t*>> ingest_raw_;   // [engine][slot]: pinned input buffers lent by the engines
+  size_t ingest_bytes_ = 0, ingest_workers_ = 0;
+  std::string* sink_ = nullptr;               // process_segment appends here instead of writing to the file
   void ensure_batches(size_t max_reads, size_t max_cont);
   void release_batches();
   struct Lent { uint32_t* results = nullptr; uint32_t* rows = nullptr; std::vector<uint32_t*> rp; std::vector<uint16_t*> ct; };
@@ -66,7 +87,7 @@ class Classifier {
   std::vector<std::pair<std::string, std::string>> targets_id_;
   std::vector<std::string> labels_, labels_c_, names_;
   std::vector<mic_engine*> engines_;
-  size_t n_objects_ = 0;
+  std::atomic<size_t> n_objects_{0};
 };
 
 // file.cc:205-268: merged FASTA text of two FASTQ mates ("seq1" + 'N' + "seq2").

@@ -152,6 +152,14 @@ size_t mic_find_record_start(const uint8_t* map, size_t nb, size_t from) {
   return find_record_start(map, nb, map[0] == '>', from);
 }
 
+// the same on a window of the input whose format is known (win[from - 1] must be inside the window): lets a caller that
+// reads a file in pieces cut it at record starts without mapping it.  A FASTQ candidate whose next two lines do not end
+// inside the window is not accepted (returns nb): read a larger window.
+size_t mic_find_record_start_in(const uint8_t* win, size_t nb, int fasta, size_t from) {
+  if (!win || from == 0 || from > nb) return nb;
+  return find_record_start(win, nb, fasta != 0, from);
+}
+
 // Parallel form of mic_index_reads: the file is cut into `n_threads` byte ranges, each range is indexed from the first
 // record that starts in it.  Same output as the serial function for well-formed FASTA/FASTQ.
 long mic_index_reads_parallel(const uint8_t* map, size_t nb, int n_threads, size_t cap, uint64_t* name_s, uint64_t* name_e,

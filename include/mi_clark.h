@@ -239,6 +239,9 @@ long mic_index_reads_parallel(const uint8_t* map, size_t nb, int n_threads, size
 /* Position of the first record ('>' at a line start; '@' line followed by a letters-only line and a '+' line) at or
  * after byte `from`, or nb: lets callers cut a large input into segments of whole records. */
 size_t mic_find_record_start(const uint8_t* map, size_t nb, size_t from);
+/* The same inside a window win[0, nb) of an input of known format (fasta != 0: FASTA, else FASTQ), from >= 1: position
+ * of the first record start at or after `from`, or nb when the window holds none that can be verified. */
+size_t mic_find_record_start_in(const uint8_t* win, size_t nb, int fasta, size_t from);
 /* Upper bound of containers mic_pack_reads can emit for these reads. */
 size_t mic_pack_bound(const uint64_t* seq_s, const uint64_t* seq_e, size_t n_reads, int k);
 /* Read packer, CuCLARK_hh.hh:1616-1716.  Returns containers written or (size_t)-1 if cap is too small. */

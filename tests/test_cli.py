@@ -315,3 +315,48 @@ def test_db_sharded_cli_matches_golden(tmp_path):
             res.append(open(out + ".csv", "rb").read())
     assert res[0] == res[2] and res[1] == res[3]
     assert res[0].splitlines()[1].startswith(b"all,") and b",L00,5," in res[0].splitlines()[1]
+
+
+@pytest.mark.gpu
+def test_device_ingest_equals_host_ingest_over_many_batches(tmp_path):
+    """The CLI's default path hands batches of raw bytes to the GPU (mic_ingest_*); MIC_HOST_INGEST=1 keeps the host
+    indexer / packer / CSV writer.  Same bytes out for FASTA, FASTQ, gzip, CRLF files, tiny and large batches, several
+    workers, and for input with records the device path hands back (empty names, a 70 kb sequence)."""
+    import gzip
+    import numpy as np
+    import test_ingest as ti
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "light_k27_u32", light=True)
+    t = _targets_file(tmp)
+    rng = np.random.default_rng(11)
+    genomes = ti._genomes()
+    odd = b">\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n>long\n" + genomes[0][:3000] * 24 + b"\n"
+    files = {
+        "a.fq": ti._random_reads(rng, genomes, 6000, fasta=False),
+        "b.fa": ti._random_reads(rng, genomes, 6000, fasta=True),
+        "c.fa": ti._random_reads(rng, genomes, 2000, fasta=True, crlf=True),
+        "d.fa": ti._random_reads(rng, genomes, 1500, fasta=True) + odd + ti._random_reads(rng, genomes, 1500, fasta=True),
+        "e.fq": ti._random_reads(rng, genomes, 3000, fasta=False)[:-1],
+    }
+    for name, data in files.items():
+        open(os.path.join(tmp, name), "wb").write(data)
+    with gzip.open(os.path.join(tmp, "a.fq.gz"), "wb") as f:
+        f.write(files["a.fq"])
+    for name in list(files) + ["a.fq.gz"]:
+        src = os.path.join(tmp, name)
+        ref = os.path.join(tmp, "host_" + name)
+        r = _run([EXE_L, "-T", t, "-D", d, "-O", src, "-R", ref, "-n", "4"], env=dict(os.environ, MIC_HOST_INGEST="1"))
+        assert r.returncode == 0, r.stderr
+        n_obj = re.search(r"\((\d+) objects\)", r.stdout).group(1)
+        for kb, n in (("16", "4"), ("300", "3"), ("0", "1")):
+            out = os.path.join(tmp, f"dev{kb}_{name}")
+            env = dict(os.environ, MIC_CLI_TIMING="1")
+            if kb != "0":
+                env["MIC_INGEST_KB"] = kb
+            r = _run([EXE_L, "-T", t, "-D", d, "-O", src, "-R", out, "-n", n], env=env)
+            assert r.returncode == 0, r.stderr
+            assert f"({n_obj} objects)" in r.stdout
+            assert "device ingest:" in r.stderr
+            if name == "d.fa":
+                assert re.search(r", [1-9]\d* through the host path", r.stderr), r.stderr
+            assert open(out + ".csv", "rb").read() == open(ref + ".csv", "rb").read(), (name, kb)
