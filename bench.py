@@ -20,6 +20,12 @@ Multi-GPU (one process per GPU, launched with torch.distributed.run):
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch / mean kernel time measured with HIP
 events on the kernel's stream; `cpu_baseline` = the CPU oracle (oracle/, a port of the reference's CPU path) timed on
 this box's host cores on a bounded sample, and that sample doubles as a bit-exact parity check of the GPU results.
+
+At N=1 two more legs are measured on the same workload and reported next to `value` (SURVEY.md §8d "what to time"):
+  "pipeline"    the batch API (mic_batches_alloc / ready / query / wait): packed reads in pinned host memory -> H2D ->
+                kernel -> D2H of the result rows, batches overlapped on their streams; Mreads/s and PCIe GB/s.
+  "end_to_end"  exe/cuCLARK on files: the table written as .sz/.ky/.lb, the same reads as a FASTQ file, results as CSV
+                (device-side ingest: DESIGN.md §5.2); the reference's own "Assignment time ... objects/min" line.
 """
 import argparse
 import ctypes as C
@@ -56,6 +62,126 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pipeline_leg(eng, L, d_rp, d_cont, n_reads, res_expect, steps, nb):
+    """the device pipeline through the batch API.  Packed reads sit in the engine's pinned host buffers
+    (as CuCLARK's packer leaves them, CuCLARK_hh.hh:1616-1716); a step = every batch submitted (H2D + kernel + D2H of the
+    result rows on its own stream, CuClarkDB.cu:878-1033) and then awaited."""
+    rp = d_rp.cpu().numpy().view(np.uint32)
+    cont = d_cont.cpu().numpy().view(np.uint16)
+    per = (n_reads + nb - 1) // nb
+    cuts = [min(n_reads, b * per) for b in range(nb + 1)]
+    max_cont = max(int(rp[cuts[b + 1]] - rp[cuts[b]]) for b in range(nb)) + 64
+    bufs = eng.malloc(n_reads, per, max_cont, cuts)
+    n_cont = []
+    for b in range(nb):
+        lo, hi = cuts[b], cuts[b + 1]
+        c0, c1 = int(rp[lo]), int(rp[hi])
+        bufs["reads_pointer"][b][: hi - lo + 1] = rp[lo:hi + 1] - rp[lo]
+        bufs["containers"][b][: c1 - c0] = cont[c0:c1]
+        n_cont.append(c1 - c0)
+
+    def step():
+        for b in range(nb):
+            eng.readyBatch(b, cuts[b + 1] - cuts[b], n_cont[b])
+            eng.queryBatch(b)
+        for b in range(nb):
+            eng.waitForBatch(b)
+    step()
+    equal = bool((bufs["results"][:, :5] == res_expect[:, :5]).all())
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    h2d = sum((cuts[b + 1] - cuts[b] + 1) * 4 + (n_cont[b] + 16) * 2 for b in range(nb))
+    d2h = n_reads * 32
+    eng.freeBatchMemory()
+    return {"value": round(n_reads / dt / 1e6, 1), "unit": "Mreads/s", "ms_per_pass": round(dt * 1e3, 3), "batches": nb, "steps": steps,
+            "h2d_GBs": round(h2d / dt / 1e9, 1), "d2h_GBs": round(d2h / dt / 1e9, 1),
+            "bytes_per_read": {"h2d": round(h2d / n_reads, 1), "d2h": 32},
+            "what": "packed reads in pinned host memory -> H2D -> query kernel -> D2H of the 32-byte result rows, per-batch streams "
+                    "(mic_batches_alloc / mic_batch_ready / mic_batch_query / mic_batch_wait)",
+            "results_equal_device_path": equal}
+
+
+def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res_expect, truth, threads, keep=False):
+    """files in, file out, through exe/cuCLARK (reference: CuCLARK_hh.hh:550-563 times index + pack +
+    GPU + CSV and prints objects/min, :1938-1944).  The table goes to disk in the reference's format, the same reads as
+    FASTQ; the binary loads the table, classifies, writes the CSV.  Checked: every CSV line against the kernel's result
+    rows of the same reads."""
+    import shutil
+    import subprocess
+    import tempfile
+    k, T = w["k"], w["n_targets"]
+    tmp = tempfile.mkdtemp(prefix="mic_e2e_", dir=os.environ.get("MIC_BENCH_TMP", "/tmp"))
+    out = {}
+    try:
+        t0 = time.time()
+        dbdir = os.path.join(tmp, "DB")
+        os.makedirs(dbdir)
+        base = os.path.join(dbdir, f"db_central_k{k}_t{T}_s{w['htsize']}_m0.tsk")
+        d_sizes.cpu().numpy().tofile(base + ".sz")
+        CH = 1 << 30
+        for arr, ext in ((d_keys, ".ky"), (d_labels, ".lb")):
+            with open(base + ext, "wb") as f:
+                for o in range(0, n_el, CH):
+                    arr[o:min(n_el, o + CH)].cpu().numpy().tofile(f)
+        dummy = os.path.join(tmp, "genome.fa")
+        open(dummy, "w").write(">g\nACGT\n")
+        with open(os.path.join(tmp, "targets.txt"), "w") as f:
+            for t in range(T):
+                f.write(f"{dummy} TARGET_{t:05d}\n")
+        rec = int(L.mic_synth_text_record_bytes(read_len, 0))
+        d_text = torch.empty(n_reads * rec, dtype=torch.uint8, device=d_sizes.device)
+        rc = L.mic_synth_reads_text_device(C.byref(spec), 5, n_reads, read_len, 0.2, 0.01, 0.001, 0, -1, d_text.data_ptr(), d_text.numel(), None)
+        assert rc == 0, f"mic_synth_reads_text_device failed ({rc})"
+        torch.cuda.synchronize()
+        fq = os.path.join(tmp, "reads.fq")
+        d_text.cpu().numpy().tofile(fq)
+        del d_text
+        t_files = time.time() - t0
+        exe = os.path.join(ROOT, "exe", "cuCLARK")
+        res_base = os.path.join(tmp, "out")
+        cmd = [exe, "-k", str(k), "--htsize", str(w["htsize"]), "-T", os.path.join(tmp, "targets.txt"), "-D", dbdir, "-O", fq, "-R", res_base,
+               "-n", str(threads)]
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MIC_CLI_TIMING="1", MIC_LOAD_TIMING="1"))
+        wall = time.time() - t0
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        import re
+        m = re.search(r"Assignment time: ([0-9.eE+-]+) s\. Speed: (\d+) objects/min\. \((\d+) objects\)", r.stdout)
+        t_assign, opm, n_obj = float(m.group(1)), int(m.group(2)), int(m.group(3))
+        ing = re.search(r"device ingest: (\d+) batches of <= (\d+) KB on (\d+) worker\(s\), (\d+) through the host path", r.stderr)
+        load = sum(float(x) for x in re.findall(r"\[load\] [^:]+: ([0-9.]+) s", r.stderr))
+        # every CSV line against the kernel's rows of the same reads
+        import pandas as pd
+        names = np.array(["NA"] + [f"TARGET_{t:05d}" for t in range(T)])
+        df = pd.read_csv(res_base + ".csv", keep_default_na=False, usecols=["Object_ID", "Length", "1st_assignment", "score1", "2nd_assignment", "score2"],
+                         dtype={"Object_ID": str, "Length": np.uint32, "1st_assignment": str, "score1": np.uint32, "2nd_assignment": str, "score2": np.uint32})
+        lines = len(df)
+        ok = lines == n_reads
+        if ok:
+            e = res_expect[:n_reads]
+            ok = bool((df["1st_assignment"].to_numpy() == names[e[:, 1]]).all() and (df["score1"].to_numpy() == e[:, 2]).all() and
+                      (df["2nd_assignment"].to_numpy() == names[e[:, 3]]).all() and (df["score2"].to_numpy() == e[:, 4]).all() and
+                      (df["Length"].to_numpy() == read_len).all() and df["Object_ID"].iloc[0] == "r000000000" and
+                      df["Object_ID"].iloc[-1] == f"r{n_reads - 1:09d}")
+        del df
+        fq_bytes = os.path.getsize(fq)
+        out = {"value": round(n_obj / t_assign / 1e6, 1), "unit": "Mreads/s", "objects_per_min": opm, "objects": n_obj,
+               "assignment_s": round(t_assign, 4), "process_wall_s": round(wall, 2), "table_load_s": round(load, 2),
+               "input": f"FASTQ, {fq_bytes / n_reads:.0f} bytes per record, {fq_bytes / 1e9:.2f} GB in the page cache",
+               "input_GBs": round(fq_bytes / t_assign / 1e9, 1), "csv_MB": round(os.path.getsize(res_base + ".csv") / 1e6, 1),
+               "host_threads": threads, "ingest": ({"batches": int(ing.group(1)), "slot_KB": int(ing.group(2)), "workers": int(ing.group(3)),
+                                                    "batches_through_host_path": int(ing.group(4))} if ing else None),
+               "command": "exe/cuCLARK -k 31 -T targets.txt -D DB/ -O reads.fq -R out -n %d" % threads,
+               "csv_lines_equal_kernel_rows": bool(ok and lines == n_reads), "setup_files_s": round(t_files, 1)}
+    finally:
+        if not keep:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +195,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the row exchange through host memory (validation on a box with fewer GPUs than ranks)")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the batch-API pipeline leg (N=1)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the files-in, CSV-out leg through exe/cuCLARK (N=1)")
+    ap.add_argument("--e2e-threads", type=int, default=8, help="-n of the end-to-end run")
     ap.add_argument("--no-db-leg", action="store_true",
                     help="N > 1, read mode: skip the extra table-sharded measurement reported as \"table_sharded\"")
     args = ap.parse_args()
@@ -115,7 +244,8 @@ def main():
 
     # ---- resident slot table (whole table, or this rank's bucket range in db mode)
     row_words = 16
-    eng = MiClarkDB(k, T, device=local_rank, row_words=row_words)
+    PIPE_BATCHES = 8
+    eng = MiClarkDB(k, T, num_batches=PIPE_BATCHES, device=local_rank, row_words=row_words)
     shard = (0, 0)
     if args.mode == "db" and world > 1:
         shard = multi.shard_range(w["htsize"], world, rank)
@@ -209,23 +339,39 @@ def main():
     achieved = alg_bytes / kern_s / 1e9
     # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, tools/profile_bench.sh); the
     # counters cannot be read from inside this process, so the committed summary of the same workload is used.
-    traffic, traffic_src, rdreq = None, None, None
+    traffic, traffic_src, rdreq, traffic_note = None, None, None, None
     import glob
+    kname = {1: "query_kernel<", 2: "query_kernel_m<", 3: "query_kernel_s<"}[info["layout"]]
+    if info["layout"] == 3:      # the instantiation the launcher picks (mic_kernels.hip: mic_launch_query)
+        km = (k, info["minimizer_len"]) if (k in (31, 27, 32) and info["minimizer_len"] == 20) else (0, 0)
+        kname = f"query_kernel_s<{km[0]}, {km[1]}, {'true' if db_mode else 'false'}>"
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_query_kernel.json")), reverse=True):
         try:
             pj = json.load(open(f))
         except Exception:
             continue
-        if (pj.get("workload") == w["name"] and pj.get("reads_per_launch") == n_reads and pj.get("layout") == info["layout"]
-                and not db_mode):
-            traffic = (pj["fetch_bytes_per_launch"] + pj["write_bytes_per_launch"]) / kern_s / 1e9
-            rdreq = pj["pmc_per_launch"].get("TCC_EA0_RDREQ_sum")
-            traffic_src = os.path.basename(f)
-            break
+        if not (pj.get("workload") == w["name"] and pj.get("reads_per_launch") == n_reads and pj.get("layout") == info["layout"]):
+            continue
+        # a committed counter profile is only used for the kernel it was taken on: same instantiation, and its rocprofv3
+        # average within 3 % of the duration just measured
+        off = abs(pj.get("rocprof_avg_ms", 0) / (kern_s * 1e3) - 1)
+        if kname not in pj.get("kernel", ""):
+            traffic_note = f"{os.path.basename(f)} was taken on '{pj.get('kernel', '?')[:60]}', this run timed '{kname}'"
+            continue
+        if off > 0.03:
+            traffic_note = f"{os.path.basename(f)}: rocprofv3 average {pj.get('rocprof_avg_ms', 0):.3f} ms is {off * 100:.1f} % off the {kern_s * 1e3:.3f} ms measured now"
+            continue
+        traffic = (pj["fetch_bytes_per_launch"] + pj["write_bytes_per_launch"]) / kern_s / 1e9
+        rdreq = pj["pmc_per_launch"].get("TCC_EA0_RDREQ_sum")
+        traffic_src = os.path.basename(f)
+        traffic_note = None
+        break
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": round(traffic, 1) if traffic else None,
-                "traffic_source": traffic_src,
-                "kernel": {1: "query_kernel", 2: "query_kernel_m", 3: "query_kernel_s"}[info["layout"]], "kernel_ms": round(kern_s * 1e3, 3),
+                "traffic_source": traffic_src, "traffic_note": traffic_note,
+                "achieved_is": "algorithmic bytes of the reference's layout (SURVEY.md 8d: 8 + key bytes x probed bucket + 2 x hit rate "
+                               "per k-mer, + packed read in + result row out) / kernel time; 'traffic' is what the counters saw",
+                "kernel": kname, "kernel_ms": round(kern_s * 1e3, 3),
                 "algorithmic_bytes_per_kmer": round(bytes_per_kmer, 2), "kmers_per_launch": st["kmers"],
                 "probes_per_launch": st["probed"], "hit_rate": round(h, 4), "mean_probed_bucket_len": round(lam_q, 3),
                 "probes_per_s_G": round(st["probed"] / kern_s / 1e9, 2),
@@ -278,6 +424,25 @@ def main():
                          f"({t_copy:.0f} s copy+prefix sums, not timed); {t_cpu:.2f} s wall",
                "objects_per_min": int(ns / t_cpu * 60), "parity_with_gpu_on_sample": equal}
         assert equal, "GPU results differ from the CPU oracle on the sample"
+
+    # ---- N = 1: the pipeline through the batch API and the end-to-end run through the CLI (SURVEY.md 8d ii, iii) -------
+    pipeline, e2e = None, None
+    if rank == 0 and world == 1:
+        if not args.no_pipeline:
+            try:
+                pipeline = pipeline_leg(eng, L, d_rp, d_cont, n_reads, res, max(2, min(args.steps, 5)), PIPE_BATCHES)
+            except Exception as ex:
+                pipeline = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            log("pipeline:", json.dumps(pipeline))
+        if not args.no_e2e:
+            try:
+                eng.close()              # the CLI builds its own resident table from the files
+                del d_res, d_cont, d_rp
+                torch.cuda.empty_cache()
+                e2e = end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res, truth, args.e2e_threads)
+            except Exception as ex:
+                e2e = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            log("end_to_end:", json.dumps(e2e))
 
     # ---- N > 1, read mode: the reference's own multi-GPU layout as a second, separate measurement --------------------
     # (BASELINE.json configs[3]): the table is re-built as this rank's bucket range, every rank probes the SAME reads,
@@ -364,6 +529,10 @@ def main():
                        "setup_s": {"synth_db": round(t_gen, 1), "table_build": round(t_build, 1)}},
             "roofline": roofline, "cpu_baseline": cpu, "known_answer": known,
         }
+        if pipeline is not None:
+            out["pipeline"] = pipeline
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if table_sharded is not None:
             out["table_sharded"] = table_sharded
         print(json.dumps(out), flush=True)

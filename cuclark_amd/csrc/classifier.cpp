@@ -148,10 +148,23 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
     mic_engine* e = nullptr;
     check(mic_create(&cfg, &e), "engine creation");
     engines_.push_back(e);
-    const uint64_t s0 = opt_.db_sharded ? htsize * d / use : 0, s1 = opt_.db_sharded ? htsize * (d + 1) / use : 0;
-    int rc = mic_db_load_files(e, db.c_str(), 0, opt_.sampling, s0, s1);
-    if (rc != MIC_OK) die(std::string("Failed to load the database: ") + mic_last_error());
   }
+  // the ingest slots (pinned and device buffers of the streaming path) are set up while the database loads
+  std::thread slots;
+  if (device_ingest() && !opt_.objects.empty()) {
+    size_t bytes = ~(size_t)0 >> 1;
+    struct stat st;
+    if (opt_.objects2.empty() && !is_gzip(opt_.objects) && stat(opt_.objects.c_str(), &st) == 0) bytes = (size_t)st.st_size;
+    slots = std::thread([this, bytes] { try { ensure_ingest(bytes); } catch (const std::exception&) { release_ingest(); } });
+  }
+  std::string load_err;
+  for (size_t d = 0; d < use && load_err.empty(); ++d) {
+    const uint64_t s0 = opt_.db_sharded ? htsize * d / use : 0, s1 = opt_.db_sharded ? htsize * (d + 1) / use : 0;
+    int rc = mic_db_load_files(engines_[d], db.c_str(), 0, opt_.sampling, s0, s1);
+    if (rc != MIC_OK) load_err = std::string("Failed to load the database: ") + mic_last_error();
+  }
+  if (slots.joinable()) slots.join();
+  if (!load_err.empty()) die(load_err);
   mic_db_info info;
   check(mic_db_get_info(engines_[0], &info), "db info");
   std::cerr << "Total DB size in HBM:\t" << info.hbm_bytes / 1000000 / 1000.0 << " GB (" << info.n_elems << " k-mers, "
@@ -593,7 +606,7 @@ void Classifier::run(const std::string& objects, const std::string& results) {
     if (is_gzip(obj)) {
       GzSource src(obj, segment_bytes_);
       if (!src.ok()) { std::cerr << "Failed to uncompress input objects." << std::endl; return; }
-      if (device_ingest()) { ensure_ingest(~(size_t)0 >> 1); SegmentFeeder feed(src); run_stream(feed, res, false); }
+      if (device_ingest()) { SegmentFeeder feed(src); run_stream(feed, res, false, ~(size_t)0 >> 1); }
       else run_segments(src, res, false);
       return;
     }
@@ -601,8 +614,7 @@ void Classifier::run(const std::string& objects, const std::string& results) {
       FileFeeder feed(obj);
       if (!feed.ok()) { std::cerr << "Failed to open " << obj << std::endl; return; }
       if (feed.first_byte() != '>' && feed.first_byte() != '@') { std::cerr << "Failed to recognize the format of the file." << std::endl; exit(-1); }
-      ensure_ingest((size_t)feed.size());
-      run_stream(feed, res, false);
+      run_stream(feed, res, false, (size_t)feed.size());
       return;
     }
     MmapSource src(obj, segment_bytes_);
@@ -643,7 +655,7 @@ void Classifier::run_paired(const std::string& f1, const std::string& f2, const 
                    << " CPU thread(s)." << std::endl;
     PairedSource src(a, b, segment_bytes_);
     if (!src.ok()) { std::cerr << "Failed to open " << merged_name << std::endl; return; }
-    if (device_ingest()) { ensure_ingest(~(size_t)0 >> 1); SegmentFeeder feed(src); run_stream(feed, res, true); }
+    if (device_ingest()) { SegmentFeeder feed(src); run_stream(feed, res, true, ~(size_t)0 >> 1); }
     else run_segments(src, res, true);
   };
   bool list_mode = false;
@@ -773,12 +785,13 @@ void Classifier::ensure_ingest(size_t total_bytes) {
   ingest_bytes_ = bytes; ingest_workers_ = workers;
 }
 
-void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool paired) {
+void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool paired, size_t total_bytes) {
   const std::string csv = results_base + ".csv";  // CuCLARK_hh.hh:539-540
   const int out_fd = open(csv.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0644);
   if (out_fd == -1) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return; }
   struct timeval t0, t1;
   gettimeofday(&t0, nullptr);
+  ensure_ingest(total_bytes);          // inside the timed region, like the reference's CuClarkDB::malloc (CuCLARK_hh.hh:1600-1606)
   n_objects_ = 0;
   uint64_t out_off = 0;
   {  // header (CuCLARK_hh.hh:1957-1972)
@@ -797,6 +810,8 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
   std::string err;
   const bool timing = getenv("MIC_CLI_TIMING") != nullptr;
   std::atomic<size_t> n_fallback{0}, n_batches{0};
+  std::atomic<uint64_t> us_load{0}, us_dev{0}, us_order{0}, us_write{0};    // MIC_CLI_TIMING: thread-microseconds per stage
+  auto now_us = [] { struct timeval t; gettimeofday(&t, nullptr); return (uint64_t)t.tv_sec * 1000000u + (uint64_t)t.tv_usec; };
   auto worker = [&](size_t w) {
     const size_t d = w % n_eng, slot = w / n_eng;
     uint8_t* raw = ingest_raw_[d][slot];
@@ -816,9 +831,12 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
         const uint8_t* bytes = raw;
         bool host = r.len > cap;
         if (!host) {
+          const uint64_t ta = timing ? now_us() : 0;
           feed.load(r, raw);
+          const uint64_t tb = timing ? now_us() : 0;
           mic_ingest_result res;
           check(mic_ingest_classify(engines_[d], slot, r.len, paired ? 1 : 0, &res), "device ingest");
+          if (timing) { us_load += tb - ta; us_dev += now_us() - tb; }
           if (res.status == MIC_INGEST_OK) { text = res.csv; text_n = (size_t)res.csv_bytes; reads = (size_t)res.n_reads; }
           else host = true;
         } else {
@@ -843,6 +861,7 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
       }
       ++n_batches;
       uint64_t my_off;
+      const uint64_t tc = timing ? now_us() : 0;
       {
         std::unique_lock<std::mutex> lk(out_mu);
         out_cv.wait(lk, [&] { return next_out == id; });
@@ -850,12 +869,14 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
         n_objects_ += reads;
       }
       out_cv.notify_all();
+      const uint64_t td = timing ? now_us() : 0;
       size_t done = 0;
       while (done < text_n) {
         const ssize_t n = pwrite(out_fd, text + done, text_n - done, (off_t)(my_off + done));
         if (n <= 0) { std::lock_guard<std::mutex> lk(feed_mu); if (err.empty()) err = "Failed to write the results file."; break; }
         done += (size_t)n;
       }
+      if (timing) { us_order += td - tc; us_write += now_us() - td; }
     }
   };
   std::vector<std::thread> th;
@@ -868,7 +889,8 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
   gettimeofday(&t1, nullptr);
   const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
   if (timing) std::cerr << "[timing] device ingest: " << n_batches << " batches of <= " << (cap >> 10) << " KB on " << workers
-                        << " worker(s), " << n_fallback << " through the host path" << std::endl;
+                        << " worker(s), " << n_fallback << " through the host path; thread-seconds: file -> pinned " << us_load / 1e6
+                        << ", device " << us_dev / 1e6 << ", wait for turn " << us_order / 1e6 << ", pinned -> file " << us_write / 1e6 << std::endl;
   std::cout << " - Assignment time: " << diff << " s. Speed: ";  // CuCLARK_hh.hh:1938-1944
   std::cout << (size_t)(((double)n_objects_) / (diff) * 60.0) << " objects/min. (" << n_objects_ << " objects)." << std::endl;
   std::cout << " - Results stored in " << csv << std::endl;

@@ -61,7 +61,7 @@ class Classifier {
     virtual bool assign(size_t want, size_t cap, Range& r) = 0;
     virtual void load(const Range& r, uint8_t* dst) = 0;     // any thread, no lock held
   };
-  void run_stream(Feeder& f, const std::string& results_base, bool paired);
+  void run_stream(Feeder& f, const std::string& results_base, bool paired, size_t total_bytes);
 
   std::string db_name() const;  // getdbName, CuCLARK_hh.hh:580-591
   const std::vector<std::string>& target_names() const { return names_; }

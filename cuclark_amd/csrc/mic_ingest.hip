@@ -23,6 +23,8 @@
 #include <string.h>
 #include <time.h>
 
+#include <string>
+#include <thread>
 #include <vector>
 
 struct mic_engine;
@@ -362,22 +364,67 @@ const uint32_t kFlaggedCapI = 1024;
 #define ITRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     return mic_set_error(e_ == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 
-template <typename T>
-int dev_alloc(Slot& s, T** p, size_t n) {
-  void* q = nullptr;
-  hipError_t e = hipMalloc(&q, n * sizeof(T) + 64);
-  if (e != hipSuccess) return mic_set_error(MIC_E_NOMEM, "ingest slot allocation of %zu bytes: %s", n * sizeof(T), hipGetErrorString(e));
-  s.dev_allocs.push_back(q);
-  *p = (T*)q;
-  return MIC_OK;
+// A slot is ONE device allocation and ONE pinned allocation carved into its arrays (a few hundred hipMalloc /
+// hipHostMalloc calls cost more than the first batches take): pass 1 adds the sizes up, pass 2 hands the pieces out.
+struct Arena {
+  char* base = nullptr; size_t off = 0;
+  template <typename T> void take(T** p, size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    if (base) *p = (T*)(base + off);
+    off += n * sizeof(T) + 64;
+  }
+};
+
+void carve_slot(Ingest* g, Slot& s, Arena& dv, Arena& hs, size_t tmp) {
+  hs.take(&s.h_raw, g->max_bytes + 64);
+  hs.take(&s.h_csv, g->csv_cap);
+  hs.take(&s.h_hdr, (size_t)H_WORDS);
+  if (g->want_results) hs.take(&s.h_results, g->max_reads * 8);
+  dv.take(&s.d_raw, g->max_bytes + 64);
+  dv.take(&s.d_tile, g->max_tiles + 1);
+  dv.take(&s.d_tile_off, g->max_tiles + 1);
+  dv.take(&s.d_line_start, g->max_lines + 2);
+  dv.take(&s.d_flag, g->max_lines + 2);
+  dv.take(&s.d_rec_of_line, g->max_lines + 2);
+  dv.take(&s.d_hdr_line, g->max_reads + 2);
+  dv.take(&s.rec.name_s, g->max_reads + 1);
+  dv.take(&s.rec.seq_s, g->max_reads + 1);
+  dv.take(&s.rec.seq_e, g->max_reads + 1);
+  dv.take(&s.rec.length, g->max_reads + 1);
+  dv.take(&s.rec.bound, g->max_reads + 1);
+  dv.take(&s.rec.name_len, g->max_reads + 1);
+  dv.take(&s.d_rp, g->max_reads + 2);
+  dv.take(&s.d_cont, g->cont_cap + 192);
+  dv.take(&s.d_results, (g->max_reads + 1) * 8);
+  dv.take(&s.d_flagged, (size_t)kFlaggedCapI + 1);
+  dv.take(&s.d_line_len, g->max_reads + 1);
+  dv.take(&s.d_line_off, g->max_reads + 1);
+  dv.take(&s.d_csv, g->csv_cap);
+  dv.take(&s.d_hdr, (size_t)H_WORDS);
+  dv.take((char**)&s.d_tmp, tmp);
+  s.tmp_bytes = tmp;
 }
-template <typename T>
-int host_alloc(Slot& s, T** p, size_t n) {
-  void* q = nullptr;
-  hipError_t e = hipHostMalloc(&q, n * sizeof(T) + 64, hipHostMallocDefault);
-  if (e != hipSuccess) return mic_set_error(MIC_E_NOMEM, "ingest pinned allocation of %zu bytes: %s", n * sizeof(T), hipGetErrorString(e));
-  s.host_allocs.push_back(q);
-  *p = (T*)q;
+
+int alloc_slot(Ingest* g, Slot& s, size_t tmp, int device) {
+  if (hipSetDevice(device) != hipSuccess) return mic_set_error(MIC_E_HIP, "hipSetDevice failed");
+  Arena dv, hs;
+  carve_slot(g, s, dv, hs, tmp);
+  void* d = nullptr; void* h = nullptr;
+  hipError_t e = hipMalloc(&d, dv.off + 256);
+  if (e != hipSuccess) return mic_set_error(MIC_E_NOMEM, "ingest slot: %zu bytes of device memory: %s", dv.off, hipGetErrorString(e));
+  s.dev_allocs.push_back(d);
+  e = hipHostMalloc(&h, hs.off + 256, hipHostMallocDefault);
+  if (e != hipSuccess) return mic_set_error(MIC_E_NOMEM, "ingest slot: %zu bytes of pinned memory: %s", hs.off, hipGetErrorString(e));
+  s.host_allocs.push_back(h);
+  Arena dv2, hs2;
+  dv2.base = (char*)d; hs2.base = (char*)h;
+  carve_slot(g, s, dv2, hs2, tmp);
+  if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)) != hipSuccess ||
+      // the query kernel's read-ahead looks past the last read of a batch: no stale length slots there
+      (e = hipMemsetAsync(s.d_cont, 0, (g->cont_cap + 192) * 2, s.stream)) != hipSuccess ||
+      (e = hipStreamSynchronize(s.stream)) != hipSuccess)
+    return mic_set_error(MIC_E_HIP, "ingest slot setup: %s", hipGetErrorString(e));
   return MIC_OK;
 }
 
@@ -443,41 +490,18 @@ int mic_ingest_alloc(mic_engine* e, size_t n_slots, size_t max_bytes, const char
   hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(g->max_lines + 1));
   hipcub::DeviceScan::ExclusiveSum(nullptr, tmp3, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(g->max_reads + 1));
   const size_t tmp = std::max(tmp1, std::max(tmp2, tmp3)) + 256;
-  for (size_t i = 0; i < n_slots; ++i) {
-    Slot& s = g->slots[i];
-    if ((rc = host_alloc(s, &s.h_raw, g->max_bytes + 64))) return rc;
-    if ((rc = host_alloc(s, &s.h_csv, g->csv_cap))) return rc;
-    if ((rc = host_alloc(s, &s.h_hdr, (size_t)H_WORDS))) return rc;
-    if (want_results && (rc = host_alloc(s, &s.h_results, g->max_reads * 8))) return rc;
-    if ((rc = dev_alloc(s, &s.d_raw, g->max_bytes + 64))) return rc;
-    if ((rc = dev_alloc(s, &s.d_tile, g->max_tiles + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.d_tile_off, g->max_tiles + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.d_line_start, g->max_lines + 2))) return rc;
-    if ((rc = dev_alloc(s, &s.d_flag, g->max_lines + 2))) return rc;
-    if ((rc = dev_alloc(s, &s.d_rec_of_line, g->max_lines + 2))) return rc;
-    if ((rc = dev_alloc(s, &s.d_hdr_line, g->max_reads + 2))) return rc;
-    if ((rc = dev_alloc(s, &s.rec.name_s, g->max_reads + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.rec.seq_s, g->max_reads + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.rec.seq_e, g->max_reads + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.rec.length, g->max_reads + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.rec.bound, g->max_reads + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.rec.name_len, g->max_reads + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.d_rp, g->max_reads + 2))) return rc;
-    if ((rc = dev_alloc(s, &s.d_cont, g->cont_cap + 128))) return rc;
-    if ((rc = dev_alloc(s, &s.d_results, (g->max_reads + 1) * 8))) return rc;
-    if ((rc = dev_alloc(s, &s.d_flagged, (size_t)kFlaggedCapI + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.d_line_len, g->max_reads + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.d_line_off, g->max_reads + 1))) return rc;
-    if ((rc = dev_alloc(s, &s.d_csv, g->csv_cap))) return rc;
-    if ((rc = dev_alloc(s, &s.d_hdr, (size_t)H_WORDS))) return rc;
-    if ((rc = dev_alloc(s, (char**)&s.d_tmp, tmp))) return rc;
-    s.tmp_bytes = tmp;
-    ITRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    ITRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
-    ITRY(hipMemsetAsync(s.d_cont, 0, (g->cont_cap + 128) * 2 + 64, s.stream));   // the query kernel's read-ahead looks past the last read
-    raw[i] = s.h_raw;
+  {  // slots are set up concurrently: pinning host pages is the slow part
+    std::vector<int> rcs(n_slots, MIC_OK);
+    std::vector<std::string> msgs(n_slots);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < n_slots; ++i)
+      th.emplace_back([&, i] { rcs[i] = alloc_slot(g, g->slots[i], tmp, dev); if (rcs[i]) msgs[i] = mic_last_error(); });
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < n_slots; ++i) {
+      if (rcs[i]) return mic_set_error(rcs[i], "%s", msgs[i].c_str());
+      raw[i] = g->slots[i].h_raw;
+    }
   }
-  for (Slot& s : g->slots) ITRY(hipStreamSynchronize(s.stream));
   return MIC_OK;
 }
 

@@ -194,6 +194,51 @@ __global__ void reads_kernel(ReadGen rg, size_t n_reads, uint32_t* __restrict__ 
   if (truth) { truth[2 * r] = rnd ? 0 : (uint32_t)(g % rg.n_targets) + 1; truth[2 * r + 1] = expect; }
 }
 
+// The same reads (same seeds: nucleotide for nucleotide what reads_kernel packs) as FASTQ / FASTA text, one record of
+// fixed size per read: "@r<9 digits>\n" SEQ "\n+\n" QUAL "\n" (2 L + 16 bytes) or ">r<9 digits>\n" SEQ "\n" (L + 13); an N
+// where reads_kernel ends a part.  mate != 0: the reverse strand of the stretch that FOLLOWS the read in its genome (the
+// second read of a pair; random reads get an independent random mate).
+__global__ void reads_text_kernel(ReadGen rg, size_t n_reads, int fasta, int mate, uint8_t* __restrict__ text) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const uint32_t L = rg.read_len;
+  const size_t rec = fasta ? (size_t)L + 13 : 2 * (size_t)L + 16;
+  uint8_t* out = text + r * rec;
+  const uint64_t h0 = mix64(rg.read_seed * 0x9E3779B97F4A7C15ULL + r);
+  const bool rnd = (uint32_t)h0 < rg.random_thr;
+  const uint64_t h1 = mix64(h0 + 1), h2 = mix64(h0 + 2);
+  const uint64_t g = h1 % rg.n_genomes;
+  const uint64_t span = mate >= 0 ? 2ull * L : L;            // pairs are drawn from a stretch of two read lengths
+  const uint64_t p0 = h2 % (rg.genome_len - span + 1);
+  const bool rev = (h0 >> 40) & 1;
+  size_t w = 0;
+  out[w++] = fasta ? '>' : '@'; out[w++] = 'r';
+  { uint32_t v = (uint32_t)(r % 1000000000u); for (int i = 8; i >= 0; --i) { out[w + i] = (uint8_t)('0' + v % 10); v /= 10; } w += 9; }
+  out[w++] = '\n';
+  for (uint32_t i = 0; i < L; ++i) {
+    const uint64_t hb = mix64((mate > 0 ? h0 + 0x51ED27ULL : h0) ^ (0xABCD0000ULL + i));
+    uint32_t nt;
+    if (rnd) nt = (uint32_t)(hb & 3);
+    else {
+      // fragment [p0, p0 + span) read from its `rev` strand: mate 0 = its first L nt, mate 1 = the reverse complement of its last L
+      const uint64_t q = mate > 0 ? (rev ? p0 + i : p0 + span - 1 - i) : (rev ? p0 + span - 1 - i : p0 + i);
+      const bool rc = mate > 0 ? !rev : rev;
+      nt = genome_nt(rg.seed, g, q);
+      if (rc) nt = 3u - nt;
+      if ((uint32_t)(hb >> 32) < rg.sub_thr) nt = (nt + 1 + (uint32_t)((hb >> 8) % 3)) & 3u;
+    }
+    uint8_t c = "TGCA"[nt];
+    if ((uint32_t)(mix64(hb) >> 32) < rg.n_thr) c = 'N';
+    out[w++] = c;
+  }
+  out[w++] = '\n';
+  if (!fasta) {
+    out[w++] = '+'; out[w++] = '\n';
+    for (uint32_t i = 0; i < L; ++i) out[w++] = 'I';
+    out[w++] = '\n';
+  }
+}
+
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "mic_synth: %s: %s\n", #x, hipGetErrorString(e_)); rc = MIC_E_HIP; goto done; } } while (0)
 
@@ -286,5 +331,23 @@ int mic_synth_reads_device(const mic_synth_spec* spec, uint64_t read_seed, size_
   return hipGetLastError() == hipSuccess ? MIC_OK : MIC_E_HIP;
 }
 
+size_t mic_synth_text_record_bytes(uint32_t read_len, int fasta) { return fasta ? (size_t)read_len + 13 : 2 * (size_t)read_len + 16; }
+
+int mic_synth_reads_text_device(const mic_synth_spec* spec, uint64_t read_seed, size_t n_reads, uint32_t read_len,
+                                double random_frac, double sub_rate, double n_rate, int fasta, int mate, uint8_t* d_text,
+                                size_t text_cap, void* stream) {
+  if (!spec || !d_text || read_len == 0) return MIC_E_INVALID;
+  ReadGen rg;
+  rg.seed = spec->seed; rg.read_seed = read_seed;
+  rg.genome_len = spec->genome_nt / spec->n_genomes;
+  if (rg.genome_len < 2ull * read_len) return MIC_E_INVALID;
+  rg.n_genomes = spec->n_genomes; rg.n_targets = spec->n_targets; rg.read_len = read_len; rg.k = spec->k;
+  rg.pitch = 0;
+  if ((uint64_t)n_reads * mic_synth_text_record_bytes(read_len, fasta) > text_cap) return MIC_E_NOMEM;
+  auto thr = [](double p) { double v = p * 4294967296.0; return v <= 0 ? 0u : (v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v); };
+  rg.random_thr = thr(random_frac); rg.sub_thr = thr(sub_rate); rg.n_thr = thr(n_rate);
+  reads_text_kernel<<<(unsigned)((n_reads + 255) / 256), 256, 0, (hipStream_t)stream>>>(rg, n_reads, fasta, mate, d_text);
+  return hipGetLastError() == hipSuccess ? MIC_OK : MIC_E_HIP;
+}
 
 }  // extern "C"

@@ -290,6 +290,14 @@ uint32_t mic_synth_read_pitch(uint32_t read_len, int k); /* containers reserved 
 int mic_synth_reads_device(const mic_synth_spec* spec, uint64_t read_seed, size_t n_reads, uint32_t read_len,
                            double random_frac, double sub_rate, double n_rate, uint32_t* d_reads_pointer,
                            uint16_t* d_containers, size_t containers_cap, uint32_t* d_truth, void* stream);
+/* The same reads as text, one fixed-size record per read: FASTQ "@r<9 digits>\n" SEQ "\n+\n" QUAL "\n"
+ * (mic_synth_text_record_bytes = 2 L + 16) or FASTA ">r<9 digits>\n" SEQ "\n" (L + 13), an N wherever the packed form ends a
+ * part.  mate < 0: exactly the reads of mic_synth_reads_device (same seeds); mate 0 / 1: the two reads of a pair drawn
+ * from both ends of a stretch of 2 L nucleotides (read 1 and the reverse strand's read 2), same genome, same label. */
+size_t mic_synth_text_record_bytes(uint32_t read_len, int fasta);
+int mic_synth_reads_text_device(const mic_synth_spec* spec, uint64_t read_seed, size_t n_reads, uint32_t read_len,
+                                double random_frac, double sub_rate, double n_rate, int fasta, int mate, uint8_t* d_text,
+                                size_t text_cap, void* stream);
 
 #ifdef __cplusplus
 }
