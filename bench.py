@@ -50,6 +50,14 @@ WORKLOADS = {
     "light": dict(htsize=57777779, genome_nt=54_000_000, n_genomes=512, n_targets=512, k=31, key_bytes=8,
                   n_reads=10_000_000, read_len=150,
                   name="10M x 150bp synthetic reads vs CuCLARK-l-scale k=31 table (HTSIZE 57777779, u64 keys, ~54M k-mers)"),
+    # config 5 shape: paired-end 2 x 150 bp, every object = read 1 + 'N' + read 2 (file.cc:205-268), same table as "full"
+    "paired": dict(htsize=1610612741, genome_nt=5_730_000_000, n_genomes=8192, n_targets=4096, k=31, key_bytes=4,
+                   n_reads=10_000_000, read_len=150, paired=True,
+                   name="10M pairs of 2x150bp synthetic reads (301-character objects) vs 36GB-scale k=31 table (HTSIZE 1610612741, u32 keys, "
+                        "~5.7e9 k-mers, 4096 targets) resident in HBM"),
+    "tiny_paired": dict(htsize=999983, genome_nt=1_500_000, n_genomes=64, n_targets=50, k=31, key_bytes=8,
+                        n_reads=100_000, read_len=100, paired=True,
+                        name="100k pairs of 2x100bp synthetic reads vs 50-target toy table (plumbing)"),
     "tiny": dict(htsize=999983, genome_nt=1_500_000, n_genomes=64, n_targets=50, k=31, key_bytes=8,
                  n_reads=100_000, read_len=100,
                  name="100k x 100bp synthetic reads vs 50-target toy table (plumbing)"),
@@ -103,7 +111,7 @@ def pipeline_leg(eng, L, d_rp, d_cont, n_reads, res_expect, steps, nb):
             "results_equal_device_path": equal}
 
 
-def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res_expect, truth, threads, keep=False):
+def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res_expect, truth, threads, keep=False, paired=False):
     """files in, file out, through exe/cuCLARK (reference: CuCLARK_hh.hh:550-563 times index + pack +
     GPU + CSV and prints objects/min, :1938-1944).  The table goes to disk in the reference's format, the same reads as
     FASTQ; the binary loads the table, classifies, writes the CSV.  Checked: every CSV line against the kernel's result
@@ -132,17 +140,19 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
                 f.write(f"{dummy} TARGET_{t:05d}\n")
         rec = int(L.mic_synth_text_record_bytes(read_len, 0))
         d_text = torch.empty(n_reads * rec, dtype=torch.uint8, device=d_sizes.device)
-        rc = L.mic_synth_reads_text_device(C.byref(spec), 5, n_reads, read_len, 0.2, 0.01, 0.001, 0, -1, d_text.data_ptr(), d_text.numel(), None)
-        assert rc == 0, f"mic_synth_reads_text_device failed ({rc})"
-        torch.cuda.synchronize()
-        fq = os.path.join(tmp, "reads.fq")
-        d_text.cpu().numpy().tofile(fq)
+        fqs = []
+        for mate in ((0, 1) if paired else (-1,)):
+            rc = L.mic_synth_reads_text_device(C.byref(spec), 5, n_reads, read_len, 0.2, 0.01, 0.001, 0, mate, d_text.data_ptr(), d_text.numel(), None)
+            assert rc == 0, f"mic_synth_reads_text_device failed ({rc})"
+            torch.cuda.synchronize()
+            fqs.append(os.path.join(tmp, f"reads_{max(mate, 0) + 1}.fq"))
+            d_text.cpu().numpy().tofile(fqs[-1])
         del d_text
         t_files = time.time() - t0
         exe = os.path.join(ROOT, "exe", "cuCLARK")
         res_base = os.path.join(tmp, "out")
-        cmd = [exe, "-k", str(k), "--htsize", str(w["htsize"]), "-T", os.path.join(tmp, "targets.txt"), "-D", dbdir, "-O", fq, "-R", res_base,
-               "-n", str(threads)]
+        cmd = [exe, "-k", str(k), "--htsize", str(w["htsize"]), "-T", os.path.join(tmp, "targets.txt"), "-D", dbdir,
+               *(["-P", fqs[0], fqs[1]] if paired else ["-O", fqs[0]]), "-R", res_base, "-n", str(threads)]
         t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MIC_CLI_TIMING="1", MIC_LOAD_TIMING="1"))
         wall = time.time() - t0
@@ -152,7 +162,7 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
         m = re.search(r"Assignment time: ([0-9.eE+-]+) s\. Speed: (\d+) objects/min\. \((\d+) objects\)", r.stdout)
         t_assign, opm, n_obj = float(m.group(1)), int(m.group(2)), int(m.group(3))
         ing = re.search(r"device ingest: (\d+) batches of <= (\d+) KB on (\d+) worker\(s\), (\d+) through the host path", r.stderr)
-        load = sum(float(x) for x in re.findall(r"\[load\] [^:]+: ([0-9.]+) s", r.stderr))
+        load = {a.strip(): float(b) for a, b in re.findall(r"\[load\] ([^:]+): ([0-9.]+) s", r.stderr)}
         # every CSV line against the kernel's rows of the same reads
         import pandas as pd
         names = np.array(["NA"] + [f"TARGET_{t:05d}" for t in range(T)])
@@ -164,17 +174,18 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
             e = res_expect[:n_reads]
             ok = bool((df["1st_assignment"].to_numpy() == names[e[:, 1]]).all() and (df["score1"].to_numpy() == e[:, 2]).all() and
                       (df["2nd_assignment"].to_numpy() == names[e[:, 3]]).all() and (df["score2"].to_numpy() == e[:, 4]).all() and
-                      (df["Length"].to_numpy() == read_len).all() and df["Object_ID"].iloc[0] == "r000000000" and
+                      (df["Length"].to_numpy() == (2 * read_len if paired else read_len)).all() and df["Object_ID"].iloc[0] == "r000000000" and
                       df["Object_ID"].iloc[-1] == f"r{n_reads - 1:09d}")
         del df
-        fq_bytes = os.path.getsize(fq)
+        fq_bytes = sum(os.path.getsize(f) for f in fqs)
         out = {"value": round(n_obj / t_assign / 1e6, 1), "unit": "Mreads/s", "objects_per_min": opm, "objects": n_obj,
-               "assignment_s": round(t_assign, 4), "process_wall_s": round(wall, 2), "table_load_s": round(load, 2),
-               "input": f"FASTQ, {fq_bytes / n_reads:.0f} bytes per record, {fq_bytes / 1e9:.2f} GB in the page cache",
+               "assignment_s": round(t_assign, 4), "process_wall_s": round(wall, 2), "table_load_s": load,
+               "input": (f"two FASTQ files (pairs), {fq_bytes / n_reads:.0f} bytes per pair, " if paired else f"FASTQ, {fq_bytes / n_reads:.0f} bytes per record, ") +
+                        f"{fq_bytes / 1e9:.2f} GB in the page cache",
                "input_GBs": round(fq_bytes / t_assign / 1e9, 1), "csv_MB": round(os.path.getsize(res_base + ".csv") / 1e6, 1),
                "host_threads": threads, "ingest": ({"batches": int(ing.group(1)), "slot_KB": int(ing.group(2)), "workers": int(ing.group(3)),
                                                     "batches_through_host_path": int(ing.group(4))} if ing else None),
-               "command": "exe/cuCLARK -k 31 -T targets.txt -D DB/ -O reads.fq -R out -n %d" % threads,
+               "command": "exe/cuCLARK -k %d -T targets.txt -D DB/ %s -R out -n %d" % (k, "-P reads_1.fq reads_2.fq" if paired else "-O reads_1.fq", threads),
                "csv_lines_equal_kernel_rows": bool(ok and lines == n_reads), "setup_files_s": round(t_files, 1)}
     finally:
         if not keep:
@@ -226,6 +237,8 @@ def main():
         w["name"] = w["name"].replace("150bp", f"{args.read_len}bp")
     k, T = w["k"], w["n_targets"]
     n_reads, read_len = w["n_reads"], w["read_len"]
+    paired = bool(w.get("paired"))
+    obj_len = 2 * read_len + 1 if paired else read_len
     t_setup = time.time()
 
     # ---- synthetic table in the on-disk layout (.sz/.ky/.lb images), in HBM
@@ -255,14 +268,14 @@ def main():
     t_build = time.time() - t0
 
     # ---- reads (packed containers) in HBM; read-sharded ranks draw different reads
-    pitch = L.mic_synth_read_pitch(read_len, k)
+    pitch = L.mic_synth_read_pitch(obj_len, k)
     read_seed = 5 + (rank if args.mode == "read" else 0)
     d_rp = torch.empty(n_reads + 1, dtype=torch.int32, device=dev)
     d_cont = torch.zeros(n_reads * pitch + 64, dtype=torch.int16, device=dev)
     d_truth = torch.empty(n_reads * 2, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    rc = L.mic_synth_reads_device(C.byref(spec), read_seed, n_reads, read_len, 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
-                                  d_cont.numel(), d_truth.data_ptr(), None)
+    rc = L.mic_synth_reads_device2(C.byref(spec), read_seed, n_reads, read_len, int(paired), 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
+                                   d_cont.numel(), d_truth.data_ptr(), None)
     assert rc == 0, f"mic_synth_reads_device failed ({rc})"
     torch.cuda.synchronize()
     d_res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
@@ -439,7 +452,7 @@ def main():
                 eng.close()              # the CLI builds its own resident table from the files
                 del d_res, d_cont, d_rp
                 torch.cuda.empty_cache()
-                e2e = end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res, truth, args.e2e_threads)
+                e2e = end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res, truth, args.e2e_threads, paired=paired)
             except Exception as ex:
                 e2e = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             log("end_to_end:", json.dumps(e2e))
@@ -459,8 +472,8 @@ def main():
                              shard=multi.shard_range(w["htsize"], world, rank))
             t_build2 = time.time() - t0
             info2 = eng2.info()
-            rc = L.mic_synth_reads_device(C.byref(spec), 5, n_reads, read_len, 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
-                                          d_cont.numel(), d_truth.data_ptr(), None)   # the same reads on every rank
+            rc = L.mic_synth_reads_device2(C.byref(spec), 5, n_reads, read_len, int(paired), 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
+                                           d_cont.numel(), d_truth.data_ptr(), None)   # the same reads on every rank
             assert rc == 0
             torch.cuda.synchronize()
             per2 = multi.read_range(n_reads, world, rank)[2]
@@ -513,7 +526,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": f"Mreads/sec (10M x {read_len}bp, k=31)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
+            "metric": f"Mreads/sec (10M x {'2x' if paired else ''}{read_len}bp{' pairs' if paired else ''}, k=31)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if db_mode else "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",

@@ -102,6 +102,8 @@ SYMBOLS = [
     ("mic_synth_read_pitch", C.c_uint32, [C.c_uint32, C.c_int]),
     ("mic_synth_reads_device", C.c_int, [C.POINTER(MicSynthSpec), C.c_uint64, _SZ, C.c_uint32, C.c_double, C.c_double,
                                          C.c_double, _VP, _VP, _SZ, _VP, _VP]),
+    ("mic_synth_reads_device2", C.c_int, [C.POINTER(MicSynthSpec), C.c_uint64, _SZ, C.c_uint32, C.c_int, C.c_double, C.c_double,
+                                          C.c_double, _VP, _VP, _SZ, _VP, _VP]),
     ("mic_synth_text_record_bytes", _SZ, [C.c_uint32, C.c_int]),
     ("mic_synth_reads_text_device", C.c_int, [C.POINTER(MicSynthSpec), C.c_uint64, _SZ, C.c_uint32, C.c_double, C.c_double,
                                               C.c_double, C.c_int, C.c_int, _VP, _SZ, _VP]),

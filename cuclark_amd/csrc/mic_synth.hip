@@ -144,19 +144,54 @@ struct ReadGen {
   uint32_t random_thr, sub_thr, n_thr;  // thresholds on a 32-bit uniform
 };
 
-__global__ void reads_kernel(ReadGen rg, size_t n_reads, uint32_t* __restrict__ rp, uint16_t* __restrict__ cont,
+// One read (or the two reads of a pair), nucleotide by nucleotide; shared by the packed and the text generators so that
+// both describe the same reads.  mate < 0: a single read of L nt at p0 on strand `rev`.  mate 0 / 1: the two reads of a
+// pair, drawn from both ends of the stretch [p0, p0 + 2L) read on strand `rev`: read 1 = its first L nt, read 2 = the
+// first L nt of its other strand; random "genome-free" reads get an independent random second read.
+struct ReadDraw {
+  uint64_t h0, g, p0; bool rnd, rev; uint32_t span;
+};
+
+__device__ inline ReadDraw draw_read(const ReadGen& rg, size_t r, bool paired) {
+  ReadDraw d;
+  d.h0 = mix64(rg.read_seed * 0x9E3779B97F4A7C15ULL + r);
+  d.rnd = (uint32_t)d.h0 < rg.random_thr;
+  const uint64_t h1 = mix64(d.h0 + 1), h2 = mix64(d.h0 + 2);
+  d.g = h1 % rg.n_genomes;
+  d.span = paired ? 2 * rg.read_len : rg.read_len;
+  d.p0 = h2 % (rg.genome_len - d.span + 1);
+  d.rev = (d.h0 >> 40) & 1;
+  return d;
+}
+
+// nucleotide i of the read (mate as above): 0..3, or -1 for an N; *clean = the nucleotide is the genome's own
+__device__ inline int draw_nt(const ReadGen& rg, const ReadDraw& d, int mate, uint32_t i, bool* clean) {
+  const uint64_t hb = mix64((mate > 0 ? d.h0 + 0x51ED27ULL : d.h0) ^ (0xABCD0000ULL + i));
+  uint32_t nt; bool sub = false;
+  if (d.rnd) nt = (uint32_t)(hb & 3);
+  else {
+    const uint64_t fwd = d.p0 + i, bwd = d.p0 + d.span - 1 - i;
+    const bool rc = mate > 0 ? !d.rev : d.rev;
+    nt = genome_nt(rg.seed, d.g, (mate > 0) != d.rev ? bwd : fwd);
+    if (rc) nt = 3u - nt;
+    sub = (uint32_t)(hb >> 32) < rg.sub_thr;
+    if (sub) nt = (nt + 1 + (uint32_t)((hb >> 8) % 3)) & 3u;
+  }
+  const bool isn = (uint32_t)(mix64(hb) >> 32) < rg.n_thr;
+  *clean = !d.rnd && !sub && !isn;
+  return isn ? -1 : (int)nt;
+}
+
+// Packed reads (CuCLARK_hh.hh:1616-1716).  paired: the object is read 1 + 'N' + read 2 (file.cc:205-268), 2L + 1 characters.
+__global__ void reads_kernel(ReadGen rg, size_t n_reads, int paired, uint32_t* __restrict__ rp, uint16_t* __restrict__ cont,
                              uint32_t* __restrict__ truth) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r > n_reads) return;
   if (r == n_reads) { rp[r] = (uint32_t)(n_reads * rg.pitch); return; }
   rp[r] = (uint32_t)(r * rg.pitch);
   uint16_t* out = cont + r * rg.pitch;
-  const uint64_t h0 = mix64(rg.read_seed * 0x9E3779B97F4A7C15ULL + r);
-  const bool rnd = (uint32_t)h0 < rg.random_thr;
-  const uint64_t h1 = mix64(h0 + 1), h2 = mix64(h0 + 2);
-  const uint64_t g = h1 % rg.n_genomes;
-  const uint64_t p0 = h2 % (rg.genome_len - rg.read_len + 1);
-  const bool rev = (h0 >> 40) & 1;
+  const ReadDraw d = draw_read(rg, r, paired != 0);
+  const uint32_t L = rg.read_len, total = paired ? 2 * L + 1 : L;
   uint32_t w = 0;            // write cursor in containers
   uint32_t hdr = 0;          // index of the current part's length slot
   uint32_t run = 0;          // nt in the current part
@@ -164,21 +199,15 @@ __global__ void reads_kernel(ReadGen rg, size_t n_reads, uint32_t* __restrict__ 
   uint32_t expect = 0;
   uint16_t cur = 0; uint32_t ncur = 0;
   bool open = false;
-  for (uint32_t i = 0; i <= rg.read_len; ++i) {
+  for (uint32_t i = 0; i <= total; ++i) {
     int code = -1;
-    if (i < rg.read_len) {
-      const uint64_t hb = mix64(h0 ^ (0xABCD0000ULL + i));
-      if (rnd) {
-        code = (int)(hb & 3);
-      } else {
-        uint32_t nt = rev ? 3u - genome_nt(rg.seed, g, p0 + rg.read_len - 1 - i) : genome_nt(rg.seed, g, p0 + i);
-        bool sub = (uint32_t)(hb >> 32) < rg.sub_thr;
-        if (sub) nt = (nt + 1 + (uint32_t)((hb >> 8) % 3)) & 3u;
-        code = (int)nt;
-        clean = sub ? 0 : clean + 1;
-      }
-      if ((uint32_t)(mix64(hb) >> 32) < rg.n_thr) { code = -1; clean = 0; }
-      if (code >= 0 && !rnd && clean >= (uint32_t)rg.k) ++expect;
+    if (i < total) {
+      bool cl = false;
+      if (!paired) code = draw_nt(rg, d, -1, i, &cl);
+      else if (i < L) code = draw_nt(rg, d, 0, i, &cl);
+      else if (i > L) code = draw_nt(rg, d, 1, i - L - 1, &cl);
+      clean = (cl && code >= 0) ? clean + 1 : 0;
+      if (code >= 0 && clean >= (uint32_t)rg.k) ++expect;
     }
     if (code >= 0) {
       if (!open) { hdr = w++; open = true; run = 0; cur = 0; ncur = 0; }
@@ -191,45 +220,26 @@ __global__ void reads_kernel(ReadGen rg, size_t n_reads, uint32_t* __restrict__ 
     }
   }
   if (w < rg.pitch) out[w] = 0;  // terminator
-  if (truth) { truth[2 * r] = rnd ? 0 : (uint32_t)(g % rg.n_targets) + 1; truth[2 * r + 1] = expect; }
+  if (truth) { truth[2 * r] = d.rnd ? 0 : (uint32_t)(d.g % rg.n_targets) + 1; truth[2 * r + 1] = expect; }
 }
 
-// The same reads (same seeds: nucleotide for nucleotide what reads_kernel packs) as FASTQ / FASTA text, one record of
-// fixed size per read: "@r<9 digits>\n" SEQ "\n+\n" QUAL "\n" (2 L + 16 bytes) or ">r<9 digits>\n" SEQ "\n" (L + 13); an N
-// where reads_kernel ends a part.  mate != 0: the reverse strand of the stretch that FOLLOWS the read in its genome (the
-// second read of a pair; random reads get an independent random mate).
+// The same reads as FASTQ / FASTA text, one record of fixed size per read: "@r<9 digits>\n" SEQ "\n+\n" QUAL "\n"
+// (2 L + 16 bytes) or ">r<9 digits>\n" SEQ "\n" (L + 13); mate as in draw_nt.
 __global__ void reads_text_kernel(ReadGen rg, size_t n_reads, int fasta, int mate, uint8_t* __restrict__ text) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_reads) return;
   const uint32_t L = rg.read_len;
   const size_t rec = fasta ? (size_t)L + 13 : 2 * (size_t)L + 16;
   uint8_t* out = text + r * rec;
-  const uint64_t h0 = mix64(rg.read_seed * 0x9E3779B97F4A7C15ULL + r);
-  const bool rnd = (uint32_t)h0 < rg.random_thr;
-  const uint64_t h1 = mix64(h0 + 1), h2 = mix64(h0 + 2);
-  const uint64_t g = h1 % rg.n_genomes;
-  const uint64_t span = mate >= 0 ? 2ull * L : L;            // pairs are drawn from a stretch of two read lengths
-  const uint64_t p0 = h2 % (rg.genome_len - span + 1);
-  const bool rev = (h0 >> 40) & 1;
+  const ReadDraw d = draw_read(rg, r, mate >= 0);
   size_t w = 0;
   out[w++] = fasta ? '>' : '@'; out[w++] = 'r';
   { uint32_t v = (uint32_t)(r % 1000000000u); for (int i = 8; i >= 0; --i) { out[w + i] = (uint8_t)('0' + v % 10); v /= 10; } w += 9; }
   out[w++] = '\n';
   for (uint32_t i = 0; i < L; ++i) {
-    const uint64_t hb = mix64((mate > 0 ? h0 + 0x51ED27ULL : h0) ^ (0xABCD0000ULL + i));
-    uint32_t nt;
-    if (rnd) nt = (uint32_t)(hb & 3);
-    else {
-      // fragment [p0, p0 + span) read from its `rev` strand: mate 0 = its first L nt, mate 1 = the reverse complement of its last L
-      const uint64_t q = mate > 0 ? (rev ? p0 + i : p0 + span - 1 - i) : (rev ? p0 + span - 1 - i : p0 + i);
-      const bool rc = mate > 0 ? !rev : rev;
-      nt = genome_nt(rg.seed, g, q);
-      if (rc) nt = 3u - nt;
-      if ((uint32_t)(hb >> 32) < rg.sub_thr) nt = (nt + 1 + (uint32_t)((hb >> 8) % 3)) & 3u;
-    }
-    uint8_t c = "TGCA"[nt];
-    if ((uint32_t)(mix64(hb) >> 32) < rg.n_thr) c = 'N';
-    out[w++] = c;
+    bool cl;
+    const int code = draw_nt(rg, d, mate, i, &cl);
+    out[w++] = code < 0 ? 'N' : "TGCA"[code];
   }
   out[w++] = '\n';
   if (!fasta) {
@@ -317,17 +327,23 @@ done:
 int mic_synth_reads_device(const mic_synth_spec* spec, uint64_t read_seed, size_t n_reads, uint32_t read_len,
                            double random_frac, double sub_rate, double n_rate, uint32_t* d_rp, uint16_t* d_cont,
                            size_t containers_cap, uint32_t* d_truth, void* stream) {
+  return mic_synth_reads_device2(spec, read_seed, n_reads, read_len, 0, random_frac, sub_rate, n_rate, d_rp, d_cont, containers_cap, d_truth, stream);
+}
+
+int mic_synth_reads_device2(const mic_synth_spec* spec, uint64_t read_seed, size_t n_reads, uint32_t read_len, int paired,
+                            double random_frac, double sub_rate, double n_rate, uint32_t* d_rp, uint16_t* d_cont,
+                            size_t containers_cap, uint32_t* d_truth, void* stream) {
   if (!spec || !d_rp || !d_cont || read_len == 0) return MIC_E_INVALID;
   ReadGen rg;
   rg.seed = spec->seed; rg.read_seed = read_seed;
   rg.genome_len = spec->genome_nt / spec->n_genomes;
-  if (rg.genome_len < read_len) return MIC_E_INVALID;
+  if (rg.genome_len < (paired ? 2ull : 1ull) * read_len) return MIC_E_INVALID;
   rg.n_genomes = spec->n_genomes; rg.n_targets = spec->n_targets; rg.read_len = read_len; rg.k = spec->k;
-  rg.pitch = mic_synth_read_pitch(read_len, spec->k);
+  rg.pitch = mic_synth_read_pitch(paired ? 2 * read_len + 1 : read_len, spec->k);
   if ((uint64_t)n_reads * rg.pitch > containers_cap || (uint64_t)n_reads * rg.pitch > 0xFFFFFFF0ull) return MIC_E_NOMEM;
   auto thr = [](double p) { double v = p * 4294967296.0; return v <= 0 ? 0u : (v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v); };
   rg.random_thr = thr(random_frac); rg.sub_thr = thr(sub_rate); rg.n_thr = thr(n_rate);
-  reads_kernel<<<(unsigned)((n_reads + 1 + 255) / 256), 256, 0, (hipStream_t)stream>>>(rg, n_reads, d_rp, d_cont, d_truth);
+  reads_kernel<<<(unsigned)((n_reads + 1 + 255) / 256), 256, 0, (hipStream_t)stream>>>(rg, n_reads, paired, d_rp, d_cont, d_truth);
   return hipGetLastError() == hipSuccess ? MIC_OK : MIC_E_HIP;
 }
 

@@ -290,6 +290,11 @@ uint32_t mic_synth_read_pitch(uint32_t read_len, int k); /* containers reserved 
 int mic_synth_reads_device(const mic_synth_spec* spec, uint64_t read_seed, size_t n_reads, uint32_t read_len,
                            double random_frac, double sub_rate, double n_rate, uint32_t* d_reads_pointer,
                            uint16_t* d_containers, size_t containers_cap, uint32_t* d_truth, void* stream);
+/* paired != 0: every object is read 1 + 'N' + read 2 of a pair (the merged form of file.cc:205-268), 2 * read_len + 1
+ * characters, containers at mic_synth_read_pitch(2 * read_len + 1, k). */
+int mic_synth_reads_device2(const mic_synth_spec* spec, uint64_t read_seed, size_t n_reads, uint32_t read_len, int paired,
+                            double random_frac, double sub_rate, double n_rate, uint32_t* d_reads_pointer,
+                            uint16_t* d_containers, size_t containers_cap, uint32_t* d_truth, void* stream);
 /* The same reads as text, one fixed-size record per read: FASTQ "@r<9 digits>\n" SEQ "\n+\n" QUAL "\n"
  * (mic_synth_text_record_bytes = 2 L + 16) or FASTA ">r<9 digits>\n" SEQ "\n" (L + 13), an N wherever the packed form ends a
  * part.  mate < 0: exactly the reads of mic_synth_reads_device (same seeds); mate 0 / 1: the two reads of a pair drawn

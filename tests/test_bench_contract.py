@@ -33,6 +33,60 @@ def test_bench_tiny_json_contract():
     assert cb["kind"] == "port" and cb["parity_with_gpu_on_sample"] is True
     assert d["value"] > 0 and abs(d["value"] - d["config"]["reads_per_gpu"] / d["ms_per_step"] / 1e3) / d["value"] < 0.02
     assert d["known_answer"]["label_and_count_ok"] == 1.0
+    # the two extra legs (SURVEY.md 8d ii, iii): batch-API pipeline and files-in / CSV-out through exe/cuCLARK
+    assert d["pipeline"]["results_equal_device_path"] is True and d["pipeline"]["value"] > 0
+    e2e = d["end_to_end"]
+    assert "error" not in e2e, e2e
+    assert e2e["csv_lines_equal_kernel_rows"] is True and e2e["objects"] == d["config"]["reads_per_gpu"]
+    assert e2e["ingest"]["batches_through_host_path"] == 0
+
+
+def _bench(*args, timeout=1500):
+    r = subprocess.run([sys.executable, os.path.join(gu.ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _check_config(d, n_reads):
+    assert d["config"]["reads_per_gpu"] == n_reads
+    assert d["cpu_baseline"]["parity_with_gpu_on_sample"] is True           # bit-exact vs the oracle on the sample
+    ka = d["known_answer"]
+    assert ka["label_and_count_ok"] == 1.0 and ka["random_reads_no_hit"] == 1.0
+    assert d["config"]["flagged_reads_dense_path"] == 0
+    assert d["pipeline"]["results_equal_device_path"] is True
+    e2e = d["end_to_end"]
+    assert "error" not in e2e, e2e
+    assert e2e["csv_lines_equal_kernel_rows"] is True and e2e["objects"] == n_reads
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.02
+
+
+@pytest.mark.gpu
+def test_bench_full_config3():
+    """BASELINE.json configs[2]: 10 M x 150 bp against the 36 GB-scale k = 31 table resident in HBM: oracle parity on a
+    sample, constructive known answer on all genome reads, batch-API pipeline equal to the device path, CLI CSV equal to
+    the kernel's rows on all 10 M reads."""
+    d = _bench("--workload", "full", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000")
+    _check_config(d, 10_000_000)
+    assert d["config"]["table"]["htsize"] == 1610612741 and d["config"]["table"]["kmers"] > 5_700_000_000
+
+
+@pytest.mark.gpu
+def test_bench_light_config2():
+    """BASELINE.json configs[1]: the same 10 M reads against the CuCLARK-l-scale table."""
+    d = _bench("--workload", "light", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000")
+    _check_config(d, 10_000_000)
+    assert d["config"]["table"]["htsize"] == 57777779
+
+
+@pytest.mark.gpu
+def test_bench_paired_config5_shape():
+    """BASELINE.json configs[4] on one GPU: paired-end 2 x 150 bp objects (read 1 + N + read 2, file.cc:205-268); the
+    end-to-end leg feeds the two FASTQ files to exe/cuCLARK -P."""
+    d = _bench("--workload", "tiny_paired", "--steps", "2", "--warmup", "1")
+    _check_config(d, 100_000)
+    d = _bench("--workload", "paired", "--steps", "2", "--warmup", "1", "--cpu-sample", "100000", "--reads", "2000000")
+    _check_config(d, 2_000_000)
+    assert "pairs" in d["end_to_end"]["input"]
 
 
 def test_bench_has_the_contract_flags():

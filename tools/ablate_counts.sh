@@ -6,7 +6,7 @@ for v in ${@:-0 1 2 3 6}; do
   timeout 300 /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -I../../include -I. -DMIC_ABLATE=$v -c mic_kernels.hip -o obj/mic_kernels.o 2>&1 | grep -E "error" -A3
   make all 2>&1 | grep -E "error" -A3
   OUT=$R/gpurun_out/ablate_$v; mkdir -p $OUT
-  ( cd /tmp && TMPDIR=/tmp timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --no-cpu --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/err.txt )
+  ( cd /tmp && TMPDIR=/tmp timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --no-cpu --no-pipeline --no-e2e --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/err.txt )
   python3 - <<PY
 import csv, glob, collections, json
 agg = collections.defaultdict(list)
