@@ -161,7 +161,7 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
         import re
         m = re.search(r"Assignment time: ([0-9.eE+-]+) s\. Speed: (\d+) objects/min\. \((\d+) objects\)", r.stdout)
         t_assign, opm, n_obj = float(m.group(1)), int(m.group(2)), int(m.group(3))
-        ing = re.search(r"device ingest: (\d+) batches of <= (\d+) KB on (\d+) worker\(s\), (\d+) through the host path", r.stderr)
+        ing = re.search(r"device ingest: (\d+) batches of <= (\d+) KB on (\d+) slot\(s\), (\d+) through the host path.*?input ([0-9.e+]+) MB, over the link ([0-9.e+]+) MB", r.stderr)
         load = {a.strip(): float(b) for a, b in re.findall(r"\[load\] ([^:]+): ([0-9.]+) s", r.stderr)}
         # every CSV line against the kernel's rows of the same reads
         import pandas as pd
@@ -183,8 +183,9 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
                "input": (f"two FASTQ files (pairs), {fq_bytes / n_reads:.0f} bytes per pair, " if paired else f"FASTQ, {fq_bytes / n_reads:.0f} bytes per record, ") +
                         f"{fq_bytes / 1e9:.2f} GB in the page cache",
                "input_GBs": round(fq_bytes / t_assign / 1e9, 1), "csv_MB": round(os.path.getsize(res_base + ".csv") / 1e6, 1),
-               "host_threads": threads, "ingest": ({"batches": int(ing.group(1)), "slot_KB": int(ing.group(2)), "workers": int(ing.group(3)),
-                                                    "batches_through_host_path": int(ing.group(4))} if ing else None),
+               "host_threads": threads, "ingest": ({"batches": int(ing.group(1)), "slot_KB": int(ing.group(2)), "slots": int(ing.group(3)),
+                                                    "batches_through_host_path": int(ing.group(4)), "input_MB": float(ing.group(5)),
+                                                    "h2d_MB": float(ing.group(6)), "h2d_GBs": round(float(ing.group(6)) / 1e3 / t_assign, 1)} if ing else None),
                "command": "exe/cuCLARK -k %d -T targets.txt -D DB/ %s -R out -n %d" % (k, "-P reads_1.fq reads_2.fq" if paired else "-O reads_1.fq", threads),
                "csv_lines_equal_kernel_rows": bool(ok and lines == n_reads), "setup_files_s": round(t_files, 1)}
     finally:
@@ -257,7 +258,7 @@ def main():
 
     # ---- resident slot table (whole table, or this rank's bucket range in db mode)
     row_words = 16
-    PIPE_BATCHES = 8
+    PIPE_BATCHES = int(os.environ.get("MIC_PIPE_BATCHES", "16"))
     eng = MiClarkDB(k, T, num_batches=PIPE_BATCHES, device=local_rank, row_words=row_words)
     shard = (0, 0)
     if args.mode == "db" and world > 1:

@@ -72,6 +72,7 @@ SYMBOLS = [
     ("mic_batch_check", C.c_int, [_VP, _SZ, C.POINTER(C.c_int)]),
     ("mic_batch_merge_shards", C.c_int, [C.POINTER(C.c_void_p), _SZ, _SZ]),
     ("mic_sync", C.c_int, [_VP]),
+    ("mic_thread_bind_near_device", C.c_int, [_VP, C.c_int]),
     ("mic_batches_free", C.c_int, [_VP]),
     ("mic_query_device", C.c_int, [_VP, _VP, _VP, _SZ, _VP, _VP, _VP]),
     ("mic_resolve_flagged_device", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_SZ)]),

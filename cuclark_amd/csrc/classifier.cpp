@@ -19,6 +19,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <fstream>
 #include <iostream>
 #include <mutex>
@@ -526,6 +527,7 @@ class FileFeeder : public Classifier::Feeder {
   bool ok() const { return ok_; }
   uint64_t size() const { return size_; }
   uint8_t first_byte() const { return first_; }
+  bool fastq() const override { return first_ == '@'; }
   bool assign(size_t want, size_t cap, Classifier::Range& r) override {
     (void)cap;
     if (pos_ >= size_) return false;
@@ -549,10 +551,10 @@ class FileFeeder : public Classifier::Feeder {
     pos_ = end;
     return true;
   }
-  void load(const Classifier::Range& r, uint8_t* dst) override {
+  void read(const Classifier::Range& r, size_t off, uint8_t* dst, size_t len) override {
     size_t got = 0;
-    while (got < r.len) {
-      const ssize_t n = pread(fd_, dst + got, r.len - got, (off_t)(r.off + got));
+    while (got < len) {
+      const ssize_t n = pread(fd_, dst + got, len - got, (off_t)(r.off + off + got));
       if (n <= 0) die("Failed to read the objects file.");
       got += (size_t)n;
     }
@@ -566,6 +568,7 @@ class FileFeeder : public Classifier::Feeder {
 class SegmentFeeder : public Classifier::Feeder {
  public:
   explicit SegmentFeeder(Classifier::SegmentSource& src) : src_(src) {}
+  bool fastq() const override { return cur_ && cur_->n && cur_->p[0] == '@'; }
   bool assign(size_t want, size_t cap, Classifier::Range& r) override {
     (void)cap;
     if (!cur_ || pos_ >= cur_->n) {
@@ -583,7 +586,7 @@ class SegmentFeeder : public Classifier::Feeder {
     pos_ = end;
     return true;
   }
-  void load(const Classifier::Range& r, uint8_t* dst) override { memcpy(dst, r.mem, r.len); }
+  void read(const Classifier::Range& r, size_t off, uint8_t* dst, size_t len) override { memcpy(dst, r.mem + off, len); }
  private:
   Classifier::SegmentSource& src_;
   std::shared_ptr<Classifier::Segment> cur_;
@@ -762,7 +765,10 @@ void Classifier::release_ingest() {
 
 void Classifier::ensure_ingest(size_t total_bytes) {
   // one worker (host thread + slot + stream) moves ~30 Mreads/s; eight saturate the link
-  size_t workers = std::min<size_t>(std::max<size_t>(opt_.threads, 1), 16);
+  // slots: one per host thread and half as many again in the queues between the stages
+  size_t workers = std::min<size_t>(std::max<size_t>(opt_.threads, 1), 48);
+  workers += workers / 2;
+  if (const char* env = getenv("MIC_INGEST_SLOTS")) { long v = atol(env); if (v >= 1 && v <= 96) workers = (size_t)v; }
   size_t bytes = 32u << 20;
   if (const char* env = getenv("MIC_INGEST_MB")) { long v = atol(env); if (v >= 1 && v <= 1024) bytes = (size_t)v << 20; }
   if (const char* env = getenv("MIC_INGEST_KB")) { long v = atol(env); if (v >= 4) bytes = (size_t)v << 10; }
@@ -785,13 +791,48 @@ void Classifier::ensure_ingest(size_t total_bytes) {
   ingest_bytes_ = bytes; ingest_workers_ = workers;
 }
 
+// FASTQ: copy the header and the sequence line of every four-line record, drop the '+' and the quality line (nothing
+// reads them: CuCLARK_hh.hh:1496-1523 only steps over them).  `phase` = line of the record the input is in (0..3),
+// carried across calls; returns the bytes written.
+static size_t strip_fastq(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap, unsigned& phase) {   // (size_t)-1: dst is full
+  size_t pos = 0, w = 0;
+  while (pos < n) {
+    if (phase == 0) {   // common case: the record's four lines are all in this piece
+      const uint8_t* a = (const uint8_t*)memchr(src + pos, '\n', n - pos);
+      const uint8_t* b = a ? (const uint8_t*)memchr(a + 1, '\n', (size_t)(src + n - (a + 1))) : nullptr;
+      const uint8_t* c = b ? (const uint8_t*)memchr(b + 1, '\n', (size_t)(src + n - (b + 1))) : nullptr;
+      const uint8_t* d = c ? (const uint8_t*)memchr(c + 1, '\n', (size_t)(src + n - (c + 1))) : nullptr;
+      if (d) {
+        const size_t len = (size_t)(b + 1 - (src + pos));
+        if (w + len > dst_cap) return (size_t)-1;
+        memcpy(dst + w, src + pos, len);
+        w += len;
+        pos = (size_t)(d + 1 - src);
+        continue;
+      }
+    }
+    const uint8_t* nl = (const uint8_t*)memchr(src + pos, '\n', n - pos);
+    const size_t end = nl ? (size_t)(nl - src) + 1 : n;
+    if (phase < 2) { if (w + (end - pos) > dst_cap) return (size_t)-1; memcpy(dst + w, src + pos, end - pos); w += end - pos; }
+    if (nl) phase = (phase + 1) & 3;
+    pos = end;
+  }
+  return w;
+}
+
 void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool paired, size_t total_bytes) {
   const std::string csv = results_base + ".csv";  // CuCLARK_hh.hh:539-540
+  // a fresh file, not a truncated one: ext4 writes a truncated-and-rewritten file's blocks out when it is closed
+  // (auto_da_alloc), 60 ms for the CSV of 16 M reads
+  unlink(csv.c_str());
   const int out_fd = open(csv.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0644);
   if (out_fd == -1) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return; }
   struct timeval t0, t1;
   gettimeofday(&t0, nullptr);
   ensure_ingest(total_bytes);          // inside the timed region, like the reference's CuClarkDB::malloc (CuCLARK_hh.hh:1600-1606)
+  std::atomic<uint64_t> ts_first_loaded{0}, ts_last_loaded{0}, ts_last_dev{0}, ts_alloc{0}, ts_last_write{0}, us_write_max{0};   // MIC_CLI_TIMING: stage ends since t0
+  const uint64_t t0_us = (uint64_t)t0.tv_sec * 1000000u + (uint64_t)t0.tv_usec;
+  { struct timeval t; gettimeofday(&t, nullptr); ts_alloc = (uint64_t)t.tv_sec * 1000000u + (uint64_t)t.tv_usec; }
   n_objects_ = 0;
   uint64_t out_off = 0;
   {  // header (CuCLARK_hh.hh:1957-1972)
@@ -801,96 +842,212 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
     const int w = mic_csv_header(hb, sizeof(hb), 0, nm.data(), (uint32_t)names_.size());
     if (w > 0 && pwrite(out_fd, hb, (size_t)w, 0) == w) out_off = (uint64_t)w;
   }
-  const size_t n_eng = engines_.size(), workers = ingest_workers_, cap = ingest_bytes_;
-  const size_t want = cap - cap / 8;                  // leaves room for the record that straddles the target
-  std::mutex feed_mu, out_mu, host_mu;
-  std::condition_variable out_cv;
-  size_t next_id = 0, next_out = 0;
+  // Three pools around a set of slots (pinned input + pinned CSV + device buffers each):
+  //   loaders   file / memory -> the slot's pinned input, FASTQ without its '+' and quality lines
+  //   device    mic_ingest_classify (blocking: H2D, kernels, D2H); a batch the device hands back goes through the host path
+  //   writers   CSV text -> file at the offset the batch's turn gives it
+  // Batches are numbered when their range is assigned; offsets in the CSV are handed out in that order.
+  const size_t n_eng = engines_.size(), cap = ingest_bytes_;
+  struct SlotRef { size_t eng, slot; uint8_t* raw; };
+  std::vector<SlotRef> slots;
+  for (size_t d = 0; d < n_eng; ++d)
+    for (size_t i = 0; i < ingest_raw_[d].size(); ++i) slots.push_back({d, i, ingest_raw_[d][i]});
+  const size_t S = slots.size();
+  // threads: opt_.threads in all; a quarter of them drive the device, an eighth write, the rest load
+  const size_t T = std::max<size_t>(opt_.threads, 1);
+  size_t ND = std::min<size_t>(8, std::max<size_t>(1, T / 4)), NW = std::min<size_t>(4, std::max<size_t>(1, T / 8));
+  if (const char* env = getenv("MIC_INGEST_ND")) { long v = atol(env); if (v >= 1 && v <= 32) ND = (size_t)v; }
+  if (const char* env = getenv("MIC_INGEST_NW")) { long v = atol(env); if (v >= 1 && v <= 32) NW = (size_t)v; }
+  size_t NL = T > ND + NW ? T - ND - NW : 1;
+  if (S == 1) { ND = NW = NL = 1; }
+  const bool strip_ok = getenv("MIC_KEEP_QUALITY") == nullptr;
+  const bool timing = getenv("MIC_CLI_TIMING") != nullptr;
+
+  struct Item {
+    size_t id = 0, slot = 0; Range r; size_t n = 0; int flags = 0; bool host = false;      // loader -> device
+    const char* text = nullptr; size_t text_n = 0, reads = 0; uint64_t off = 0;             // device -> writer
+    std::shared_ptr<std::string> own;                                                      // CSV of a host-path batch
+  };
+  std::mutex mu;                       // queues, turn bookkeeping, error
+  std::condition_variable cv_free, cv_loaded, cv_write;
+  std::vector<size_t> free_slots;
+  for (size_t i = 0; i < S; ++i) free_slots.push_back(S - 1 - i);
+  std::deque<Item> loaded, to_write;
+  std::map<size_t, Item> waiting;      // finished batches whose turn has not come
+  size_t next_id = 0, next_out = 0, loaders_left = NL, device_left = ND;
   bool fed_all = false;
   std::string err;
-  const bool timing = getenv("MIC_CLI_TIMING") != nullptr;
+  std::mutex feed_mu, host_mu;
   std::atomic<size_t> n_fallback{0}, n_batches{0};
-  std::atomic<uint64_t> us_load{0}, us_dev{0}, us_order{0}, us_write{0};    // MIC_CLI_TIMING: thread-microseconds per stage
+  std::atomic<uint64_t> us_load{0}, us_dev{0}, us_write{0}, bytes_in{0}, bytes_h2d{0};
   auto now_us = [] { struct timeval t; gettimeofday(&t, nullptr); return (uint64_t)t.tv_sec * 1000000u + (uint64_t)t.tv_usec; };
-  auto worker = [&](size_t w) {
-    const size_t d = w % n_eng, slot = w / n_eng;
-    uint8_t* raw = ingest_raw_[d][slot];
-    std::string heap, host_csv;
+  auto fail = [&](const std::string& what) {
+    { std::lock_guard<std::mutex> lk(mu); if (err.empty()) err = what; }
+    cv_free.notify_all();
+  };
+
+  auto loader = [&]() {
+    mic_thread_bind_near_device(engines_[0], 1);     // the pinned slots sit on the device's socket
+    std::vector<uint8_t> stage;
     for (;;) {
-      Range r; size_t id;
+      Item it;
       {
+        // the slot is taken BEFORE the batch gets its number: a later batch can then never hold the last free slot while an
+        // earlier one, whose turn everybody waits for, has none
         std::lock_guard<std::mutex> lk(feed_mu);
-        if (!err.empty() || fed_all) return;
-        bool more = false;
-        try { more = feed.assign(want, cap, r); } catch (const std::exception& ex) { err = ex.what(); }
-        if (!more) { fed_all = true; return; }
-        id = next_id++;
-      }
-      const char* text = nullptr; size_t text_n = 0, reads = 0;
-      try {
-        const uint8_t* bytes = raw;
-        bool host = r.len > cap;
-        if (!host) {
-          const uint64_t ta = timing ? now_us() : 0;
-          feed.load(r, raw);
-          const uint64_t tb = timing ? now_us() : 0;
-          mic_ingest_result res;
-          check(mic_ingest_classify(engines_[d], slot, r.len, paired ? 1 : 0, &res), "device ingest");
-          if (timing) { us_load += tb - ta; us_dev += now_us() - tb; }
-          if (res.status == MIC_INGEST_OK) { text = res.csv; text_n = (size_t)res.csv_bytes; reads = (size_t)res.n_reads; }
-          else host = true;
-        } else {
-          heap.resize(r.len);
-          feed.load(r, (uint8_t*)&heap[0]);
-          bytes = (const uint8_t*)heap.data();
+        {
+          std::unique_lock<std::mutex> lk2(mu);
+          cv_free.wait(lk2, [&] { return !free_slots.empty() || fed_all || !err.empty(); });
+          if (fed_all || !err.empty()) break;
+          it.slot = free_slots.back(); free_slots.pop_back();
         }
-        r.keep.reset();
-        if (host) {   // the host indexer / packer / CSV writer on this batch (rare: one at a time)
+        bool more = false;
+        // FASTQ travels without its quality lines: about half the bytes of a range reach the slot
+        const bool fq = strip_ok && feed.fastq();
+        const size_t want = fq ? cap + cap / 2 : cap - cap / 8;
+        try { more = feed.assign(want, cap, it.r); } catch (const std::exception& ex) { fail(ex.what()); }
+        if (!more) {
+          { std::lock_guard<std::mutex> lk2(mu); fed_all = true; free_slots.push_back(it.slot); }
+          cv_free.notify_all();
+          break;
+        }
+        it.id = next_id++;
+        it.flags = (paired ? MIC_INGEST_PAIRED : 0) | (fq ? MIC_INGEST_FASTQ_2LINE : 0);
+      }
+      const uint64_t ta = timing ? now_us() : 0;
+      try {
+        uint8_t* dst = slots[it.slot].raw;
+        if (it.flags & MIC_INGEST_FASTQ_2LINE) {
+          unsigned phase = 0; size_t w = 0; bool fits = true;
+          const uint8_t* mem = it.r.mem;
+          const size_t CH = 1u << 20;
+          for (size_t o = 0; o < it.r.len && fits; o += CH) {
+            const size_t n = std::min(CH, it.r.len - o);
+            const uint8_t* src = mem ? mem + o : nullptr;
+            if (!src) { if (stage.size() < CH) stage.resize(CH); feed.read(it.r, o, stage.data(), n); src = stage.data(); }
+            const size_t got = strip_fastq(src, n, dst + w, cap - w, phase);
+            if (got == (size_t)-1) { fits = false; break; }
+            w += got;
+          }
+          // a range that ends inside a record (file cut short) or does not fit goes through the host path as it is
+          if (!fits || phase != 0) it.host = true;
+          it.n = w;
+        } else if (it.r.len <= cap) {
+          feed.read(it.r, 0, dst, it.r.len);
+          it.n = it.r.len;
+        } else {
+          it.host = true;
+        }
+        if (timing) {
+          const uint64_t tn = now_us();
+          us_load += tn - ta; bytes_in += it.r.len; if (!it.host) bytes_h2d += it.n;
+          uint64_t z = 0; ts_first_loaded.compare_exchange_strong(z, tn); ts_last_loaded = tn;
+        }
+      } catch (const std::exception& ex) { fail(ex.what()); it.host = true; it.n = 0; }
+      { std::lock_guard<std::mutex> lk(mu); loaded.push_back(std::move(it)); }
+      cv_loaded.notify_one();
+    }
+    { std::lock_guard<std::mutex> lk(mu); --loaders_left; }
+    cv_loaded.notify_all();
+  };
+
+  auto device = [&]() {
+    mic_thread_bind_near_device(engines_[0], 1);
+    for (;;) {
+      Item it;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_loaded.wait(lk, [&] { return !loaded.empty() || loaders_left == 0; });
+        if (loaded.empty()) break;
+        it = std::move(loaded.front()); loaded.pop_front();
+      }
+      const uint64_t ta = timing ? now_us() : 0;
+      bool failed;
+      { std::lock_guard<std::mutex> lk(mu); failed = !err.empty(); }
+      try {
+        if (!failed && !it.host) {
+          mic_ingest_result res;
+          check(mic_ingest_classify(engines_[slots[it.slot].eng], slots[it.slot].slot, it.n, it.flags, &res), "device ingest");
+          if (res.status == MIC_INGEST_OK) { it.text = res.csv; it.text_n = (size_t)res.csv_bytes; it.reads = (size_t)res.n_reads; }
+          else it.host = true;
+        }
+        if (!failed && it.host) {   // the host indexer / packer / CSV writer on the ORIGINAL bytes of the range (rare: one at a time)
+          std::string bytes(it.r.len, '\0');
+          feed.read(it.r, 0, (uint8_t*)&bytes[0], it.r.len);
+          it.own = std::make_shared<std::string>();
           std::lock_guard<std::mutex> lk(host_mu);
           ++n_fallback;
-          host_csv.clear();
-          sink_ = &host_csv;
-          try { reads = process_segment(bytes, r.len, paired, nullptr); } catch (...) { sink_ = nullptr; throw; }
+          sink_ = it.own.get();
+          try { it.reads = process_segment((const uint8_t*)bytes.data(), bytes.size(), paired, nullptr); } catch (...) { sink_ = nullptr; throw; }
           sink_ = nullptr;
-          text = host_csv.data(); text_n = host_csv.size();
+          it.text = it.own->data(); it.text_n = it.own->size();
         }
-      } catch (const std::exception& ex) {
-        std::lock_guard<std::mutex> lk(feed_mu);
-        if (err.empty()) err = ex.what();
-        text_n = 0; reads = 0;
-      }
+      } catch (const std::exception& ex) { fail(ex.what()); it.text_n = 0; it.reads = 0; }
+      it.r.keep.reset();
+      if (timing) { const uint64_t tn = now_us(); us_dev += tn - ta; ts_last_dev = tn; }
       ++n_batches;
-      uint64_t my_off;
-      const uint64_t tc = timing ? now_us() : 0;
       {
-        std::unique_lock<std::mutex> lk(out_mu);
-        out_cv.wait(lk, [&] { return next_out == id; });
-        my_off = out_off; out_off += text_n; ++next_out;
-        n_objects_ += reads;
+        std::lock_guard<std::mutex> lk(mu);
+        waiting.emplace(it.id, std::move(it));
+        for (auto f = waiting.find(next_out); f != waiting.end(); f = waiting.find(next_out)) {   // whose turn has come
+          f->second.off = out_off; out_off += f->second.text_n; n_objects_ += f->second.reads; ++next_out;
+          to_write.push_back(std::move(f->second));
+          waiting.erase(f);
+        }
       }
-      out_cv.notify_all();
-      const uint64_t td = timing ? now_us() : 0;
+      cv_write.notify_all();
+    }
+    { std::lock_guard<std::mutex> lk(mu); --device_left; }
+    cv_write.notify_all();
+  };
+
+  auto writer = [&]() {
+    mic_thread_bind_near_device(engines_[0], 1);
+    for (;;) {
+      Item it;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_write.wait(lk, [&] { return !to_write.empty() || device_left == 0; });
+        if (to_write.empty()) break;
+        it = std::move(to_write.front()); to_write.pop_front();
+      }
+      const uint64_t ta = timing ? now_us() : 0;
       size_t done = 0;
-      while (done < text_n) {
-        const ssize_t n = pwrite(out_fd, text + done, text_n - done, (off_t)(my_off + done));
-        if (n <= 0) { std::lock_guard<std::mutex> lk(feed_mu); if (err.empty()) err = "Failed to write the results file."; break; }
+      while (done < it.text_n) {
+        const ssize_t n = pwrite(out_fd, it.text + done, it.text_n - done, (off_t)(it.off + done));
+        if (n <= 0) { fail("Failed to write the results file."); break; }
         done += (size_t)n;
       }
-      if (timing) { us_order += td - tc; us_write += now_us() - td; }
+      if (timing) { const uint64_t tn = now_us(); us_write += tn - ta; ts_last_write = tn; if (tn - ta > us_write_max) us_write_max = tn - ta; }
+      { std::lock_guard<std::mutex> lk(mu); free_slots.push_back(it.slot); }
+      cv_free.notify_one();
     }
+    mic_thread_bind_near_device(engines_[0], 0);
   };
+
   std::vector<std::thread> th;
-  for (size_t w = 1; w < workers; ++w) th.emplace_back(worker, w);
-  worker(0);
+  for (size_t i = 0; i < NL; ++i) th.emplace_back(loader);
+  for (size_t i = 0; i < ND; ++i) th.emplace_back(device);
+  for (size_t i = 1; i < NW; ++i) th.emplace_back(writer);
+  writer();
+  const uint64_t tj0 = now_us();
   for (auto& t : th) t.join();
+  const uint64_t tj1 = now_us();
   close(out_fd);
+  const uint64_t tj2 = now_us();
   release_batches();
+  const uint64_t tj3 = now_us();
+  if (timing) std::cerr << "[timing] teardown: join " << (tj1 - tj0) / 1e3 << " ms, close " << (tj2 - tj1) / 1e3 << " ms, batch buffers " << (tj3 - tj2) / 1e3 << " ms" << std::endl;
   if (!err.empty()) die(err);
   gettimeofday(&t1, nullptr);
   const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
-  if (timing) std::cerr << "[timing] device ingest: " << n_batches << " batches of <= " << (cap >> 10) << " KB on " << workers
-                        << " worker(s), " << n_fallback << " through the host path; thread-seconds: file -> pinned " << us_load / 1e6
-                        << ", device " << us_dev / 1e6 << ", wait for turn " << us_order / 1e6 << ", pinned -> file " << us_write / 1e6 << std::endl;
+  if (timing) std::cerr << "[timing] device ingest: " << n_batches << " batches of <= " << (cap >> 10) << " KB on " << S
+                        << " slot(s), " << n_fallback << " through the host path; threads: " << NL << " load, " << ND << " device, " << NW
+                        << " write; thread-seconds: load " << us_load / 1e6 << ", device " << us_dev / 1e6 << ", write " << us_write / 1e6
+                        << "; input " << bytes_in / 1e6 << " MB, over the link " << bytes_h2d / 1e6 << " MB; ms since start: slots ready "
+                        << (ts_alloc - t0_us) / 1e3 << ", first batch loaded " << (ts_first_loaded - t0_us) / 1e3 << ", last loaded "
+                        << (ts_last_loaded - t0_us) / 1e3 << ", last off the device " << (ts_last_dev - t0_us) / 1e3 << ", last write done " << (ts_last_write - t0_us) / 1e3
+                        << " (longest " << us_write_max / 1e3 << "), end " << diff * 1e3 << std::endl;
   std::cout << " - Assignment time: " << diff << " s. Speed: ";  // CuCLARK_hh.hh:1938-1944
   std::cout << (size_t)(((double)n_objects_) / (diff) * 60.0) << " objects/min. (" << n_objects_ << " objects)." << std::endl;
   std::cout << " - Results stored in " << csv << std::endl;

@@ -59,7 +59,8 @@ class Classifier {
    public:
     virtual ~Feeder() {}
     virtual bool assign(size_t want, size_t cap, Range& r) = 0;
-    virtual void load(const Range& r, uint8_t* dst) = 0;     // any thread, no lock held
+    virtual void read(const Range& r, size_t off, uint8_t* dst, size_t len) = 0;   // bytes [off, off + len) of the range; any thread
+    virtual bool fastq() const = 0;                          // the input's records are four-line FASTQ records
   };
   void run_stream(Feeder& f, const std::string& results_base, bool paired, size_t total_bytes);
 

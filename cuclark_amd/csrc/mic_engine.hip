@@ -11,12 +11,16 @@
 #include <string.h>
 #include <time.h>
 
+#include <sched.h>
+
 #include <mutex>
 #include <string>
 #include <atomic>
 #include <thread>
 #include <unistd.h>
 #include <vector>
+
+int mic_bind_thread_near_device(int device, int on);   // below: host memory near the device
 
 namespace {
 
@@ -41,7 +45,7 @@ struct Batch {
   uint32_t* d_peer = nullptr; uint32_t* d_acc = nullptr;   // table-sharded merge: another engine's rows, the running sum
   size_t first_read = 0, n_reads = 0, n_cont = 0, max_reads = 0, max_cont = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t done = nullptr;
+  hipEvent_t done = nullptr, ev_up = nullptr, ev_k = nullptr;   // batch finished; its upload finished; its kernels finished
   bool scheduled = false, resolved = true, extended = false;
 };
 
@@ -51,6 +55,10 @@ struct mic_engine {
   mic_config cfg;
   int device = 0, n_cu = 256;
   hipStream_t stream = nullptr;
+  // ALL uploads of the batch / ingest paths go through one stream and all downloads through another (events tie a
+  // batch's kernels in between): with the copies of every batch on that batch's own stream the two directions share
+  // copy engines and the link moves 41 instead of 54 GB/s in this traffic shape (tools/host_link_probe.hip)
+  hipStream_t up_stream = nullptr, down_stream = nullptr;
   // table
   bool db_loaded = false;
   uint4* slots = nullptr;
@@ -123,6 +131,9 @@ int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStrea
   hipEvent_t ev[2] = {nullptr, nullptr};
   int rc = MIC_OK;
   if (bytes == 0) return MIC_OK;
+  int dev_now = 0;
+  hipGetDevice(&dev_now);
+  mic_bind_thread_near_device(dev_now, 1);
   for (int i = 0; i < 2 && rc == MIC_OK; ++i) {
     if (hipHostMalloc(&stage[i], CH, hipHostMallocDefault) != hipSuccess) rc = fail(MIC_E_NOMEM, "pinned staging alloc failed");
     else if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(MIC_E_HIP, "event create failed");
@@ -157,6 +168,7 @@ int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStrea
   }
   hipStreamSynchronize(s);
   for (int i = 0; i < 2; ++i) { if (stage[i]) hipHostFree(stage[i]); if (ev[i]) hipEventDestroy(ev[i]); }
+  mic_bind_thread_near_device(dev_now, 0);
   return rc;
 }
 
@@ -215,6 +227,8 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
 void free_batches(mic_engine* e) {
   for (Batch& b : e->batches) {
     if (b.done) hipEventDestroy(b.done);
+    if (b.ev_up) hipEventDestroy(b.ev_up);
+    if (b.ev_k) hipEventDestroy(b.ev_k);
     if (b.stream) hipStreamDestroy(b.stream);
     if (b.d_peer) hipFree(b.d_peer);
     if (b.d_acc) hipFree(b.d_acc);
@@ -262,6 +276,69 @@ int run_dense(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, const
 
 }  // namespace
 
+// ---- host memory near the device ----------------------------------------------------------------------------------------
+// On a two-socket host the device hangs off one socket; pinned buffers on the other socket are reached through the
+// inter-socket link and the host link then runs at ~39 instead of ~57 GB/s (measured).  Pinned
+// allocations are therefore made - and the CLI's loader threads run - on the CPUs of the device's NUMA node.
+namespace {
+int device_numa_node(int device) {
+  static std::mutex mu;
+  static int cache[64]; static bool have[64];
+  std::lock_guard<std::mutex> lk(mu);
+  if (device >= 0 && device < 64 && have[device]) return cache[device];
+  int node = -1;
+  char bus[64] = "";
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) == hipSuccess) {
+    for (char* c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+  }
+  if (device >= 0 && device < 64) { cache[device] = node; have[device] = true; }
+  return node;
+}
+
+bool node_cpu_set(int node, cpu_set_t* set) {
+  char path[96];
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) return false;
+  CPU_ZERO(set);
+  int a, b; char c; bool any = false;
+  while (fscanf(f, "%d", &a) == 1) {
+    b = a;
+    if (fscanf(f, "%c", &c) == 1 && c == '-') { if (fscanf(f, "%d", &b) != 1) b = a; if (fscanf(f, "%c", &c) != 1) c = 0; }
+    for (int i = a; i <= b && i < CPU_SETSIZE; ++i) { CPU_SET(i, set); any = true; }
+    if (c != ',') break;
+  }
+  fclose(f);
+  return any;
+}
+
+thread_local cpu_set_t t_saved_mask;
+thread_local int t_bound_depth = 0;
+}  // namespace
+
+// binds the calling thread to the CPUs of the device's NUMA node (on != 0) or gives it its previous mask back (on == 0);
+// nests; a no-op (returns 0) when the node is unknown or MIC_NO_NUMA is set.  Returns 1 if the mask was changed.
+int mic_bind_thread_near_device(int device, int on) {
+  static const bool off = getenv("MIC_NO_NUMA") != nullptr;
+  if (off) return 0;
+  if (on) {
+    if (t_bound_depth++ > 0) return 0;
+    const int node = device_numa_node(device);
+    cpu_set_t want, cur, both;
+    if (node < 0 || !node_cpu_set(node, &want) || sched_getaffinity(0, sizeof(cur), &cur) != 0) { --t_bound_depth; return 0; }
+    CPU_AND(&both, &want, &cur);
+    if (CPU_COUNT(&both) == 0 || CPU_EQUAL(&both, &cur)) { --t_bound_depth; return 0; }
+    t_saved_mask = cur;
+    if (sched_setaffinity(0, sizeof(both), &both) != 0) { --t_bound_depth; return 0; }
+    return 1;
+  }
+  if (t_bound_depth > 0 && --t_bound_depth == 0) sched_setaffinity(0, sizeof(t_saved_mask), &t_saved_mask);
+  return 0;
+}
+
 // ---- what mic_ingest.hip needs from the engine ------------------------------------------------------------------------
 int mic_set_error(int code, const char* fmt, ...) {
   va_list ap;
@@ -280,6 +357,7 @@ int mic_engine_table(mic_engine* e, MicTable* t, int* slot_class, int* n_cu, int
 }
 
 void** mic_engine_ingest_slot(mic_engine* e) { return &e->ingest; }
+void mic_engine_copy_streams(mic_engine* e, hipStream_t* up, hipStream_t* down) { *up = e->up_stream; *down = e->down_stream; }
 
 extern "C" {
 
@@ -320,6 +398,8 @@ int mic_create(const mic_config* cfg, mic_engine** out) {
   memset(&e->info, 0, sizeof(e->info));
   memset(&e->table, 0, sizeof(e->table));
   hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->down_stream, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
   if (he == hipSuccess) he = hipMalloc(&e->d_flagged, (size_t)(kFlaggedCap + 1) * 4);
@@ -341,6 +421,8 @@ int mic_destroy(mic_engine* e) {
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   if (e->stream) hipStreamDestroy(e->stream);
+  if (e->up_stream) hipStreamDestroy(e->up_stream);
+  if (e->down_stream) hipStreamDestroy(e->down_stream);
   delete e;
   return MIC_OK;
 }
@@ -483,7 +565,13 @@ int mic_batches_alloc(mic_engine* e, size_t num_reads_total, size_t max_reads, s
   const size_t h_res = up((num_reads_total + 1) * MIC_RESULT_WORDS * 4), h_rows = extended ? up((num_reads_total + 1) * (size_t)rw * 4) : 0;
   const size_t h_total = h_res + h_rows + nb * (sz_rp + sz_ct + sz_fl);
   const size_t d_total = nb * (sz_rp + sz_ct + sz_res + sz_rows + sz_fl);
-  HIPTRY(hipHostMalloc(&e->h_block, h_total, hipHostMallocDefault));
+  {
+    mic_bind_thread_near_device(e->device, 1);      // pinned memory on the device's socket
+    hipError_t he = hipHostMalloc(&e->h_block, h_total, hipHostMallocDefault);
+    if (he == hipSuccess) memset(e->h_block, 0, h_total);
+    mic_bind_thread_near_device(e->device, 0);
+    HIPTRY(he);
+  }
   HIPTRY(hipMalloc(&e->d_block, d_total));
   char* hp = (char*)e->h_block; char* dp = (char*)e->d_block;
   e->h_results = (uint32_t*)hp; hp += h_res;
@@ -504,6 +592,8 @@ int mic_batches_alloc(mic_engine* e, size_t num_reads_total, size_t max_reads, s
     B.d_flagged = (uint32_t*)dp; dp += sz_fl;
     HIPTRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
     HIPTRY(hipEventCreateWithFlags(&B.done, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&B.ev_up, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&B.ev_k, hipEventDisableTiming));
     reads_pointer[b] = B.h_rp;
     containers[b] = B.h_cont;
   }
@@ -530,22 +620,26 @@ int mic_batch_query(mic_engine* e, size_t batch, int extended, int followup) {
   if (rc) return rc;
   Batch& B = e->batches[batch];
   if (extended && !B.d_rows) return fail(MIC_E_STATE, "batches were not allocated for extended results");
-  hipStream_t s = B.stream;
-  HIPTRY(hipMemcpyAsync(B.d_rp, B.h_rp, (B.n_reads + 1) * 4, hipMemcpyHostToDevice, s));
-  HIPTRY(hipMemcpyAsync(B.d_cont, B.h_cont, (B.n_cont + 16) * 2, hipMemcpyHostToDevice, s));
+  hipStream_t s = B.stream, up = e->up_stream, down = e->down_stream;
+  HIPTRY(hipMemcpyAsync(B.d_rp, B.h_rp, (B.n_reads + 1) * 4, hipMemcpyHostToDevice, up));
+  HIPTRY(hipMemcpyAsync(B.d_cont, B.h_cont, (B.n_cont + 16) * 2, hipMemcpyHostToDevice, up));
+  HIPTRY(hipEventRecord(B.ev_up, up));
+  HIPTRY(hipStreamWaitEvent(s, B.ev_up, 0));
   HIPTRY(hipMemsetAsync(B.d_flagged, 0, 4, s));
   MicQueryArgs a;
   a.t = e->table; a.reads_ptr = B.d_rp; a.cont = B.d_cont; a.n_reads = (uint32_t)B.n_reads;
   a.row_words = e->cfg.row_words; a.results = B.d_results; a.rows = extended ? B.d_rows : nullptr;
   a.flagged = B.d_flagged; a.flagged_cap = kFlaggedCap;
   HIPTRY(mic_launch_query(a, e->slot_class, e->n_cu, s));
+  HIPTRY(hipEventRecord(B.ev_k, s));
+  HIPTRY(hipStreamWaitEvent(down, B.ev_k, 0));
   HIPTRY(hipMemcpyAsync(e->h_results + B.first_read * MIC_RESULT_WORDS, B.d_results, B.n_reads * MIC_RESULT_WORDS * 4,
-                        hipMemcpyDeviceToHost, s));
+                        hipMemcpyDeviceToHost, down));
   if (extended)
     HIPTRY(hipMemcpyAsync(e->h_rows + B.first_read * (size_t)e->cfg.row_words, B.d_rows,
-                          B.n_reads * (size_t)e->cfg.row_words * 4, hipMemcpyDeviceToHost, s));
-  HIPTRY(hipMemcpyAsync(B.h_flagged, B.d_flagged, 4, hipMemcpyDeviceToHost, s));   // count only; ids stay on the device
-  HIPTRY(hipEventRecord(B.done, s));
+                          B.n_reads * (size_t)e->cfg.row_words * 4, hipMemcpyDeviceToHost, down));
+  HIPTRY(hipMemcpyAsync(B.h_flagged, B.d_flagged, 4, hipMemcpyDeviceToHost, down));   // count only; ids stay on the device
+  HIPTRY(hipEventRecord(B.done, down));
   B.scheduled = true; B.resolved = false; B.extended = extended != 0;
   return MIC_OK;
 }
@@ -657,6 +751,12 @@ int mic_batch_check(mic_engine* e, size_t batch, int* done) {
   if (he == hipSuccess) *done = 1;
   else if (he == hipErrorNotReady) *done = 0;
   else return fail(MIC_E_HIP, "hipEventQuery: %s", hipGetErrorString(he));
+  return MIC_OK;
+}
+
+int mic_thread_bind_near_device(mic_engine* e, int on) {
+  if (!e) return fail(MIC_E_INVALID, "null engine");
+  mic_bind_thread_near_device(e->device, on);
   return MIC_OK;
 }
 

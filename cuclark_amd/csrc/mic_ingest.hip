@@ -31,6 +31,8 @@ struct mic_engine;
 // engine internals this file needs (mic_engine.hip)
 int mic_engine_table(mic_engine* e, MicTable* t, int* slot_class, int* n_cu, int* device, int* k, uint32_t* n_targets);
 int mic_set_error(int code, const char* fmt, ...);
+int mic_bind_thread_near_device(int device, int on);
+void mic_engine_copy_streams(mic_engine* e, hipStream_t* up, hipStream_t* down);
 
 namespace {
 
@@ -95,7 +97,8 @@ __global__ void __launch_bounds__(256) line_start_kernel(const uint8_t* __restri
 
 // one thread: number of lines (an unterminated last line counts and gets a virtual line end at nb), FASTQ record count
 __global__ void lines_finish_kernel(const uint8_t* __restrict__ raw, uint32_t nb, const uint32_t* __restrict__ tile_off, uint32_t n_tiles,
-                                    uint32_t* __restrict__ line_start, uint32_t cap, int fasta, uint32_t max_reads, uint32_t* __restrict__ hdr) {
+                                    uint32_t* __restrict__ line_start, uint32_t cap, int fasta, uint32_t lpr, uint32_t max_reads,
+                                    uint32_t* __restrict__ hdr) {
   const uint32_t nl = tile_off[n_tiles];
   uint32_t n_lines = nl;
   if (nb && raw[nb - 1] != '\n') { ++n_lines; if (n_lines < cap) line_start[n_lines] = nb + 1; }
@@ -104,8 +107,8 @@ __global__ void lines_finish_kernel(const uint8_t* __restrict__ raw, uint32_t nb
   hdr[H_NEWLINES] = nl;
   hdr[H_NLINES] = n_lines;
   if (!fasta) {
-    if (n_lines & 3u) status |= MIC_INGEST_TRUNCATED;
-    const uint32_t nr = n_lines >> 2;
+    if (n_lines % lpr) status |= MIC_INGEST_TRUNCATED;
+    const uint32_t nr = n_lines / lpr;
     if (nr > max_reads) status |= MIC_INGEST_TOO_MANY;
     hdr[H_NREADS] = nr;
   }
@@ -150,13 +153,13 @@ __device__ __forceinline__ bool name_sep_dev(uint8_t c) { return c == ' ' || c =
 // next header (CuCLARK_hh.hh:1369-1389), Length = bytes of the sequence lines without their line ends.
 template <bool FASTA>
 __global__ void __launch_bounds__(256) record_kernel(const uint8_t* __restrict__ raw, uint32_t nb, const uint32_t* __restrict__ line_start,
-                                                     const uint32_t* __restrict__ hdr_line, uint32_t n_reads, int k, RecArrays a,
+                                                     const uint32_t* __restrict__ hdr_line, uint32_t n_reads, uint32_t lpr, int k, RecArrays a,
                                                      uint32_t* __restrict__ hdr) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
   if (r > n_reads) return;
   if (r == n_reads) { a.bound[r] = 0; return; }
   uint32_t hl, hn;
-  if (FASTA) { hl = hdr_line[r]; hn = hdr_line[r + 1]; } else { hl = 4 * r; hn = 4 * r + 2; }
+  if (FASTA) { hl = hdr_line[r]; hn = hdr_line[r + 1]; } else { hl = lpr * r; hn = lpr * r + 2; }
   const uint32_t hs = line_start[hl], ss = line_start[hl + 1], se = line_start[hn] - 1;
   uint32_t status = 0, len;
   if (FASTA) {
@@ -346,7 +349,7 @@ struct Slot {
   uint32_t* d_line_len = nullptr; uint32_t* d_line_off = nullptr; char* d_csv = nullptr; uint32_t* d_hdr = nullptr;
   void* d_tmp = nullptr; size_t tmp_bytes = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev = nullptr;
+  hipEvent_t ev = nullptr, ev_up = nullptr, ev_k = nullptr;
   uint32_t n_reads = 0, cont_used = 0;
   std::vector<void*> dev_allocs, host_allocs;
 };
@@ -413,7 +416,10 @@ int alloc_slot(Ingest* g, Slot& s, size_t tmp, int device) {
   hipError_t e = hipMalloc(&d, dv.off + 256);
   if (e != hipSuccess) return mic_set_error(MIC_E_NOMEM, "ingest slot: %zu bytes of device memory: %s", dv.off, hipGetErrorString(e));
   s.dev_allocs.push_back(d);
+  mic_bind_thread_near_device(device, 1);           // pinned memory on the device's socket: the link runs ~1.4x faster
   e = hipHostMalloc(&h, hs.off + 256, hipHostMallocDefault);
+  if (e == hipSuccess) memset(h, 0, hs.off + 256);
+  mic_bind_thread_near_device(device, 0);
   if (e != hipSuccess) return mic_set_error(MIC_E_NOMEM, "ingest slot: %zu bytes of pinned memory: %s", hs.off, hipGetErrorString(e));
   s.host_allocs.push_back(h);
   Arena dv2, hs2;
@@ -421,6 +427,8 @@ int alloc_slot(Ingest* g, Slot& s, size_t tmp, int device) {
   carve_slot(g, s, dv2, hs2, tmp);
   if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&s.ev_k, hipEventDisableTiming)) != hipSuccess ||
       // the query kernel's read-ahead looks past the last read of a batch: no stale length slots there
       (e = hipMemsetAsync(s.d_cont, 0, (g->cont_cap + 192) * 2, s.stream)) != hipSuccess ||
       (e = hipStreamSynchronize(s.stream)) != hipSuccess)
@@ -435,6 +443,8 @@ void free_ingest(Ingest* g) {
     for (void* p : s.dev_allocs) hipFree(p);
     for (void* p : s.host_allocs) hipHostFree(p);
     if (s.ev) hipEventDestroy(s.ev);
+    if (s.ev_up) hipEventDestroy(s.ev_up);
+    if (s.ev_k) hipEventDestroy(s.ev_k);
     if (s.stream) hipStreamDestroy(s.stream);
   }
   if (g->d_tnames) hipFree(g->d_tnames);
@@ -512,7 +522,9 @@ int mic_ingest_free(mic_engine* e) {
   return MIC_OK;
 }
 
-int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int paired, mic_ingest_result* out) {
+int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int flags, mic_ingest_result* out) {
+  const int paired = flags & MIC_INGEST_PAIRED;
+  const uint32_t lpr = (flags & MIC_INGEST_FASTQ_2LINE) ? 2u : 4u;      // lines per FASTQ record
   if (!e || !out) return mic_set_error(MIC_E_INVALID, "null argument");
   Ingest* g = (Ingest*)*mic_engine_ingest_slot(e);
   if (!g || slot_id >= g->slots.size()) return mic_set_error(MIC_E_STATE, "ingest slots are not allocated");
@@ -532,15 +544,20 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int paire
   hipStream_t st = s.stream;
   const uint32_t nb = (uint32_t)n_bytes;
   const uint32_t n_tiles = (nb + ING_TILE - 1) / ING_TILE;
-  // ---- phase 1: bytes -> lines -> number of records
-  ITRY(hipMemcpyAsync(s.d_raw, s.h_raw, n_bytes, hipMemcpyHostToDevice, st));
+  // ---- phase 1: bytes -> lines -> number of records.  The upload runs on the engine's upload stream, the CSV comes
+  // back on its download stream (mic_engine.hip: one stream per direction keeps both directions of the link busy)
+  hipStream_t up, down;
+  mic_engine_copy_streams(e, &up, &down);
+  ITRY(hipMemcpyAsync(s.d_raw, s.h_raw, n_bytes, hipMemcpyHostToDevice, up));
+  ITRY(hipEventRecord(s.ev_up, up));
+  ITRY(hipStreamWaitEvent(st, s.ev_up, 0));
   ITRY(hipMemsetAsync(s.d_hdr, 0, H_WORDS * 4, st));
   line_count_kernel<<<n_tiles, 256, 0, st>>>(s.d_raw, nb, s.d_tile);
   ITRY(hipMemsetAsync(s.d_tile + n_tiles, 0, 4, st));
   size_t tb = s.tmp_bytes;
   ITRY(hipcub::DeviceScan::ExclusiveSum(s.d_tmp, tb, s.d_tile, s.d_tile_off, (int)(n_tiles + 1), st));
   line_start_kernel<<<n_tiles, 256, 0, st>>>(s.d_raw, nb, s.d_tile_off, s.d_line_start, (uint32_t)g->max_lines);
-  lines_finish_kernel<<<1, 1, 0, st>>>(s.d_raw, nb, s.d_tile_off, n_tiles, s.d_line_start, (uint32_t)g->max_lines, fasta, (uint32_t)g->max_reads, s.d_hdr);
+  lines_finish_kernel<<<1, 1, 0, st>>>(s.d_raw, nb, s.d_tile_off, n_tiles, s.d_line_start, (uint32_t)g->max_lines, fasta, lpr, (uint32_t)g->max_reads, s.d_hdr);
   if (fasta) {
     // a line is at least one byte long, so there are at most nb of them: flags and their scan cover lines 0 .. n_scan - 1
     // (n_lines < n_scan whenever the batch is within the slot's line capacity)
@@ -560,8 +577,8 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int paire
   if (s.h_hdr[H_STATUS] || n_reads == 0) { out->status = MIC_INGEST_FALLBACK | s.h_hdr[H_STATUS]; return MIC_OK; }
   // ---- phase 2: records -> packed reads -> query -> CSV line lengths
   const uint32_t gr = (n_reads + 1 + 255) / 256;
-  if (fasta) record_kernel<true><<<gr, 256, 0, st>>>(s.d_raw, nb, s.d_line_start, s.d_hdr_line, n_reads, k, s.rec, s.d_hdr);
-  else record_kernel<false><<<gr, 256, 0, st>>>(s.d_raw, nb, s.d_line_start, nullptr, n_reads, k, s.rec, s.d_hdr);
+  if (fasta) record_kernel<true><<<gr, 256, 0, st>>>(s.d_raw, nb, s.d_line_start, s.d_hdr_line, n_reads, lpr, k, s.rec, s.d_hdr);
+  else record_kernel<false><<<gr, 256, 0, st>>>(s.d_raw, nb, s.d_line_start, nullptr, n_reads, lpr, k, s.rec, s.d_hdr);
   tb = s.tmp_bytes;
   ITRY(hipcub::DeviceScan::ExclusiveSum(s.d_tmp, tb, s.rec.bound, s.d_rp, (int)(n_reads + 1), st));
   {
@@ -593,9 +610,11 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int paire
   // ---- phase 3: CSV text -> host
   csv_fmt_kernel<<<(n_reads + 255) / 256, 256, 0, st>>>(ca, s.d_line_off, s.d_csv);
   ITRY(hipGetLastError());
-  ITRY(hipMemcpyAsync(s.h_csv, s.d_csv, csv_bytes, hipMemcpyDeviceToHost, st));
-  if (g->want_results) ITRY(hipMemcpyAsync(s.h_results, s.d_results, (size_t)n_reads * 32, hipMemcpyDeviceToHost, st));
-  ITRY(hipEventRecord(s.ev, st));
+  ITRY(hipEventRecord(s.ev_k, st));
+  ITRY(hipStreamWaitEvent(down, s.ev_k, 0));
+  ITRY(hipMemcpyAsync(s.h_csv, s.d_csv, csv_bytes, hipMemcpyDeviceToHost, down));
+  if (g->want_results) ITRY(hipMemcpyAsync(s.h_results, s.d_results, (size_t)n_reads * 32, hipMemcpyDeviceToHost, down));
+  ITRY(hipEventRecord(s.ev, down));
   ITRY(hipEventSynchronize(s.ev));
   out->n_reads = n_reads; out->csv_bytes = csv_bytes; out->csv = s.h_csv; out->results = g->want_results ? s.h_results : nullptr;
   out->status = MIC_INGEST_OK;

@@ -143,6 +143,10 @@ int mic_batch_check(mic_engine* e, size_t batch, int* done);
  * caller: the sum over the engines of mic_batch_dense_counts.  Synchronous.  Engines may share a device. */
 int mic_batch_merge_shards(mic_engine* const* engines, size_t n_engines, size_t batch);
 int mic_sync(mic_engine* e);
+/* Host threads that fill the engine's pinned buffers should run on the socket the device hangs off: on != 0 binds the
+ * calling thread to the CPUs of the device's NUMA node, on == 0 restores its previous mask (no-op when the node is
+ * unknown or MIC_NO_NUMA is set).  The engine's own pinned allocations are made there already. */
+int mic_thread_bind_near_device(mic_engine* e, int on);
 int mic_batches_free(mic_engine* e);
 
 /* ---- device-resident entry points (kernels only; inputs/outputs already in HBM) --------------
@@ -190,13 +194,16 @@ int mic_last_query_ms(mic_engine* e, float* ms);
  * mic_ingest_alloc    engine-owned pinned input buffers (raw[i], max_bytes each) lent to the caller, as
  *                     CuClarkDB::malloc lends its batch buffers (CuClarkDB.cu:355-360); target_names as in mic_csv_line.
  * mic_ingest_classify blocking; slot-private stream: call it from one host thread per slot to keep the device busy.
- *                     The slot's first byte must be '>' (FASTA, also the merged paired-end text of file.cc:205-268;
- *                     paired != 0 then subtracts the separator from the Length column, CuCLARK_hh.hh:2119) or '@' (FASTQ).
+ *                     The slot's first byte must be '>' (FASTA, also the merged paired-end text of file.cc:205-268 with
+ *                     MIC_INGEST_PAIRED in flags) or '@' (FASTQ; with MIC_INGEST_FASTQ_2LINE two lines per record).
  *                     out->status == MIC_INGEST_OK: out->csv / csv_bytes / n_reads are valid until the slot's next call.
  *                     out->status & MIC_INGEST_FALLBACK: the batch holds something the device path does not
  *                     reproduce (the other bits say what); nothing was produced and the caller runs the host path
  *                     (mic_index_reads ... mic_csv_line) on these bytes.
  * mic_ingest_fetch_packed  test hook: the packed reads of the slot's last batch as the query kernel saw them. */
+#define MIC_INGEST_PAIRED 1        /* flags: objects are merged pairs: Length column minus the separator (CuCLARK_hh.hh:2119)        */
+#define MIC_INGEST_FASTQ_2LINE 2   /* flags: FASTQ records come as header + sequence line only (the caller dropped the '+' and
+                                      quality lines, which nothing reads: halves the bytes that cross the host link)           */
 #define MIC_INGEST_OK 0u
 #define MIC_INGEST_FALLBACK 1u     /* run the host path on this batch                                        */
 #define MIC_INGEST_ODD_RECORD 2u   /* empty read name, FASTA record without a sequence line, unknown format   */
@@ -216,7 +223,7 @@ typedef struct mic_ingest_result {
 
 int mic_ingest_alloc(mic_engine* e, size_t n_slots, size_t max_bytes, const char* const* target_names, uint32_t n_targets,
                      int want_results, uint8_t** raw /*[n_slots]*/);
-int mic_ingest_classify(mic_engine* e, size_t slot, size_t n_bytes, int paired, mic_ingest_result* out);
+int mic_ingest_classify(mic_engine* e, size_t slot, size_t n_bytes, int flags, mic_ingest_result* out);
 int mic_ingest_fetch_packed(mic_engine* e, size_t slot, uint32_t* reads_pointer, size_t rp_cap, uint16_t* containers,
                             size_t cont_cap, uint64_t* n_reads, uint64_t* n_containers);
 int mic_ingest_free(mic_engine* e);

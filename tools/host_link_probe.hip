@@ -12,6 +12,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <algorithm>
 #include <thread>
 #include <vector>
 
@@ -25,6 +26,59 @@ static void par(int n, F&& f) {
   for (int t = 1; t < n; ++t) th.emplace_back([&f, t] { f(t); });
   f(0);
   for (auto& x : th) x.join();
+}
+
+__global__ void spin_kernel(unsigned long long cycles, unsigned* sink) {
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < cycles) {}
+  if (sink && threadIdx.x == 1024) *sink = 1;
+}
+
+// the batch pipeline's shape: NB batches on NB streams, each H2D (in) -> kernel (kus microseconds) -> D2H (out)
+static void pipeline_shape(void* h_in, void* d_in, void* h_out, void* d_out, size_t in_bytes, size_t out_bytes, int NB, int kus, bool d2h) {
+  std::vector<hipStream_t> st(NB);
+  for (auto& s : st) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  const size_t pi = in_bytes / NB & ~(size_t)255, po = out_bytes / NB & ~(size_t)255;
+  double best = 1e9;
+  for (int rep = 0; rep < 4; ++rep) {
+    const double t = now();
+    for (int b = 0; b < NB; ++b) {
+      CK(hipMemcpyAsync((char*)d_in + b * pi, (char*)h_in + b * pi, pi, hipMemcpyHostToDevice, st[b]));
+      if (kus) spin_kernel<<<256 * 8, 256, 0, st[b]>>>((unsigned long long)kus * 100, nullptr);   // s_memtime-ish counter: 100 MHz
+      if (d2h) CK(hipMemcpyAsync((char*)h_out + b * po, (char*)d_out + b * po, po, hipMemcpyDeviceToHost, st[b]));
+    }
+    for (auto& s : st) CK(hipStreamSynchronize(s));
+    best = std::min(best, now() - t);
+  }
+  printf("pipeline shape: %2d batches, H2D %.0f MB%s%s: %.2f ms -> H2D %.1f GB/s\n", NB, in_bytes / 1e6, kus ? ", kernel" : "", d2h ? ", D2H" : "",
+         best * 1e3, pi * NB / best / 1e9);
+  for (auto& s : st) hipStreamDestroy(s);
+}
+
+// the same with ONE upload stream and ONE download stream (events tie a batch's kernel between them)
+static void pipeline_shape2(void* h_in, void* d_in, void* h_out, void* d_out, size_t in_bytes, size_t out_bytes, int NB, int kus) {
+  std::vector<hipStream_t> st(NB);
+  std::vector<hipEvent_t> e1(NB), e2(NB);
+  hipStream_t up, down;
+  CK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+  for (int b = 0; b < NB; ++b) { CK(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking)); CK(hipEventCreateWithFlags(&e1[b], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&e2[b], hipEventDisableTiming)); }
+  const size_t pi = in_bytes / NB & ~(size_t)255, po = out_bytes / NB & ~(size_t)255;
+  double best = 1e9;
+  for (int rep = 0; rep < 4; ++rep) {
+    const double t = now();
+    for (int b = 0; b < NB; ++b) {
+      CK(hipMemcpyAsync((char*)d_in + b * pi, (char*)h_in + b * pi, pi, hipMemcpyHostToDevice, up));
+      CK(hipEventRecord(e1[b], up));
+      CK(hipStreamWaitEvent(st[b], e1[b], 0));
+      spin_kernel<<<256 * 8, 256, 0, st[b]>>>((unsigned long long)kus * 100, nullptr);
+      CK(hipEventRecord(e2[b], st[b]));
+      CK(hipStreamWaitEvent(down, e2[b], 0));
+      CK(hipMemcpyAsync((char*)h_out + b * po, (char*)d_out + b * po, po, hipMemcpyDeviceToHost, down));
+    }
+    CK(hipStreamSynchronize(down));
+    best = std::min(best, now() - t);
+  }
+  printf("pipeline shape, one upload + one download stream: %2d batches: %.2f ms -> H2D %.1f GB/s\n", NB, best * 1e3, pi * NB / best / 1e9);
 }
 
 int main(int argc, char** argv) {
@@ -53,6 +107,12 @@ int main(int argc, char** argv) {
     for (size_t o = 0; o < GB; o += ch, ++i) CK(hipMemcpyAsync((char*)d0 + o, (char*)h0 + o, ch, hipMemcpyHostToDevice, (i & 1) ? s1 : s0));
     CK(hipStreamSynchronize(s0)); CK(hipStreamSynchronize(s1));
     printf("H2D in %zu MB pieces on 2 streams: %.1f GB/s\n", ch >> 20, GB / (now() - t) / 1e9);
+  }
+  for (int NB : {1, 4, 16}) {
+    pipeline_shape(h0, d0, h1, d1, 760u << 20, 320u << 20, NB, 0, false);
+    pipeline_shape(h0, d0, h1, d1, 760u << 20, 320u << 20, NB, 0, true);
+    pipeline_shape(h0, d0, h1, d1, 760u << 20, 320u << 20, NB, 7200 / NB, true);
+    if (NB > 1) pipeline_shape2(h0, d0, h1, d1, 760u << 20, 320u << 20, NB, 7200 / NB);
   }
   // host memcpy pageable -> pinned with T threads
   char* src = (char*)malloc(GB); memset(src, 3, GB);
