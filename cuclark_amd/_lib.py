@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmi_clark.so")
+# MIC_LIB_PATH selects a measuring build (make variant ...: csrc/Makefile); the product library is the default
+LIB_PATH = os.environ.get("MIC_LIB_PATH") or os.path.join(_PKG, "lib", "libmi_clark.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 MIC_RESULT_WORDS = 8

@@ -121,6 +121,12 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
     std::cerr << (opt_.light ? "Creating light database in disk..." : "Creating database in disk...") << std::endl;
     std::cerr << n_kmers << " " << opt_.k << "-mers successfully stored in database." << std::endl;
   }
+  {  // the table size is part of the database name: a .sz of another size is not this database (e.g. a build cut short)
+    struct stat st;
+    if (stat((db + ".sz").c_str(), &st) == 0 && (uint64_t)st.st_size != opt_.htsize)
+      die("The database file " + db + ".sz holds " + std::to_string((unsigned long long)st.st_size) + " buckets, expected " +
+          std::to_string((unsigned long long)opt_.htsize) + ": remove the database files and build them again.");
+  }
   int n_dev = 0;
   check(mic_device_count(&n_dev), "device discovery");
   if (n_dev == 0) die("No HIP device found.");

@@ -179,8 +179,11 @@ __global__ void reduce_sizes_kernel(const uint8_t* __restrict__ sizes, uint64_t 
   if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], tot); atomicAdd(&out[1], nz); }
 }
 
+// an allocation that fails for lack of memory is reported as -3 (MIC_E_NOMEM): the engine then falls back to a smaller
+// layout when the layout was chosen by default (mic_engine.hip: build_from_device)
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
-    snprintf(err, err_cap, "%s failed: %s", #x, hipGetErrorString(e_)); rc = -4; goto done; } } while (0)
+    snprintf(err, err_cap, "%s failed: %s", #x, hipGetErrorString(e_)); (void)hipGetLastError(); \
+    rc = e_ == hipErrorOutOfMemory ? -3 : -4; goto done; } } while (0)
 
 }  // namespace
 
@@ -935,7 +938,9 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       const double lim = atof(env) * 1e9;
       if (lim > 0 && avail_b > lim) avail_b = lim;
     }
-    const double need = (double)n_cand * 12 + (double)n_slots * (16 + 128);
+    // per slot: counts 4 + offsets 8 + cursors 4 + chain offsets 8 + chain demand 4 = 28 bytes, the 128-byte slot itself,
+    // and the scans' temporary storage (a few MB)
+    const double need = (double)n_cand * 12 + (double)n_slots * (28 + 128) + 64e6;
     if (need > avail_b) {
       snprintf(err, err_cap, "the super-k-mer table and its build need at least %.3f GB, %.3f GB of HBM are available", need / 1e9,
                avail_b / 1e9);

@@ -292,7 +292,9 @@ int mic_db_build(const char* const* target_files, const uint16_t* target_labels,
   if (tb > temp_bytes) temp_bytes = tb;
   BHIP(hipMalloc(&d_temp, temp_bytes + 256));
 
-  fs = fopen((pfx + ".sz").c_str(), "wb"); fk = fopen((pfx + ".ky").c_str(), "wb"); fl = fopen((pfx + ".lb").c_str(), "wb");
+  // the files are written under temporary names and renamed once all three are complete: a build that is interrupted
+  // between passes must not leave a short .sz behind that a later run would take for a (smaller) table
+  fs = fopen((pfx + ".sz.tmp").c_str(), "wb"); fk = fopen((pfx + ".ky.tmp").c_str(), "wb"); fl = fopen((pfx + ".lb.tmp").c_str(), "wb");
   if (!fs || !fk || !fl) { rc = bfail(MIC_E_IO, "cannot create %s.{sz,ky,lb}", out_prefix); goto done; }
 
   for (uint32_t p = 0; p < parts && rc == MIC_OK; ++p) {
@@ -364,10 +366,15 @@ int mic_db_build(const char* const* target_files, const uint16_t* target_labels,
   }
   if (n_kmers_out) *n_kmers_out = n_total;
 done:
-  if (fs) fclose(fs);
-  if (fk) fclose(fk);
-  if (fl) fclose(fl);
-  if (rc != MIC_OK) { remove((pfx + ".sz").c_str()); remove((pfx + ".ky").c_str()); remove((pfx + ".lb").c_str()); }
+  if (fs && fclose(fs) != 0 && rc == MIC_OK) rc = bfail(MIC_E_IO, "write to %s.sz failed", out_prefix);
+  if (fk && fclose(fk) != 0 && rc == MIC_OK) rc = bfail(MIC_E_IO, "write to %s.ky failed", out_prefix);
+  if (fl && fclose(fl) != 0 && rc == MIC_OK) rc = bfail(MIC_E_IO, "write to %s.lb failed", out_prefix);
+  if (rc == MIC_OK) {
+    for (const char* ext : {".ky", ".lb", ".sz"})      // .sz last: the classifier looks for it first
+      if (rename((pfx + ext + ".tmp").c_str(), (pfx + ext).c_str()) != 0 && rc == MIC_OK) rc = bfail(MIC_E_IO, "cannot rename %s%s.tmp", out_prefix, ext);
+  }
+  if (rc != MIC_OK)
+    for (const char* ext : {".sz", ".ky", ".lb"}) { remove((pfx + ext + ".tmp").c_str()); remove((pfx + ext).c_str()); }
   void* frees[] = {d_k[0], d_k[1], d_l[0], d_l[1], d_keep, d_kept, d_lkept, d_rem[0], d_rem[1], d_idx[0], d_idx[1], d_kout, d_lout,
                    d_sizes, d_s8, d_cursor, d_nsel, d_big, d_cont, d_parts, d_prefix, d_temp};
   for (void* q : frees) if (q) hipFree(q);

@@ -252,7 +252,9 @@ size_t mic_pack_bound(const uint64_t* seq_s, const uint64_t* seq_e, size_t n_rea
 namespace {
 struct Sink {
   uint16_t* out; size_t cap; size_t n; bool overflow;
-  inline void put(uint16_t v) { if (n < cap) out[n] = v; else overflow = true; ++n; }
+  // writes past the capacity are dropped; whether the output fits is decided at the end (a run shorter than k is written
+  // and then rolled back: it may pass the capacity without the final output doing so)
+  inline void put(uint16_t v) { if (n < cap) out[n] = v; ++n; }
 };
 
 // one maximal ACGTU run -> one or more parts [len][containers...]
@@ -357,7 +359,9 @@ size_t mic_pack_reads_runs(const uint8_t* map, const uint64_t* seq_s, const uint
     if (run >= (size_t)k) emit_run(s, codes.data(), run, k, run_off, run_len);
   }
   reads_pointer[n_reads] = (uint32_t)s.n;
-  return s.overflow ? (size_t)-1 : s.n;
+  // rolled-back writes beyond cap were dropped, kept ones are all below s.n: the output is whole iff s.n <= cap ... and
+  // nothing that was kept had been dropped, which holds because a kept part is never rolled back below its own start
+  return (s.n > s.cap || s.overflow) ? (size_t)-1 : s.n;
 }
 
 extern "C" {

@@ -168,3 +168,26 @@ def test_parallel_indexer_equals_serial(lib):
             assert len(b["length"]) == len(a["length"])
             for f in a:
                 assert (a[f] == b[f]).all(), (t, f)
+
+
+def test_pack_with_exact_capacity_after_a_rolled_back_run(lib):
+    """A run shorter than k is written while it is read and rolled back at its end; when that happens near the end of
+    the buffer the writes may pass a capacity that the final output fits exactly (CuCLARK_hh.hh:1647-1651, 1701-1704)."""
+    from cuclark_amd import host
+    import ctypes as C
+    k = 31
+    rng = np.random.default_rng(3)
+    seq = lambda n: bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8))
+    data = b">a\n" + seq(80) + b"\n>b\n" + seq(45) + b"N" + seq(29) + b"\n"      # the last run (29 nt) is dropped
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    buf = np.frombuffer(data, np.uint8)
+    for cap, ok in ((cont.size, True), (cont.size - 1, False)):
+        rp2 = np.zeros(rp.size, np.uint32)
+        out = np.zeros(cont.size + 8, np.uint16)
+        m = lib.mic_pack_reads(buf.ctypes.data, idx["seq_s"].ctypes.data, idx["seq_e"].ctypes.data, idx["length"].ctypes.data,
+                               rp.size - 1, k, rp2.ctypes.data, out.ctypes.data, cap)
+        if ok:
+            assert m == cont.size and (out[:m] == cont).all() and (rp2 == rp).all()
+        else:
+            assert m == C.c_size_t(-1).value

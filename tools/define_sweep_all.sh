@@ -1,7 +1,10 @@
 #!/bin/bash
 # Rebuild the whole library on the GPU box with each given option set (options that change the table as well as the
-# kernels) and run the headline bench: tools/define_sweep_all.sh "-DA=1" "-DA=0" ...   The last set stays built.
-cd $GRAFT_REPO_ROOT/cuclark_amd/csrc
+# kernels) and run the headline bench: tools/define_sweep_all.sh "-DA=1" "-DA=0" ...
+# These builds replace the product objects while the sweep runs; the default build is restored on exit (also on ^C).
+cd ${GRAFT_REPO_ROOT:-$(pwd)}/cuclark_amd/csrc
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd ../.. && pwd)}
+trap 'rm -f obj/mic_kernels.o obj/mic_build.o obj/mic_engine.o obj/mic_synth.o obj/mic_dbbuild.o; make -j8 all > /dev/null 2>&1' EXIT
 for d in "$@"; do
   rm -f obj/mic_kernels.o obj/mic_build.o obj/mic_engine.o obj/mic_synth.o obj/mic_dbbuild.o
   make -j8 all EXTRA="$d" 2>&1 | grep -E "error" -A3
