@@ -290,6 +290,23 @@ def main():
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
 
+    def complete_rows(engine, cur, res_part):
+        """table-sharded: reads whose merged row does not fit get their dense counts summed over the ranks (flagged reads only)"""
+        def count_dense(ids):
+            d_ids = ids.to(torch.int32).to(dev)
+            d_counts = torch.zeros((ids.numel(), T), dtype=torch.int32, device=dev)
+            engine.count_dense_device(d_rp.data_ptr(), d_cont.data_ptr(), d_ids.data_ptr(), ids.numel(), d_counts.data_ptr(), sptr)
+            torch.cuda.synchronize()
+            return d_counts if args.backend == "nccl" else d_counts.cpu()
+        rows_view = cur if args.backend == "nccl" else cur.cpu()
+        idx, counts = multi.complete_overflowed(rows_view, world, rank, n_reads, count_dense)
+        if idx is not None and idx.numel():
+            d_idx = idx.to(torch.int32).to(dev)
+            d_cnt = counts.to(dev).contiguous()
+            engine.result_from_dense_device(d_cnt.data_ptr(), d_idx.data_ptr(), idx.numel(), res_part.data_ptr(), 0, sptr)
+            torch.cuda.synchronize()
+        return 0 if idx is None else int(idx.numel())
+
     def step():
         if not db_mode:
             eng.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), 0, sptr)
@@ -307,6 +324,7 @@ def main():
             eng.merge_rows_device(cur.data_ptr(), d_recv[r].data_ptr(), out.data_ptr(), per_r, sptr)
             cur = out
         eng.result_from_rows_device(cur.data_ptr(), d_res_part.data_ptr(), per_r, sptr)
+        complete_rows(eng, cur, d_res_part)
 
     def barrier():
         torch.cuda.synchronize()
@@ -497,6 +515,7 @@ def main():
                     eng2.merge_rows_device(cur.data_ptr(), r_recv[r].data_ptr(), o2.data_ptr(), per2, sptr)
                     cur = o2
                 eng2.result_from_rows_device(cur.data_ptr(), r_part.data_ptr(), per2, sptr)
+                complete_rows(eng2, cur, r_part)
             steps2 = max(1, min(args.steps, 5))
             for _ in range(min(args.warmup, 2)):
                 step_db()

@@ -842,6 +842,16 @@ int mic_result_from_rows_device(mic_engine* e, const uint32_t* rows, uint32_t* r
   return MIC_OK;
 }
 
+int mic_result_from_dense_device(mic_engine* e, const uint32_t* d_counts, const uint32_t* d_ids, size_t n_ids, uint32_t* d_results,
+                                 uint32_t* d_rows, void* stream) {
+  if (!e || !d_counts || !d_results) return fail(MIC_E_INVALID, "null argument");
+  int rc = set_device(e);
+  if (rc) return rc;
+  HIPTRY(mic_launch_dense_finish(d_counts, d_ids, n_ids, e->cfg.num_targets ? e->cfg.num_targets : 1, d_results, d_rows,
+                                 e->cfg.row_words, stream ? (hipStream_t)stream : e->stream));
+  return MIC_OK;
+}
+
 int mic_probe_stats_device(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, size_t n_reads, uint64_t out[4]) {
   if (!e || !d_rp || !d_cont || !out) return fail(MIC_E_INVALID, "null argument");
   if (!e->db_loaded) return fail(MIC_E_STATE, "no database loaded");

@@ -205,6 +205,9 @@ class MiClarkDB:
         check(self.L.mic_count_dense_device(self.h, d_reads_pointer, d_containers, d_ids or None, n_ids, d_counts,
                                             stream or None))
 
+    def result_from_dense_device(self, d_counts, d_ids, n_ids, d_results, d_rows=0, stream=0):
+        check(self.L.mic_result_from_dense_device(self.h, d_counts, d_ids or None, n_ids, d_results, d_rows or None, stream or None))
+
     def probe_stats_device(self, d_reads_pointer, d_containers, n_reads):
         out = (C.c_uint64 * 4)()
         check(self.L.mic_probe_stats_device(self.h, d_reads_pointer, d_containers, n_reads, out))

@@ -174,6 +174,11 @@ int mic_result_from_rows_device(mic_engine* e, const uint32_t* d_rows, uint32_t*
  * fallback for reads whose rows overflow, and the --extended source of truth. */
 int mic_count_dense_device(mic_engine* e, const uint32_t* d_reads_pointer, const uint16_t* d_containers,
                            const uint32_t* d_read_ids, size_t n_ids, uint32_t* d_counts, void* stream);
+/* resultKernel on DENSE counts (u32 [n_ids * num_targets], e.g. mic_count_dense_device's, or their sum over the shards of
+ * a table-sharded run): writes result row d_ids[i] (or i when d_ids is NULL) of d_results, and the sparse row when d_rows is
+ * given and it fits.  This is how a read with more targets than a sparse row holds is completed exactly across shards. */
+int mic_result_from_dense_device(mic_engine* e, const uint32_t* d_counts, const uint32_t* d_ids, size_t n_ids,
+                                 uint32_t* d_results, uint32_t* d_rows, void* stream);
 /* Bookkeeping for the roofline figure (not timed): out = {k-mers in the reads, k-mers whose bucket lies in this
  * engine's shard, hits, sum of the lengths of the probed buckets}.  Synchronous. */
 int mic_probe_stats_device(mic_engine* e, const uint32_t* d_reads_pointer, const uint16_t* d_containers, size_t n_reads,

@@ -10,47 +10,83 @@
 #define CUCLARKDB_
 #include <vector>
 #include <cstdlib>
+#include <cstring>
+#include <cstdio>
+#include <string>
 #include <iostream>
 #include "dataType.hh"      // ILBL, RESULTS, CONTAINER, ITYPE, HTSIZE
 #include "mi_clark.h"
 
 template <typename HKMERr> class CuClarkDB {
-  mic_engine* e_ = nullptr; size_t nb_; uint8_t k_; bool ext_ = false;
+  // numDevices engines, each holding one bucket range of the table (the reference's multi-device mode,
+  // CuClarkDB.cu:104-208, 566-574, 886-974): every engine gets the batch's reads, the sparse rows are summed into engine 0
+  std::vector<mic_engine*> e_; size_t nb_; uint8_t k_; bool ext_ = false; uint32_t rw_ = 16;   // rw_: u32 words per sparse row
   uint32_t *res32_ = nullptr, *rows32_ = nullptr; RESULTS *final_ = nullptr, *full_ = nullptr;
-  std::vector<ITYPE> index_; std::vector<size_t> nreads_; size_t rowSize_ = 0, finalRowSize_ = 5;
+  std::vector<ITYPE> index_; std::vector<size_t> nreads_, ncont_; size_t rowSize_ = 0, finalRowSize_ = 5;
+  std::vector<std::vector<uint32_t*> > rp_; std::vector<std::vector<uint16_t*> > ct_;   // [engine][batch]
   static void ck(int rc) { if (rc) { std::cerr << mic_last_error() << std::endl; exit(1); } }   // CUERR behaviour
  public:
   CuClarkDB(size_t numDevices, uint8_t k, size_t numBatches, size_t numTargets) : nb_(numBatches), k_(k) {
-    mic_config c = {0, (int32_t)k, (uint32_t)numTargets, (uint32_t)numBatches, 0, 0};      // CuClarkDB.cu:85-253
-    ck(mic_create(&c, &e_)); nreads_.resize(numBatches);
+    int have = 0; ck(mic_device_count(&have));                                              // CuClarkDB.cu:104-181
+    if (numDevices == 0 || numDevices > (size_t)have) numDevices = have > 0 ? (size_t)have : 1;
+    if (const char* env = getenv("MIC_SHARD_ENGINES")) { long v = atol(env); if (v >= 1 && v <= 64) numDevices = (size_t)v; }
+    for (size_t d = 0; d < numDevices; ++d) {
+      mic_config c = {(int32_t)(d % (size_t)(have > 0 ? have : 1)), (int32_t)k, (uint32_t)numTargets, (uint32_t)numBatches, rw_, 0};
+      mic_engine* e = nullptr; ck(mic_create(&c, &e)); e_.push_back(e);
+    }
+    nreads_.resize(numBatches); ncont_.resize(numBatches);
   }
-  ~CuClarkDB() { mic_destroy(e_); free(final_); free(full_); }
+  ~CuClarkDB() { for (size_t d = 0; d < e_.size(); ++d) mic_destroy(e_[d]); free(final_); free(full_); }
   bool read(const char* prefix, size_t& fileSize, size_t& dbParts, const ITYPE& mod = 1, const bool& = false) {
-    int rc = mic_db_load_files(e_, prefix, sizeof(HKMERr), mod, 0, 0);                      // CuClarkDB.cu:461-808
-    if (rc == MIC_E_IO) { std::cerr << mic_last_error() << std::endl; return false; }       // "Failed to open ..."
-    ck(rc); mic_db_info i; mic_db_get_info(e_, &i); fileSize = i.hbm_bytes; dbParts = 1; return true;
+    fileSize = 0;
+    uint64_t H = (uint64_t)HTSIZE;                                // the table size is the size of the .sz file (= HTSIZE in a CuCLARK build)
+    if (FILE* f = fopen((std::string(prefix) + ".sz").c_str(), "rb")) { fseek(f, 0, SEEK_END); H = (uint64_t)ftell(f); fclose(f); }
+    for (size_t d = 0; d < e_.size(); ++d) {                                                // CuClarkDB.cu:461-808
+      const uint64_t s0 = e_.size() > 1 ? H * d / e_.size() : 0, s1 = e_.size() > 1 ? H * (d + 1) / e_.size() : 0;
+      int rc = mic_db_load_files(e_[d], prefix, sizeof(HKMERr), mod, s0, s1);               // bucket ranges: CuClarkDB.cu:566-574
+      if (rc == MIC_E_IO) { std::cerr << mic_last_error() << std::endl; return false; }     // "Failed to open ..."
+      ck(rc); mic_db_info i; mic_db_get_info(e_[d], &i); fileSize += i.hbm_bytes;
+    }
+    dbParts = 1; return true;
   }
   bool swapDbParts() { return false; }            // whole table resident: no cycles        // CuClarkDB.cu:813-858
-  bool sync() { ck(mic_sync(e_)); return true; }
+  bool sync() { for (size_t d = 0; d < e_.size(); ++d) ck(mic_sync(e_[d])); return true; }
   size_t malloc(size_t numReads, size_t maxReads, size_t maxCont, std::vector<ITYPE>& indexBatches, RESULTS*& full,
                 size_t rowSize, RESULTS*& fin, size_t finRowSize, bool isExtended,
                 std::vector<uint32_t*>& rp, std::vector<CONTAINER*>& ct) {                  // CuClarkDB.cu:317-419
     index_ = indexBatches; ext_ = isExtended; rowSize_ = rowSize; finalRowSize_ = finRowSize;
-    rp.resize(nb_); ct.resize(nb_);
-    ck(mic_batches_alloc(e_, numReads, maxReads, maxCont, indexBatches.data(), isExtended, &res32_, &rows32_,
-                         rp.data(), (uint16_t**)ct.data()));
+    const bool rows = isExtended || e_.size() > 1;                // shards exchange their sparse rows
+    rp_.assign(e_.size(), std::vector<uint32_t*>(nb_)); ct_.assign(e_.size(), std::vector<uint16_t*>(nb_));
+    for (size_t d = 0; d < e_.size(); ++d) {
+      uint32_t *res = nullptr, *rw = nullptr;
+      ck(mic_batches_alloc(e_[d], numReads, maxReads, maxCont, indexBatches.data(), rows, &res, &rw, rp_[d].data(), ct_[d].data()));
+      if (d == 0) { res32_ = res; rows32_ = rw; }
+    }
+    rp = rp_[0]; ct.resize(nb_); for (size_t b = 0; b < nb_; ++b) ct[b] = (CONTAINER*)ct_[0][b];
     fin = final_ = (RESULTS*)calloc(numReads * finRowSize, sizeof(RESULTS));
     full = full_ = isExtended ? (RESULTS*)calloc(numReads * rowSize, sizeof(RESULTS)) : nullptr;
     return numReads;
   }
-  bool readyBatch(size_t b, size_t nReads, size_t nCont) { nreads_[b] = nReads; ck(mic_batch_ready(e_, b, nReads, nCont)); return true; }
-  bool queryBatch(size_t b, bool isExtended, bool isFollowup = false) { ck(mic_batch_query(e_, b, isExtended, isFollowup)); return true; }
+  bool readyBatch(size_t b, size_t nReads, size_t nCont) {
+    nreads_[b] = nReads; ncont_[b] = nCont;
+    for (size_t d = 0; d < e_.size(); ++d) ck(mic_batch_ready(e_[d], b, nReads, nCont));
+    return true;
+  }
+  bool queryBatch(size_t b, bool isExtended, bool isFollowup = false) {                     // CuClarkDB.cu:878-1033
+    for (size_t d = 0; d < e_.size(); ++d) {
+      if (d) { memcpy(rp_[d][b], rp_[0][b], (nreads_[b] + 1) * sizeof(uint32_t));           // every device sees all reads, :886-890
+               memcpy(ct_[d][b], ct_[0][b], ncont_[b] * sizeof(uint16_t)); }
+      ck(mic_batch_query(e_[d], b, isExtended || e_.size() > 1, isFollowup));
+    }
+    return true;
+  }
   bool waitForBatch(size_t b) {                                                             // CuClarkDB.cu:440-445
-    ck(mic_batch_wait(e_, b));
+    if (e_.size() > 1) ck(mic_batch_merge_shards(e_.data(), e_.size(), b));                 // copy + mergeKernel + resultKernel, :954-1024
+    else ck(mic_batch_wait(e_[0], b));
     for (size_t r = index_[b]; r < index_[b] + nreads_[b]; ++r) {      // u32 -> RESULTS, the layout CuCLARK_hh.hh reads
       for (int w = 0; w < 5; ++w) final_[r * finalRowSize_ + w] = (RESULTS)res32_[r * MIC_RESULT_WORDS + w];
       if (ext_) {
-        const uint32_t* row = rows32_ + r * 16; uint32_t n = row[0] == MIC_ROW_INVALID ? 0 : row[0];
+        const uint32_t* row = rows32_ + r * rw_; uint32_t n = row[0] == MIC_ROW_INVALID ? 0 : row[0];
         full_[r * rowSize_] = (RESULTS)n;
         for (uint32_t i = 0; i < n && 2 * i + 2 < rowSize_; ++i) { full_[r * rowSize_ + 2 * i + 1] = row[1 + i] & 0xFFFF;
                                                                    full_[r * rowSize_ + 2 * i + 2] = row[1 + i] >> 16; }
@@ -58,8 +94,8 @@ template <typename HKMERr> class CuClarkDB {
     }
     return true;
   }
-  bool checkBatch(size_t b) { int d = 0; ck(mic_batch_check(e_, b, &d)); return d; }
-  void freeBatchMemory() { mic_batches_free(e_); free(final_); free(full_); final_ = full_ = nullptr; }
+  bool checkBatch(size_t b) { int d = 1; for (size_t i = 0; i < e_.size() && d; ++i) ck(mic_batch_check(e_[i], b, &d)); return d; }
+  void freeBatchMemory() { for (size_t d = 0; d < e_.size(); ++d) mic_batches_free(e_[d]); free(final_); free(full_); final_ = full_ = nullptr; }
 };
 
 #endif

@@ -2,7 +2,7 @@
 // (CuCLARK_hh.hh:608 ctor, :621 read, :514-515 swapDbParts+sync, :1600-1606 malloc, :1735 readyBatch, :1743 queryBatch,
 // :1997 waitForBatch, :335 freeBatchMemory).  Reads a packed batch (reads_pointer u32, containers u16) from two binary
 // files, prints "sum idxBest best idxSecond second" per read.
-//   shim_driver <db prefix> <k> <num targets> <reads_pointer.bin> <containers.bin>
+//   shim_driver <db prefix> <k> <num targets> <reads_pointer.bin> <containers.bin> [numDevices [extended]]
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -20,7 +20,9 @@ int main(int argc, char** argv) {
   std::vector<char> b2((std::istreambuf_iterator<char>(f2)), std::istreambuf_iterator<char>());
   const size_t numReads = b1.size() / 4 - 1, numCont = b2.size() / 2;
   const size_t numBatches = 1;
-  CuClarkDB<T32> db(1, k, numBatches, numTargets);
+  const size_t numDevices = argc > 6 ? (size_t)atol(argv[6]) : 1;
+  const bool extended = argc > 7 && atoi(argv[7]) != 0;
+  CuClarkDB<T32> db(numDevices, k, numBatches, numTargets);
   size_t fileSize = 0, dbParts = 0;
   if (!db.read(argv[1], fileSize, dbParts, 1, false)) return 3;
   db.swapDbParts();
@@ -31,16 +33,22 @@ int main(int argc, char** argv) {
   std::vector<uint32_t*> readsPointer;
   std::vector<CONTAINER*> readsInContainers;
   const size_t rowSize = 2 * MAXHITS + 2, finalRowSize = 5;
-  db.malloc(numReads, numReads, numCont, indexBatches, full, rowSize, fin, finalRowSize, false, readsPointer, readsInContainers);
+  db.malloc(numReads, numReads, numCont, indexBatches, full, rowSize, fin, finalRowSize, extended, readsPointer, readsInContainers);
   memcpy(readsPointer[0], b1.data(), b1.size());
   memcpy(readsInContainers[0], b2.data(), b2.size());
   db.readyBatch(0, numReads, numCont);
-  db.queryBatch(0, false);
+  db.queryBatch(0, extended);
   db.waitForBatch(0);
   if (!db.checkBatch(0)) return 4;
   for (size_t t = 0; t < numReads; ++t)
     printf("%u %u %u %u %u\n", fin[t * finalRowSize], fin[t * finalRowSize + 1], fin[t * finalRowSize + 2],
            fin[t * finalRowSize + 3], fin[t * finalRowSize + 4]);
+  if (extended)      // the sparse rows as CuCLARK_hh.hh:2014-2031 reads them: n, then (target, count) pairs
+    for (size_t t = 0; t < numReads; ++t) {
+      printf("row %u", full[t * rowSize]);
+      for (unsigned i = 0; i < full[t * rowSize]; ++i) printf(" %u:%u", full[t * rowSize + 2 * i + 1], full[t * rowSize + 2 * i + 2]);
+      printf("\n");
+    }
   db.freeBatchMemory();
   return 0;
 }

@@ -45,6 +45,113 @@ def _merge_u32(a, b):
     return out
 
 
+INVALID = 0xFFFFFFFF
+
+
+def _rows_u32_or_invalid(o, counts, row_words):
+    """the query kernel's rows: a read with more targets than the row holds carries MIC_ROW_INVALID"""
+    rows = np.zeros((counts.shape[0], row_words), np.uint32)
+    for r in range(counts.shape[0]):
+        nz = np.nonzero(counts[r])[0]
+        if nz.size > row_words - 1:
+            rows[r, 0] = INVALID
+            continue
+        rows[r, 0] = nz.size
+        rows[r, 1:1 + nz.size] = (counts[r][nz].astype(np.uint32) << 16) | nz.astype(np.uint32)
+    return rows
+
+
+def _merge_u32_or_invalid(a, b):
+    """merge_rows_kernel's rule: invalid in, or too many targets out -> invalid"""
+    out = np.zeros_like(a)
+    for r in range(a.shape[0]):
+        if a[r, 0] == INVALID or b[r, 0] == INVALID:
+            out[r, 0] = INVALID
+            continue
+        d = {}
+        for row in (a[r], b[r]):
+            for v in row[1:1 + row[0]]:
+                d[int(v) & 0xFFFF] = d.get(int(v) & 0xFFFF, 0) + (int(v) >> 16)
+        if len(d) > a.shape[1] - 1:
+            out[r, 0] = INVALID
+            continue
+        out[r, 0] = len(d)
+        for i, t in enumerate(sorted(d)):
+            out[r, 1 + i] = (d[t] << 16) | t
+    return out
+
+
+def _overflow_worker(rank, world, port, ret):
+    """Table-sharded ranks, reads that hit 3 .. 40 targets with 15-entry rows: the rows of the crowded reads overflow (in a
+    shard or only after the merge) and are completed exactly from dense counts summed over the ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuclark_amd import multi
+        o = gu.oracle()
+        rng = np.random.default_rng(21)                 # same data on every rank
+        k, T, RW, htsize = 27, 40, 16, 4099
+        sizes, keys, labels, canon = gu.random_db(rng, htsize, 3000, k, 8, T)
+        odb = o.db_from_arrays(sizes, keys, labels, 1)
+        by_label = {t: [c for c, l in zip(canon, labels) if l == t] for t in range(T)}
+        recs = []
+        for i, n_t in enumerate([3, 40, 14, 15, 16, 17, 30, 2, 25, 16, 9, 40]):
+            parts = [gu.kmer_to_ascii(by_label[t][(i + j) % len(by_label[t])], k) for j, t in enumerate(rng.permutation(T)[:n_t])]
+            recs.append(f">r{i}\n" + "N".join(parts) + "\n")
+        data = "".join(recs).encode()
+        ix = o.index_reads(data)
+        rp, ct = o.pack_batch(data, ix["seq_s"], ix["seq_e"], ix["length"], k)
+        n = rp.size - 1
+        whole, _ = odb.query_batch(k, rp, ct, T)
+        expect = o.result_from_counts(whole)
+        assert (np.count_nonzero(whole, axis=1) > RW - 1).sum() >= 6
+        s0, s1 = multi.shard_range(htsize, world, rank)
+        counts, _ = odb.query_batch(k, rp, ct, T, part=(s0, s1))
+        rows = multi.padded_rows(n, world, RW, "cpu")
+        rows[:n] = torch.from_numpy(_rows_u32_or_invalid(o, counts, RW).view(np.int32))
+        recv = multi.exchange_rows(rows, world)
+        merged = multi.merge_exchanged(recv, lambda a, b: torch.from_numpy(
+            _merge_u32_or_invalid(a.numpy().view(np.uint32), b.numpy().view(np.uint32)).view(np.int32)))
+        lo, hi, per = multi.read_range(n, world, rank)
+        m = merged.numpy().view(np.uint32)
+        res = np.zeros((per, 8), np.uint32)
+        for i in range(hi - lo):
+            if m[i, 0] == INVALID:
+                continue
+            row16 = np.zeros(2 * RW, np.uint16)
+            row16[0] = m[i, 0]
+            row16[1:1 + 2 * m[i, 0]:2] = m[i, 1:1 + m[i, 0]] & 0xFFFF
+            row16[2:2 + 2 * m[i, 0]:2] = m[i, 1:1 + m[i, 0]] >> 16
+            res[i, :5] = o.result_from_row(row16)
+        idx, dense = multi.complete_overflowed(merged, world, rank, n, lambda ids: torch.from_numpy(
+            counts[ids.numpy()].astype(np.int32)))
+        n_fixed = 0
+        if idx is not None:
+            res[idx.numpy(), :5] = o.result_from_counts(dense.numpy().view(np.uint32))
+            n_fixed = int(idx.numel())
+        allres = multi.gather_results(torch.from_numpy(res.view(np.int32)), world).numpy().view(np.uint32)
+        t = torch.tensor([n_fixed])
+        dist.all_reduce(t)
+        ret[rank] = bool((allres[:n, :5] == expect).all()) and int(t.item()) == int((np.count_nonzero(whole, axis=1) > RW - 1).sum())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_complete_overflowed_rows():
+    world = 2
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
 def _worker(rank, world, port, mode, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)

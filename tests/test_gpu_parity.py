@@ -266,6 +266,43 @@ def test_many_targets_dense_path():
     assert res[1, 6] & 1                                    # fits the register row but not 15 pairs
 
 
+def test_dense_counts_of_shards_sum_to_the_exact_result():
+    """What the table-sharded ranks do for a read whose merged row overflows (cuclark_amd/multi.py: complete_overflowed):
+    dense counts per bucket range (mic_count_dense_device), summed, finished by mic_result_from_dense_device."""
+    import torch
+    rng = np.random.default_rng(12)
+    htsize, k, T = 200003, 21, 300
+    sizes, keys, labels, canon = gu.random_db(rng, htsize, 20000, k, 4, T)
+    odb = gu.oracle().db_from_arrays(sizes, keys, labels)
+    picks = rng.choice(canon.size, 200, replace=False)
+    reads = ["N".join(gu.kmer_to_ascii(canon[i], k) for i in picks[a:b]) for a, b in ((0, 200), (0, 20), (50, 90), (10, 12))]
+    data = "".join(f">r{i}\n{r}\n" for i, r in enumerate(reads)).encode()
+    from cuclark_amd import host
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    counts, expect = _oracle_results(odb, k, rp, cont, T)
+    dev = torch.device("cuda:0")
+    d_rp = torch.from_numpy(rp.view(np.int32)).to(dev)
+    d_ct = torch.zeros(cont.size + 64, dtype=torch.int16, device=dev)
+    d_ct[:cont.size] = torch.from_numpy(cont.view(np.int16)).to(dev)
+    ids = torch.tensor([0, 2, 3], dtype=torch.int32, device=dev)
+    total = torch.zeros((3, T), dtype=torch.int32, device=dev)
+    for s0, s1 in ((0, 70000), (70000, 150000), (150000, htsize)):
+        with _engine(k, T, row_words=16) as e:
+            e.read_arrays(sizes, keys, labels, shard=(s0, s1))
+            part = torch.zeros((3, T), dtype=torch.int32, device=dev)
+            e.count_dense_device(d_rp.data_ptr(), d_ct.data_ptr(), ids.data_ptr(), 3, part.data_ptr())
+            e.sync()
+            total += part
+    assert (total.cpu().numpy().view(np.uint32) == counts[[0, 2, 3]]).all()
+    res = torch.zeros((4, 8), dtype=torch.int32, device=dev)
+    with _engine(k, T, row_words=16) as e:
+        e.result_from_dense_device(total.data_ptr(), ids.data_ptr(), 3, res.data_ptr())
+        e.sync()
+    got = res.cpu().numpy().view(np.uint32)
+    assert (got[[0, 2, 3], :5] == expect[[0, 2, 3]]).all() and (got[1] == 0).all()
+
+
 def test_long_reads_and_part_splitting():
     """A 200 kb sequence (parts longer than 65528 nt are split with k-1 overlap) and a multi-chunk read."""
     from cuclark_amd import host

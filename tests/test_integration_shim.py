@@ -43,3 +43,16 @@ def test_shim_drives_the_engine_like_cuclark(tmp_path):
     odb, _ = gu.oracle_db_from_golden("light_k27_u32")
     counts, _ = odb.query_batch(27, rp, cont, 6)
     assert (got == gu.oracle().result_from_counts(counts)).all()
+    # numDevices > 1: the reference's table-sharded mode through the same class (three engines share the one GPU here),
+    # with the sparse rows CuCLARK_hh.hh:2014-2031 reads in --extended mode
+    r = subprocess.run([DRIVER, prefix, "27", "6", str(tmp_path / "rp.bin"), str(tmp_path / "ct.bin"), "3", "1"],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, MIC_SHARD_ENGINES="3"))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    n = got.shape[0]
+    got3 = np.array([[int(x) for x in l.split()] for l in lines[:n]], dtype=np.uint32)
+    assert (got3 == got).all()
+    for i, l in enumerate(lines[n:]):
+        f = l.split()
+        assert f[0] == "row" and int(f[1]) == int(np.count_nonzero(counts[i]))
+        assert [tuple(int(x) for x in p.split(":")) for p in f[2:]] == [(t, int(counts[i][t])) for t in np.nonzero(counts[i])[0]]
