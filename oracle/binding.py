@@ -55,6 +55,16 @@ class Oracle:
         L.orc_db_from_arrays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]
         L.orc_db_wrap_arrays.restype = C.POINTER(_OrcDb)
         L.orc_db_wrap_arrays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_classify_batch_fast.restype = C.c_uint64
+        L.orc_classify_batch_fast.argtypes = [C.POINTER(_OrcDb), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
+                                              C.c_void_p, C.c_int]
+        L.orc_db_copy_spread.restype = C.POINTER(_OrcDb)
+        L.orc_db_copy_spread.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_numa_db_create.restype = C.c_void_p
+        L.orc_numa_db_create.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_numa_db_free.argtypes = [C.c_void_p]
+        L.orc_classify_batch_numa.restype = C.c_uint64
+        L.orc_classify_batch_numa.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
         L.orc_classify_batch.restype = C.c_uint64
         L.orc_classify_batch.argtypes = [C.POINTER(_OrcDb), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                          C.c_void_p, C.c_int]
@@ -124,6 +134,23 @@ class Oracle:
         db._keep = (sizes, keys, labels)
         return db
 
+    def db_copy_spread(self, sizes, keys, labels, threads=0):
+        """A private copy written by all threads (pages on every NUMA node, huge pages requested): the CPU baseline's table."""
+        assert sizes.dtype == np.uint8 and labels.dtype == np.uint16 and sizes.flags.c_contiguous
+        p = self.L.orc_db_copy_spread(sizes.ctypes.data, sizes.size, keys.ctypes.data, keys.dtype.itemsize, labels.ctypes.data,
+                                      int(threads))
+        if not p:
+            raise RuntimeError("orc_db_copy_spread failed")
+        return OracleDb(self, p)
+
+    def numa_db(self, sizes, keys, labels, threads=0):
+        """One replica of the table per NUMA node (threads pinned to their node's replica): the CPU baseline's table."""
+        assert sizes.dtype == np.uint8 and labels.dtype == np.uint16 and sizes.flags.c_contiguous
+        p = self.L.orc_numa_db_create(sizes.ctypes.data, sizes.size, keys.ctypes.data, keys.dtype.itemsize, labels.ctypes.data, int(threads))
+        if not p:
+            raise RuntimeError("orc_numa_db_create failed")
+        return NumaDb(self, p)
+
     # -- rows / results
     def sparse_row(self, counts, max_pairs=64):
         counts = np.ascontiguousarray(counts, np.uint32)
@@ -183,6 +210,31 @@ class Oracle:
         return rp, cont[:m].copy()
 
 
+class NumaDb:
+    def __init__(self, orc, p):
+        self.orc, self.p = orc, p
+
+    def classify_batch(self, k, reads_pointer, containers, n_targets):
+        rp = np.ascontiguousarray(reads_pointer, np.uint32)
+        ct = np.ascontiguousarray(containers, np.uint16)
+        n = rp.size - 1
+        res = np.zeros((n, 5), np.uint32)
+        bad = self.orc.L.orc_classify_batch_numa(self.p, k, rp.ctypes.data, ct.ctypes.data, n, n_targets, res.ctypes.data)
+        assert bad == 0
+        return res
+
+    def close(self):
+        if self.p:
+            self.orc.L.orc_numa_db_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class OracleDb:
     def __init__(self, orc, p):
         self.orc, self.p = orc, p
@@ -238,6 +290,16 @@ class OracleDb:
         n = rp.size - 1
         res = np.zeros((n, 5), np.uint32)
         bad = self.orc.L.orc_classify_batch(self.p, k, rp.ctypes.data, ct.ctypes.data, n, n_targets, res.ctypes.data, threads)
+        assert bad == 0
+        return res
+
+    def classify_batch_fast(self, k, reads_pointer, containers, n_targets, threads=0):
+        """orc_classify_batch's results through the prefetching form (the CPU baseline bench.py times)."""
+        rp = np.ascontiguousarray(reads_pointer, np.uint32)
+        ct = np.ascontiguousarray(containers, np.uint16)
+        n = rp.size - 1
+        res = np.zeros((n, 5), np.uint32)
+        bad = self.orc.L.orc_classify_batch_fast(self.p, k, rp.ctypes.data, ct.ctypes.data, n, n_targets, res.ctypes.data, threads)
         assert bad == 0
         return res
 

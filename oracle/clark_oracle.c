@@ -12,9 +12,13 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+static orc_db* orc_db_copy_pinned(const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes, const uint16_t* labels,
+                                  int threads, const cpu_set_t* pin);
 
 /* ------------------------------------------------------------------ codec */
 
@@ -165,8 +169,16 @@ orc_db* orc_db_wrap_arrays(const uint8_t* sizes, uint64_t htsize, const void* ke
   return db;
 }
 
+static void big_free(void* p, size_t bytes);
 void orc_db_free(orc_db* db) {
   if (!db) return;
+  if (db->borrowed == 2) {            /* orc_db_copy_spread */
+    big_free(db->bucket_off, (db->htsize + 1) * sizeof(uint64_t));
+    big_free(db->keys, db->n_elems * (size_t)db->key_bytes + 64);
+    big_free(db->labels, db->n_elems * sizeof(uint16_t) + 64);
+    free(db);
+    return;
+  }
   free(db->bucket_off);
   if (!db->borrowed) { free(db->keys); free(db->labels); }
   free(db);
@@ -337,6 +349,293 @@ uint64_t orc_classify_batch(const orc_db* db, int k, const uint32_t* reads_point
     free(counts);
   }
   return bad;
+}
+
+/* ---- throughput form of orc_classify_batch (bench.py's cpu_baseline) --------------------------------------------
+ * Same rules, same results; what changes is how a core keeps memory busy:
+ *   - the k-mers of a read are collected first, then the probes run as three sweeps with software prefetch between them
+ *     (bucket bounds -> first keys of the bucket -> scan), so a core has dozens of cache misses in flight instead of two
+ *     dependent ones per k-mer;
+ *   - hits are tallied in a per-thread table of which only the touched entries are read back and cleared (ascending target
+ *     order, so the tie rule of CuClarkDB.cu:1440-1459 sees the same sequence), not all T per read. */
+#define ORC_FAST_MAX 1024
+static uint64_t classify_fast(const orc_db* db0, const orc_numa_db* nd, int k, const uint32_t* reads_pointer,
+                              const uint16_t* containers, size_t n_reads, uint32_t n_targets, uint32_t* results, int threads);
+
+uint64_t orc_classify_batch_fast(const orc_db* db, int k, const uint32_t* reads_pointer, const uint16_t* containers,
+                                 size_t n_reads, uint32_t n_targets, uint32_t* results, int threads) {
+  return classify_fast(db, NULL, k, reads_pointer, containers, n_reads, n_targets, results, threads);
+}
+
+uint64_t orc_classify_batch_numa(const orc_numa_db* nd, int k, const uint32_t* reads_pointer, const uint16_t* containers,
+                                 size_t n_reads, uint32_t n_targets, uint32_t* results) {
+  return classify_fast(nd->db[0], nd, k, reads_pointer, containers, n_reads, n_targets, results, nd->threads);
+}
+
+static uint64_t classify_fast(const orc_db* db0, const orc_numa_db* nd, int k, const uint32_t* reads_pointer,
+                              const uint16_t* containers, size_t n_reads, uint32_t n_targets, uint32_t* results, int threads) {
+  const uint64_t cutoff = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  const uint64_t H = db0->htsize;
+  const int kb = db0->key_bytes;
+  uint64_t bad = 0;
+  int G = 32;                                     /* k-mers per probe group */
+  { const char* env = getenv("ORC_FAST_GROUP"); if (env && atoi(env) > 0) G = atoi(env); }
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#else
+  (void)threads;
+#endif
+#pragma omp parallel reduction(+ : bad)
+  {
+    const orc_db* db = db0;
+    cpu_set_t old_mask;
+    if (nd) {       /* thread t works on node t % nodes with that node's replica */
+#ifdef _OPENMP
+      const int node = omp_get_thread_num() % nd->n;
+#else
+      const int node = 0;
+#endif
+      sched_getaffinity(0, sizeof(old_mask), &old_mask);
+      sched_setaffinity(0, sizeof(cpu_set_t), (const cpu_set_t*)&nd->cpus[node]);
+      db = nd->db[node];
+    }
+    uint32_t* counts = (uint32_t*)calloc(n_targets ? n_targets : 1, sizeof(uint32_t));
+    uint32_t* touched = (uint32_t*)malloc((n_targets ? n_targets : 1) * sizeof(uint32_t));
+    uint64_t quot[ORC_FAST_MAX], rem[ORC_FAST_MAX], b0[ORC_FAST_MAX], b1[ORC_FAST_MAX];
+#pragma omp for schedule(dynamic, 64)
+    for (long r = 0; r < (long)n_reads; ++r) {
+      uint32_t p = reads_pointer[r], end = reads_pointer[r + 1];
+      uint32_t n_touched = 0;
+      size_t nk = 0;
+      int more = 1;
+      while (more) {
+        /* sweep 0: k-mers of the read (all its parts), ORC_FAST_MAX at a time */
+        more = 0;
+        while (p < end) {
+          uint32_t plen = containers[p];
+          if (plen == 0) { p = end; break; }
+          uint32_t first = p + 1;
+          uint64_t kmer = 0;
+          uint32_t i0 = 0;
+          if (plen >= (uint32_t)k && nk + (plen - k + 1) > ORC_FAST_MAX) {      /* very long part: probe it the plain way */
+            for (uint32_t i = 0; i < plen; ++i) {
+              uint32_t nt = (containers[first + i / 8] >> (14 - 2 * (i % 8))) & 3u;
+              kmer = ((kmer << 2) | nt) & cutoff;
+              if (i + 1 >= (uint32_t)k) {
+                uint16_t label;
+                if (orc_db_find(db, kmer, k, 0, H, &label)) {
+                  if (label < n_targets) { if (counts[label]++ == 0) touched[n_touched++] = label; } else ++bad;
+                }
+              }
+            }
+            p = first + (plen - 1) / 8 + 1;
+            continue;
+          }
+          for (uint32_t i = i0; i < plen; ++i) {
+            uint32_t nt = (containers[first + i / 8] >> (14 - 2 * (i % 8))) & 3u;
+            kmer = ((kmer << 2) | nt) & cutoff;
+            if (i + 1 >= (uint32_t)k) {
+              uint64_t c = orc_canonical(kmer, k);
+              quot[nk] = c / H; rem[nk] = c - quot[nk] * H;
+              ++nk;
+            }
+          }
+          p = first + (plen - 1) / 8 + 1;
+        }
+        /* the three probe stages run one group of G k-mers apart (a core tracks a few dozen misses; prefetches beyond
+         * that are dropped): prefetch of the bucket bounds for group g0, bounds + key prefetch for g0 - G, scan for g0 - 2G */
+        for (size_t g0 = 0; g0 < nk + 2 * (size_t)G; g0 += (size_t)G) {
+        for (size_t i = g0; i < nk && i < g0 + (size_t)G; ++i) __builtin_prefetch(&db->bucket_off[rem[i]]);
+        if (g0 < (size_t)G) continue;
+        /* stage 2 (group g0 - G): bucket bounds, prefetch of the first keys (and of the last one, for the pre-check) */
+        for (size_t i = g0 - (size_t)G; i < nk && i < g0; ++i) {
+          b0[i] = db->bucket_off[rem[i]]; b1[i] = db->bucket_off[rem[i] + 1];
+          if (b1[i] > b0[i]) {
+            __builtin_prefetch((const char*)db->keys + b0[i] * kb);
+            __builtin_prefetch((const char*)db->keys + (b1[i] - 1) * kb);
+            __builtin_prefetch(db->labels + b0[i]);
+          }
+        }
+        /* stage 3 (group g0 - 2G): the scan of CuClarkDB.cu:1291-1307 */
+        if (g0 < 2 * (size_t)G) continue;
+        for (size_t i = g0 - 2 * (size_t)G; i < nk && i < g0 - (size_t)G; ++i) {
+          uint64_t b = b0[i], e = b1[i];
+          if (e == b) continue;
+          uint64_t key = key_at(db, b);
+          if (key > quot[i] || key_at(db, e - 1) < quot[i]) continue;
+          uint64_t j = b;
+          while (key <= quot[i]) {
+            if (key == quot[i]) {
+              uint16_t label = db->labels[j];
+              if (label < n_targets) { if (counts[label]++ == 0) touched[n_touched++] = label; } else ++bad;
+              break;
+            }
+            key = key_at(db, ++j);
+          }
+        }
+        }
+        nk = 0;
+      }
+      /* result over the touched targets in ascending order (CuClarkDB.cu:1440-1459), then clear them */
+      for (uint32_t a = 1; a < n_touched; ++a) {      /* insertion sort: a handful of entries */
+        uint32_t v = touched[a], j = a;
+        while (j > 0 && touched[j - 1] > v) { touched[j] = touched[j - 1]; --j; }
+        touched[j] = v;
+      }
+      uint32_t* out = results + 5 * (size_t)r;
+      memset(out, 0, 5 * sizeof(uint32_t));
+      for (uint32_t a = 0; a < n_touched; ++a) {
+        const uint32_t t = touched[a], sc = counts[t];
+        if (sc > out[2]) { out[4] = out[2]; out[3] = out[1]; out[2] = sc; out[1] = t + 1; }
+        else if (sc > out[4]) { out[4] = sc; out[3] = t + 1; }
+        out[0] += sc;
+        counts[t] = 0;
+      }
+    }
+    free(counts); free(touched);
+    if (nd) sched_setaffinity(0, sizeof(old_mask), &old_mask);
+  }
+  return bad;
+}
+
+/* A private copy of the table spread over the machine: every array is allocated with huge pages requested and written by
+ * all threads in static ranges (first touch), so its pages sit on every NUMA node and a probe does not pay a TLB miss
+ * per access.  bench.py hands the oracle the arrays it downloaded from the GPU; one thread touching 40+ GB puts them
+ * all on that thread's node. */
+#include <sys/mman.h>
+static void* big_alloc(size_t bytes) {
+  bytes = (bytes + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1);
+  void* p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) return NULL;
+#ifdef MADV_HUGEPAGE
+  madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+  return p;
+}
+static void big_free(void* p, size_t bytes) {
+  if (p) munmap(p, (bytes + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1));
+}
+
+orc_db* orc_db_copy_spread(const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes, const uint16_t* labels,
+                           int threads) {
+  return orc_db_copy_pinned(sizes, htsize, keys, key_bytes, labels, threads, NULL);
+}
+
+/* pin != NULL: every copying thread binds itself to that CPU set first (one replica per NUMA node) */
+static orc_db* orc_db_copy_pinned(const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes, const uint16_t* labels,
+                           int threads, const cpu_set_t* pin) {
+  if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return NULL;
+  orc_db* db = (orc_db*)calloc(1, sizeof(orc_db));
+  if (!db) return NULL;
+  db->htsize = htsize; db->key_bytes = key_bytes; db->borrowed = 2;      /* 2: arrays come from big_alloc */
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+  const int nt = omp_get_max_threads();
+#else
+  const int nt = 1; (void)threads;
+#endif
+  uint64_t* part = (uint64_t*)calloc((size_t)nt + 1, sizeof(uint64_t));
+  db->bucket_off = (uint64_t*)big_alloc((htsize + 1) * sizeof(uint64_t));
+  if (!db->bucket_off || !part) { free(part); free(db); return NULL; }
+  const uint64_t per = (htsize + nt - 1) / nt;
+#pragma omp parallel num_threads(nt)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#else
+    const int t = 0;
+#endif
+    if (pin) sched_setaffinity(0, sizeof(cpu_set_t), pin);
+    const uint64_t lo = (uint64_t)t * per < htsize ? (uint64_t)t * per : htsize, hi = lo + per < htsize ? lo + per : htsize;
+    uint64_t sum = 0;
+    for (uint64_t i = lo; i < hi; ++i) sum += sizes[i];
+    part[t + 1] = sum;
+#pragma omp barrier
+#pragma omp single
+    { for (int i = 0; i < nt; ++i) part[i + 1] += part[i]; }
+    uint64_t run = part[t];
+    for (uint64_t i = lo; i < hi; ++i) { db->bucket_off[i] = run; run += sizes[i]; }
+  }
+  const uint64_t n = part[nt];
+  db->bucket_off[htsize] = n;
+  db->n_elems = n;
+  db->keys = big_alloc(n * (size_t)key_bytes + 64);
+  db->labels = (uint16_t*)big_alloc(n * sizeof(uint16_t) + 64);
+  if (!db->keys || !db->labels) { free(part); orc_db_free(db); return NULL; }
+#pragma omp parallel num_threads(nt)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#else
+    const int t = 0;
+#endif
+    if (pin) sched_setaffinity(0, sizeof(cpu_set_t), pin);
+    const uint64_t eper = (n + nt - 1) / nt;
+    const uint64_t lo = (uint64_t)t * eper < n ? (uint64_t)t * eper : n, hi = lo + eper < n ? lo + eper : n;
+    memcpy((char*)db->keys + lo * key_bytes, (const char*)keys + lo * key_bytes, (size_t)(hi - lo) * key_bytes);
+    memcpy(db->labels + lo, labels + lo, (size_t)(hi - lo) * sizeof(uint16_t));
+  }
+  free(part);
+  return db;
+}
+
+/* ---- one table replica per NUMA node ----------------------------------------------------------------------------------
+ * A probe is two or three random cache misses; on a two-socket host half of them cross the socket link when the table is
+ * spread over both nodes.  With one replica per node (288 GB-class hosts have the RAM) every miss is local: thread t is
+ * pinned to node t % nodes for the copy (first touch) and for the classification. */
+static int node_cpus(int node, cpu_set_t* set) {
+  char path[96];
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) return 0;
+  CPU_ZERO(set);
+  int a, b, any = 0; char c;
+  while (fscanf(f, "%d", &a) == 1) {
+    b = a; c = 0;
+    if (fscanf(f, "%c", &c) == 1 && c == '-') { if (fscanf(f, "%d", &b) != 1) b = a; if (fscanf(f, "%c", &c) != 1) c = 0; }
+    for (int i = a; i <= b && i < CPU_SETSIZE; ++i) { CPU_SET(i, set); any = 1; }
+    if (c != ',') break;
+  }
+  fclose(f);
+  return any;
+}
+
+orc_numa_db* orc_numa_db_create(const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes, const uint16_t* labels,
+                                int threads) {
+  orc_numa_db* nd = (orc_numa_db*)calloc(1, sizeof(orc_numa_db));
+  if (!nd) return NULL;
+  cpu_set_t allowed, set;
+  sched_getaffinity(0, sizeof(allowed), &allowed);
+  for (int node = 0; node < ORC_MAX_NODES; ++node) {
+    if (!node_cpus(node, &set)) break;
+    CPU_AND(&set, &set, &allowed);
+    if (CPU_COUNT(&set) == 0) continue;
+    memcpy(&nd->cpus[nd->n], &set, sizeof(set));
+    nd->n++;
+  }
+  if (nd->n == 0) { memcpy(&nd->cpus[0], &allowed, sizeof(allowed)); nd->n = 1; }
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+#else
+  threads = 1;
+#endif
+  nd->threads = threads;
+  for (int r = 0; r < nd->n; ++r) {
+    /* the replica is written by threads pinned to node r: first touch puts its pages there */
+    cpu_set_t old; sched_getaffinity(0, sizeof(old), &old);
+    sched_setaffinity(0, sizeof(cpu_set_t), (cpu_set_t*)&nd->cpus[r]);
+    int per = threads / nd->n > 0 ? threads / nd->n : 1;
+    nd->db[r] = orc_db_copy_pinned(sizes, htsize, keys, key_bytes, labels, per, (const cpu_set_t*)&nd->cpus[r]);
+    sched_setaffinity(0, sizeof(old), &old);
+    if (!nd->db[r]) { orc_numa_db_free(nd); return NULL; }
+  }
+  return nd;
+}
+
+void orc_numa_db_free(orc_numa_db* nd) {
+  if (!nd) return;
+  for (int r = 0; r < nd->n; ++r) orc_db_free(nd->db[r]);
+  free(nd);
 }
 
 uint64_t orc_count_read_ascii(const orc_db* db, int k, const uint8_t* seq, size_t n_bytes, uint64_t length,

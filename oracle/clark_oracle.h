@@ -104,6 +104,27 @@ uint64_t orc_query_batch(const orc_db* db, int k, const uint32_t* reads_pointer,
 
 /* {sum, idxBest, best, idxSecond, second} for every read of a packed batch (results[n_reads*5]), reads spread
  * over `threads` OpenMP threads (0 = runtime default).  The CPU baseline timed by bench.py. */
+/* The same results, organised for memory throughput (three probe sweeps with software prefetch per read, sparse tally):
+ * what bench.py times as the CPU baseline.  tests/test_oracle.py checks it against orc_classify_batch. */
+uint64_t orc_classify_batch_fast(const orc_db* db, int k, const uint32_t* reads_pointer, const uint16_t* containers,
+                                 size_t n_reads, uint32_t n_targets, uint32_t* results, int threads);
+/* A private copy of the table for that baseline: huge pages requested, written by all threads in static ranges so that
+ * its pages are spread over the NUMA nodes (sampling is not applied: every bucket is kept). */
+orc_db* orc_db_copy_spread(const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes, const uint16_t* labels,
+                           int threads);
+/* One replica of the table per NUMA node, threads pinned to the node whose replica they probe (no miss crosses the socket
+ * link).  threads <= 0: all.  The results are orc_classify_batch's. */
+#define ORC_MAX_NODES 8
+typedef struct orc_numa_db {
+  int n, threads;
+  orc_db* db[ORC_MAX_NODES];
+  unsigned long cpus[ORC_MAX_NODES][1024 / (8 * sizeof(unsigned long))];     /* cpu_set_t of each node (glibc: 1024 bits) */
+} orc_numa_db;
+orc_numa_db* orc_numa_db_create(const uint8_t* sizes, uint64_t htsize, const void* keys, int key_bytes, const uint16_t* labels,
+                                int threads);
+void orc_numa_db_free(orc_numa_db* nd);
+uint64_t orc_classify_batch_numa(const orc_numa_db* nd, int k, const uint32_t* reads_pointer, const uint16_t* containers,
+                                 size_t n_reads, uint32_t n_targets, uint32_t* results);
 uint64_t orc_classify_batch(const orc_db* db, int k, const uint32_t* reads_pointer, const uint16_t* containers,
                             size_t n_reads, uint32_t n_targets, uint32_t* results, int threads);
 

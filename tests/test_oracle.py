@@ -15,7 +15,10 @@ REF_LIGHT = os.path.join(gu.ROOT, "oracle", "_ref", "ref_table_light")
 def test_oracle_matches_reference_queries(name):
     """Golden vectors = answers of the reference's EHashtable::queryElement on the DB the reference wrote."""
     if name.startswith("full"):
-        pytest.skip("1.6e9-bucket table: covered on the GPU box (tests/test_gpu_parity.py) and by the light twin")
+        # the reference's real table size (1 610 612 741 buckets): 1.6 GB of sizes + 12.9 GB of prefix sums in the oracle
+        import psutil
+        if psutil.virtual_memory().available < 24e9:
+            pytest.skip("needs ~15 GB of free memory for the 1.6e9-bucket table")
     odb, meta = gu.oracle_db_from_golden(name)
     q = np.load(os.path.join(gu.GOLDEN, f"queries_{name}.npz"))
     f, l = odb.find_many(q["kmers"], meta["k"])
@@ -136,3 +139,37 @@ def test_merge_rows(orc):
 def test_key_width_rule(orc):
     assert [orc.key_bytes_rule(1610612741, k) for k in (23, 24, 31, 32)] == [2, 4, 4, 8]
     assert [orc.key_bytes_rule(57777779, k) for k in (20, 21, 27, 28, 29)] == [2, 4, 4, 4, 8]
+
+
+def test_fast_batch_classifier_equals_the_plain_one(orc):
+    """bench.py times orc_classify_batch_fast (prefetch sweeps, sparse tally) on a table copied by orc_db_copy_spread;
+    both must give what the plain restatement gives: golden reads, ties, many targets, long parts, padded batches."""
+    for k, name in ((31, "light_k31_u64"), (27, "light_k27_u32")):
+        db = gu.load_golden_db(name)
+        sizes = gu.golden_sizes(db)
+        odb = orc.db_from_arrays(sizes, db["ky"], db["lb"])
+        spread = orc.db_copy_spread(sizes, np.ascontiguousarray(db["ky"]), np.ascontiguousarray(db["lb"], np.uint16), threads=3)
+        data = open(os.path.join(gu.GOLDEN, f"reads_k{k}.fa"), "rb").read()
+        ix = orc.index_reads(data)
+        rp, ct = orc.pack_batch(data, ix["seq_s"], ix["seq_e"], ix["length"], k)
+        ref = odb.classify_batch(k, rp, ct, 6)
+        assert (odb.classify_batch_fast(k, rp, ct, 6, threads=2) == ref).all()
+        assert (spread.classify_batch_fast(k, rp, ct, 6, threads=4) == ref).all()
+    rng = np.random.default_rng(5)
+    k, T, htsize = 21, 300, 20011
+    sizes, keys, labels, canon = gu.random_db(rng, htsize, 6000, k, 4, T)
+    odb = orc.db_from_arrays(sizes, keys, labels)
+    spread = orc.db_copy_spread(sizes, keys, labels, threads=2)
+    picks = rng.choice(canon.size, 1500, replace=False)
+    long_part = "".join(gu.kmer_to_ascii(canon[i], k) for i in picks[:200])            # one part of 4200 nt: > 1024 k-mers
+    many = "N".join(gu.kmer_to_ascii(canon[i], k) for i in picks[200:1500])             # 1300 parts, ~290 targets
+    tie = gu.kmer_to_ascii(canon[picks[0]], k) + "N" + gu.kmer_to_ascii(canon[picks[1]], k)
+    data = f">a\n{long_part}\n>b\n{many}\n>c\n{tie}\n>d\nACGT\n>e\n{many}N{long_part}\n".encode()
+    ix = orc.index_reads(data)
+    rp, ct = orc.pack_batch(data, ix["seq_s"], ix["seq_e"], ix["length"], k)
+    ref = odb.classify_batch(k, rp, ct, T)
+    assert (odb.classify_batch_fast(k, rp, ct, T, threads=3) == ref).all()
+    assert (spread.classify_batch_fast(k, rp, ct, T, threads=1) == ref).all()
+    nd = orc.numa_db(sizes, keys, labels, threads=4)           # one replica per NUMA node, threads pinned
+    assert (nd.classify_batch(k, rp, ct, T) == ref).all()
+    nd.close()
