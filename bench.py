@@ -55,6 +55,11 @@ WORKLOADS = {
                    n_reads=10_000_000, read_len=150, paired=True,
                    name="10M pairs of 2x150bp synthetic reads (301-character objects) vs 36GB-scale k=31 table (HTSIZE 1610612741, u32 keys, "
                         "~5.7e9 k-mers, 4096 targets) resident in HBM"),
+    # the label space at its limit (dataType.hh:48: ILBL = u16): 65 535 targets, one small genome each
+    "full_t65535": dict(htsize=1610612741, genome_nt=5_730_000_000, n_genomes=65535, n_targets=65535, k=31, key_bytes=4,
+                        n_reads=10_000_000, read_len=150,
+                        name="10M x 150bp synthetic reads vs 36GB-scale k=31 table with 65535 targets (HTSIZE 1610612741, u32 keys, ~5.7e9 k-mers) "
+                             "resident in HBM"),
     "tiny_paired": dict(htsize=999983, genome_nt=1_500_000, n_genomes=64, n_targets=50, k=31, key_bytes=8,
                         n_reads=100_000, read_len=100, paired=True,
                         name="100k pairs of 2x100bp synthetic reads vs 50-target toy table (plumbing)"),

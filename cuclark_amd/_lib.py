@@ -36,7 +36,7 @@ class MicDbInfo(C.Structure):
                 ("n_elems", C.c_uint64), ("n_elems_file", C.c_uint64), ("n_slots", C.c_uint64),
                 ("n_overflow", C.c_uint64), ("hbm_bytes", C.c_uint64), ("key_bytes", C.c_int32),
                 ("slot_class", C.c_int32), ("max_bucket", C.c_uint32), ("sampling", C.c_uint32), ("layout", C.c_int32),
-                ("minimizer_len", C.c_int32), ("max_chain", C.c_uint32), ("reserved", C.c_uint32)]
+                ("minimizer_len", C.c_int32), ("max_chain", C.c_uint32), ("reserved", C.c_uint32), ("n_entries", C.c_uint64)]
 
 
 class MicSynthSpec(C.Structure):

@@ -600,6 +600,26 @@ __global__ void s_nonzero_kernel(const uint32_t* __restrict__ cnt, uint64_t n, u
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
 }
 
+__global__ void s_sum_kernel(const uint32_t* __restrict__ v, uint64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long mine = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mine += v[i];
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
+// How far lookups have to walk: sum over the slots of (candidates staged for the slot) x (continuation slots behind it).
+// Divided by the number of candidates this is the mean number of EXTRA slots a stored k-mer sits behind - the cost of
+// crowded minimizers (tandem repeats, low complexity: one minimizer value in thousands of contexts).
+__global__ void s_walk_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ n_ent, uint64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long mine = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t e = n_ent[i];
+    if (e > MIC_S_CAP) mine += (unsigned long long)cnt[i] * ((e - 1) / MIC_S_CAP);
+  }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
 struct SOpen { u128 S, known; uint32_t pmask, label; };
 
 __device__ inline uint64_t s_x_of(unsigned long long K, uint32_t j, int k, int m) {
@@ -856,7 +876,7 @@ static hipError_t scan_u32_to_u64(const uint32_t* in, unsigned long long* out, u
 
 int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
                      int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
-                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap) {
+                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap, int allow_fallback) {
   int rc = 0;
   const unsigned n_tiles = (unsigned)((n_buckets + TILE - 1) / TILE);
   TileA* d_a = nullptr; uint32_t* d_cnt = nullptr; uint32_t* d_cur = nullptr; unsigned long long* d_off = nullptr;
@@ -864,7 +884,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   unsigned long long* d_ck = nullptr; uint32_t* d_cm = nullptr; uint32_t* slots = nullptr; uint32_t* d_dem = nullptr;
   std::vector<TileA> h_a(n_tiles);
   uint64_t tot_elems = 0, tot_nz = 0, n_slots = 0, n_cand = 0, n_chain = 0;
-  unsigned long long h_scal[2] = {0, 0}; uint32_t h_max = 0; double avail_b = 0;
+  unsigned long long h_scal[2] = {0, 0}, h_entries = 0; uint32_t h_max = 0; double avail_b = 0;
   MBuildArgs a;
   const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
   struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
@@ -964,6 +984,37 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
                                                                          nullptr, d_max);
   HIPCK(hipGetLastError());
   HIPCK(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
+  HIPCK(hipMemsetAsync(d_scal + 1, 0, 8, s));
+  s_sum_kernel<<<4096, 256, 0, s>>>(d_cur, n_slots, d_scal + 1);       // entries = super-k-mers stored (statistics)
+  HIPCK(hipMemcpyAsync(&h_entries, d_scal + 1, 8, hipMemcpyDeviceToHost, s));
+  {
+    unsigned long long h_walk = 0;
+    HIPCK(hipMemsetAsync(d_scal, 0, 8, s));
+    s_walk_kernel<<<4096, 256, 0, s>>>(d_cnt, d_cur, n_slots, d_scal);
+    HIPCK(hipMemcpyAsync(&h_walk, d_scal, 8, hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    const double walk = n_cand ? (double)h_walk / (double)n_cand : 0.0;
+    out->walk_ppm = walk * 1e6 > 4e9 ? 4000000000u : (uint32_t)(walk * 1e6);
+    // A table whose stored k-mers sit, on average, behind more than this many continuation slots is answered faster by the
+    // minimizer layout (fan-out-12 trees: logarithmic in the bucket size): measured with tandem repeats in the targets,
+    // profiles/r02_nonideal_databases.json, DESIGN.md 5.3.  Only when the layout was not asked for explicitly.
+    // Measured (2 G k-mers, 4 M reads): 0.0046 random genomes and 0.0060 with 10 % homologous segments (super-k-mer layout
+    // 1 300 Mreads/s, minimizer layout 930); 0.0148 with 2 % tandem repeats (790 vs 945) and 0.0192 with 5 % (550 vs 925).
+    double limit = 0.010;
+    if (const char* env = getenv("MIC_S_WALK_LIMIT")) limit = atof(env);
+    if (allow_fallback && limit > 0 && walk > limit) {
+      snprintf(err, err_cap, "crowded minimizers: a stored k-mer sits behind %.4f continuation slots on average (limit %.4f)", walk, limit);
+      rc = -5; goto done;
+    }
+    // ... and a database whose k-mers do not overlap (cuCLARK-l's sampled blocks: one k-mer per entry) gains nothing from
+    // super-k-mers: the minimizer layout holds it in a quarter of the memory and answers 10 % faster (1 360 vs 1 240)
+    double min_per_entry = 1.3;
+    if (const char* env = getenv("MIC_S_MIN_KMERS_PER_ENTRY")) min_per_entry = atof(env);
+    if (allow_fallback && h_entries && (double)h_scal[0] / (double)h_entries < min_per_entry) {
+      snprintf(err, err_cap, "%.2f k-mers per super-k-mer entry (limit %.2f): no adjacency to exploit", (double)h_scal[0] / (double)h_entries, min_per_entry);
+      rc = -5; goto done;
+    }
+  }
   lap("sort + merge (count)");
   {
     // chain slots: demand per slot into a scratch u32 array (the candidate offsets stay), scanned to 64-bit bases
@@ -1002,7 +1053,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
 #undef BY_RAW
   out->slots = (uint4*)slots; slots = nullptr;
   out->n_main = n_slots; out->n_overflow = n_chain; out->n_elems = h_scal[0]; out->n_elems_file = tot_elems;
-  out->max_bucket = 0; out->max_chain = h_max;
+  out->max_bucket = 0; out->max_chain = h_max; out->n_entries = h_entries;
 done:
   if (d_a) hipFree(d_a);
   if (d_cnt) hipFree(d_cnt);

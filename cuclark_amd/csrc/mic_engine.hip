@@ -109,7 +109,8 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   i.hbm_bytes = (b.n_main + b.n_overflow + 1) * (uint64_t)(layout != MIC_LAYOUT_DIRECT ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
   i.key_bytes = key_bytes; i.slot_class = layout != MIC_LAYOUT_DIRECT ? 128 : e->slot_class; i.max_bucket = b.max_bucket;
   i.sampling = sampling; i.layout = layout; i.minimizer_len = layout != MIC_LAYOUT_DIRECT ? m : 0;
-  i.max_chain = layout != MIC_LAYOUT_DIRECT ? b.max_chain : 0; i.reserved = 0;
+  i.max_chain = layout != MIC_LAYOUT_DIRECT ? b.max_chain : 0; i.reserved = layout == MIC_LAYOUT_SUPER ? b.walk_ppm : 0;
+  i.n_entries = b.n_entries ? b.n_entries : b.n_elems;
   e->db_loaded = true;
 }
 
@@ -207,8 +208,9 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   // area), then the direct layout (64 B per bucket).  An explicitly requested layout fails with the sizes in the message.
   if (layout == MIC_LAYOUT_SUPER) {
     rc = mic_build_stable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
-                          e->cfg.k, m, e->stream, &b, err, sizeof(err));
-    if (rc == -3 && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; }
+                          e->cfg.k, m, e->stream, &b, err, sizeof(err), by_default ? 1 : 0);
+    // -3: does not fit; -5: crowded minimizers (tandem repeats): the minimizer layout's trees answer those faster
+    if ((rc == -3 || rc == -5) && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; }
   }
   if (layout == MIC_LAYOUT_MINIMIZER) {
     rc = mic_build_mtable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,

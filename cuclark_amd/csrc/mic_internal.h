@@ -127,6 +127,8 @@ struct MicBuildOut {
   uint64_t n_main, n_overflow, n_elems, n_elems_file;
   uint32_t max_bucket;
   uint32_t max_chain;   // layout 1: entries in the fullest slot chain
+  uint32_t walk_ppm;    // super-k-mer table: mean continuation slots in front of a stored k-mer, x 1e6
+  uint64_t n_entries;   // super-k-mer table: entries (super-k-mers) stored; other layouts: 0 (= one entry per k-mer)
 };
 // d_sizes/d_keys/d_labels point at the first bucket / first element of the shard.
 // rank_base = number of non-empty buckets before the shard (sampling is defined on the whole table).
@@ -140,7 +142,8 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
 // Super-k-mer table (layout 3, mic_device.h) from the same inputs.
 int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
                      int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
-                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap);
+                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap, int allow_fallback);
+// (allow_fallback: return -5 instead of building a table whose minimizers are crowded: see s_walk_kernel)
 // sums over d_sizes[0..n): total elements and non-empty buckets
 int mic_reduce_sizes(const uint8_t* d_sizes, uint64_t n, uint64_t* total, uint64_t* nonzero, hipStream_t s);
 

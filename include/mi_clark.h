@@ -80,7 +80,8 @@ typedef struct mic_db_info {
   int32_t layout;          /* MIC_LAYOUT_DIRECT, _MINIMIZER or _SUPER                   */
   int32_t minimizer_len;   /* m (layouts MINIMIZER, SUPER), else 0                      */
   uint32_t max_chain;      /* entries in the fullest slot chain (MINIMIZER, SUPER)      */
-  uint32_t reserved;
+  uint32_t reserved;       /* SUPER: mean number of continuation slots in front of a stored k-mer, x 1e6 (crowded minimizers) */
+  uint64_t n_entries;      /* entries stored: super-k-mers (SUPER: several k-mers each), else = n_elems */
 } mic_db_info;
 
 /* ---- engine lifetime: CuClarkDB ctor/dtor (CuClarkDB.cu:85-253) ----------------------------- */

@@ -490,6 +490,44 @@ def test_skewed_minimizer_bucket():
     assert f[:4096].all()
 
 
+def test_default_layout_follows_the_database(monkeypatch, table_layout):
+    """Nobody asks for a layout (MIC_LAYOUT unset, cfg.layout 0): adjacent k-mers of genomes -> super-k-mer slots;
+    unrelated k-mers (one per entry: cuCLARK-l's sampled blocks) or one minimizer in thousands of contexts (tandem
+    repeats) -> the minimizer layout.  Same answers either way."""
+    if table_layout != "super":
+        pytest.skip("one run is enough")
+    monkeypatch.delenv("MIC_LAYOUT")
+    import itertools
+    rng = np.random.default_rng(29)
+    k, T, htsize = 31, 7, 3000017
+    o = gu.oracle()
+    code = lambda s_: int("".join(str("TGCA".index(ch)) for ch in s_), 4)
+    genome = "".join(rng.choice(list("ACGT"), 60000))
+    genome_kmers = [code(genome[i:i + k]) for i in range(len(genome) - k + 1)]
+    unrelated = [int(v) for v in rng.integers(0, 1 << 62, 40000, dtype=np.uint64)]
+    core = "AT" * 12 + "A"                                      # a low-complexity stretch of 25 nt in 4096 contexts
+    crowded = [code(core + "".join(t)) for t in itertools.product("ACGT", repeat=6)] + [code(genome[i:i + k]) for i in range(0, 3000)]
+    for name, kmers, want in (("genome", genome_kmers, 3), ("unrelated", unrelated, 2), ("crowded", crowded, 2)):
+        canon = sorted({o.canonical(v, k) for v in kmers}, key=lambda c: (c % htsize, c // htsize))
+        sizes = np.zeros(htsize, np.int64)
+        for c in canon:
+            sizes[c % htsize] += 1
+        keys = np.array([c // htsize for c in canon], dtype=np.uint64)
+        # one target for the genome (adjacent k-mers merge into super-k-mers); unrelated labels keep the other contexts apart
+        labels = np.array([3 if name == "genome" else (c * 2654435761 >> 11) % T for c in canon], dtype=np.uint16)
+        odb = o.db_from_arrays(sizes.astype(np.uint8), keys, labels)
+        q = np.array(kmers[::3] + [o.revcomp(v, k) for v in kmers[1::7]] + [v ^ 2 for v in kmers[::11]], dtype=np.uint64)
+        rp, cont = _kmer_reads(q, k)
+        f, l = odb.find_many(q, k)
+        with _engine(k, T) as e:
+            e.read_arrays(sizes.astype(np.uint8), keys, labels)
+            info = e.info()
+            res = e.classify_packed(rp, cont)
+        assert info["layout"] == want, (name, info["layout"], info["reserved"], info["n_elems"], info["n_entries"])
+        assert ((res[:, 0] == 1) == (f == 1)).all()
+        assert (res[f == 1, 1] == l[f == 1].astype(np.uint32) + 1).all()
+
+
 def test_low_complexity_and_palindromic_minimizers():
     """k-mers whose m-mers repeat (poly-A, dinucleotide and trinucleotide repeats: every window position ties) or whose
     minimizer is its own reverse complement ((ACGT)n): the minimizer-keyed layouts must find them from either strand of a
