@@ -214,7 +214,7 @@ def main():
                     help="gloo stages the row exchange through host memory (validation on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the batch-API pipeline leg (N=1)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-in, CSV-out leg through exe/cuCLARK (N=1)")
-    ap.add_argument("--e2e-threads", type=int, default=8, help="-n of the end-to-end run")
+    ap.add_argument("--e2e-threads", type=int, default=12, help="-n of the end-to-end run")
     ap.add_argument("--no-db-leg", action="store_true",
                     help="N > 1, read mode: skip the extra table-sharded measurement reported as \"table_sharded\"")
     args = ap.parse_args()

@@ -534,6 +534,7 @@ class FileFeeder : public Classifier::Feeder {
   uint64_t size() const { return size_; }
   uint8_t first_byte() const { return first_; }
   bool fastq() const override { return first_ == '@'; }
+  uint64_t remaining() const override { return size_ - pos_; }
   bool assign(size_t want, size_t cap, Classifier::Range& r) override {
     (void)cap;
     if (pos_ >= size_) return false;
@@ -775,7 +776,7 @@ void Classifier::ensure_ingest(size_t total_bytes) {
   size_t workers = std::min<size_t>(std::max<size_t>(opt_.threads, 1), 48);
   workers += workers / 2;
   if (const char* env = getenv("MIC_INGEST_SLOTS")) { long v = atol(env); if (v >= 1 && v <= 96) workers = (size_t)v; }
-  size_t bytes = 32u << 20;
+  size_t bytes = 64u << 20;
   if (const char* env = getenv("MIC_INGEST_MB")) { long v = atol(env); if (v >= 1 && v <= 1024) bytes = (size_t)v << 20; }
   if (const char* env = getenv("MIC_INGEST_KB")) { long v = atol(env); if (v >= 4) bytes = (size_t)v << 10; }
   if (const char* env = getenv("MIC_INGEST_WORKERS")) { long v = atol(env); if (v >= 1 && v <= 64) workers = (size_t)v; }
@@ -861,7 +862,8 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
   const size_t S = slots.size();
   // threads: opt_.threads in all; a quarter of them drive the device, an eighth write, the rest load
   const size_t T = std::max<size_t>(opt_.threads, 1);
-  size_t ND = std::min<size_t>(8, std::max<size_t>(1, T / 4)), NW = std::min<size_t>(4, std::max<size_t>(1, T / 8));
+  // one writer: concurrent pwrite()s to one file take turns on the inode lock and come out slower than a single stream
+  size_t ND = std::min<size_t>(6, std::max<size_t>(1, T / 4)), NW = 1;
   if (const char* env = getenv("MIC_INGEST_ND")) { long v = atol(env); if (v >= 1 && v <= 32) ND = (size_t)v; }
   if (const char* env = getenv("MIC_INGEST_NW")) { long v = atol(env); if (v >= 1 && v <= 32) NW = (size_t)v; }
   size_t NL = T > ND + NW ? T - ND - NW : 1;
@@ -910,7 +912,16 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
         bool more = false;
         // FASTQ travels without its quality lines: about half the bytes of a range reach the slot
         const bool fq = strip_ok && feed.fastq();
-        const size_t want = fq ? cap + cap / 2 : cap - cap / 8;
+        size_t want = fq ? cap + cap / 2 : cap - cap / 8;
+        {
+          // the first batches are small so that the device and the writer start early (a full batch takes a loader ~10 ms),
+          // the last ones are cut so that the loaders finish together
+          const double ramp = std::min(1.0, std::max(0.125, (double)(next_id + 1) / (2.0 * (double)NL)));
+          const uint64_t left = feed.remaining();
+          size_t w = (size_t)((double)want * ramp);
+          if (left / NL < w) w = (size_t)(left / NL);
+          want = std::max<size_t>(std::min(w, want), (size_t)1 << 20);
+        }
         try { more = feed.assign(want, cap, it.r); } catch (const std::exception& ex) { fail(ex.what()); }
         if (!more) {
           { std::lock_guard<std::mutex> lk2(mu); fed_all = true; free_slots.push_back(it.slot); }

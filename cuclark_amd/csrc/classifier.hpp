@@ -61,6 +61,7 @@ class Classifier {
     virtual bool assign(size_t want, size_t cap, Range& r) = 0;
     virtual void read(const Range& r, size_t off, uint8_t* dst, size_t len) = 0;   // bytes [off, off + len) of the range; any thread
     virtual bool fastq() const = 0;                          // the input's records are four-line FASTQ records
+    virtual uint64_t remaining() const { return ~(uint64_t)0 >> 1; }   // bytes not yet handed out, if known
   };
   void run_stream(Feeder& f, const std::string& results_base, bool paired, size_t total_bytes);
 
