@@ -17,7 +17,7 @@ MIC_RESULT_WORDS = 8
 MIC_FLAG_ROW_OVERFLOW = 1
 MIC_FLAG_DENSE_PATH = 2
 MIC_ROW_INVALID = 0xFFFFFFFF
-MIC_LAYOUT_AUTO, MIC_LAYOUT_DIRECT, MIC_LAYOUT_MINIMIZER, MIC_LAYOUT_SUPER = 0, 1, 2, 3
+MIC_LAYOUT_AUTO, MIC_LAYOUT_DIRECT, MIC_LAYOUT_MINIMIZER, MIC_LAYOUT_SUPER, MIC_LAYOUT_SUPER2 = 0, 1, 2, 3, 4
 
 
 class MicError(RuntimeError):

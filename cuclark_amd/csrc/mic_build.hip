@@ -309,6 +309,7 @@ struct MBuildArgs {
   const void* keys; const uint16_t* labels;
   const TileA* base_a; uint32_t sampling; uint64_t rank_base;
   int k, m; uint64_t n_mslots;
+  int fwd;     // super-k-mer table: both strands under forward-strand minimizers (mic_device.h: s_candidates_fwd)
 };
 
 // visit the reachable entries of this thread's bucket: f(c, label)
@@ -574,22 +575,28 @@ __global__ void __launch_bounds__(TILE) s_count_kernel(MBuildArgs a, uint32_t* _
                                                        unsigned long long* __restrict__ kept) {
   unsigned long long mine = 0;
   for_reachable<RAW>(a, [&](uint64_t c, uint16_t) {
-    s_candidates(c, a.k, a.m, [&](uint64_t, int, uint64_t x) { atomicAdd(&cnt[sslot_of_x(x, (uint32_t)a.n_mslots)], 1u); });
+    auto add = [&](uint64_t, int, uint64_t x) { atomicAdd(&cnt[sslot_of_x(x, (uint32_t)a.n_mslots)], 1u); };
+    if (a.fwd) s_candidates_fwd(c, a.k, a.m, add); else s_candidates(c, a.k, a.m, add);
     ++mine;
   });
   if (mine) atomicAdd(kept, mine);
 }
 
 template <typename RAW>
+// Only the candidates of the slots [slot_lo, slot_hi) are staged (at their offset minus `base`): a table whose staging
+// area does not fit next to it is built in several passes over slot ranges.
 __global__ void __launch_bounds__(TILE) s_scatter_kernel(MBuildArgs a, const unsigned long long* __restrict__ off,
                                                          uint32_t* __restrict__ cursor, unsigned long long* __restrict__ cand_k,
-                                                         uint32_t* __restrict__ cand_m) {
+                                                         uint32_t* __restrict__ cand_m, uint32_t slot_lo, uint32_t slot_hi,
+                                                         unsigned long long base) {
   for_reachable<RAW>(a, [&](uint64_t c, uint16_t lb) {
-    s_candidates(c, a.k, a.m, [&](uint64_t K, int j, uint64_t x) {
+    auto put = [&](uint64_t K, int j, uint64_t x) {
       const uint32_t s = sslot_of_x(x, (uint32_t)a.n_mslots);
-      const unsigned long long pos = off[s] + atomicAdd(&cursor[s], 1u);
+      if (s < slot_lo || s >= slot_hi) return;
+      const unsigned long long pos = off[s] - base + atomicAdd(&cursor[s], 1u);
       cand_k[pos] = K; cand_m[pos] = (uint32_t)j | ((uint32_t)lb << 8);
-    });
+    };
+    if (a.fwd) s_candidates_fwd(c, a.k, a.m, put); else s_candidates(c, a.k, a.m, put);
   });
 }
 
@@ -659,12 +666,13 @@ __global__ void __launch_bounds__(256) s_merge_kernel(const unsigned long long* 
                                                       uint64_t n_slots, unsigned long long* __restrict__ cand_k,
                                                       uint32_t* __restrict__ cand_m, int k, int m,
                                                       uint32_t* __restrict__ n_ent, const unsigned long long* __restrict__ chain_off,
-                                                      uint32_t* __restrict__ slots, uint32_t* __restrict__ max_ent) {
-  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_slots) return;
+                                                      uint32_t* __restrict__ slots, uint32_t* __restrict__ max_ent,
+                                                      uint64_t slot_lo, uint64_t slot_hi, unsigned long long base, int sort_now) {
+  const uint64_t s = slot_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= slot_hi) return;
   const uint32_t n = cnt[s];
-  unsigned long long* K = cand_k + off[s];
-  uint32_t* M = cand_m + off[s];
+  unsigned long long* K = cand_k + (off[s] - base);
+  uint32_t* M = cand_m + (off[s] - base);
   const int w = k - m + 1, L = k + w - 1;
   SWriter wr; wr.slots = slots; wr.main = s; wr.chain = 0; wr.n_total = 0; wr.n_out = 0;
   if (WRITE) {
@@ -679,8 +687,9 @@ __global__ void __launch_bounds__(256) s_merge_kernel(const unsigned long long* 
       q[30] = (wr.n_total ? here : 0) | (c < n_chain ? MIC_S_NEXT : 0);
       q[31] = c < n_chain ? (uint32_t)(wr.chain + c) : 0;
     }
-  } else {
-    // shell sort of the staged candidates (in place; the second run finds them sorted)
+  }
+  if (sort_now) {
+    // shell sort of the staged candidates (in place; a second run over the same staging area finds them sorted)
     const uint32_t gaps[] = {701, 301, 132, 57, 23, 10, 4, 1};
     for (int g = 0; g < 8; ++g) {
       const uint32_t gap = gaps[g];
@@ -767,7 +776,7 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   // clustering of k-mers by minimizer makes the load lumpy and overflowing slots cost a second round.  When the table
   // would not fit in the free HBM the load is raised step by step (each trial is one counting pass, exact size).
   a.sizes = d_sizes; a.n_buckets = n_buckets; a.bucket0 = bucket0; a.htsize = htsize; a.keys = d_keys; a.labels = d_labels;
-  a.base_a = d_a; a.sampling = sampling; a.rank_base = rank_base; a.k = k; a.m = m;
+  a.base_a = d_a; a.sampling = sampling; a.rank_base = rank_base; a.k = k; a.m = m; a.fwd = 0;
 #define BY_RAW(KERN, ...) do { if (key_bytes == 8) KERN<uint64_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); \
     else if (key_bytes == 4) KERN<uint32_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); \
     else KERN<uint16_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); } while (0)
@@ -876,7 +885,7 @@ static hipError_t scan_u32_to_u64(const uint32_t* in, unsigned long long* out, u
 
 int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
                      int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
-                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap, int allow_fallback) {
+                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap, int allow_fallback, int both_strands) {
   int rc = 0;
   const unsigned n_tiles = (unsigned)((n_buckets + TILE - 1) / TILE);
   TileA* d_a = nullptr; uint32_t* d_cnt = nullptr; uint32_t* d_cur = nullptr; unsigned long long* d_off = nullptr;
@@ -885,6 +894,8 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   std::vector<TileA> h_a(n_tiles);
   uint64_t tot_elems = 0, tot_nz = 0, n_slots = 0, n_cand = 0, n_chain = 0;
   unsigned long long h_scal[2] = {0, 0}, h_entries = 0; uint32_t h_max = 0; double avail_b = 0;
+  uint32_t* d_nent = nullptr; uint64_t stage_cap = 0; size_t n_ranges = 0;
+  std::vector<uint64_t> range_lo; std::vector<unsigned long long> range_base;
   MBuildArgs a;
   const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
   struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
@@ -911,12 +922,12 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   }
   HIPCK(hipMemcpyAsync(d_a, h_a.data(), sizeof(TileA) * n_tiles, hipMemcpyHostToDevice, s));
   a.sizes = d_sizes; a.n_buckets = n_buckets; a.bucket0 = bucket0; a.htsize = htsize; a.keys = d_keys; a.labels = d_labels;
-  a.base_a = d_a; a.sampling = sampling; a.rank_base = rank_base; a.k = k; a.m = m;
+  a.base_a = d_a; a.sampling = sampling; a.rank_base = rank_base; a.k = k; a.m = m; a.fwd = both_strands ? 1 : 0;
   // Sizing: the number of entries is about the number of distinct minimizers D among the stored k-mers.  A first
   // counting pass over G provisional slots leaves N non-empty ones, so D ~ -G ln(1 - N/G); the table then gets
   // D / 1.5 slots (6 entries each: P(overflow) ~ 2e-4 for Poisson(1.5)).  MIC_SSLOT_LOAD overrides the 1.5.
   for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 0) n_slots = tot_elems / (sampling > 1 ? 4ull * sampling : 4ull) + 64;
+    if (pass == 0) n_slots = (both_strands ? 2 : 1) * (tot_elems / (sampling > 1 ? 4ull * sampling : 4ull)) + 64;
     // the scans below take an int item count; a table this large (> 2^31 slots = 275 GB) does not fit one GPU anyway
     if (n_slots > 0x7FFFFF00ull) { snprintf(err, err_cap, "the super-k-mer table would need %llu slots", (unsigned long long)n_slots); rc = -3; goto done; }
     if (d_cnt) { hipFree(d_cnt); d_cnt = nullptr; }
@@ -950,7 +961,9 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     n_cand = last_off + last_cnt;
   }
   {
-    // staging (12 B per candidate) + per-slot arrays + at least the main slots must fit next to what is resident already
+    // What must fit next to what is resident already: the table (128 B per slot, ~1 % continuation slots), 32 B of per-slot
+    // arrays, and a staging area of 12 B per candidate.  When all candidates do not fit at once the staging area takes what
+    // is left and the table is built in several passes over slot ranges (each pass scatters only its range's candidates).
     size_t free_b = 0, total_b = 0;
     HIPCK(hipMemGetInfo(&free_b, &total_b));
     avail_b = (double)free_b - 1.5e9;
@@ -958,39 +971,74 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       const double lim = atof(env) * 1e9;
       if (lim > 0 && avail_b > lim) avail_b = lim;
     }
-    // per slot: counts 4 + offsets 8 + cursors 4 + chain offsets 8 + chain demand 4 = 28 bytes, the 128-byte slot itself,
-    // and the scans' temporary storage (a few MB)
-    const double need = (double)n_cand * 12 + (double)n_slots * (28 + 128) + 64e6;
-    if (need > avail_b) {
-      snprintf(err, err_cap, "the super-k-mer table and its build need at least %.3f GB, %.3f GB of HBM are available", need / 1e9,
-               avail_b / 1e9);
+    const double fixed = (double)n_slots * (128 * 1.02 + 24) + 64e6;    // table + chain offsets / cursors / entry counts (counts and offsets exist already)
+    double budget = avail_b - fixed;
+    if (const char* env = getenv("MIC_S_STAGING_LIMIT_MB")) {           // test hook: a small staging area forces several passes
+      const double lim = atof(env) * 1e6;
+      if (lim > 0 && budget > lim) budget = lim;
+    }
+    if (budget < (double)n_cand * 12 / 16 || budget < 4096) {
+      snprintf(err, err_cap, "the super-k-mer table and its build need at least %.3f GB, %.3f GB of HBM are available",
+               (fixed + (double)n_cand * 12 / 16) / 1e9, avail_b / 1e9);
       rc = -3; goto done;
     }
+    stage_cap = (double)n_cand * 12 <= budget ? n_cand : (uint64_t)(budget / 12);
   }
   {
-    hipError_t e1 = hipMalloc(&d_ck, (n_cand + 1) * 8), e2 = hipMalloc(&d_cm, (n_cand + 1) * 4);
+    // slot ranges whose candidates fit the staging area: boundaries at multiples of G slots (2^16 for a large table), from a
+    // strided copy of the offsets
+    uint64_t G = 1u << 16;
+    while (G > 64 && n_slots / G < 64) G >>= 1;
+    const uint64_t n_samples = n_slots / G + 1;
+    std::vector<unsigned long long> samp(n_samples);
+    HIPCK(hipMemcpy2D(samp.data(), 8, d_off, 8 * G, 8, n_samples, hipMemcpyDeviceToHost));
+    range_lo.clear(); range_base.clear();
+    uint64_t lo = 0; unsigned long long lo_off = 0;
+    while (lo < n_slots) {
+      // largest multiple of G (or the end) whose offset stays within the staging capacity
+      uint64_t hi = n_slots;
+      if (n_cand - lo_off > stage_cap) {
+        uint64_t g = lo / G + 1;
+        while (g < n_samples && samp[g] - lo_off <= stage_cap) ++g;
+        hi = (g - 1) * G;
+        if (hi <= lo) { snprintf(err, err_cap, "a block of %llu slots holds more candidates than the staging area", (unsigned long long)G); rc = -3; goto done; }
+      }
+      range_lo.push_back(lo); range_base.push_back(lo_off);
+      lo = hi; lo_off = hi < n_slots ? samp[hi / G] : n_cand;
+    }
+    range_lo.push_back(n_slots); range_base.push_back(n_cand);
+    n_ranges = range_lo.size() - 1;
+    uint64_t biggest = 0;
+    for (size_t r = 0; r < n_ranges; ++r) biggest = std::max<uint64_t>(biggest, range_base[r + 1] - range_base[r]);
+    hipError_t e1 = hipMalloc(&d_ck, (biggest + 1) * 8), e2 = hipMalloc(&d_cm, (biggest + 1) * 4);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       (void)hipGetLastError();
-      snprintf(err, err_cap, "the super-k-mer build needs %.2f GB of staging", (double)n_cand * 12 / 1e9); rc = -3; goto done;
+      snprintf(err, err_cap, "the super-k-mer build needs %.2f GB of staging", (double)biggest * 12 / 1e9); rc = -3; goto done;
     }
+    if (timing) fprintf(stderr, "[load]   %zu pass(es) over slot ranges, staging %.2f GB for %.2f G candidates\n", n_ranges, (double)biggest * 12 / 1e9, n_cand / 1e9);
   }
-  HIPCK(hipMalloc(&d_cur, n_slots * 4));
+  HIPCK(hipMalloc(&d_cur, n_slots * 4));      // scatter cursors
+  HIPCK(hipMalloc(&d_nent, n_slots * 4));     // entries per slot
   HIPCK(hipMemsetAsync(d_cur, 0, n_slots * 4, s));
-  BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm);
-  HIPCK(hipGetLastError());
-  lap("scatter of the candidates");
   HIPCK(hipMemsetAsync(d_max, 0, 4, s));
-  s_merge_kernel<false><<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_cur, nullptr,
-                                                                         nullptr, d_max);
-  HIPCK(hipGetLastError());
+  // phase A: entries per slot (scatter + sort + merge without writing), range by range
+  for (size_t r = 0; r < n_ranges; ++r) {
+    const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
+    BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
+    HIPCK(hipGetLastError());
+    s_merge_kernel<false><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_nent, nullptr,
+                                                                           nullptr, d_max, lo, hi, range_base[r], 1);
+    HIPCK(hipGetLastError());
+  }
+  lap("scatter of the candidates + sort + merge (count)");
   HIPCK(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
   HIPCK(hipMemsetAsync(d_scal + 1, 0, 8, s));
-  s_sum_kernel<<<4096, 256, 0, s>>>(d_cur, n_slots, d_scal + 1);       // entries = super-k-mers stored (statistics)
+  s_sum_kernel<<<4096, 256, 0, s>>>(d_nent, n_slots, d_scal + 1);       // entries = super-k-mers stored (statistics)
   HIPCK(hipMemcpyAsync(&h_entries, d_scal + 1, 8, hipMemcpyDeviceToHost, s));
   {
     unsigned long long h_walk = 0;
     HIPCK(hipMemsetAsync(d_scal, 0, 8, s));
-    s_walk_kernel<<<4096, 256, 0, s>>>(d_cnt, d_cur, n_slots, d_scal);
+    s_walk_kernel<<<4096, 256, 0, s>>>(d_cnt, d_nent, n_slots, d_scal);
     HIPCK(hipMemcpyAsync(&h_walk, d_scal, 8, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     const double walk = n_cand ? (double)h_walk / (double)n_cand : 0.0;
@@ -1010,16 +1058,16 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     // super-k-mers: the minimizer layout holds it in a quarter of the memory and answers 10 % faster (1 360 vs 1 240)
     double min_per_entry = 1.3;
     if (const char* env = getenv("MIC_S_MIN_KMERS_PER_ENTRY")) min_per_entry = atof(env);
-    if (allow_fallback && h_entries && (double)h_scal[0] / (double)h_entries < min_per_entry) {
-      snprintf(err, err_cap, "%.2f k-mers per super-k-mer entry (limit %.2f): no adjacency to exploit", (double)h_scal[0] / (double)h_entries, min_per_entry);
+    const double stored = (double)h_scal[0] * (both_strands ? 2.0 : 1.0);
+    if (allow_fallback && h_entries && stored / (double)h_entries < min_per_entry) {
+      snprintf(err, err_cap, "%.2f k-mers per super-k-mer entry (limit %.2f): no adjacency to exploit", stored / (double)h_entries, min_per_entry);
       rc = -5; goto done;
     }
   }
-  lap("sort + merge (count)");
   {
     // chain slots: demand per slot into a scratch u32 array (the candidate offsets stay), scanned to 64-bit bases
     HIPCK(hipMalloc(&d_dem, n_slots * 4));
-    s_chain_demand_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_cur, n_slots, d_dem);
+    s_chain_demand_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_nent, n_slots, d_dem);
     HIPCK(hipMalloc(&d_coff, (n_slots + 1) * 8));
     hipError_t e = scan_u32_to_u64(d_dem, d_coff, n_slots, s);
     unsigned long long last_off = 0; uint32_t last_dem = 0;
@@ -1030,11 +1078,6 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     n_chain = last_off + last_dem;
   }
   if (n_slots + n_chain > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many S-slots"); rc = -1; goto done; }
-  if ((double)(n_slots + n_chain + 1) * 128 + (double)n_cand * 12 > avail_b) {
-    snprintf(err, err_cap, "the super-k-mer table and its build need at least %.3f GB, %.3f GB of HBM are available",
-             ((double)(n_slots + n_chain + 1) * 128 + (double)n_cand * 12) / 1e9, avail_b / 1e9);
-    rc = -3; goto done;
-  }
   {
     hipError_t e_ = hipMalloc(&slots, (size_t)(n_slots + n_chain + 1) * 128);
     if (e_ != hipSuccess) {
@@ -1044,9 +1087,18 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       rc = -3; goto done;
     }
   }
-  s_merge_kernel<true><<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_cur, d_coff,
-                                                                        slots, d_max);
-  HIPCK(hipGetLastError());
+  // phase B: write the slots.  One range: its candidates are still staged and sorted.  Several: scatter and sort each again.
+  if (n_ranges > 1) HIPCK(hipMemsetAsync(d_cur, 0, n_slots * 4, s));
+  for (size_t r = 0; r < n_ranges; ++r) {
+    const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
+    if (n_ranges > 1) {
+      BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
+      HIPCK(hipGetLastError());
+    }
+    s_merge_kernel<true><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_nent, d_coff,
+                                                                          slots, d_max, lo, hi, range_base[r], n_ranges > 1 ? 1 : 0);
+    HIPCK(hipGetLastError());
+  }
   HIPCK(hipMemsetAsync(slots + (size_t)(n_slots + n_chain) * 32, 0xFF, 128, s));   // the spare slot after the table: empty
   HIPCK(hipStreamSynchronize(s));
   lap("merge (write)");
@@ -1065,6 +1117,7 @@ done:
   if (d_ck) hipFree(d_ck);
   if (d_cm) hipFree(d_cm);
   if (d_dem) hipFree(d_dem);
+  if (d_nent) hipFree(d_nent);
   if (slots) hipFree(slots);
   return rc;
 }

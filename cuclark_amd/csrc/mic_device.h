@@ -141,10 +141,36 @@ __device__ __forceinline__ void s_candidates(uint64_t c, int k, int m, F&& f) {
   }
 }
 
+// Two-strand form of the same table ("S2", MIC_LAYOUT_SUPER2): BOTH orientations of every database k-mer are stored,
+// each under the minimizer of its own m-mers AS THEY READ (no canonical m-mer).  A query k-mer is then looked up exactly as
+// it stands in the read: no reverse complement, no canonical m-mer and no strand bookkeeping in the query kernel (60 of
+// its 414 VALU instructions per 150-bp read) at the price of twice the entries.  A k-mer that is its own reverse
+// complement is stored once.
+template <typename F>
+__device__ __forceinline__ void s_candidates_fwd(uint64_t c, int k, int m, F&& f) {
+  const int w = k - m + 1;
+  const uint64_t mask = (1ULL << (2 * m)) - 1;
+  const uint64_t rc = revcomp_bits(c, k);
+  for (int strand = 0; strand < 2; ++strand) {
+    if (strand && rc == c) break;
+    const uint64_t K = strand ? rc : c;
+    uint32_t hmin = 0xFFFFFFFFu;
+    for (int i = 0; i < w; ++i) {
+      const uint32_t h = s_order27((K >> (2 * (k - m - i))) & mask);
+      hmin = h < hmin ? h : hmin;
+    }
+    for (int i = 0; i < w; ++i) {
+      const uint64_t mf = (K >> (2 * (k - m - i))) & mask;
+      if (s_order27(mf) == hmin) f(K, i, mf);
+    }
+  }
+}
+
 // sequential lookup (dense fallback, statistics, tests of the build): label + 1 or 0
-__device__ inline uint32_t s_probe(const uint4* __restrict__ slots, uint32_t n_slots, uint64_t c, int k, int m) {
+__device__ inline uint32_t s_probe(const uint4* __restrict__ slots, uint32_t n_slots, uint64_t c, int k, int m, bool fwd = false) {
   uint64_t K = 0, x = 0; int j = -1;
-  s_candidates(c, k, m, [&](uint64_t kk, int jj, uint64_t xx) { if (j < 0) { K = kk; j = jj; x = xx; } });
+  if (fwd) s_candidates_fwd(c, k, m, [&](uint64_t kk, int jj, uint64_t xx) { if (j < 0) { K = kk; j = jj; x = xx; } });
+  else s_candidates(c, k, m, [&](uint64_t kk, int jj, uint64_t xx) { if (j < 0) { K = kk; j = jj; x = xx; } });
   const int w = k - m + 1;
   uint64_t slot = sslot_of_x(x, n_slots);
   for (;;) {

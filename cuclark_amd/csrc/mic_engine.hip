@@ -98,7 +98,8 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   e->table.shard_end = s1;
   e->table.div = mic_make_div(htsize);
   e->table.k = e->cfg.k;
-  e->table.layout = layout == MIC_LAYOUT_MINIMIZER ? 1 : layout == MIC_LAYOUT_SUPER ? 2 : 0;
+  e->table.layout = layout == MIC_LAYOUT_MINIMIZER ? 1 : (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2) ? 2 : 0;
+  e->table.fwd = layout == MIC_LAYOUT_SUPER2 ? 1 : 0;
   e->table.m = m;
   e->table.sharded = (s0 != 0 || s1 != htsize) ? 1 : 0;
   e->table.sizes = e->d_sizes;
@@ -109,7 +110,7 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   i.hbm_bytes = (b.n_main + b.n_overflow + 1) * (uint64_t)(layout != MIC_LAYOUT_DIRECT ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
   i.key_bytes = key_bytes; i.slot_class = layout != MIC_LAYOUT_DIRECT ? 128 : e->slot_class; i.max_bucket = b.max_bucket;
   i.sampling = sampling; i.layout = layout; i.minimizer_len = layout != MIC_LAYOUT_DIRECT ? m : 0;
-  i.max_chain = layout != MIC_LAYOUT_DIRECT ? b.max_chain : 0; i.reserved = layout == MIC_LAYOUT_SUPER ? b.walk_ppm : 0;
+  i.max_chain = layout != MIC_LAYOUT_DIRECT ? b.max_chain : 0; i.reserved = (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2) ? b.walk_ppm : 0;
   i.n_entries = b.n_entries ? b.n_entries : b.n_elems;
   e->db_loaded = true;
 }
@@ -188,6 +189,7 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
     if (env && !strcmp(env, "direct")) layout = MIC_LAYOUT_DIRECT;
     else if (env && !strcmp(env, "minimizer")) layout = MIC_LAYOUT_MINIMIZER;
     else if (env && !strcmp(env, "super")) layout = MIC_LAYOUT_SUPER;
+    else if (env && !strcmp(env, "super2")) layout = MIC_LAYOUT_SUPER2;
     else { layout = e->cfg.k >= 24 ? MIC_LAYOUT_SUPER : MIC_LAYOUT_DIRECT; by_default = true; }  // measured: DESIGN.md §3
   }
   int m = 20;   // measured best for k = 31: minimizers long enough to be nearly unique in the table
@@ -196,7 +198,7 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   if (m > 31) m = 31;
   if (layout == MIC_LAYOUT_MINIMIZER && (m < 8 || e->cfg.k - m + 1 > 64)) layout = MIC_LAYOUT_DIRECT;
   const int m0 = m;
-  if (layout == MIC_LAYOUT_SUPER) {          // the super-k-mer entries hold windows of at most 16 m-mers
+  if (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2) {          // the super-k-mer entries hold windows of at most 16 m-mers
     if (m < e->cfg.k - 15) m = e->cfg.k - 15;
     if (m < 8 || m > 31 || e->cfg.k - m + 1 < 2) layout = MIC_LAYOUT_DIRECT;
   }
@@ -206,9 +208,16 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   int rc = 0;
   // By default: super-k-mer slots; if their build does not fit in the free HBM, the minimizer-keyed slots (no staging
   // area), then the direct layout (64 B per bucket).  An explicitly requested layout fails with the sizes in the message.
+  if (layout == MIC_LAYOUT_SUPER2) {
+    // both strands stored: the fastest kernel, twice the entries; falls back to the one-strand table when it does not fit
+    rc = mic_build_stable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
+                          e->cfg.k, m, e->stream, &b, err, sizeof(err), by_default ? 1 : 0, 1);
+    if (rc == -3 && (by_default || getenv("MIC_SUPER2_MAY_FALL_BACK"))) { layout = MIC_LAYOUT_SUPER; memset(&b, 0, sizeof(b)); }
+    else if (rc == -5 && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; }
+  }
   if (layout == MIC_LAYOUT_SUPER) {
     rc = mic_build_stable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
-                          e->cfg.k, m, e->stream, &b, err, sizeof(err), by_default ? 1 : 0);
+                          e->cfg.k, m, e->stream, &b, err, sizeof(err), by_default ? 1 : 0, 0);
     // -3: does not fit; -5: crowded minimizers (tandem repeats): the minimizer layout's trees answer those faster
     if ((rc == -3 || rc == -5) && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; }
   }
@@ -377,7 +386,7 @@ int mic_create(const mic_config* cfg, mic_engine** out) {
   if (!cfg || !out) return fail(MIC_E_INVALID, "null argument");
   if (cfg->k < 2 || cfg->k > 32) return fail(MIC_E_INVALID, "The k-mer length should be in [2,32].");
   if (cfg->num_targets > 65535) return fail(MIC_E_INVALID, "too many targets (%u > 65535)", cfg->num_targets);
-  if (cfg->layout > MIC_LAYOUT_SUPER) return fail(MIC_E_INVALID, "unknown table layout %u", cfg->layout);
+  if (cfg->layout > MIC_LAYOUT_SUPER2) return fail(MIC_E_INVALID, "unknown table layout %u", cfg->layout);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
     return fail(MIC_E_NODEVICE, "no HIP device available: the MI355X engine cannot run (there is no CPU fallback)");

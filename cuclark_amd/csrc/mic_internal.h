@@ -80,6 +80,9 @@ static inline __host__ __device__ uint64_t mic_div(uint64_t n, const MicDiv& dv)
 #ifndef MIC_LAYOUT_SUPER
 #define MIC_LAYOUT_SUPER 3
 #endif
+#ifndef MIC_LAYOUT_SUPER2
+#define MIC_LAYOUT_SUPER2 4
+#endif
 
 struct MicTable {
   const uint4* slots;    // layout 0: 4 x uint4 per slot; layout 1: 8 x uint4 per slot
@@ -91,6 +94,7 @@ struct MicTable {
   int layout;            // 0 = direct slots, 1 = minimizer-keyed slots, 2 = super-k-mer slots
   int m;                 // minimizer length (layout 1)
   int sharded;           // 1 if [shard_start, shard_end) is a strict subset of the table
+  int fwd;               // layout 2: both strands stored under forward-strand minimizers (mic_device.h: s_candidates_fwd)
   const uint8_t* sizes;  // kept copy of the shard's on-disk bucket sizes (statistics only)
 };
 
@@ -142,7 +146,7 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
 // Super-k-mer table (layout 3, mic_device.h) from the same inputs.
 int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
                      int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
-                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap, int allow_fallback);
+                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap, int allow_fallback, int both_strands);
 // (allow_fallback: return -5 instead of building a table whose minimizers are crowded: see s_walk_kernel)
 // sums over d_sizes[0..n): total elements and non-empty buckets
 int mic_reduce_sizes(const uint8_t* d_sizes, uint64_t n, uint64_t* total, uint64_t* nonzero, hipStream_t s);

@@ -747,7 +747,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
 // entries with that value by a 3-step search over the slot's six sort keys and compares itself with the super-k-mer at
 // its alignment.  A slot holds ~1.5 entries on average: continuation slots are rare and there is no second level.
 // =====================================================================================================================
-template <int KK, int MM, bool SHARDED>
+// FWD: the table holds both strands of every k-mer under forward-strand minimizers (MIC_LAYOUT_SUPER2, mic_device.h:
+// s_candidates_fwd): a k-mer is looked up as it stands in the read - no reverse complement, no canonical m-mer, no strand.
+template <int KK, int MM, bool SHARDED, bool FWD>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s(const MicQueryArgs a) {
   __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE];
   __shared__ uint32_t s_run[MIC_M_WPB][MIC_RMAX];
@@ -847,7 +849,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
           const int idx = 4 * h + (lane >> 4);
           uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
           uint64_t kmer = kmer_from_dwords(d0, d1, d2, ln & 15, k);
-          const uint64_t rck = revcomp_bits(kmer, k);
+          // the reverse complement is needed for the canonical m-mers and the orientation (one-strand table) and for the
+          // bucket filter of the table-sharded mode (the buckets are those of the canonical k-mer)
+          const uint64_t rck = (!FWD || SHARDED) ? revcomp_bits(kmer, k) : 0;
           km[h] = kmer; rk[h] = rck;
           act[h] = base + 64 * h + lane < nk;
           if (SHARDED) {   // table-sharded mode only (its own instantiation: the unsharded kernel carries none of this): divisor and bounds are re-read from the kernarg segment (see finish)
@@ -862,15 +866,25 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
             act[h] = act[h] && rem >= s_lo && rem < s_hi;
           }
           // m-mer at this position = first m nt of the k-mer; its reverse complement = last m nt of rc(k-mer)
-          const uint64_t mf = kmer >> (2 * (k - m)), mr = rck & ((1ULL << (2 * m)) - 1);
-          const bool fw = mf < mr;
-          uint32_t key = (mmer_order_key_canon(fw ? mf : mr) & ~31u) | (fw ? 0u : 16u) | (uint32_t)(ln & 15);
+          const uint64_t mf = kmer >> (2 * (k - m));
+          uint32_t key;
+          if (FWD) key = (mmer_order_key_canon(mf) & ~31u) | (uint32_t)(ln & 15);
+          else {
+            const uint64_t mr = rck & ((1ULL << (2 * m)) - 1);
+            const bool fw = mf < mr;
+            key = (mmer_order_key_canon(fw ? mf : mr) & ~31u) | (fw ? 0u : 16u) | (uint32_t)(ln & 15);
+          }
           if (h == 0) hk0 = key; else hk1 = key;
           if (h == 1 && past) {
             // last m-mer of the k-mer (position 64 + lane + w - 1) = its last m nt; reverse complement = first m nt of rc(k-mer)
-            const uint64_t tf = kmer & ((1ULL << (2 * m)) - 1), tr = rck >> (2 * (k - m));
-            const bool tfw = tf < tr;
-            const uint32_t tk = (mmer_order_key_canon(tfw ? tf : tr) & ~31u) | (tfw ? 0u : 16u) | (uint32_t)((ln + w - 1) & 15);
+            const uint64_t tf = kmer & ((1ULL << (2 * m)) - 1);
+            uint32_t tk;
+            if (FWD) tk = (mmer_order_key_canon(tf) & ~31u) | (uint32_t)((ln + w - 1) & 15);
+            else {
+              const uint64_t tr = rck >> (2 * (k - m));
+              const bool tfw = tf < tr;
+              tk = (mmer_order_key_canon(tfw ? tf : tr) & ~31u) | (tfw ? 0u : 16u) | (uint32_t)((ln + w - 1) & 15);
+            }
             tail = row_prefix_min(ln >= 65 - w ? tk : 0xFFFFFFFFu);
           }
         }
@@ -883,7 +897,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
         for (int h = 0; h < 2; ++h) {
           const uint32_t mk = h == 0 ? hk0 : hk1;
           const uint32_t j = (mk - (uint32_t)ln) & 15;
-          const bool rev = (mk & 16u) != 0;
+          const bool rev = !FWD && (mk & 16u) != 0;
           ko[h] = rev ? rk[h] : km[h];
           // minimizer position in the oriented k-mer: jo = rev ? w-1-j : j; offset of the k-mer in the super-k-mer:
           // w-1-jo; and because k-m = w-1 that offset is also the number of nucleotides to the right of the minimizer
@@ -1142,7 +1156,7 @@ __device__ inline uint32_t probe_any(const MicTable& t, uint64_t kmer) {
       const uint64_t q = mic_div(c, t.div), rem = c - q * t.div.d;
       if (rem < t.shard_start || rem >= t.shard_end) return 0;
     }
-    return s_probe(t.slots, (uint32_t)t.n_main, c, t.k, t.m);
+    return s_probe(t.slots, (uint32_t)t.n_main, c, t.k, t.m, t.fwd != 0);
   }
   return t.layout ? probe_scalar_m(t, kmer) : probe_scalar<KEY64>(t, kmer);
 }
@@ -1304,12 +1318,17 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   if (a.t.layout == 2) {
     const unsigned g = (blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, b = 64 * MIC_M_WPB;
     static const bool generic = getenv("MIC_S_GENERIC") != nullptr;
-    const bool sh = a.t.sharded != 0;
-    if (!generic && a.t.k == 31 && a.t.m == 20) { if (sh) query_kernel_s<31, 20, true><<<g, b, 0, s>>>(a); else query_kernel_s<31, 20, false><<<g, b, 0, s>>>(a); }
-    else if (!generic && a.t.k == 27 && a.t.m == 20) { if (sh) query_kernel_s<27, 20, true><<<g, b, 0, s>>>(a); else query_kernel_s<27, 20, false><<<g, b, 0, s>>>(a); }
-    else if (!generic && a.t.k == 32 && a.t.m == 20) { if (sh) query_kernel_s<32, 20, true><<<g, b, 0, s>>>(a); else query_kernel_s<32, 20, false><<<g, b, 0, s>>>(a); }
-    else if (sh) query_kernel_s<0, 0, true><<<g, b, 0, s>>>(a);
-    else query_kernel_s<0, 0, false><<<g, b, 0, s>>>(a);
+    const bool sh = a.t.sharded != 0, fw = a.t.fwd != 0;
+    // instantiations: k and m as constants for cuCLARK's 31, cuCLARK-l's 27 and k = 32 with m = 20; the table-sharded filter
+    // and the two-strand table each in their own (the common kernel carries neither's scalars)
+#define LAUNCH_S(KK_, MM_) do { \
+      if (fw) { if (sh) query_kernel_s<KK_, MM_, true, true><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, true><<<g, b, 0, s>>>(a); } \
+      else { if (sh) query_kernel_s<KK_, MM_, true, false><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, false><<<g, b, 0, s>>>(a); } } while (0)
+    if (!generic && a.t.k == 31 && a.t.m == 20) LAUNCH_S(31, 20);
+    else if (!generic && a.t.k == 27 && a.t.m == 20) LAUNCH_S(27, 20);
+    else if (!generic && a.t.k == 32 && a.t.m == 20) LAUNCH_S(32, 20);
+    else LAUNCH_S(0, 0);
+#undef LAUNCH_S
 #ifdef MIC_PHASE_TIMING
     unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipStreamSynchronize(s);

@@ -63,6 +63,7 @@ typedef struct mic_config {
 #define MIC_LAYOUT_DIRECT 1    /* one 64-byte slot per on-disk bucket (one HBM request per k-mer) */
 #define MIC_LAYOUT_MINIMIZER 2 /* 128-byte slots keyed by the k-mer's minimizer (one HBM request per ~7 k-mers) */
 #define MIC_LAYOUT_SUPER 3     /* 128-byte slots of super-k-mers: the k-mers sharing a minimizer occurrence are one entry; one slot per lookup */
+#define MIC_LAYOUT_SUPER2 4    /* the same with BOTH strands of every k-mer stored: the query kernel needs no reverse complement (fastest; twice the table) */
 
 typedef struct mic_db_info {
   uint64_t htsize;         /* buckets in the whole table (= size of .sz)               */
@@ -77,7 +78,7 @@ typedef struct mic_db_info {
   int32_t slot_class;      /* 32: 8 entries/slot (u32 quotients); 64: 4 entries/slot; 128: minimizer / super-k-mer table */
   uint32_t max_bucket;     /* largest kept bucket                                       */
   uint32_t sampling;
-  int32_t layout;          /* MIC_LAYOUT_DIRECT, _MINIMIZER or _SUPER                   */
+  int32_t layout;          /* MIC_LAYOUT_DIRECT, _MINIMIZER, _SUPER or _SUPER2          */
   int32_t minimizer_len;   /* m (layouts MINIMIZER, SUPER), else 0                      */
   uint32_t max_chain;      /* entries in the fullest slot chain (MINIMIZER, SUPER)      */
   uint32_t reserved;       /* SUPER: mean number of continuation slots in front of a stored k-mer, x 1e6 (crowded minimizers) */

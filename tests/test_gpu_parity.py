@@ -10,10 +10,11 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["direct", "minimizer", "super"])
+@pytest.fixture(autouse=True, params=["direct", "minimizer", "super", "super2"])
 def table_layout(request, monkeypatch):
     """Every test runs against the resident layouts: one 64-byte slot per on-disk bucket, the
-    minimizer-keyed 128-byte slots, and the super-k-mer slots.  The engine reads MIC_LAYOUT when a table is built."""
+    minimizer-keyed 128-byte slots, the super-k-mer slots and their two-strand form.  The engine reads MIC_LAYOUT when a
+    table is built."""
     monkeypatch.setenv("MIC_LAYOUT", request.param)
     return request.param
 
@@ -59,7 +60,7 @@ def test_golden_queries_from_files(name, db_dir):
         info = e.info()
         assert info["htsize"] == meta["htsize"] and info["key_bytes"] == meta["key_bytes"]
         assert info["n_elems"] == meta["ky"].size
-        assert info["layout"] == {"direct": 1, "minimizer": 2, "super": 3}[os.environ["MIC_LAYOUT"]]
+        assert info["layout"] == {"direct": 1, "minimizer": 2, "super": 3, "super2": 4}[os.environ["MIC_LAYOUT"]]
         rp, cont = _kmer_reads(q["kmers"], k)
         res = e.classify_packed(rp, cont)
     found = res[:, 0] == 1
@@ -483,7 +484,7 @@ def test_skewed_minimizer_bucket():
         res = e.classify_packed(rp, cont)
     if info["layout"] == 2:
         assert info["max_chain"] > 500           # one bucket holds a large share of the 4096 core k-mers (3-level tree)
-    if info["layout"] == 3:
+    if info["layout"] in (3, 4):
         assert info["max_chain"] > 300           # random labels keep the k-mers of a minimizer apart: a long slot chain
     assert ((res[:, 0] == 1) == (f == 1)).all()
     assert (res[f == 1, 1] == l[f == 1].astype(np.uint32) + 1).all()
@@ -582,7 +583,7 @@ def test_super_table_with_crowded_slots(monkeypatch):
     """The super-k-mer table at 5.9 entries per 6-entry slot instead of 1.5 (MIC_SSLOT_LOAD): most slots continue in a
     chain of further slots; unrelated k-mers (one entry each) and k-mers cut from genomes (shared entries); answers equal
     the sparse table's and the oracle's."""
-    if os.environ["MIC_LAYOUT"] != "super":
+    if os.environ["MIC_LAYOUT"] not in ("super", "super2"):
         pytest.skip("sizing of the super-k-mer table")
     rng = np.random.default_rng(29)
     k, T, htsize = 31, 9, 2000003
@@ -614,10 +615,17 @@ def test_super_table_with_crowded_slots(monkeypatch):
     base_info, base = run()
     monkeypatch.setenv("MIC_SSLOT_LOAD", "5.9")
     info, res = run()
-    assert info["layout"] == 3 and info["n_slots"] < base_info["n_slots"] / 2 and info["n_overflow"] > base_info["n_overflow"]
+    assert info["layout"] in (3, 4) and info["n_slots"] < base_info["n_slots"] / 2 and info["n_overflow"] > base_info["n_overflow"]
     assert (res == base).all()
     assert ((res[:, 0] == 1) == (f == 1)).all()
     assert (res[f == 1, 1] == l[f == 1].astype(np.uint32) + 1).all()
+    # a staging area that holds a fraction of the candidates: the table is built in several passes over slot ranges and
+    # must come out the same (MIC_S_STAGING_LIMIT_MB is the test hook; the headline's two-strand table needs this path)
+    monkeypatch.delenv("MIC_SSLOT_LOAD")
+    monkeypatch.setenv("MIC_S_STAGING_LIMIT_MB", "0.4")
+    info3, res3 = run()
+    assert info3["n_slots"] == base_info["n_slots"] and info3["n_entries"] == base_info["n_entries"]
+    assert (res3 == base).all()
 
 
 def test_table_adapts_to_the_free_hbm(monkeypatch):
