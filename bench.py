@@ -212,6 +212,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the row exchange through host memory (validation on a box with fewer GPUs than ranks)")
+    ap.add_argument("--layout", default="super2", choices=["auto", "direct", "minimizer", "super", "super2"],
+                    help="resident table layout (DESIGN.md 3): super2 = super-k-mer slots with both strands stored, the fastest query "
+                         "kernel at twice the table (150 GB for the headline); falls back to super when it does not fit. "
+                         "The command line's default (auto) is super: half the load time, and it is host-bound anyway")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the batch-API pipeline leg (N=1)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-in, CSV-out leg through exe/cuCLARK (N=1)")
     ap.add_argument("--e2e-threads", type=int, default=12, help="-n of the end-to-end run")
@@ -264,7 +268,10 @@ def main():
     # ---- resident slot table (whole table, or this rank's bucket range in db mode)
     row_words = 16
     PIPE_BATCHES = int(os.environ.get("MIC_PIPE_BATCHES", "16"))
-    eng = MiClarkDB(k, T, num_batches=PIPE_BATCHES, device=local_rank, row_words=row_words)
+    LAYOUTS = {"auto": 0, "direct": 1, "minimizer": 2, "super": 3, "super2": 4}
+    layout = 0 if os.environ.get("MIC_LAYOUT") else LAYOUTS[args.layout]      # MIC_LAYOUT (tools/, tests) wins over the flag
+    os.environ.setdefault("MIC_SUPER2_MAY_FALL_BACK", "1")
+    eng = MiClarkDB(k, T, num_batches=PIPE_BATCHES, device=local_rank, row_words=row_words, layout=layout)
     shard = (0, 0)
     if args.mode == "db" and world > 1:
         shard = multi.shard_range(w["htsize"], world, rank)
@@ -378,10 +385,10 @@ def main():
     # counters cannot be read from inside this process, so the committed summary of the same workload is used.
     traffic, traffic_src, rdreq, traffic_note = None, None, None, None
     import glob
-    kname = {1: "query_kernel<", 2: "query_kernel_m<", 3: "query_kernel_s<"}[info["layout"]]
-    if info["layout"] == 3:      # the instantiation the launcher picks (mic_kernels.hip: mic_launch_query)
+    kname = {1: "query_kernel<", 2: "query_kernel_m<", 3: "query_kernel_s<", 4: "query_kernel_s<"}[info["layout"]]
+    if info["layout"] in (3, 4):      # the instantiation the launcher picks (mic_kernels.hip: mic_launch_query)
         km = (k, info["minimizer_len"]) if (k in (31, 27, 32) and info["minimizer_len"] == 20) else (0, 0)
-        kname = f"query_kernel_s<{km[0]}, {km[1]}, {'true' if db_mode else 'false'}>"
+        kname = f"query_kernel_s<{km[0]}, {km[1]}, {'true' if db_mode else 'false'}, {'true' if info['layout'] == 4 else 'false'}>"
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_query_kernel.json")), reverse=True):
         try:
             pj = json.load(open(f))
@@ -506,7 +513,7 @@ def main():
             eng.close()
             del d_res
             torch.cuda.empty_cache()
-            eng2 = MiClarkDB(k, T, device=local_rank, row_words=row_words)
+            eng2 = MiClarkDB(k, T, device=local_rank, row_words=row_words, layout=layout)
             t0 = time.time()
             eng2.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr(),
                              shard=multi.shard_range(w["htsize"], world, rank))
@@ -575,7 +582,8 @@ def main():
                        "mode": ("table-sharded by bucket range + all_to_all of sparse rows" if db_mode else
                                 ("read-sharded, table replicated" if world > 1 else "single GPU, table resident")),
                        "table": {"htsize": info["htsize"], "kmers": info["n_elems"], "slot_class": info["slot_class"],
-                                 "layout": {1: "direct: one 64-B slot per on-disk bucket", 2: "minimizer-keyed 128-B slots", 3: "super-k-mer 128-B slots"}[info["layout"]],
+                                 "layout": {1: "direct: one 64-B slot per on-disk bucket", 2: "minimizer-keyed 128-B slots", 3: "super-k-mer 128-B slots",
+                                            4: "super-k-mer 128-B slots, both strands stored (no reverse complement in the query)"}[info["layout"]],
                                  "minimizer_len": info["minimizer_len"], "largest_minimizer_bucket": info["max_chain"],
                                  "hbm_GB": round(info["hbm_bytes"] / 1e9, 2), "overflow_slots": info["n_overflow"],
                                  "max_bucket": info["max_bucket"], "on_disk_equiv_GB": round((info["htsize"] + n_el * (key_b + 2)) / 1e9, 2)},

@@ -927,7 +927,12 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   // counting pass over G provisional slots leaves N non-empty ones, so D ~ -G ln(1 - N/G); the table then gets
   // D / 1.5 slots (6 entries each: P(overflow) ~ 2e-4 for Poisson(1.5)).  MIC_SSLOT_LOAD overrides the 1.5.
   for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 0) n_slots = (both_strands ? 2 : 1) * (tot_elems / (sampling > 1 ? 4ull * sampling : 4ull)) + 64;
+    if (pass == 0) {
+      // provisional slots of the counting pass that sizes the table; the occupancy estimate below works at any load
+      // factor short of saturation, so the count is capped where the scans' item count would overflow
+      n_slots = (both_strands ? 2 : 1) * (tot_elems / (sampling > 1 ? 4ull * sampling : 4ull)) + 64;
+      if (n_slots > 0x7FF00000ull) n_slots = 0x7FF00000ull;
+    }
     // the scans below take an int item count; a table this large (> 2^31 slots = 275 GB) does not fit one GPU anyway
     if (n_slots > 0x7FFFFF00ull) { snprintf(err, err_cap, "the super-k-mer table would need %llu slots", (unsigned long long)n_slots); rc = -3; goto done; }
     if (d_cnt) { hipFree(d_cnt); d_cnt = nullptr; }

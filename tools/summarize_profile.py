@@ -56,7 +56,7 @@ for name in ("cal128_fetch", "cal128_rdreq"):
             cal128[c] = v[-1]
 q = [r for r in rows if "query_kernel" in r["Name"]][0]
 slots_cal128 = 256 * 64 * 4 * 8 * 128   # blocks (64 per CU) x waves x reads per wave x 128 one-slot probes of runs_kernel<128, 1, 0>
-layout_id = 3 if "super" in bench["config"]["table"]["layout"] else 2 if "minimizer" in bench["config"]["table"]["layout"] else 1
+layout_id = (4 if "both strands" in bench["config"]["table"]["layout"] else 3) if "super" in bench["config"]["table"]["layout"] else 2 if "minimizer" in bench["config"]["table"]["layout"] else 1
 # bytes per tallied FETCH_SIZE byte in this layout's access shape: measured on the known slot count when present
 fetch_scale = 1.0
 if layout_id >= 2 and cal128.get("FETCH_SIZE"):
