@@ -167,7 +167,7 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
         m = re.search(r"Assignment time: ([0-9.eE+-]+) s\. Speed: (\d+) objects/min\. \((\d+) objects\)", r.stdout)
         t_assign, opm, n_obj = float(m.group(1)), int(m.group(2)), int(m.group(3))
         ing = re.search(r"device ingest: (\d+) batches of <= (\d+) KB on (\d+) slot\(s\), (\d+) through the host path.*?input ([0-9.e+]+) MB, over the link ([0-9.e+]+) MB", r.stderr)
-        load = {a.strip(): float(b) for a, b in re.findall(r"\[load\] ([^:]+): ([0-9.]+) s", r.stderr)}
+        load = {a.strip(): float(b) for a, b in re.findall(r"\[load\] ([^:\n]+): ([0-9.]+) s", r.stderr)}
         # every CSV line against the kernel's rows of the same reads
         import pandas as pd
         names = np.array(["NA"] + [f"TARGET_{t:05d}" for t in range(T)])

@@ -13,6 +13,7 @@
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
+#include <immintrin.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -600,6 +601,254 @@ class SegmentFeeder : public Classifier::Feeder {
   size_t pos_ = 0;
 };
 
+// newline count of a buffer; the AVX2 variant is picked at run time
+static size_t count_newlines_plain(const uint8_t* p, size_t n) {
+  size_t c = 0;
+  for (size_t i = 0; i < n; ++i) c += p[i] == '\n';
+  return c;
+}
+__attribute__((target("avx2"))) static size_t count_newlines_avx2(const uint8_t* p, size_t n) {
+  const __m256i nl = _mm256_set1_epi8('\n');
+  size_t c = 0, i = 0;
+  for (; i + 128 <= n; i += 128) {
+    const unsigned m0 = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i)), nl));
+    const unsigned m1 = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i + 32)), nl));
+    const unsigned m2 = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i + 64)), nl));
+    const unsigned m3 = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i + 96)), nl));
+    c += (size_t)__builtin_popcountll(((unsigned long long)m1 << 32) | m0) + (size_t)__builtin_popcountll(((unsigned long long)m3 << 32) | m2);
+  }
+  for (; i < n; ++i) c += p[i] == '\n';
+  return c;
+}
+static size_t count_newlines(const uint8_t* p, size_t n) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  return avx2 ? count_newlines_avx2(p, n) : count_newlines_plain(p, n);
+}
+
+// Two plain FASTQ files of a paired-end run, merged by the loaders in parallel.  The reference merges the pair line by
+// line into a temporary FASTA file (file.cc:205-268: ">id\nseq1Nseq2\n") and classifies that file.  Here a first pass
+// counts the line ends of both files in 1-MB pieces on all threads, which tells where record r starts in either file;
+// each loader then writes the merged text of its batch's records straight into its slot.  Whatever the line arithmetic
+// does not cover (line counts that differ or are no multiple of four, a header line without '@', ids that differ)
+// makes the feeder give up: the caller then runs the serial reader, which does what the reference does with such
+// files, messages included.
+class PairedFileFeeder : public Classifier::Feeder {
+  static constexpr size_t CH = (size_t)1 << 20;
+  struct File {
+    int fd = -1; uint64_t size = 0, lines = 0;
+    std::vector<uint64_t> cum;          // cum[c] = line ends before byte c * CH
+  };
+  // lines of a byte range of a file, read in pieces
+  struct Lines {
+    Lines(int fd, uint64_t off, size_t len, std::vector<uint8_t>& buf) : fd_(fd), off_(off), left_(len), buf_(buf) {
+      if (buf_.size() < 2 * CH) buf_.resize(2 * CH);
+    }
+    bool next(const uint8_t*& p, size_t& n) {     // the next line without its '\n'; false at the end of the range
+      for (;;) {
+        const uint8_t* nl = have_ > pos_ ? (const uint8_t*)memchr(buf_.data() + pos_, '\n', have_ - pos_) : nullptr;
+        if (nl) { p = buf_.data() + pos_; n = (size_t)(nl - p); pos_ += n + 1; return true; }
+        if (left_ == 0) {
+          if (have_ == pos_) return false;
+          p = buf_.data() + pos_; n = have_ - pos_; pos_ = have_;   // last line of a file that does not end with '\n'
+          return true;
+        }
+        // keep the unfinished line, read more
+        if (pos_) { memmove(buf_.data(), buf_.data() + pos_, have_ - pos_); have_ -= pos_; pos_ = 0; }
+        if (buf_.size() - have_ < CH) buf_.resize(buf_.size() * 2);
+        const size_t take = std::min(left_, buf_.size() - have_);
+        size_t got = 0;
+        while (got < take) {
+          const ssize_t r = pread(fd_, buf_.data() + have_ + got, take - got, (off_t)(off_ + got));
+          if (r <= 0) die("Failed to read the objects file.");
+          got += (size_t)r;
+        }
+        off_ += take; left_ -= take; have_ += take;
+      }
+    }
+    int fd_; uint64_t off_; size_t left_; std::vector<uint8_t>& buf_; size_t pos_ = 0, have_ = 0;
+  };
+  struct SlotSink {
+    uint8_t* d; size_t cap, w = 0;
+    bool room(size_t n) const { return w + n <= cap; }
+    void put(const void* p, size_t n) { memcpy(d + w, p, n); w += n; }
+    void put(char c) { d[w++] = (uint8_t)c; }
+  };
+  struct StringSink {
+    std::string& s;
+    bool room(size_t) const { return true; }
+    void put(const void* p, size_t n) { s.append((const char*)p, n); }
+    void put(char c) { s.push_back(c); }
+  };
+
+ public:
+  PairedFileFeeder(const std::string& f1, const std::string& f2, unsigned threads) : threads_(std::max(1u, threads)) {
+    const std::string* names[2] = {&f1, &f2};
+    for (int i = 0; i < 2; ++i) {
+      f_[i].fd = open(names[i]->c_str(), O_RDONLY);
+      struct stat st;
+      if (f_[i].fd == -1 || fstat(f_[i].fd, &st) != 0 || st.st_size == 0) return;
+      f_[i].size = (uint64_t)st.st_size;
+      uint8_t c = 0;
+      if (pread(f_[i].fd, &c, 1, 0) != 1 || c != '@') return;
+    }
+    ok_ = true;
+  }
+  ~PairedFileFeeder() override { for (File& f : f_) if (f.fd != -1) close(f.fd); }
+  bool ok() const { return ok_; }
+  uint64_t merged_estimate() const { return (f_[0].size + f_[1].size) / 2; }
+  bool fastq() const override { return false; }          // what the slots get is the merged FASTA text
+  bool gave_up() const override { return gave_up_.load(); }
+  uint64_t remaining() const override { return (f_[0].size - pos_[0] + f_[1].size - pos_[1]) / 2; }
+
+  bool assign(size_t want, size_t cap, Classifier::Range& r) override {
+    if (!counted_) {
+      count_lines();
+      counted_ = true;
+      if (f_[0].lines != f_[1].lines || f_[0].lines % 4 != 0) { gave_up_ = true; return false; }
+      records_ = f_[0].lines / 4;
+    }
+    if (gave_up_ || next_ >= records_) return false;
+    // records up to the one that starts behind pos + want in the first file
+    uint64_t r1 = records_;
+    if (f_[0].size - pos_[0] > want + want / 8) {
+      const size_t c = (size_t)((pos_[0] + want) / CH);
+      r1 = std::min<uint64_t>(records_, std::max<uint64_t>(f_[0].cum[c] / 4 + 1, next_ + 1));
+    }
+    uint64_t e0, e1;
+    for (int tries = 0;; ++tries) {
+      e0 = line_start(f_[0], 4 * r1); e1 = line_start(f_[1], 4 * r1);
+      // merged text: one header and both sequences, at most half of what the two files hold for the records
+      const uint64_t est = ((e0 - pos_[0]) + (e1 - pos_[1])) / 2;
+      if (est <= cap - cap / 16 || r1 == next_ + 1 || tries == 8) break;
+      r1 = next_ + std::max<uint64_t>(1, (uint64_t)((double)(r1 - next_) * (double)(cap - cap / 8) / (double)est));
+    }
+    r.off = pos_[0]; r.len = (size_t)(e0 - pos_[0]); r.off2 = pos_[1]; r.len2 = (size_t)(e1 - pos_[1]); r.mem = nullptr; r.keep.reset();
+    pos_[0] = e0; pos_[1] = e1; next_ = r1;
+    return true;
+  }
+  void read(const Classifier::Range&, size_t, uint8_t*, size_t) override { die("paired-end ranges are read through fill()"); }
+  size_t fill(const Classifier::Range& r, uint8_t* dst, size_t cap) override {
+    SlotSink s{dst, cap};
+    return merge(r, s) ? s.w : (size_t)-1;
+  }
+  void text(const Classifier::Range& r, std::string& out) override {
+    out.clear();
+    out.reserve((r.len + r.len2) / 2 + 64);
+    StringSink s{out};
+    merge(r, s);
+  }
+
+ private:
+  static bool sep(uint8_t c) { return c == ' ' || c == '/' || c == '\t' || c == '@'; }    // file.cc:224
+  static void id_of(const uint8_t* p, size_t n, const uint8_t*& id, size_t& len) {
+    size_t a = 0;
+    while (a < n && sep(p[a])) ++a;
+    size_t b = a;
+    while (b < n && !sep(p[b])) ++b;
+    id = p + a; len = b - a;
+  }
+  [[noreturn]] void give_up() { gave_up_ = true; throw std::runtime_error("paired-end input needs the serial reader"); }
+
+  template <typename Sink> bool merge(const Classifier::Range& r, Sink& s) {
+    static thread_local std::vector<uint8_t> b0, b1;
+    Lines A(f_[0].fd, r.off, r.len, b0), B(f_[1].fd, r.off2, r.len2, b1);
+    const uint8_t *p, *q; size_t n, m;
+    for (;;) {
+      const bool ha = A.next(p, n), hb = B.next(q, m);
+      if (!ha && !hb) return true;
+      if (!ha || !hb || n == 0 || m == 0 || p[0] != '@' || q[0] != '@') give_up();
+      const uint8_t *ia, *ib; size_t la, lb;
+      id_of(p, n, ia, la); id_of(q, m, ib, lb);
+      if (la == 0 || la != lb || memcmp(ia, ib, la) != 0) give_up();
+      if (!s.room(la + 2)) return false;
+      s.put('>'); s.put(ia, la); s.put('\n');
+      if (!A.next(p, n)) give_up();
+      if (!s.room(n + 1)) return false;
+      s.put(p, n); s.put('N');
+      if (!B.next(q, m)) give_up();
+      if (!s.room(m + 1)) return false;
+      s.put(q, m); s.put('\n');
+      if (!A.next(p, n) || !A.next(p, n) || !B.next(q, m) || !B.next(q, m)) give_up();
+    }
+  }
+
+  void count_lines() {
+    struct timeval ta, tb;
+    gettimeofday(&ta, nullptr);
+    size_t nch[2];
+    for (int i = 0; i < 2; ++i) { nch[i] = (size_t)((f_[i].size + CH - 1) / CH); f_[i].cum.assign(nch[i] + 1, 0); }
+    std::atomic<size_t> next{0};
+    const size_t total = nch[0] + nch[1];
+    auto work = [&] {
+      const size_t SUB = (size_t)256 << 10;      // read and count in pieces that stay in the core's cache
+      std::vector<uint8_t> buf(SUB);
+      for (;;) {
+        const size_t j = next.fetch_add(1);
+        if (j >= total) return;
+        File& f = j < nch[0] ? f_[0] : f_[1];
+        const size_t c = j < nch[0] ? j : j - nch[0];
+        const uint64_t o = (uint64_t)c * CH;
+        const size_t n = (size_t)std::min<uint64_t>(CH, f.size - o);
+        size_t got = 0, lines = 0;
+        while (got < n) {
+          const ssize_t r = pread(f.fd, buf.data(), std::min(SUB, n - got), (off_t)(o + got));
+          if (r <= 0) die("Failed to read the objects file.");
+          lines += count_newlines(buf.data(), (size_t)r);
+          got += (size_t)r;
+        }
+        f.cum[c + 1] = lines;
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < threads_ && t < total; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    for (int i = 0; i < 2; ++i) {
+      File& f = f_[i];
+      for (size_t c = 0; c < nch[i]; ++c) f.cum[c + 1] += f.cum[c];
+      uint8_t last = 0;
+      if (pread(f.fd, &last, 1, (off_t)(f.size - 1)) != 1) die("Failed to read the objects file.");
+      f.lines = f.cum[nch[i]] + (last != '\n' ? 1 : 0);
+    }
+    gettimeofday(&tb, nullptr);
+    if (getenv("MIC_CLI_TIMING"))
+      std::cerr << "[timing] paired-end files: " << f_[0].lines << " + " << f_[1].lines << " lines counted in "
+                << ((tb.tv_sec - ta.tv_sec) * 1e3 + (tb.tv_usec - ta.tv_usec) / 1e3) << " ms on " << threads_ << " threads" << std::endl;
+  }
+  // offset of the first byte of line L (0 <= L <= lines; line `lines` starts at the end of the file)
+  uint64_t line_start(File& f, uint64_t L) {
+    if (L == 0) return 0;
+    if (L >= f.lines) return f.size;
+    const size_t i = (size_t)(std::lower_bound(f.cum.begin(), f.cum.end(), L) - f.cum.begin());   // cum[i-1] < L <= cum[i]
+    const size_t c = i - 1;
+    const uint64_t o = (uint64_t)c * CH;
+    const size_t n = (size_t)std::min<uint64_t>(CH, f.size - o);
+    scan_.resize(CH);
+    size_t got = 0;
+    while (got < n) {
+      const ssize_t r = pread(f.fd, scan_.data() + got, n - got, (off_t)(o + got));
+      if (r <= 0) die("Failed to read the objects file.");
+      got += (size_t)r;
+    }
+    uint64_t k = L - f.cum[c];
+    const uint8_t* p = scan_.data();
+    const uint8_t* end = p + n;
+    while (k) {
+      const uint8_t* nl = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));
+      if (!nl) die("Failed to read the objects file.");      // the file changed under us
+      p = nl + 1; --k;
+    }
+    return o + (uint64_t)(p - scan_.data());
+  }
+
+  File f_[2];
+  unsigned threads_;
+  bool ok_ = false, counted_ = false;
+  std::atomic<bool> gave_up_{false};
+  uint64_t pos_[2] = {0, 0}, records_ = 0, next_ = 0;
+  std::vector<uint8_t> scan_;
+};
+
 }  // namespace
 
 std::string merge_paired(const std::string& file1, const std::string& file2) {
@@ -663,6 +912,12 @@ void Classifier::run_paired(const std::string& f1, const std::string& f2, const 
     if (list_mode) std::cout << "> Processing file: '" << merged_name << "' in " << opt_.batches << " batches." << std::endl;
     else std::cout << "Processing file: '" << merged_name << "' in " << opt_.batches << " batches using " << opt_.threads
                    << " CPU thread(s)." << std::endl;
+    if (device_ingest() && !is_gzip(a) && !is_gzip(b) && !getenv("MIC_SERIAL_PAIRS")) {
+      // two plain FASTQ files: the loaders merge the pair in parallel; files that need the reference's line-by-line
+      // treatment come back here
+      PairedFileFeeder feed(a, b, (unsigned)opt_.threads);
+      if (feed.ok() && run_stream(feed, res, true, (size_t)feed.merged_estimate())) return;
+    }
     PairedSource src(a, b, segment_bytes_);
     if (!src.ok()) { std::cerr << "Failed to open " << merged_name << std::endl; return; }
     if (device_ingest()) { SegmentFeeder feed(src); run_stream(feed, res, true, ~(size_t)0 >> 1); }
@@ -827,13 +1082,13 @@ static size_t strip_fastq(const uint8_t* src, size_t n, uint8_t* dst, size_t dst
   return w;
 }
 
-void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool paired, size_t total_bytes) {
+bool Classifier::run_stream(Feeder& feed, const std::string& results_base, bool paired, size_t total_bytes) {
   const std::string csv = results_base + ".csv";  // CuCLARK_hh.hh:539-540
   // a fresh file, not a truncated one: ext4 writes a truncated-and-rewritten file's blocks out when it is closed
   // (auto_da_alloc), 60 ms for the CSV of 16 M reads
   unlink(csv.c_str());
   const int out_fd = open(csv.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0644);
-  if (out_fd == -1) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return; }
+  if (out_fd == -1) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return true; }
   struct timeval t0, t1;
   gettimeofday(&t0, nullptr);
   ensure_ingest(total_bytes);          // inside the timed region, like the reference's CuClarkDB::malloc (CuCLARK_hh.hh:1600-1606)
@@ -949,15 +1204,13 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
           // a range that ends inside a record (file cut short) or does not fit goes through the host path as it is
           if (!fits || phase != 0) it.host = true;
           it.n = w;
-        } else if (it.r.len <= cap) {
-          feed.read(it.r, 0, dst, it.r.len);
-          it.n = it.r.len;
         } else {
-          it.host = true;
+          const size_t got = feed.fill(it.r, dst, cap);
+          if (got == (size_t)-1) it.host = true; else it.n = got;
         }
         if (timing) {
           const uint64_t tn = now_us();
-          us_load += tn - ta; bytes_in += it.r.len; if (!it.host) bytes_h2d += it.n;
+          us_load += tn - ta; bytes_in += it.r.len + it.r.len2; if (!it.host) bytes_h2d += it.n;
           uint64_t z = 0; ts_first_loaded.compare_exchange_strong(z, tn); ts_last_loaded = tn;
         }
       } catch (const std::exception& ex) { fail(ex.what()); it.host = true; it.n = 0; }
@@ -989,8 +1242,8 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
           else it.host = true;
         }
         if (!failed && it.host) {   // the host indexer / packer / CSV writer on the ORIGINAL bytes of the range (rare: one at a time)
-          std::string bytes(it.r.len, '\0');
-          feed.read(it.r, 0, (uint8_t*)&bytes[0], it.r.len);
+          std::string bytes;
+          feed.text(it.r, bytes);
           it.own = std::make_shared<std::string>();
           std::lock_guard<std::mutex> lk(host_mu);
           ++n_fallback;
@@ -1055,6 +1308,7 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
   release_batches();
   const uint64_t tj3 = now_us();
   if (timing) std::cerr << "[timing] teardown: join " << (tj1 - tj0) / 1e3 << " ms, close " << (tj2 - tj1) / 1e3 << " ms, batch buffers " << (tj3 - tj2) / 1e3 << " ms" << std::endl;
+  if (feed.gave_up()) { unlink(csv.c_str()); return false; }
   if (!err.empty()) die(err);
   gettimeofday(&t1, nullptr);
   const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
@@ -1068,6 +1322,7 @@ void Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
   std::cout << " - Assignment time: " << diff << " s. Speed: ";  // CuCLARK_hh.hh:1938-1944
   std::cout << (size_t)(((double)n_objects_) / (diff) * 60.0) << " objects/min. (" << n_objects_ << " objects)." << std::endl;
   std::cout << " - Results stored in " << csv << std::endl;
+  return true;
 }
 
 size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, FILE* fout) {

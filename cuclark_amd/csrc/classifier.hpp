@@ -54,7 +54,10 @@ class Classifier {
   // Device-ingest streaming (the default for the non-extended CSV): batches of whole records go to the GPU as the bytes
   // of the file and come back as the bytes of the CSV (mic_ingest_*); host threads only move bytes.  A batch the device
   // path hands back (MIC_INGEST_FALLBACK) or that does not fit a slot goes through process_segment instead.
-  struct Range { uint64_t off = 0; size_t len = 0; const uint8_t* mem = nullptr; std::shared_ptr<Segment> keep; };
+  struct Range {
+    uint64_t off = 0; size_t len = 0; const uint8_t* mem = nullptr; std::shared_ptr<Segment> keep;
+    uint64_t off2 = 0; size_t len2 = 0;      // paired-end files: the same records in the second file
+  };
   class Feeder {            // assign() is called under a lock and hands out consecutive ranges of whole records
    public:
     virtual ~Feeder() {}
@@ -62,8 +65,13 @@ class Classifier {
     virtual void read(const Range& r, size_t off, uint8_t* dst, size_t len) = 0;   // bytes [off, off + len) of the range; any thread
     virtual bool fastq() const = 0;                          // the input's records are four-line FASTQ records
     virtual uint64_t remaining() const { return ~(uint64_t)0 >> 1; }   // bytes not yet handed out, if known
+    // the text of the range as the classifier sees it, into a slot (returns its size, (size_t)-1 when it does not fit) or
+    // into a string; for most feeders that is the bytes of the range, for a pair of files it is the merged text
+    virtual size_t fill(const Range& r, uint8_t* dst, size_t cap) { if (r.len > cap) return (size_t)-1; read(r, 0, dst, r.len); return r.len; }
+    virtual void text(const Range& r, std::string& out) { out.resize(r.len); if (r.len) read(r, 0, (uint8_t*)&out[0], r.len); }
+    virtual bool gave_up() const { return false; }           // the input is not what the feeder can cut: run the serial reader instead
   };
-  void run_stream(Feeder& f, const std::string& results_base, bool paired, size_t total_bytes);
+  bool run_stream(Feeder& f, const std::string& results_base, bool paired, size_t total_bytes);   // false: feeder gave up, nothing written
 
   std::string db_name() const;  // getdbName, CuCLARK_hh.hh:580-591
   const std::vector<std::string>& target_names() const { return names_; }

@@ -360,3 +360,80 @@ def test_device_ingest_equals_host_ingest_over_many_batches(tmp_path):
             if name == "d.fa":
                 assert re.search(r", [1-9]\d* through the host path", r.stderr), r.stderr
             assert open(out + ".csv", "rb").read() == open(ref + ".csv", "rb").read(), (name, kb)
+
+
+def _pair_files(rng, genomes, n, crlf=False):
+    """two FASTQ files of n pairs: ids with /1 /2 suffixes, descriptions, reads shorter than k, N and lower case"""
+    import numpy as np
+    a, b = [], []
+    eol = b"\r\n" if crlf else b"\n"
+    for i in range(n):
+        recs = []
+        for _ in range(2):
+            g = genomes[int(rng.integers(len(genomes)))]
+            L = int(rng.choice([0, 5, 26, 27, 31, 40, 64, 100, 101, 150, 151, 250]))
+            p = int(rng.integers(0, len(g) - L))
+            s = bytearray(g[p:p + L]) if rng.random() < 0.8 else bytearray(rng.choice(list(b"ACGT"), L).astype(np.uint8).tobytes())
+            if len(s) and rng.random() < 0.3:
+                s[int(rng.integers(len(s)))] = ord("N")
+            if rng.random() < 0.2:
+                s = bytearray(bytes(s).lower())
+            recs.append(bytes(s))
+        style = int(rng.integers(5))
+        ids = [(b"p%d/1" % i, b"p%d/2" % i), (b"pair_%d 1:N:0" % i, b"pair_%d 2:N:0" % i), (b"q%d\tfirst" % i, b"q%d\tsecond" % i),
+               (b"y" * 44 + b"%d/1" % i, b"y" * 44 + b"%d/2" % i), (b"@z%d" % i, b"z%d" % i)][style]
+        plus = b"+" + (ids[0] if rng.random() < 0.2 else b"")
+        a.append(b"@" + ids[0] + eol + recs[0] + eol + plus + eol + b"@" * len(recs[0]) + eol)    # quality lines full of '@'
+        b.append(b"@" + ids[1] + eol + recs[1] + eol + b"+" + eol + b"+" * len(recs[1]) + eol)
+    return b"".join(a), b"".join(b)
+
+
+@pytest.mark.gpu
+def test_paired_files_merged_by_the_loaders_equal_the_serial_reader(tmp_path):
+    """-P with two plain FASTQ files: the loaders cut both files at the same record numbers (line counts) and merge their
+    batches in parallel; MIC_SERIAL_PAIRS=1 keeps the line-by-line reader of file.cc:205-268.  Same CSV over tiny and
+    large batches, CRLF files and a last line without its line end; files the line arithmetic does not cover (a blank line
+    in front of a record, unequal record counts, ids that differ) end exactly as the serial reader ends them."""
+    import numpy as np
+    import test_ingest as ti
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "light_k27_u32", light=True)
+    t = _targets_file(tmp)
+    rng = np.random.default_rng(23)
+    genomes = ti._genomes()
+    cases = {"plain": _pair_files(rng, genomes, 5000), "crlf": _pair_files(rng, genomes, 800, crlf=True)}
+    a, b = _pair_files(rng, genomes, 700)
+    cases["no_last_eol"] = (a[:-1], b[:-1])
+    a, b = _pair_files(rng, genomes, 900)
+    recs = a.split(b"\n")
+    cases["blank_line"] = (b"\n".join(recs[:400] + [b""] + recs[400:]), b"\n".join(b.split(b"\n")[:400] + [b""] + b.split(b"\n")[400:]))
+    a, b = _pair_files(rng, genomes, 600)
+    cases["unequal"] = (a, b"\n".join(b.split(b"\n")[:4 * 450]) + b"\n")
+    for name, (f1, f2) in cases.items():
+        p1, p2 = os.path.join(tmp, name + "_1.fq"), os.path.join(tmp, name + "_2.fq")
+        open(p1, "wb").write(f1)
+        open(p2, "wb").write(f2)
+        ref = os.path.join(tmp, "serial_" + name)
+        r0 = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", ref, "-n", "3"], env=dict(os.environ, MIC_SERIAL_PAIRS="1"))
+        assert r0.returncode == 0, r0.stderr
+        n_obj = re.search(r"\((\d+) objects\)", r0.stdout).group(1)
+        for kb, n in (("16", "4"), ("200", "6"), ("0", "2")):
+            out = os.path.join(tmp, f"par{kb}_{name}")
+            env = dict(os.environ, MIC_CLI_TIMING="1")
+            if kb != "0":
+                env["MIC_INGEST_KB"] = kb
+            r = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", out, "-n", n], env=env)
+            assert r.returncode == 0, r.stderr
+            assert f"({n_obj} objects)" in r.stdout and r.stdout.count("Assignment time") == 1
+            assert open(out + ".csv", "rb").read() == open(ref + ".csv", "rb").read(), (name, kb)
+            if name in ("plain", "crlf", "no_last_eol") and kb == "16":
+                assert int(re.search(r"device ingest: (\d+) batches", r.stderr).group(1)) > 8, r.stderr
+    # ids that differ: both readers stop with the reference's message
+    a, b = _pair_files(rng, genomes, 300)
+    p1, p2 = os.path.join(tmp, "bad_1.fq"), os.path.join(tmp, "bad_2.fq")
+    open(p1, "wb").write(a)
+    open(p2, "wb").write(b.replace(b"@p7/2", b"@p8/2").replace(b"@pair_7 ", b"@pair_8 ").replace(b"@q7\t", b"@q8\t").replace(b"@z7\n", b"@z8\n"))
+    if open(p2, "rb").read() != b:
+        for env in (dict(os.environ, MIC_SERIAL_PAIRS="1"), dict(os.environ, MIC_INGEST_KB="16")):
+            r = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", os.path.join(tmp, "bad"), "-n", "3"], env=env)
+            assert r.returncode != 0 and "read id does not match between files" in (r.stderr + r.stdout)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--kmers", type=int, default=50_000_000)
     ap.add_argument("--targets", type=int, default=200)
+    ap.add_argument("--paired", action="store_true", help="also write reads_1.fq / reads_2.fq (the two mates of every pair)")
     a = ap.parse_args()
     from cuclark_amd import _lib
     L = _lib.load()
@@ -73,6 +74,13 @@ def main():
             for i in range(s, min(a.reads, s + CH)):
                 parts.append(b"@r%d\n" % i + seq[i].tobytes() + b"\n+\n" + qual.tobytes() + b"\n")
             f.write(b"".join(parts))
+    if a.paired:
+        rec = int(L.mic_synth_text_record_bytes(read_len, 0))
+        d_text = torch.empty(a.reads * rec, dtype=torch.uint8, device=dev)
+        for mate in (0, 1):
+            assert L.mic_synth_reads_text_device(C.byref(spec), 5, a.reads, read_len, 0.2, 0.01, 0.001, 0, mate, d_text.data_ptr(), d_text.numel(), None) == 0
+            torch.cuda.synchronize()
+            d_text.cpu().numpy().tofile(os.path.join(a.out, f"reads_{mate + 1}.fq"))
     print(f"wrote {dbdir}/{name}.* ({n_el} k-mers), {a.reads} reads, k={k}")
 
 
