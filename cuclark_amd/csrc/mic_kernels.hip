@@ -345,6 +345,18 @@ __global__ void __launch_bounds__(256) query_kernel(const MicQueryArgs a) {
 // =====================================================================================================================
 #define MIC_RMAX 32        // slots staged per round
 #define MIC_MSTRIDE 8      // uint4 per staged slot in LDS (linear: LDS-DMA writes lane L at base + 16*L)
+// Staged slots lie 128 bytes apart inside the 8 slots of one LDS-DMA instruction - all on two banks for a given word.  Each
+// group of 8 therefore starts MIC_R_SKEW uint4 further: reads of the same word of different slots spread over four times as
+// many banks (per-run kernel: 16-way -> 4-way conflicts, +4.5 %).
+#ifndef MIC_R_SKEW
+#define MIC_R_SKEW 2
+#endif
+__device__ __forceinline__ uint32_t staged_at(uint32_t i) { return i * MIC_MSTRIDE + (i >> 3) * MIC_R_SKEW; }   // uint4 offset of staged slot i
+// the minimizer kernel reads its staged keys as 64-bit words and loses 5 % with the skew (11.5 against 11.0 ms): none there
+#ifndef MIC_M_SKEW
+#define MIC_M_SKEW 0
+#endif
+__device__ __forceinline__ uint32_t staged_at_m(uint32_t i) { return i * MIC_MSTRIDE + (i >> 3) * MIC_M_SKEW; }
 
 __device__ __forceinline__ void sliding_min3(uint32_t& a0, uint32_t& a1, uint32_t& a2, int w, int lane) {
   // a_h(l) holds the order key of position 64h+l; afterwards a_h(l) = min over positions [64h+l, 64h+l+w)
@@ -434,7 +446,7 @@ __device__ unsigned long long g_phase[8];
 // instantiation for cuCLARK's k = 31 and cuCLARK-l's k = 27 with m = 20; shift counts, masks and the window loop fold.
 template <int KK, int MM>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m(const MicQueryArgs a PERTURB_PARAMS) {
-  __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE];
+  __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE + (MIC_RMAX / 8 - 1) * MIC_M_SKEW];
   __shared__ uint32_t s_run[MIC_M_WPB][MIC_RMAX];
   __shared__ uint32_t s_ahead[MIC_M_WPB][2][64];
   const int lane = threadIdx.x & 63;
@@ -599,7 +611,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
               if (8u * i >= nrun) break;                 // wave-uniform: no address arithmetic for unused groups
               if (8u * i + (lane >> 3) < nrun)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
-                                                 (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(stage + (64 + MIC_M_SKEW) * i), 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -608,8 +620,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
             // after the other.  Lanes without a search read slot 0 of the area and discard.
             {
               const bool v0 = s0_ != 0xFFFFFFFFu && rid0 - rbase < MIC_RMAX, v1 = s1_ != 0xFFFFFFFFu && rid1 - rbase < MIC_RMAX;
-              const uint4* sp0 = stage + (v0 ? rid0 - rbase : 0) * MIC_MSTRIDE;
-              const uint4* sp1 = stage + (v1 ? rid1 - rbase : 0) * MIC_MSTRIDE;
+              const uint4* sp0 = stage + (v0 ? staged_at_m(rid0 - rbase) : 0);
+              const uint4* sp1 = stage + (v1 ? staged_at_m(rid1 - rbase) : 0);
               const unsigned long long* k0 = (const unsigned long long*)sp0;
               const unsigned long long* k1 = (const unsigned long long*)sp1;
               const uint64_t c0 = k0_, c1 = k1_;
@@ -687,12 +699,12 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
                   if (8u * i >= nrun) break;
                   if (8u * i + (lane >> 3) < nrun)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
-                                                     (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(stage + (64 + MIC_M_SKEW) * i), 16, 0, 0);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 const bool v2 = s2 != 0xFFFFFFFFu && rid2 - rbase < MIC_RMAX;
-                const uint4* sp = stage + (v2 ? rid2 - rbase : 0) * MIC_MSTRIDE;
+                const uint4* sp = stage + (v2 ? staged_at_m(rid2 - rbase) : 0);
                 const unsigned long long* kk = (const unsigned long long*)sp;
                 const uint32_t mz = sp[7].z;
                 uint32_t pos = 0; bool eq;
@@ -751,7 +763,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
 // s_candidates_fwd): a k-mer is looked up as it stands in the read - no reverse complement, no canonical m-mer, no strand.
 template <int KK, int MM, bool SHARDED, bool FWD>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s(const MicQueryArgs a) {
-  __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE];
+  __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE + (MIC_RMAX / 8 - 1) * MIC_R_SKEW];
   __shared__ uint32_t s_run[MIC_M_WPB][MIC_RMAX];
   __shared__ uint32_t s_ahead[MIC_M_WPB][2][64];
   const int lane = threadIdx.x & 63;
@@ -939,7 +951,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
               if (8u * i >= nrun) break;                 // wave-uniform: no address arithmetic for unused groups
               if (8u * i + (lane >> 3) < nrun)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
-                                                 (__attribute__((address_space(3))) void*)(stage + 64 * i), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(stage + (64 + MIC_R_SKEW) * i), 16, 0, 0);
             }
             PH(1)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -949,8 +961,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
             // (three reads), then the entry: key, super-k-mer, mask | label.  Lanes without a search read slot 0 and discard.
             {
               const bool v0 = s0_ != 0xFFFFFFFFu && rid0 - rbase < MIC_RMAX, v1 = s1_ != 0xFFFFFFFFu && rid1 - rbase < MIC_RMAX;
-              const uint32_t* q0 = (const uint32_t*)(stage + (v0 ? rid0 - rbase : 0) * MIC_MSTRIDE);
-              const uint32_t* q1 = (const uint32_t*)(stage + (v1 ? rid1 - rbase : 0) * MIC_MSTRIDE);
+              const uint32_t* q0 = (const uint32_t*)(stage + (v0 ? staged_at(rid0 - rbase) : 0));
+              const uint32_t* q1 = (const uint32_t*)(stage + (v1 ? staged_at(rid1 - rbase) : 0));
               const uint32_t t0 = tk32[0], t1 = tk32[1];
 #if MIC_S_LINEAR
               // all six sort keys in one LDS round trip; rank = number of keys below t
@@ -1039,6 +1051,256 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
     PH(5)
   }
   PH_END
+}
+
+
+// =====================================================================================================================
+// query_kernel_r - the two-strand super-k-mer table (MIC_LAYOUT_SUPER2) probed per RUN, not per k-mer.  Front half as in
+// query_kernel_s<.., FWD>: window, m-mer order keys, sliding minimum - every k-mer knows the position of its minimizer.
+// Consecutive k-mers with the minimizer at the same read position form a run; they are the k-mers of ONE super-k-mer of
+// the read, and the table stores super-k-mers.  So the back half works on runs (<= 32 per round, one lane each, ~19 per
+// 150-bp read) instead of on 2 x 64 k-mers:
+//   * the run's lane cuts the k+w-1 nucleotides around the minimizer out of the window (4 ds_bpermute + 3 alignbit), in
+//     the entry's own alignment (minimizer at nucleotide w-1); the minimizer value x, the slot and the sort key come out
+//     of that region - one slot hash per run instead of one per k-mer;
+//   * entry against region: XOR, then the number of equal nucleotides to the left (count trailing zeros) and to the right
+//     (count leading zeros) of the minimizer.  The k-mer with its minimizer at position j lies inside the equal stretch
+//     iff w-1-right <= j <= left: the run's k-mers are a range of j, the entry's presence mask has a bit per j, and the
+//     hits of the run against the entry are one popcount;
+//   * entries of one minimizer value are adjacent in the slot (sorted by key); the lane walks them while k-mers of its run
+//     are unaccounted for, then the continuation slot (rare, wave-uniform loops as before);
+//   * the tally adds (label, count) pairs: per distinct label the counts are summed with one ballot per count bit.
+// Exactness: a database k-mer is stored once per minimizer position (mic_device.h: s_candidates_fwd), so no k-mer is
+// counted twice; nucleotides outside the read part take part in the comparison only beyond the run's own range of j.
+// =====================================================================================================================
+__device__ __forceinline__ uint64_t wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+__device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cbits, RowAcc& acc, uint32_t& n_ent, uint32_t& overflow,
+                                             uint32_t& total, int lane) {
+  uint64_t mm = wballot(lab1 != 0);
+  while (mm) {
+    const uint32_t l1 = __builtin_amdgcn_readlane(lab1, __builtin_ctzll(mm));
+    const bool mine = lab1 == l1;
+    mm &= ~wballot(mine);
+    const uint32_t c = mine ? cnt : 0u;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+      if (b < cbits) sum += (uint32_t)__popcll(wballot((c & (1u << b)) != 0)) << b;
+    total += sum;
+    row_add(acc, n_ent, overflow, l1, sum, lane);
+  }
+}
+
+template <int KK, int MM>
+__global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r(const MicQueryArgs a) {
+  // staged slots: 8 per LDS-DMA instruction, 128 bytes apart (the DMA's own layout: lane L lands at base + 16 L); each
+  // group of 8 starts MIC_R_SKEW uint4 further so that the run lanes' reads of the same word of their slots spread over
+  // four times as many banks.  The list of slots to load sits in the same area: it is consumed before the DMA lands.
+  __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE + (MIC_RMAX / 8 - 1) * MIC_R_SKEW];
+  __shared__ uint16_t s_rec[MIC_M_WPB][132];              // runs of a chunk: minimizer position | first k-mer << 8
+  __shared__ uint32_t s_ahead[MIC_M_WPB][2][64];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint4* stage = s_stage[wv];
+  uint16_t* rec = s_rec[wv];
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * MIC_M_WPB + wv);
+  const uint32_t n_waves = gridDim.x * MIC_M_WPB;
+  const MicTable& t = a.t;
+  const int k = KK ? KK : t.k, m = MM ? MM : t.m, w = k - m + 1, ctx = k - m;
+  const uint4* __restrict__ slots = t.slots;
+  const uint16_t* __restrict__ cont = a.cont;
+  auto below = [](uint64_t mask) { return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
+
+  // read-ahead through LDS: see query_kernel_s
+  uint32_t* ahead0 = s_ahead[wv][0];
+  uint32_t* ahead1 = s_ahead[wv][1];
+  auto ahead_issue = [&](uint32_t* entry, uint32_t pp_w, uint32_t r_ptr) {
+    const uint64_t abase = ((uint64_t)(cont + pp_w)) & ~3ULL;
+    const uint32_t rr = r_ptr < a.n_reads ? r_ptr : a.n_reads - 1;
+    const uint64_t pbase = (uint64_t)(a.reads_ptr + rr) - 48;
+    uint32_t lv = (uint32_t)lane;
+    asm volatile("" : "+v"(lv));
+    const uint32_t li = lv < 14 ? lv : 0u;
+    const uint64_t addr = (li < 12 ? abase : pbase) + 4 * li;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
+                                     (__attribute__((address_space(3))) void*)entry, 4, 0, 0);
+  };
+  auto ahead_take = [&](const uint32_t* entry, uint32_t pp_w, uint32_t& hdr, uint32_t& npp, uint32_t& npe) {
+    const uint32_t raw = entry[lane];
+    npp = __builtin_amdgcn_readlane(raw, 12); npe = __builtin_amdgcn_readlane(raw, 13);
+    const bool odd = (((uint64_t)(cont + pp_w)) >> 1) & 1;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(raw);
+    hdr = odd ? first >> 16 : first & 0xFFFFu;
+  };
+  auto ahead_word = [&](const uint32_t* entry, uint32_t pp_w) {
+    const uint32_t raw = entry[lane];
+    const bool odd = (((uint64_t)(cont + pp_w)) >> 1) & 1;
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw, 0x101, 0xF, 0xF, true);
+    return odd ? ((up << 16) | (up >> 16)) : ((raw & 0xFFFF0000u) | (up & 0xFFFFu));
+  };
+  uint32_t cur_pp, cur_pe, cur_hdr, n_pp, n_pe, ahead_sel;
+  {
+    const uint32_t r0 = wave0 < a.n_reads ? wave0 : a.n_reads - 1;
+    cur_pp = __builtin_amdgcn_readfirstlane(a.reads_ptr[r0]); cur_pe = __builtin_amdgcn_readfirstlane(a.reads_ptr[r0 + 1]);
+    ahead_issue(ahead0, cur_pp, wave0 + n_waves);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    ahead_take(ahead0, cur_pp, cur_hdr, n_pp, n_pe);
+    ahead_issue(ahead1, n_pp, wave0 + 2 * n_waves);
+    ahead_sel = 1;
+  }
+  const int cbits = w > 15 ? 5 : 4;                        // a run has at most w k-mers
+  for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
+    uint32_t pp = cur_pp;
+    const uint32_t pe = cur_pe;
+    RowAcc acc; acc.label1 = 0; acc.count = 0;
+    uint32_t n_ent = 0, overflow = 0, total = 0;
+    bool first_part = true;
+
+    while (pp < pe) {
+      const uint32_t plen = __builtin_amdgcn_readfirstlane(first_part ? cur_hdr : (uint32_t)cont[pp]);
+      const bool ahead_ok = first_part;
+      first_part = false;
+      if (plen == 0) break;
+      const uint32_t first = pp + 1;
+      pp = first + (plen + 7) / 8;
+      if (plen < (uint32_t)k) continue;
+      const uint32_t nk = plen - k + 1;
+      const uint32_t cend = pp;
+      for (uint32_t base = 0; base < nk; base += 128) {
+        const bool use_ahead = ahead_ok && base == 0;
+        const uint32_t wd = window_word_w(cont, first, cend, base, lane, use_ahead,
+                                          use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp) : 0u);
+        // order keys of the m-mers at positions 64h + lane: order (27 bits) | position & 15
+        uint32_t hk0, hk1;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const bool past = nk - base > (uint32_t)(129 - w);     // the last k-mers' windows reach m-mers past position 127
+        uint32_t tail = 0xFFFFFFFFu;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int idx = 4 * h + (lane >> 4);
+          const uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
+          const uint64_t kmer = kmer_from_dwords(d0, d1, d2, ln & 15, k);
+          const uint32_t key = (mmer_order_key_canon(kmer >> (2 * (k - m))) & ~31u) | (uint32_t)(ln & 15);
+          if (h == 0) hk0 = key; else hk1 = key;
+          if (h == 1 && past) {   // m-mer 64 + lane + w - 1 = the last m nucleotides of this k-mer (see query_kernel_s)
+            const uint32_t tk = (mmer_order_key_canon(kmer & ((1ULL << (2 * m)) - 1)) & ~31u) | (uint32_t)((ln + w - 1) & 15);
+            tail = row_prefix_min(ln >= 65 - w ? tk : 0xFFFFFFFFu);
+          }
+        }
+        sliding_min2(hk0, hk1, w, lane);
+        hk1 = tail < hk1 ? tail : hk1;
+        // runs: k-mers next to each other whose minimizer sits at the same position of the chunk
+        const uint32_t n_act = nk - base < 128u ? nk - base : 128u;
+        const uint32_t qa0 = (uint32_t)ln + ((hk0 - (uint32_t)ln) & 15u);
+        const uint32_t qa1 = 64u + (uint32_t)ln + ((hk1 - (uint32_t)ln) & 15u);
+        const uint32_t last0 = __builtin_amdgcn_readlane(qa0, 63);
+        uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)qa0, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 keeps -1
+        uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)last0, (int)qa1, 0x138, 0xF, 0xF, false);
+        const bool f0 = (uint32_t)lane < n_act && qa0 != p0, f1 = 64u + (uint32_t)lane < n_act && qa1 != p1;
+        // (a ballot of a compound predicate costs a select and a compare: the leaders' masks are the ballots of the plain
+        // comparisons cut to the active k-mers in scalar registers)
+        // (the leaders' masks cut to the active k-mers in scalar registers instead of a ballot of the compound predicate:
+        // 4 VALU fewer, 16 SALU more per read, measured 1.5 % slower - the scalar unit is as busy as the vector units)
+        const uint64_t b0 = wballot(f0), b1 = wballot(f1);
+        const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1);
+        __builtin_amdgcn_wave_barrier();
+        if (f0) rec[below(b0)] = (uint16_t)(qa0 | ((uint32_t)lane << 8));
+        if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
+        if (lane == 0) rec[R] = (uint16_t)(n_act << 8);
+        __builtin_amdgcn_wave_barrier();
+
+        for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
+          const uint32_t nrun = R - rbase < MIC_RMAX ? R - rbase : MIC_RMAX;
+          const bool vr = (uint32_t)lane < nrun;
+          const uint32_t ri = vr ? rbase + (uint32_t)lane : 0u;
+          const uint32_t rc0 = rec[ri], rc1 = rec[ri + 1];
+          const int qa = (int)(rc0 & 255u), i0 = (int)(rc0 >> 8), n = (int)(rc1 >> 8) - i0;
+          // the region [qa - ctx, qa + k) of the chunk, left-aligned in three words like the entry's super-k-mer: it starts
+          // off = 1..16 nucleotides into window dword D (off = 16 instead of 0 keeps the alignbit shift below 32)
+          const int s1 = qa - ctx - 1;
+          const int D = s1 >> 4;                                  // -1 (the region starts in front of the chunk) .. 8
+          const uint32_t tsh = 30u - 2u * (uint32_t)(s1 & 15);
+          const uint32_t W0 = bperm((D) & 63, wd), W1 = bperm((D + 1) & 63, wd), W2 = bperm((D + 2) & 63, wd), W3 = bperm((D + 3) & 63, wd);
+          const uint32_t G0 = __builtin_amdgcn_alignbit(W0, W1, tsh), G1 = __builtin_amdgcn_alignbit(W1, W2, tsh), G2 = __builtin_amdgcn_alignbit(W2, W3, tsh);
+          const uint64_t x = ((((uint64_t)G0 << 32) | G1) << (2 * ctx)) >> (64 - 2 * m);
+          const uint32_t key = (uint32_t)x;
+          const int jmax = qa - i0, jmin = jmax - n + 1;         // minimizer position inside the run's first / last k-mer
+          uint32_t cur = vr ? sslot_of_x(x, (uint32_t)t.n_main) : 0xFFFFFFFFu;
+          int remaining = vr ? n : 0;
+          do {
+            uint32_t sidx[MIC_RMAX / 8];
+            // the list of slots to load sits in the stage area itself: it is consumed before the DMA lands.  (Handing the
+            // indices to the DMA lanes by ds_bpermute instead: +8 VALU, +22 SALU per read, slower.)
+            __builtin_amdgcn_wave_barrier();
+            if (lane < MIC_RMAX) ((uint32_t*)stage)[lane] = cur;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = ((const uint32_t*)stage)[8 * i + (lane >> 3)];
+#pragma unroll
+            for (int i = 0; i < MIC_RMAX / 8; ++i) {
+              if (8u * i >= nrun) break;
+              if (sidx[i] != 0xFFFFFFFFu)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
+                                                 (__attribute__((address_space(3))) void*)(stage + (64 + MIC_R_SKEW) * i), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const bool vl = cur != 0xFFFFFFFFu;
+            const uint32_t* q = (const uint32_t*)(stage + (vl ? staged_at((uint32_t)lane) : 0));
+            uint32_t e = q[3] < key ? 4u : 0u;
+            e += q[e + 1] < key ? 2u : 0u;                                  // index <= 5
+            e += q[e < 5 ? e : 5] < key ? 1u : 0u;
+            const uint32_t mz = q[30];
+            bool more = vl && e < 6;
+            e = e < 5 ? e : 5;
+            for (;;) {
+              const uint32_t g = q[e], S0 = q[6 + 3 * e], S1 = q[7 + 3 * e], S2 = q[8 + 3 * e], pl = q[24 + e];
+              const bool same = more && g == key;
+              const uint32_t d0 = G0 ^ S0, d1 = G1 ^ S1, d2 = G2 ^ S2;
+              const uint64_t dtop = ((uint64_t)d0 << 32) | d1;
+              const bool mineq = ((dtop << (2 * ctx)) >> (64 - 2 * m)) == 0;                 // the whole minimizer, not only its low 32 bits
+              const uint32_t dl = (uint32_t)((uint64_t)d0 >> (32 - 2 * ctx));               // left context, nucleotide ctx-1 in the low bits
+              const uint32_t dr = 2 * k >= 32 ? (uint32_t)(((((uint64_t)d1 << 32) | d2) << (2 * k - 32)) >> 32)
+                                              : (uint32_t)((dtop << (2 * k)) >> 32);       // right context, its first nucleotide on top
+              const int left = __builtin_ctz(dl | (1u << (2 * ctx))) >> 1;                   // equal nucleotides next to the minimizer
+              const int right = __builtin_clz(dr | (1u << (31 - 2 * ctx))) >> 1;
+              const int hi = left < jmax ? left : jmax, lo = ctx - right > jmin ? ctx - right : jmin;
+              const uint32_t range = ((2u << (hi & 31)) - 1u) & (~0u << (lo & 31));         // empty when hi < lo
+              const uint32_t hits = (same && mineq) ? (uint32_t)__popc((pl >> 16) & range) : 0u;
+              tally_counts(hits ? (pl & 0xFFFFu) + 1u : 0u, hits, cbits, acc, n_ent, overflow, total, lane);
+              remaining -= (int)hits;
+              more = same && remaining > 0 && e < 5;                        // another entry of the same minimizer?
+              e += more ? 1u : 0u;
+              if (!wballot(more)) break;
+            }
+            // continuation slot (rare): entries are sorted across the chain, so only if this slot's last key is not above ours
+            const bool nx = vl && remaining > 0 && (mz & MIC_S_NEXT);
+            cur = 0xFFFFFFFFu;
+            if (wballot(nx)) { if (nx && q[5] <= key) cur = q[31]; }
+          } while (wballot(cur != 0xFFFFFFFFu));
+        }
+      }
+    }
+    uint32_t t_hdr, t_pp, t_pe;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_pp, t_pe);
+    __builtin_amdgcn_wave_barrier();
+    {
+      uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));
+      const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+      struct { uint32_t* results; uint32_t* rows; uint32_t* flagged; uint32_t row_words, flagged_cap; } fa;
+      fa.results = kc->results; fa.rows = kc->rows; fa.flagged = kc->flagged; fa.row_words = kc->row_words; fa.flagged_cap = kc->flagged_cap;
+      finish_read(acc, n_ent, total, overflow, r, fa, lane);
+    }
+    ahead_issue(ahead_sel ? ahead0 : ahead1, t_pp, r + 3 * n_waves);
+    ahead_sel ^= 1;
+    cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; n_pp = t_pp; n_pe = t_pe;
+  }
 }
 
 
@@ -1321,8 +1583,12 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     const bool sh = a.t.sharded != 0, fw = a.t.fwd != 0;
     // instantiations: k and m as constants for cuCLARK's 31, cuCLARK-l's 27 and k = 32 with m = 20; the table-sharded filter
     // and the two-strand table each in their own (the common kernel carries neither's scalars)
+    // the two-strand table is probed per run (query_kernel_r); MIC_S_PER_KMER=1 keeps the per-k-mer kernel for comparison
+    static const bool per_kmer = getenv("MIC_S_PER_KMER") != nullptr;
+    static const unsigned extra_lds = [] { const char* e = getenv("MIC_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();   // occupancy experiments
 #define LAUNCH_S(KK_, MM_) do { \
-      if (fw) { if (sh) query_kernel_s<KK_, MM_, true, true><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, true><<<g, b, 0, s>>>(a); } \
+      if (fw && !sh && !per_kmer) query_kernel_r<KK_, MM_><<<g, b, extra_lds, s>>>(a); \
+      else if (fw) { if (sh) query_kernel_s<KK_, MM_, true, true><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, true><<<g, b, 0, s>>>(a); } \
       else { if (sh) query_kernel_s<KK_, MM_, true, false><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, false><<<g, b, 0, s>>>(a); } } while (0)
     if (!generic && a.t.k == 31 && a.t.m == 20) LAUNCH_S(31, 20);
     else if (!generic && a.t.k == 27 && a.t.m == 20) LAUNCH_S(27, 20);
