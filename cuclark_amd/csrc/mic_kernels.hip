@@ -761,6 +761,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
 // =====================================================================================================================
 // FWD: the table holds both strands of every k-mer under forward-strand minimizers (MIC_LAYOUT_SUPER2, mic_device.h:
 // s_candidates_fwd): a k-mer is looked up as it stands in the read - no reverse complement, no canonical m-mer, no strand.
+#ifndef MIC_R_HDR_LDS
+#define MIC_R_HDR_LDS 1
+#endif
 template <int KK, int MM, bool SHARDED, bool FWD>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s(const MicQueryArgs a) {
   __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE + (MIC_RMAX / 8 - 1) * MIC_R_SKEW];
@@ -837,7 +840,17 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
     bool first_part = true;
 
     while (pp < pe) {
-      const uint32_t plen = __builtin_amdgcn_readfirstlane(first_part ? cur_hdr : (uint32_t)cont[pp]);
+      // the header of a later part - for nearly every read the 0 that ends it - is among the 24 containers of the read-ahead
+      // entry more often than not: an LDS read instead of a global load the whole wave waits for
+      uint32_t plen;
+      {
+        const uint32_t rel = pp - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);    // u16 offset inside the entry
+        if (first_part) plen = cur_hdr;
+        else if (MIC_R_HDR_LDS && rel < 24u) {
+          const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
+          plen = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu);
+        } else plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
+      }
       const bool ahead_ok = first_part;
       first_part = false;
       if (plen == 0) break;
@@ -1159,7 +1172,17 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     bool first_part = true;
 
     while (pp < pe) {
-      const uint32_t plen = __builtin_amdgcn_readfirstlane(first_part ? cur_hdr : (uint32_t)cont[pp]);
+      // the header of a later part - for nearly every read the 0 that ends it - is among the 24 containers of the read-ahead
+      // entry more often than not: an LDS read instead of a global load the whole wave waits for
+      uint32_t plen;
+      {
+        const uint32_t rel = pp - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);    // u16 offset inside the entry
+        if (first_part) plen = cur_hdr;
+        else if (MIC_R_HDR_LDS && rel < 24u) {
+          const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
+          plen = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu);
+        } else plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
+      }
       const bool ahead_ok = first_part;
       first_part = false;
       if (plen == 0) break;

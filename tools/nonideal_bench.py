@@ -129,7 +129,7 @@ def run_case(name, args, L, rng):
         dev = torch.device("cuda:0")
         names = [f"T{g}" for g in range(n_genomes)]
         layouts = {}
-        for layout_name, layout in (("auto", 0), ("super", 3), ("minimizer", 2), ("direct", 1)):
+        for layout_name, layout in (("auto", 0), ("super2", 4), ("super", 3), ("minimizer", 2), ("direct", 1)):
             with MiClarkDB(k, n_genomes, layout=layout) as e:
                 t0 = time.time()
                 e.read(prefix)
@@ -175,7 +175,7 @@ def run_case(name, args, L, rng):
                     "entries": info["n_entries"], "kmers_per_entry": round(info["n_elems"] / max(info["n_entries"], 1), 2),
                     "fullest_chain_entries": info["max_chain"], "mean_continuation_slots_before_a_kmer": info["reserved"] / 1e6, "reads_through_dense_path": flagged, "load_s": round(t_load, 1),
                     "classified": float((res[:, 0] > 0).mean())}
-                layouts[layout_name]["layout_built"] = {1: "direct", 2: "minimizer", 3: "super"}[info["layout"]]
+                layouts[layout_name]["layout_built"] = {1: "direct", 2: "minimizer", 3: "super", 4: "super2"}[info["layout"]]
                 if layout_name == "auto":
                     ref = res[:, :5].copy()
                 else:
