@@ -373,6 +373,8 @@ __device__ __forceinline__ void sliding_min3(uint32_t& a0, uint32_t& a1, uint32_
 }
 
 // Two-array form: the m-mers past position 127 are not a third array but arrive as `tail` (see the kernel).
+// (Fetching the last two window starts - shifts 4 and 8 for w = 12 - in one LDS round trip instead of a fourth step:
+// measured, no gain.)
 __device__ __forceinline__ void sliding_min2(uint32_t& a0, uint32_t& a1, int w, int lane) {
   auto step = [&](int s) {
     const int src = (lane + s) & 63;
@@ -386,7 +388,6 @@ __device__ __forceinline__ void sliding_min2(uint32_t& a0, uint32_t& a1, int w, 
   if (cover < w) step(w - cover);
 }
 
-// inclusive prefix minimum within each row of 16 lanes (four DPP row_shr steps, no LDS)
 __device__ __forceinline__ uint32_t row_prefix_min(uint32_t t) {
   uint32_t x;
   x = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)t, 0x111, 0xF, 0xF, false); t = x < t ? x : t;
@@ -1105,6 +1106,12 @@ __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cb
   }
 }
 
+#ifndef MIC_R_LINEAR
+#define MIC_R_LINEAR 1      // 0: three-step binary search over the six keys (three dependent LDS reads): 1.2 % slower
+#endif
+#ifndef MIC_R_EAGER_ENTRY
+#define MIC_R_EAGER_ENTRY 1
+#endif
 template <int KK, int MM>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r(const MicQueryArgs a) {
   // staged slots: 8 per LDS-DMA instruction, 128 bytes apart (the DMA's own layout: lane L lands at base + 16 L); each
@@ -1273,14 +1280,24 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             __builtin_amdgcn_wave_barrier();
             const bool vl = cur != 0xFFFFFFFFu;
             const uint32_t* q = (const uint32_t*)(stage + (vl ? staged_at((uint32_t)lane) : 0));
+#if MIC_R_LINEAR
+            // all six sort keys in one LDS round trip (the slot is 16-byte aligned); rank = number of keys below ours
+            const uint4 ka = *(const uint4*)q;
+            const uint2 kb = *(const uint2*)(q + 4);
+            uint32_t e = (ka.x < key) + (ka.y < key) + (ka.z < key) + (ka.w < key) + (kb.x < key) + (kb.y < key);
+#else
             uint32_t e = q[3] < key ? 4u : 0u;
             e += q[e + 1] < key ? 2u : 0u;                                  // index <= 5
             e += q[e < 5 ? e : 5] < key ? 1u : 0u;
+#endif
             const uint32_t mz = q[30];
             bool more = vl && e < 6;
             e = e < 5 ? e : 5;
             for (;;) {
-              const uint32_t g = q[e], S0 = q[6 + 3 * e], S1 = q[7 + 3 * e], S2 = q[8 + 3 * e], pl = q[24 + e];
+              uint32_t g = q[e], S0 = q[6 + 3 * e], S1 = q[7 + 3 * e], S2 = q[8 + 3 * e], pl = q[24 + e];
+#if MIC_R_EAGER_ENTRY
+              asm volatile("" : "+v"(S2));     // read with the others: the compiler would sink it into the branch below, one more LDS round trip
+#endif
               const bool same = more && g == key;
               const uint32_t d0 = G0 ^ S0, d1 = G1 ^ S1, d2 = G2 ^ S2;
               const uint64_t dtop = ((uint64_t)d0 << 32) | d1;
