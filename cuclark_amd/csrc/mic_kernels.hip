@@ -1200,12 +1200,14 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
       const uint32_t cend = pp;
       for (uint32_t base = 0; base < nk; base += 128) {
         const bool use_ahead = ahead_ok && base == 0;
-        const uint32_t wd = window_word_w(cont, first, cend, base, lane, use_ahead,
+        // lane-derived shift counts, positions and lane masks are recomputed per chunk from this opaque copy: kept across
+        // the kernel they cost scalar register pairs the kernel does not have (34 -> 15 spill moves, +4 VALU, -6 SALU per read)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t wd = window_word_w(cont, first, cend, base, ln, use_ahead,
                                           use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp) : 0u);
         // order keys of the m-mers at positions 64h + lane: order (27 bits) | position & 15
         uint32_t hk0, hk1;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
         const bool past = nk - base > (uint32_t)(129 - w);     // the last k-mers' windows reach m-mers past position 127
         uint32_t tail = 0xFFFFFFFFu;
 #pragma unroll
@@ -1220,7 +1222,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             tail = row_prefix_min(ln >= 65 - w ? tk : 0xFFFFFFFFu);
           }
         }
-        sliding_min2(hk0, hk1, w, lane);
+        sliding_min2(hk0, hk1, w, ln);
         hk1 = tail < hk1 ? tail : hk1;
         // runs: k-mers next to each other whose minimizer sits at the same position of the chunk
         const uint32_t n_act = nk - base < 128u ? nk - base : 128u;
@@ -1239,7 +1241,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         __builtin_amdgcn_wave_barrier();
         if (f0) rec[below(b0)] = (uint16_t)(qa0 | ((uint32_t)lane << 8));
         if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
-        if (lane == 0) rec[R] = (uint16_t)(n_act << 8);
+        if (ln == 0) rec[R] = (uint16_t)(n_act << 8);
         __builtin_amdgcn_wave_barrier();
 
         for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
@@ -1265,7 +1267,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             // the list of slots to load sits in the stage area itself: it is consumed before the DMA lands.  (Handing the
             // indices to the DMA lanes by ds_bpermute instead: +8 VALU, +22 SALU per read, slower.)
             __builtin_amdgcn_wave_barrier();
-            if (lane < MIC_RMAX) ((uint32_t*)stage)[lane] = cur;
+            if (ln < MIC_RMAX) ((uint32_t*)stage)[lane] = cur;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = ((const uint32_t*)stage)[8 * i + (lane >> 3)];
