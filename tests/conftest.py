@@ -32,3 +32,13 @@ def lib():
 @pytest.fixture(scope="session")
 def db_dir(tmp_path_factory):
     return str(tmp_path_factory.mktemp("golden_db"))
+
+
+@pytest.fixture(autouse=True)
+def _hang_watchdog():
+    """A test that blocks for more than 6 minutes (a GPU call that never returns) ends the session with the Python stacks on stderr
+    instead of sitting there until the runner's own limit kills it without a word."""
+    import faulthandler
+    faulthandler.dump_traceback_later(400, exit=True)
+    yield
+    faulthandler.cancel_dump_traceback_later()
