@@ -74,6 +74,12 @@ def test_light_cli_matches_golden(tmp_path):
         r = _run([EXE_L, "-T", t, "-D", d, *src, "-R", out2, *flag])
         assert r.returncode == 0, r.stderr
         assert open(out2 + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, exp), "rb").read(), exp
+    # every table layout behind the same command line, the two-strand one (per-run kernel) included
+    for layout in ("super2", "super", "minimizer", "direct"):
+        out3 = os.path.join(tmp, "res_" + layout)
+        r = _run([EXE_L, "-T", t, "-D", d, "-O", os.path.join(gu.GOLDEN, "reads_k27.fq"), "-R", out3, "-n", "3"], env=dict(os.environ, MIC_LAYOUT=layout))
+        assert r.returncode == 0, r.stderr
+        assert open(out3 + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, "expected_k27_fq.csv"), "rb").read(), layout
 
 
 @pytest.mark.gpu
