@@ -389,8 +389,8 @@ def main():
     if info["layout"] in (3, 4):      # the instantiation the launcher picks (mic_kernels.hip: mic_launch_query)
         km = (k, info["minimizer_len"]) if (k in (31, 27, 32) and info["minimizer_len"] == 20) else (0, 0)
         kname = f"query_kernel_s<{km[0]}, {km[1]}, {'true' if db_mode else 'false'}, {'true' if info['layout'] == 4 else 'false'}>"
-        if info["layout"] == 4 and not db_mode and not os.environ.get("MIC_S_PER_KMER"):
-            kname = f"query_kernel_r<{km[0]}, {km[1]}>"          # the two-strand table is probed per run
+        if not db_mode and not os.environ.get("MIC_S_PER_KMER") and 32 < 2 * k - info["minimizer_len"] <= 48:
+            kname = f"query_kernel_r<{km[0]}, {km[1]}, {'true' if info['layout'] == 4 else 'false'}>"   # super-k-mer tables are probed per run
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_query_kernel.json")), reverse=True):
         try:
             pj = json.load(open(f))

@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cb
 #ifndef MIC_R_EAGER_ENTRY
 #define MIC_R_EAGER_ENTRY 1
 #endif
-template <int KK, int MM>
+template <int KK, int MM, bool FWD>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r(const MicQueryArgs a) {
   // staged slots: 8 per LDS-DMA instruction, 128 bytes apart (the DMA's own layout: lane L lands at base + 16 L); each
   // group of 8 starts MIC_R_SKEW uint4 further so that the run lanes' reads of the same word of their slots spread over
@@ -1215,10 +1215,26 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
           const int idx = 4 * h + (lane >> 4);
           const uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
           const uint64_t kmer = kmer_from_dwords(d0, d1, d2, ln & 15, k);
-          const uint32_t key = (mmer_order_key_canon(kmer >> (2 * (k - m))) & ~31u) | (uint32_t)(ln & 15);
+          // one-strand table: the m-mer counts in its canonical form and the key carries the strand (bit 4), as in query_kernel_s
+          const uint64_t rck = FWD ? 0 : revcomp_bits(kmer, k);
+          const uint64_t mf = kmer >> (2 * (k - m));
+          uint32_t key;
+          if (FWD) key = (mmer_order_key_canon(mf) & ~31u) | (uint32_t)(ln & 15);
+          else {
+            const uint64_t mr = rck & ((1ULL << (2 * m)) - 1);
+            const bool fw = mf < mr;
+            key = (mmer_order_key_canon(fw ? mf : mr) & ~31u) | (fw ? 0u : 16u) | (uint32_t)(ln & 15);
+          }
           if (h == 0) hk0 = key; else hk1 = key;
           if (h == 1 && past) {   // m-mer 64 + lane + w - 1 = the last m nucleotides of this k-mer (see query_kernel_s)
-            const uint32_t tk = (mmer_order_key_canon(kmer & ((1ULL << (2 * m)) - 1)) & ~31u) | (uint32_t)((ln + w - 1) & 15);
+            const uint64_t tf = kmer & ((1ULL << (2 * m)) - 1);
+            uint32_t tk;
+            if (FWD) tk = (mmer_order_key_canon(tf) & ~31u) | (uint32_t)((ln + w - 1) & 15);
+            else {
+              const uint64_t tr = rck >> (2 * (k - m));
+              const bool tfw = tf < tr;
+              tk = (mmer_order_key_canon(tfw ? tf : tr) & ~31u) | (tfw ? 0u : 16u) | (uint32_t)((ln + w - 1) & 15);
+            }
             tail = row_prefix_min(ln >= 65 - w ? tk : 0xFFFFFFFFu);
           }
         }
@@ -1226,8 +1242,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         hk1 = tail < hk1 ? tail : hk1;
         // runs: k-mers next to each other whose minimizer sits at the same position of the chunk
         const uint32_t n_act = nk - base < 128u ? nk - base : 128u;
-        const uint32_t qa0 = (uint32_t)ln + ((hk0 - (uint32_t)ln) & 15u);
-        const uint32_t qa1 = 64u + (uint32_t)ln + ((hk1 - (uint32_t)ln) & 15u);
+        // position of the minimizer in the chunk, | strand << 8 for the one-strand table (a run has one strand)
+        const uint32_t qa0 = (uint32_t)ln + ((hk0 - (uint32_t)ln) & 15u) + (FWD ? 0u : (hk0 & 16u) << 4);
+        const uint32_t qa1 = 64u + (uint32_t)ln + ((hk1 - (uint32_t)ln) & 15u) + (FWD ? 0u : (hk1 & 16u) << 4);
         const uint32_t last0 = __builtin_amdgcn_readlane(qa0, 63);
         uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)qa0, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 keeps -1
         uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)last0, (int)qa1, 0x138, 0xF, 0xF, false);
@@ -1239,9 +1256,10 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         const uint64_t b0 = wballot(f0), b1 = wballot(f1);
         const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1);
         __builtin_amdgcn_wave_barrier();
-        if (f0) rec[below(b0)] = (uint16_t)(qa0 | ((uint32_t)lane << 8));
-        if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
-        if (ln == 0) rec[R] = (uint16_t)(n_act << 8);
+        // record: minimizer position (8 bits) | first k-mer (7 bits) | strand; the closing record holds n_act mod 128
+        if (f0) rec[below(b0)] = (uint16_t)((qa0 & 255u) | ((uint32_t)lane << 8) | ((qa0 >> 8) << 15));
+        if (f1) rec[R0 + below(b1)] = (uint16_t)((qa1 & 255u) | ((64u + (uint32_t)lane) << 8) | ((qa1 >> 8) << 15));
+        if (ln == 0) rec[R] = (uint16_t)((n_act & 127u) << 8);
         __builtin_amdgcn_wave_barrier();
 
         for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
@@ -1249,17 +1267,34 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
           const bool vr = (uint32_t)lane < nrun;
           const uint32_t ri = vr ? rbase + (uint32_t)lane : 0u;
           const uint32_t rc0 = rec[ri], rc1 = rec[ri + 1];
-          const int qa = (int)(rc0 & 255u), i0 = (int)(rc0 >> 8), n = (int)(rc1 >> 8) - i0;
+          const int qa = (int)(rc0 & 255u), i0 = (int)((rc0 >> 8) & 127u), n = (int)((((rc1 >> 8) - (rc0 >> 8) - 1u) & 127u) + 1u);
+          const bool rev = !FWD && (rc0 >> 15) != 0;
           // the region [qa - ctx, qa + k) of the chunk, left-aligned in three words like the entry's super-k-mer: it starts
           // off = 1..16 nucleotides into window dword D (off = 16 instead of 0 keeps the alignbit shift below 32)
           const int s1 = qa - ctx - 1;
           const int D = s1 >> 4;                                  // -1 (the region starts in front of the chunk) .. 8
           const uint32_t tsh = 30u - 2u * (uint32_t)(s1 & 15);
           const uint32_t W0 = bperm((D) & 63, wd), W1 = bperm((D + 1) & 63, wd), W2 = bperm((D + 2) & 63, wd), W3 = bperm((D + 3) & 63, wd);
-          const uint32_t G0 = __builtin_amdgcn_alignbit(W0, W1, tsh), G1 = __builtin_amdgcn_alignbit(W1, W2, tsh), G2 = __builtin_amdgcn_alignbit(W2, W3, tsh);
+          uint32_t G0 = __builtin_amdgcn_alignbit(W0, W1, tsh), G1 = __builtin_amdgcn_alignbit(W1, W2, tsh), G2 = __builtin_amdgcn_alignbit(W2, W3, tsh);
+          if (!FWD) {
+            // a run on the reverse strand is looked up as the reverse complement of the SAME region (the minimizer sits ctx
+            // nucleotides from either end): reverse the 96 bits, drop the 96 - 2 (k + ctx) bits that were behind the region,
+            // swap the two bits of every nucleotide back, complement - once per run, not twice per k-mer
+            const uint32_t sh = 96u - 2u * (uint32_t)(k + ctx);                  // 0 .. 31 (the launcher checks)
+            const uint32_t r0 = __builtin_bitreverse32(G2), r1 = __builtin_bitreverse32(G1), r2 = __builtin_bitreverse32(G0);
+            uint32_t q0 = sh ? __builtin_amdgcn_alignbit(r0, r1, 32u - sh) : r0;
+            uint32_t q1 = sh ? __builtin_amdgcn_alignbit(r1, r2, 32u - sh) : r1;
+            uint32_t q2 = r2 << sh;
+            q0 = ~(((q0 >> 1) & 0x55555555u) | ((q0 << 1) & 0xAAAAAAAAu));
+            q1 = ~(((q1 >> 1) & 0x55555555u) | ((q1 << 1) & 0xAAAAAAAAu));
+            q2 = ~(((q2 >> 1) & 0x55555555u) | ((q2 << 1) & 0xAAAAAAAAu));
+            G0 = rev ? q0 : G0; G1 = rev ? q1 : G1; G2 = rev ? q2 : G2;
+          }
           const uint64_t x = ((((uint64_t)G0 << 32) | G1) << (2 * ctx)) >> (64 - 2 * m);
           const uint32_t key = (uint32_t)x;
-          const int jmax = qa - i0, jmin = jmax - n + 1;         // minimizer position inside the run's first / last k-mer
+          // minimizer position inside the run's first / last k-mer; in the reverse complement position j becomes ctx - j
+          const int jmaxf = qa - i0, jminf = jmaxf - n + 1;
+          const int jmax = rev ? ctx - jminf : jmaxf, jmin = rev ? ctx - jmaxf : jminf;
           uint32_t cur = vr ? sslot_of_x(x, (uint32_t)t.n_main) : 0xFFFFFFFFu;
           int remaining = vr ? n : 0;
           do {
@@ -1627,9 +1662,13 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     // and the two-strand table each in their own (the common kernel carries neither's scalars)
     // the two-strand table is probed per run (query_kernel_r); MIC_S_PER_KMER=1 keeps the per-k-mer kernel for comparison
     static const bool per_kmer = getenv("MIC_S_PER_KMER") != nullptr;
+    // the one-strand table's per-run kernel reverse-complements a region of 2k - m nucleotides inside three words: its
+    // realignment is a single funnel shift when the region is longer than 32 nucleotides (always for cuCLARK's k and m)
+    const bool run_ok = 2 * a.t.k - a.t.m > 32 && 2 * a.t.k - a.t.m <= 48;
     static const unsigned extra_lds = [] { const char* e = getenv("MIC_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();   // occupancy experiments
 #define LAUNCH_S(KK_, MM_) do { \
-      if (fw && !sh && !per_kmer) query_kernel_r<KK_, MM_><<<g, b, extra_lds, s>>>(a); \
+      if (fw && !sh && !per_kmer) query_kernel_r<KK_, MM_, true><<<g, b, extra_lds, s>>>(a); \
+      else if (!fw && !sh && !per_kmer && run_ok) query_kernel_r<KK_, MM_, false><<<g, b, extra_lds, s>>>(a); \
       else if (fw) { if (sh) query_kernel_s<KK_, MM_, true, true><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, true><<<g, b, 0, s>>>(a); } \
       else { if (sh) query_kernel_s<KK_, MM_, true, false><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, false><<<g, b, 0, s>>>(a); } } while (0)
     if (!generic && a.t.k == 31 && a.t.m == 20) LAUNCH_S(31, 20);
