@@ -398,14 +398,20 @@ def main():
             continue
         if not (pj.get("workload") == w["name"] and pj.get("reads_per_launch") == n_reads and pj.get("layout") == info["layout"]):
             continue
-        # a committed counter profile is only used for the kernel it was taken on: same instantiation, and its rocprofv3
-        # average within 3 % of the duration just measured
-        off = abs(pj.get("rocprof_avg_ms", 0) / (kern_s * 1e3) - 1)
+        # a committed counter profile is only used for the kernel it was taken on: same instantiation; its rocprofv3 average
+        # must agree within 3 % with the HIP-event time of the very run it was taken in (profiles/*_bench_under_rocprof.json),
+        # and that run must be within 5 % of the duration measured now (boxes of the pool differ by +-2 %)
         if kname not in pj.get("kernel", ""):
             traffic_note = f"{os.path.basename(f)} was taken on '{pj.get('kernel', '?')[:60]}', this run timed '{kname}'"
             continue
-        if off > 0.03:
-            traffic_note = f"{os.path.basename(f)}: rocprofv3 average {pj.get('rocprof_avg_ms', 0):.3f} ms is {off * 100:.1f} % off the {kern_s * 1e3:.3f} ms measured now"
+        ev_ms = pj.get("bench_hip_event_ms") or pj.get("rocprof_avg_ms", 0)
+        off_self = abs(pj.get("rocprof_avg_ms", 0) / max(ev_ms, 1e-9) - 1)
+        off = abs(ev_ms / (kern_s * 1e3) - 1)
+        if off_self > 0.03:
+            traffic_note = f"{os.path.basename(f)}: rocprofv3 average {pj.get('rocprof_avg_ms', 0):.3f} ms and the HIP-event time of the same run {ev_ms:.3f} ms disagree by {off_self * 100:.1f} %"
+            continue
+        if off > 0.05:
+            traffic_note = f"{os.path.basename(f)}: the profiled run's kernel took {ev_ms:.3f} ms, {off * 100:.1f} % off the {kern_s * 1e3:.3f} ms measured now"
             continue
         traffic = (pj["fetch_bytes_per_launch"] + pj["write_bytes_per_launch"]) / kern_s / 1e9
         rdreq = pj["pmc_per_launch"].get("TCC_EA0_RDREQ_sum")
