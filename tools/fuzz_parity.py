@@ -36,7 +36,7 @@ while time.time() < t_end:
     idx = host.index_reads(data)
     rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
     counts, expect = tp._oracle_results(odb, k, rp, cont, T)
-    for layout in (1, 2, 3):
+    for layout in (1, 2, 3, 4):
         with MiClarkDB(k, T, layout=layout) as e:
             e.read_arrays(sizes, keys, labels)
             res, rows = e.classify_packed(rp, cont, extended=True)
@@ -70,4 +70,4 @@ while time.time() < t_end:
     n_cases += 1
     n_reads += rp.size - 1
     seed += 1
-print(f"fuzz ok: {n_cases} random configurations x 3 layouts, {n_reads} reads, seeds {seed0}..{seed - 1}")
+print(f"fuzz ok: {n_cases} random configurations x 4 layouts, {n_reads} reads, seeds {seed0}..{seed - 1}")
