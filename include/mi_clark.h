@@ -56,10 +56,10 @@ typedef struct mic_config {
   uint32_t num_targets; /* number of labels T (<= 65535)             dataType.hh:48   */
   uint32_t num_batches; /* batches of the batch API (>=1)            main.cc:220-226  */
   uint32_t row_words;   /* u32 words per sparse row (0 = default 16 => 15 pairs = MAXHITS, parameters.hh:44) */
-  uint32_t layout;      /* resident table layout: MIC_LAYOUT_AUTO / _DIRECT / _MINIMIZER */
+  uint32_t layout;      /* resident table layout: MIC_LAYOUT_AUTO / _DIRECT / _MINIMIZER / _SUPER / _SUPER2 */
 } mic_config;
 
-#define MIC_LAYOUT_AUTO 0      /* super-k-mer table for k >= 24 (minimizer, then direct if it does not fit), else direct; env MIC_LAYOUT=direct|minimizer|super overrides */
+#define MIC_LAYOUT_AUTO 0      /* super-k-mer table for k >= 24 (minimizer, then direct if it does not fit), else direct; env MIC_LAYOUT=direct|minimizer|super|super2 overrides */
 #define MIC_LAYOUT_DIRECT 1    /* one 64-byte slot per on-disk bucket (one HBM request per k-mer) */
 #define MIC_LAYOUT_MINIMIZER 2 /* 128-byte slots keyed by the k-mer's minimizer (one HBM request per ~7 k-mers) */
 #define MIC_LAYOUT_SUPER 3     /* 128-byte slots of super-k-mers: the k-mers sharing a minimizer occurrence are one entry; one slot per lookup */
