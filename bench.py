@@ -116,6 +116,57 @@ def pipeline_leg(eng, L, d_rp, d_cont, n_reads, res_expect, steps, nb):
             "results_equal_device_path": equal}
 
 
+def gzip_sub_leg(cmd, fqs, rec, n, res_base, tmp):
+    """BASELINE config 5 names gzip input: the first n pairs of the same files as plain gzip (one zlib stream per file, what
+    `gzip` writes) and as block gzip (BGZF, what bgzip / samtools write), through the same command line; the CSV must be the
+    first n lines of the plain run's.  The reference gunzips to a temporary file first (classify_metagenome.sh:116-142)."""
+    import re
+    import struct
+    import subprocess
+    import zlib
+    with open(res_base + ".csv", "rb") as f:
+        expect = b"".join(f.readline() for _ in range(n + 1))
+    out = {"pairs": n}
+    heads = []
+    for i, fq in enumerate(fqs):
+        with open(fq, "rb") as f:
+            heads.append(f.read(n * rec))
+    for kind in ("gzip", "bgzf"):
+        names = []
+        t0 = time.time()
+        for i, data in enumerate(heads):
+            name = os.path.join(tmp, f"{kind}_{i + 1}.fq.gz")
+            names.append(name)
+            if kind == "gzip":
+                with open(name, "wb") as f:
+                    subprocess.run(["gzip", "-1", "-c"], input=data, stdout=f, check=True)
+            else:
+                with open(name, "wb") as f:
+                    for o in range(0, len(data), 0xFF00):
+                        blk = data[o:o + 0xFF00]
+                        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+                        body = c.compress(blk) + c.flush()
+                        f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body +
+                                struct.pack("<II", zlib.crc32(blk), len(blk)))
+                    f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")
+        t_make = time.time() - t0
+        res = os.path.join(tmp, "out_" + kind)
+        c2 = list(cmd)
+        ip = c2.index("-P")
+        c2[ip + 1], c2[ip + 2] = names
+        c2[c2.index("-R") + 1] = res
+        r = subprocess.run(c2, capture_output=True, text=True, env=dict(os.environ, MIC_CLI_TIMING="1"))
+        if r.returncode != 0:
+            out[kind] = {"error": (r.stderr or r.stdout)[-300:]}
+            continue
+        m = re.search(r"Assignment time: ([0-9.eE+-]+) s\. Speed: (\d+) objects/min\. \((\d+) objects\)", r.stdout)
+        t_assign = float(m.group(1))
+        out[kind] = {"Mpairs_s": round(int(m.group(3)) / t_assign / 1e6, 2), "assignment_s": round(t_assign, 3),
+                     "compressed_MB": round(sum(os.path.getsize(x) for x in names) / 1e6, 1), "made_in_s": round(t_make, 1),
+                     "csv_equals_plain_run": open(res + ".csv", "rb").read() == expect}
+    return out
+
+
 def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res_expect, truth, threads, keep=False, paired=False):
     """files in, file out, through exe/cuCLARK (reference: CuCLARK_hh.hh:550-563 times index + pack +
     GPU + CSV and prints objects/min, :1938-1944).  The table goes to disk in the reference's format, the same reads as
@@ -193,6 +244,8 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
                                                     "h2d_MB": float(ing.group(6)), "h2d_GBs": round(float(ing.group(6)) / 1e3 / t_assign, 1)} if ing else None),
                "command": "exe/cuCLARK -k %d -T targets.txt -D DB/ %s -R out -n %d" % (k, "-P reads_1.fq reads_2.fq" if paired else "-O reads_1.fq", threads),
                "csv_lines_equal_kernel_rows": bool(ok and lines == n_reads), "setup_files_s": round(t_files, 1)}
+        if paired:
+            out["gzip_input"] = gzip_sub_leg(cmd, fqs, rec, min(n_reads, 1_000_000), res_base, tmp)
     finally:
         if not keep:
             shutil.rmtree(tmp, ignore_errors=True)
