@@ -70,4 +70,6 @@ while time.time() < t_end:
     n_cases += 1
     n_reads += rp.size - 1
     seed += 1
+    if n_cases % 200 == 0:
+        print(f"... {n_cases} configurations, {n_reads} reads, {t_end - time.time():.0f} s left", flush=True)
 print(f"fuzz ok: {n_cases} random configurations x 4 layouts, {n_reads} reads, seeds {seed0}..{seed - 1}")
