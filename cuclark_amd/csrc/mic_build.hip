@@ -642,14 +642,45 @@ __device__ inline bool s_less(unsigned long long Ka, uint32_t ma, unsigned long 
 
 struct SWriter {   // where the entries of one slot go: the main slot, then its contiguous continuation slots
   uint32_t* slots; uint64_t main, chain; uint32_t n_total, n_out;
+  uint64_t cur, n_slots; uint32_t n_here, pool_cap; uint32_t* pool; bool full;     // one-pass form
   __device__ uint32_t* slot_of(uint32_t idx) const {
     return slots + (idx < MIC_S_CAP ? main : chain + (idx - MIC_S_CAP) / MIC_S_CAP) * 32;
   }
 };
 
-template <bool WRITE>
+// One-pass form: the number of entries of a bucket is not known when its first entry is written, so continuation slots
+// are taken one at a time from a pool behind the main slots (an atomic counter) and linked through word 31; a bucket's
+// chain is then not contiguous, which no reader assumes.  A full pool is reported (pool[1]) and the caller builds the
+// table the two-pass way.
+__device__ inline void s_slot_init(uint32_t* q) {
+  for (int e = 0; e < 6; ++e) q[e] = 0xFFFFFFFFu;
+  for (int e = 6; e < 32; ++e) q[e] = 0;
+}
+// MODE 0: count the entries, 1: write them (entry counts and chain bases known), 2: write them in one pass (pool)
+template <int MODE>
 __device__ inline void s_emit(const SOpen& o, uint64_t x, int L, SWriter& wr) {
-  if (WRITE) {
+  if (MODE == 2) {
+    if (wr.n_here == MIC_S_CAP && !wr.full) {
+      const uint32_t idx = atomicAdd(wr.pool, 1u);
+      if (idx >= wr.pool_cap) { wr.full = true; atomicMax(wr.pool + 1, 1u); }
+      else {
+        uint32_t* q = wr.slots + wr.cur * 32;
+        const uint64_t nxt = wr.n_slots + idx;
+        q[30] = MIC_S_CAP | MIC_S_NEXT; q[31] = (uint32_t)nxt;
+        s_slot_init(wr.slots + nxt * 32);
+        wr.cur = nxt; wr.n_here = 0;
+      }
+    }
+    if (!wr.full) {
+      uint32_t* q = wr.slots + wr.cur * 32;
+      const uint32_t e = wr.n_here++;
+      const u128 v = o.S << (96 - 2 * L);
+      q[e] = (uint32_t)x;
+      q[6 + 3 * e] = (uint32_t)(v >> 64); q[7 + 3 * e] = (uint32_t)(v >> 32); q[8 + 3 * e] = (uint32_t)v;
+      q[24 + e] = (o.pmask << 16) | o.label;
+    }
+  }
+  if (MODE == 1) {
     uint32_t* q = wr.slot_of(wr.n_out);
     const uint32_t e = wr.n_out % MIC_S_CAP;
     const u128 v = o.S << (96 - 2 * L);
@@ -661,13 +692,15 @@ __device__ inline void s_emit(const SOpen& o, uint64_t x, int L, SWriter& wr) {
 }
 
 #define S_MAXOPEN 4
-template <bool WRITE>
+template <int MODE>
 __global__ void __launch_bounds__(256) s_merge_kernel(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ cnt,
                                                       uint64_t n_slots, unsigned long long* __restrict__ cand_k,
                                                       uint32_t* __restrict__ cand_m, int k, int m,
                                                       uint32_t* __restrict__ n_ent, const unsigned long long* __restrict__ chain_off,
                                                       uint32_t* __restrict__ slots, uint32_t* __restrict__ max_ent,
-                                                      uint64_t slot_lo, uint64_t slot_hi, unsigned long long base, int sort_now) {
+                                                      uint64_t slot_lo, uint64_t slot_hi, unsigned long long base, int sort_now,
+                                                      uint32_t* __restrict__ pool, uint32_t pool_cap) {
+  constexpr bool WRITE = MODE == 1;
   const uint64_t s = slot_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= slot_hi) return;
   const uint32_t n = cnt[s];
@@ -675,6 +708,8 @@ __global__ void __launch_bounds__(256) s_merge_kernel(const unsigned long long* 
   uint32_t* M = cand_m + (off[s] - base);
   const int w = k - m + 1, L = k + w - 1;
   SWriter wr; wr.slots = slots; wr.main = s; wr.chain = 0; wr.n_total = 0; wr.n_out = 0;
+  wr.cur = s; wr.n_slots = n_slots; wr.n_here = 0; wr.pool_cap = pool_cap; wr.pool = pool; wr.full = false;
+  if (MODE == 2) s_slot_init(slots + s * 32);
   if (WRITE) {
     wr.n_total = n_ent[s];
     const uint32_t n_chain = wr.n_total > MIC_S_CAP ? (wr.n_total - 1) / MIC_S_CAP : 0;
@@ -708,7 +743,7 @@ __global__ void __launch_bounds__(256) s_merge_kernel(const unsigned long long* 
     const unsigned long long kv = K[i]; const uint32_t mv = M[i];
     const uint32_t j = mv & 0xFF, lb = mv >> 8;
     const uint64_t x = s_x_of(kv, j, k, m);
-    if (n_open && x != cur_x) { for (int o = 0; o < n_open; ++o) s_emit<WRITE>(open[o], cur_x, L, wr); n_open = 0; }
+    if (n_open && x != cur_x) { for (int o = 0; o < n_open; ++o) s_emit<MODE>(open[o], cur_x, L, wr); n_open = 0; }
     cur_x = x;
     const u128 SK = (u128)kv << (2 * j), MK = kmask << (2 * j);
     bool done = false;
@@ -719,15 +754,16 @@ __global__ void __launch_bounds__(256) s_merge_kernel(const unsigned long long* 
     }
     if (!done) {
       if (n_open == S_MAXOPEN) {                              // keep the most recent contexts open
-        s_emit<WRITE>(open[0], cur_x, L, wr);
+        s_emit<MODE>(open[0], cur_x, L, wr);
         for (int o = 1; o < S_MAXOPEN; ++o) open[o - 1] = open[o];
         --n_open;
       }
       open[n_open].S = SK; open[n_open].known = MK; open[n_open].pmask = 1u << j; open[n_open].label = lb; ++n_open;
     }
   }
-  for (int o = 0; o < n_open; ++o) s_emit<WRITE>(open[o], cur_x, L, wr);
-  if (!WRITE) { n_ent[s] = wr.n_out; if (wr.n_out > MIC_S_CAP) atomicMax(max_ent, wr.n_out); }
+  for (int o = 0; o < n_open; ++o) s_emit<MODE>(open[o], cur_x, L, wr);
+  if (MODE != 1) { n_ent[s] = wr.n_out; if (wr.n_out > MIC_S_CAP) atomicMax(max_ent, wr.n_out); }
+  if (MODE == 2 && !wr.full) { uint32_t* q = slots + wr.cur * 32; q[30] = wr.n_here; q[31] = 0; }
 }
 
 __global__ void s_chain_demand_kernel(const uint32_t* __restrict__ n_ent, uint64_t n, uint32_t* __restrict__ demand) {
@@ -894,7 +930,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   std::vector<TileA> h_a(n_tiles);
   uint64_t tot_elems = 0, tot_nz = 0, n_slots = 0, n_cand = 0, n_chain = 0;
   unsigned long long h_scal[2] = {0, 0}, h_entries = 0; uint32_t h_max = 0; double avail_b = 0;
-  uint32_t* d_nent = nullptr; uint64_t stage_cap = 0; size_t n_ranges = 0;
+  uint32_t* d_nent = nullptr; uint64_t stage_cap = 0; size_t n_ranges = 0; bool one_pass = false; uint64_t alloc_slots = 0;
   std::vector<uint64_t> range_lo; std::vector<unsigned long long> range_base;
   MBuildArgs a;
   const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
@@ -1026,16 +1062,51 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   HIPCK(hipMalloc(&d_nent, n_slots * 4));     // entries per slot
   HIPCK(hipMemsetAsync(d_cur, 0, n_slots * 4, s));
   HIPCK(hipMemsetAsync(d_max, 0, 4, s));
-  // phase A: entries per slot (scatter + sort + merge without writing), range by range
-  for (size_t r = 0; r < n_ranges; ++r) {
+  // One pass when it works: the table is allocated with a pool of continuation slots (2 % of the main slots; Poisson(1.5)
+  // entries per slot needs 0.1 %) and every range is scattered, sorted, merged and WRITTEN in one go - no counting merge, and
+  // for a table built in several ranges no second scatter + sort either.  A pool that runs out (a database of crowded
+  // minimizers, which the rule below hands to the minimizer layout anyway) or an allocation that fails falls back to the
+  // two-pass form: count the entries, size the chains exactly, write.  MIC_S_TWO_PASS=1 forces that form.
+  if (!getenv("MIC_S_TWO_PASS")) {
+    uint64_t pool_cap = n_slots / 50 + 65536;
+    if (const char* env = getenv("MIC_S_POOL_SLOTS")) { long v = atol(env); if (v > 0) pool_cap = (uint64_t)v; }   // test hook: a pool that runs out
+    if (n_slots + pool_cap > 0xFFFFFF00ull) pool_cap = 0xFFFFFF00ull > n_slots ? 0xFFFFFF00ull - n_slots : 0;
+    uint32_t* d_pool = nullptr;
+    hipError_t e_ = pool_cap ? hipMalloc(&slots, (size_t)(n_slots + pool_cap + 1) * 128) : hipErrorOutOfMemory;
+    if (e_ == hipSuccess) e_ = hipMalloc(&d_pool, 8);
+    if (e_ == hipSuccess) e_ = hipMemsetAsync(d_pool, 0, 8, s);
+    if (e_ == hipSuccess) {
+      for (size_t r = 0; r < n_ranges && e_ == hipSuccess; ++r) {
+        const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
+        BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
+        s_merge_kernel<2><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_nent, nullptr, slots,
+                                                                           d_max, lo, hi, range_base[r], 1, d_pool, (uint32_t)pool_cap);
+        e_ = hipGetLastError();
+      }
+      uint32_t h_pool[2] = {0, 0};
+      if (e_ == hipSuccess) e_ = hipMemcpyAsync(h_pool, d_pool, 8, hipMemcpyDeviceToHost, s);
+      if (e_ == hipSuccess) e_ = hipStreamSynchronize(s);
+      if (e_ == hipSuccess && !h_pool[1]) { one_pass = true; n_chain = h_pool[0]; alloc_slots = n_slots + pool_cap + 1; }
+    }
+    if (d_pool) hipFree(d_pool);
+    if (!one_pass) {
+      (void)hipGetLastError();
+      if (slots) { hipFree(slots); slots = nullptr; }
+      HIPCK(hipMemsetAsync(d_cur, 0, n_slots * 4, s));
+      HIPCK(hipMemsetAsync(d_max, 0, 4, s));
+    }
+    lap(one_pass ? "scatter of the candidates + sort + merge + write (one pass)" : "one-pass build abandoned (continuation pool full or no memory)");
+  }
+  // phase A (two-pass form): entries per slot (scatter + sort + merge without writing), range by range
+  for (size_t r = 0; r < n_ranges && !one_pass; ++r) {
     const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
     BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
     HIPCK(hipGetLastError());
-    s_merge_kernel<false><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_nent, nullptr,
-                                                                           nullptr, d_max, lo, hi, range_base[r], 1);
+    s_merge_kernel<0><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_nent, nullptr,
+                                                                       nullptr, d_max, lo, hi, range_base[r], 1, nullptr, 0);
     HIPCK(hipGetLastError());
   }
-  lap("scatter of the candidates + sort + merge (count)");
+  if (!one_pass) lap("scatter of the candidates + sort + merge (count)");
   HIPCK(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
   HIPCK(hipMemsetAsync(d_scal + 1, 0, 8, s));
   s_sum_kernel<<<4096, 256, 0, s>>>(d_nent, n_slots, d_scal + 1);       // entries = super-k-mers stored (statistics)
@@ -1069,7 +1140,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       rc = -5; goto done;
     }
   }
-  {
+  if (!one_pass) {
     // chain slots: demand per slot into a scratch u32 array (the candidate offsets stay), scanned to 64-bit bases
     HIPCK(hipMalloc(&d_dem, n_slots * 4));
     s_chain_demand_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(d_nent, n_slots, d_dem);
@@ -1083,7 +1154,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     n_chain = last_off + last_dem;
   }
   if (n_slots + n_chain > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many S-slots"); rc = -1; goto done; }
-  {
+  if (!one_pass) {
     hipError_t e_ = hipMalloc(&slots, (size_t)(n_slots + n_chain + 1) * 128);
     if (e_ != hipSuccess) {
       (void)hipGetLastError();
@@ -1093,24 +1164,24 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     }
   }
   // phase B: write the slots.  One range: its candidates are still staged and sorted.  Several: scatter and sort each again.
-  if (n_ranges > 1) HIPCK(hipMemsetAsync(d_cur, 0, n_slots * 4, s));
-  for (size_t r = 0; r < n_ranges; ++r) {
+  if (n_ranges > 1 && !one_pass) HIPCK(hipMemsetAsync(d_cur, 0, n_slots * 4, s));
+  for (size_t r = 0; r < n_ranges && !one_pass; ++r) {
     const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
     if (n_ranges > 1) {
       BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
       HIPCK(hipGetLastError());
     }
-    s_merge_kernel<true><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_nent, d_coff,
-                                                                          slots, d_max, lo, hi, range_base[r], n_ranges > 1 ? 1 : 0);
+    s_merge_kernel<1><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_nent, d_coff,
+                                                                       slots, d_max, lo, hi, range_base[r], n_ranges > 1 ? 1 : 0, nullptr, 0);
     HIPCK(hipGetLastError());
   }
   HIPCK(hipMemsetAsync(slots + (size_t)(n_slots + n_chain) * 32, 0xFF, 128, s));   // the spare slot after the table: empty
   HIPCK(hipStreamSynchronize(s));
-  lap("merge (write)");
+  if (!one_pass) lap("merge (write)");
 #undef BY_RAW
   out->slots = (uint4*)slots; slots = nullptr;
   out->n_main = n_slots; out->n_overflow = n_chain; out->n_elems = h_scal[0]; out->n_elems_file = tot_elems;
-  out->max_bucket = 0; out->max_chain = h_max; out->n_entries = h_entries;
+  out->max_bucket = 0; out->max_chain = h_max; out->n_entries = h_entries; out->alloc_slots = alloc_slots;
 done:
   if (d_a) hipFree(d_a);
   if (d_cnt) hipFree(d_cnt);

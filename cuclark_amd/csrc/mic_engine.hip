@@ -107,7 +107,7 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   i.htsize = htsize; i.shard_start = s0; i.shard_end = s1;
   i.n_elems = b.n_elems; i.n_elems_file = b.n_elems_file;
   i.n_slots = b.n_main + b.n_overflow; i.n_overflow = b.n_overflow;
-  i.hbm_bytes = (b.n_main + b.n_overflow + 1) * (uint64_t)(layout != MIC_LAYOUT_DIRECT ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
+  i.hbm_bytes = (b.alloc_slots ? b.alloc_slots : b.n_main + b.n_overflow + 1) * (uint64_t)(layout != MIC_LAYOUT_DIRECT ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
   i.key_bytes = key_bytes; i.slot_class = layout != MIC_LAYOUT_DIRECT ? 128 : e->slot_class; i.max_bucket = b.max_bucket;
   i.sampling = sampling; i.layout = layout; i.minimizer_len = layout != MIC_LAYOUT_DIRECT ? m : 0;
   i.max_chain = layout != MIC_LAYOUT_DIRECT ? b.max_chain : 0; i.reserved = (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2) ? b.walk_ppm : 0;

@@ -133,6 +133,7 @@ struct MicBuildOut {
   uint32_t max_chain;   // layout 1: entries in the fullest slot chain
   uint32_t walk_ppm;    // super-k-mer table: mean continuation slots in front of a stored k-mer, x 1e6
   uint64_t n_entries;   // super-k-mer table: entries (super-k-mers) stored; other layouts: 0 (= one entry per k-mer)
+  uint64_t alloc_slots; // slots allocated when that is more than n_main + n_overflow + 1 (one-pass super-k-mer build: the unused part of its continuation pool), else 0
 };
 // d_sizes/d_keys/d_labels point at the first bucket / first element of the shard.
 // rank_base = number of non-empty buckets before the shard (sampling is defined on the whole table).

@@ -619,6 +619,15 @@ def test_super_table_with_crowded_slots(monkeypatch):
     assert (res == base).all()
     assert ((res[:, 0] == 1) == (f == 1)).all()
     assert (res[f == 1, 1] == l[f == 1].astype(np.uint32) + 1).all()
+    # the table is normally written in ONE pass with continuation slots from a pool; a pool that runs out (test hook) or
+    # MIC_S_TWO_PASS falls back to counting the entries first: same slots, same chains, same answers
+    for name, value in (("MIC_S_POOL_SLOTS", "8"), ("MIC_S_TWO_PASS", "1")):
+        monkeypatch.setenv(name, value)
+        info2, res2 = run()
+        monkeypatch.delenv(name)
+        assert info2["n_slots"] == info["n_slots"] and info2["n_overflow"] == info["n_overflow"] and info2["n_entries"] == info["n_entries"]
+        assert info2["hbm_bytes"] < info["hbm_bytes"]          # no unused pool behind the table
+        assert (res2 == base).all()
     # a staging area that holds a fraction of the candidates: the table is built in several passes over slot ranges and
     # must come out the same (MIC_S_STAGING_LIMIT_MB is the test hook; the headline's two-strand table needs this path)
     monkeypatch.delenv("MIC_SSLOT_LOAD")
