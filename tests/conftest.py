@@ -42,3 +42,30 @@ def _hang_watchdog():
     faulthandler.dump_traceback_later(400, exit=True)
     yield
     faulthandler.cancel_dump_traceback_later()
+
+
+def _start_heartbeat():
+    """On the GPU box a runner that sees no output for minutes takes the run for hung; a cold box can spend that long paging
+    libraries in.  A line every 30 s in gpurun_out/ says the session is alive; a test that really blocks is ended by the
+    watchdog above."""
+    root = os.environ.get("GRAFT_REPO_ROOT")
+    if not root:
+        return
+    import threading
+    import time
+    path = os.path.join(root, "gpurun_out", "pytest_heartbeat.txt")
+
+    def beat():
+        t0 = time.time()
+        while True:
+            try:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, "w") as f:
+                    f.write(f"pytest pid {os.getpid()} alive, {time.time() - t0:.0f} s\n")
+            except OSError:
+                pass
+            time.sleep(30)
+    threading.Thread(target=beat, daemon=True).start()
+
+
+_start_heartbeat()
