@@ -1257,9 +1257,15 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1);
         __builtin_amdgcn_wave_barrier();
         // record: minimizer position (8 bits) | first k-mer (7 bits) | strand; the closing record holds n_act mod 128
-        if (f0) rec[below(b0)] = (uint16_t)((qa0 & 255u) | ((uint32_t)lane << 8) | ((qa0 >> 8) << 15));
-        if (f1) rec[R0 + below(b1)] = (uint16_t)((qa1 & 255u) | ((64u + (uint32_t)lane) << 8) | ((qa1 >> 8) << 15));
-        if (ln == 0) rec[R] = (uint16_t)((n_act & 127u) << 8);
+        if (FWD) {      // no strand: the first k-mer has all eight bits, the closing record holds n_act itself
+          if (f0) rec[below(b0)] = (uint16_t)(qa0 | ((uint32_t)lane << 8));
+          if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
+          if (ln == 0) rec[R] = (uint16_t)(n_act << 8);
+        } else {
+          if (f0) rec[below(b0)] = (uint16_t)((qa0 & 255u) | ((uint32_t)lane << 8) | ((qa0 >> 8) << 15));
+          if (f1) rec[R0 + below(b1)] = (uint16_t)((qa1 & 255u) | ((64u + (uint32_t)lane) << 8) | ((qa1 >> 8) << 15));
+          if (ln == 0) rec[R] = (uint16_t)((n_act & 127u) << 8);
+        }
         __builtin_amdgcn_wave_barrier();
 
         for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
@@ -1267,7 +1273,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
           const bool vr = (uint32_t)lane < nrun;
           const uint32_t ri = vr ? rbase + (uint32_t)lane : 0u;
           const uint32_t rc0 = rec[ri], rc1 = rec[ri + 1];
-          const int qa = (int)(rc0 & 255u), i0 = (int)((rc0 >> 8) & 127u), n = (int)((((rc1 >> 8) - (rc0 >> 8) - 1u) & 127u) + 1u);
+          const int qa = (int)(rc0 & 255u), i0 = FWD ? (int)(rc0 >> 8) : (int)((rc0 >> 8) & 127u);
+          const int n = FWD ? (int)(rc1 >> 8) - i0 : (int)((((rc1 >> 8) - (rc0 >> 8) - 1u) & 127u) + 1u);
           const bool rev = !FWD && (rc0 >> 15) != 0;
           // the region [qa - ctx, qa + k) of the chunk, left-aligned in three words like the entry's super-k-mer: it starts
           // off = 1..16 nucleotides into window dword D (off = 16 instead of 0 keeps the alignbit shift below 32)
