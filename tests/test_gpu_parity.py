@@ -341,6 +341,60 @@ def test_long_reads_and_part_splitting():
     assert expect[0, 0] > 60000
 
 
+def _canonical_np(v, k):
+    """canonical k-mer values of a uint64 array (A=3 C=2 G=1 T=0: the complement is the bitwise NOT)"""
+    x = ~v
+    x = ((x >> np.uint64(2)) & np.uint64(0x3333333333333333)) | ((x & np.uint64(0x3333333333333333)) << np.uint64(2))
+    x = ((x >> np.uint64(4)) & np.uint64(0x0F0F0F0F0F0F0F0F)) | ((x & np.uint64(0x0F0F0F0F0F0F0F0F)) << np.uint64(4))
+    x = ((x >> np.uint64(8)) & np.uint64(0x00FF00FF00FF00FF)) | ((x & np.uint64(0x00FF00FF00FF00FF)) << np.uint64(8))
+    x = ((x >> np.uint64(16)) & np.uint64(0x0000FFFF0000FFFF)) | ((x & np.uint64(0x0000FFFF0000FFFF)) << np.uint64(16))
+    x = (x >> np.uint64(32)) | (x << np.uint64(32))
+    rc = x >> np.uint64(64 - 2 * k)
+    return np.minimum(v, rc)
+
+
+def test_thousands_of_chunks_of_long_reads():
+    """2.4 M nucleotides of 40-kb reads cut from a 2.5-Mb genome whose k-mers are the database: 19 000 full 128-k-mer chunks,
+    among them the few with more than 32 super-k-mers (more runs than one round of staged slots holds) and every strand and
+    alignment of a run against its entry; substitutions every ~200 nt cut runs at all positions."""
+    from cuclark_amd import host
+    rng = np.random.default_rng(77)
+    htsize, k, T = 1 << 20, 31, 16
+    G = 2_500_000
+    codes = rng.integers(0, 4, G, dtype=np.uint8)             # 0..3 = T G C A (the packed code)
+    v = np.zeros(G - k + 1, np.uint64)
+    for j in range(k):
+        v = (v << np.uint64(2)) | codes[j:j + G - k + 1].astype(np.uint64)
+    canon, first = np.unique(_canonical_np(v, k), return_index=True)
+    lab = ((first // 40000) % T).astype(np.uint16)
+    order = np.lexsort((canon // np.uint64(htsize), canon % np.uint64(htsize)))
+    canon, lab = canon[order], lab[order]
+    sizes = np.bincount((canon % np.uint64(htsize)).astype(np.int64), minlength=htsize)
+    assert sizes.max() < 256
+    keys = (canon // np.uint64(htsize)).astype(np.uint64)
+    o = gu.oracle()
+    odb = o.db_from_arrays(sizes.astype(np.uint8), keys, lab)
+    ascii_of = np.frombuffer(b"TGCA", np.uint8)
+    recs = []
+    for i in range(60):
+        p = int(rng.integers(0, G - 40000))
+        seq = ascii_of[codes[p:p + 40000]].copy()
+        if i % 2:
+            seq = np.frombuffer(bytes(seq[::-1]).translate(bytes.maketrans(b"ACGT", b"TGCA")), np.uint8).copy()
+        mut = rng.random(seq.size) < 0.005
+        seq[mut] = ascii_of[rng.integers(0, 4, int(mut.sum()))]
+        recs.append(b">r%d\n" % i + seq.tobytes() + b"\n")
+    data = b"".join(recs)
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    counts, expect = _oracle_results(odb, k, rp, cont, T)
+    assert expect[:, 0].min() > 20000
+    with _engine(k, T) as e:
+        e.read_arrays(sizes.astype(np.uint8), keys, lab)
+        res = e.classify_packed(rp, cont)
+    assert (res[:, :5] == expect).all()
+
+
 def test_malformed_buckets_follow_reference_scan():
     """Unsorted buckets / duplicate keys: the table must answer exactly like the reference's linear scan."""
     rng = np.random.default_rng(9)
