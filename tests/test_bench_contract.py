@@ -87,6 +87,11 @@ def test_bench_paired_config5_shape():
     d = _bench("--workload", "paired", "--steps", "2", "--warmup", "1", "--cpu-sample", "100000", "--reads", "2000000")
     _check_config(d, 2_000_000)
     assert "pairs" in d["end_to_end"]["input"]
+    # config 5 names gzip input: plain gzip and block gzip of the same pairs give the plain run's CSV
+    gz = d["end_to_end"]["gzip_input"]
+    assert gz["pairs"] == 1_000_000
+    for kind in ("gzip", "bgzf"):
+        assert gz[kind]["csv_equals_plain_run"] is True and gz[kind]["Mpairs_s"] > 0, gz
 
 
 def test_bench_has_the_contract_flags():
