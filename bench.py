@@ -9,12 +9,17 @@ per-target hit counts + best/second) over one batch of synthetic reads that is a
 Workloads, all synthetic, generated in HBM by libmi_clark.so's generators:
   full   config 3: 10 M x 150 bp reads (80 % sampled from the genomes with 1 % substitutions and 0.1 % N, 20 % random)
          vs. a 36 GB-on-disk-equivalent k=31 table: HTSIZE 1610612741, u32 keys, ~5.7e9 k-mers, 4096 targets,
-         resident as 75 GB of 128-byte super-k-mer slots (MIC_LAYOUT=minimizer|direct for the other layouts).  [default]
-  light  config 2: same reads vs. the CuCLARK-l-scale table: HTSIZE 57777779, k=31 (u64 keys), ~54 M k-mers.
+         resident as 150 GB of 128-byte super-k-mer slots, both strands stored (--layout super2, the bench's default; the
+         command line's default is the one-strand table, 75 GB: `default_layout` in the JSON line times its kernel too). [default]
+  light27 config 2 proper: the CuCLARK-l table as cuCLARK-l builds it: HTSIZE 57777779, k=27 (forced, main.cc:241-249), u32 keys,
+         ~90 M k-mers; 10 M x 150 bp reads.
+  light  config 2, k=31 side variant: same reads vs. HTSIZE 57777779, k=31 (u64 keys), ~54 M k-mers (not reachable through the
+         reference's binaries; kept because the metric says k=31).
   tiny   plumbing-size case for quick checks.
 Multi-GPU (one process per GPU, launched with torch.distributed.run):
   read   reads sharded, table replicated, no collective (config 5 shape)      -> "scaling": "weak"   [default]
-  db     table sharded by bucket range, every rank sees all reads, per-read sparse target-score rows exchanged
+  db     table sharded (mic_db_set_part: super-k-mer layouts by resident slot range, so a run of a read belongs to one rank;
+         other layouts by on-disk bucket range), every rank sees all reads, per-read sparse target-score rows exchanged
          with all_to_all over RCCL, merged and finalised per read range (config 4) -> "scaling": "strong"
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch / mean kernel time measured with HIP
@@ -50,6 +55,10 @@ WORKLOADS = {
     "light": dict(htsize=57777779, genome_nt=54_000_000, n_genomes=512, n_targets=512, k=31, key_bytes=8,
                   n_reads=10_000_000, read_len=150,
                   name="10M x 150bp synthetic reads vs CuCLARK-l-scale k=31 table (HTSIZE 57777779, u64 keys, ~54M k-mers)"),
+    # SURVEY.md 8d config 2 as the reference's cuCLARK-l builds it: k forced to 27 (main.cc:241-249), u32 keys, ~90 M k-mers
+    "light27": dict(htsize=57777779, genome_nt=90_000_000, n_genomes=512, n_targets=512, k=27, key_bytes=4,
+                    n_reads=10_000_000, read_len=150,
+                    name="10M x 150bp synthetic reads vs the CuCLARK-l table proper (HTSIZE 57777779, k=27, u32 keys, ~90M k-mers)"),
     # config 5 shape: paired-end 2 x 150 bp, every object = read 1 + 'N' + read 2 (file.cc:205-268), same table as "full"
     "paired": dict(htsize=1610612741, genome_nt=5_730_000_000, n_genomes=8192, n_targets=4096, k=31, key_bytes=4,
                    n_reads=10_000_000, read_len=150, paired=True,
@@ -67,6 +76,9 @@ WORKLOADS = {
                  n_reads=100_000, read_len=100,
                  name="100k x 100bp synthetic reads vs 50-target toy table (plumbing)"),
 }
+PART_MODE = {1: "table-sharded by on-disk bucket range", 2: "table-sharded by on-disk bucket range",
+             3: "table-sharded by resident slot range (a run of a read belongs to one rank)",
+             4: "table-sharded by resident slot range (a run of a read belongs to one rank)"}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 RANDOM_SECTOR_GREQ = 51.4      # measured: random 64-B nontemporal requests/s this chip sustains (tools/gather_runs_bench.hip)
 
@@ -272,10 +284,17 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the batch-API pipeline leg (N=1)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-in, CSV-out leg through exe/cuCLARK (N=1)")
     ap.add_argument("--e2e-threads", type=int, default=12, help="-n of the end-to-end run")
+    ap.add_argument("--no-parts-proxy", action="store_true",
+                    help="N=1: skip \"table_sharded_proxy\" (kernel time of part 0 of 2/4/8 of the table against all reads)")
+    ap.add_argument("--allow-variant-lib", action="store_true",
+                    help="accept MIC_LIB_PATH (a measuring build of the library, tools/*_sweep.sh); refused otherwise: the line must "
+                         "describe the product library")
     ap.add_argument("--no-db-leg", action="store_true",
                     help="N > 1, read mode: skip the extra table-sharded measurement reported as \"table_sharded\"")
     args = ap.parse_args()
 
+    if os.environ.get("MIC_LIB_PATH") and not args.allow_variant_lib:
+        sys.exit("bench.py: MIC_LIB_PATH is set (a measuring build of the library); unset it or pass --allow-variant-lib")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -284,7 +303,15 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # --mode db at N = 1 still goes through the collectives (a degenerate all_to_all, merge loop of length 0, the overflow
+    # all-gather): the RCCL path of the table-sharded mode runs on one GPU exactly as the driver launches it on eight
+    db_mode = args.mode == "db"
+    use_dist = world > 1 or db_mode
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -292,6 +319,10 @@ def main():
 
     from cuclark_amd import MiClarkDB, _lib, multi
     L = _lib.load()
+    import hashlib
+    with open(_lib.LIB_PATH, "rb") as f:
+        lib_id = {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "sha256_16": hashlib.sha256(f.read()).hexdigest()[:16],
+                  "variant": bool(os.environ.get("MIC_LIB_PATH"))}
     w = dict(WORKLOADS[args.workload])
     if args.reads:
         w["n_reads"] = args.reads
@@ -325,13 +356,13 @@ def main():
     layout = 0 if os.environ.get("MIC_LAYOUT") else LAYOUTS[args.layout]      # MIC_LAYOUT (tools/, tests) wins over the flag
     os.environ.setdefault("MIC_SUPER2_MAY_FALL_BACK", "1")
     eng = MiClarkDB(k, T, num_batches=PIPE_BATCHES, device=local_rank, row_words=row_words, layout=layout)
-    shard = (0, 0)
-    if args.mode == "db" and world > 1:
-        shard = multi.shard_range(w["htsize"], world, rank)
+    if db_mode and world > 1:
+        eng.set_part(rank, world)       # this rank's part of the table (super-k-mer layouts: a slot range of the resident table)
     t0 = time.time()
-    eng.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr(), shard=shard)
+    eng.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr())
     info = eng.info()
     t_build = time.time() - t0
+    build_stages = {a.strip(): float(b) for a, b in (ln.rsplit(":", 1) for ln in L.mic_db_last_build_report().decode().splitlines() if ":" in ln)}
 
     # ---- reads (packed containers) in HBM; read-sharded ranks draw different reads
     pitch = L.mic_synth_read_pitch(obj_len, k)
@@ -345,7 +376,7 @@ def main():
     assert rc == 0, f"mic_synth_reads_device failed ({rc})"
     torch.cuda.synchronize()
     d_res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
-    db_mode = args.mode == "db" and world > 1
+    n_flagged = [0]
     if db_mode:
         per_r = multi.read_range(n_reads, world, rank)[2]
         d_rows = multi.padded_rows(n_reads, world, row_words, dev)
@@ -375,9 +406,12 @@ def main():
     def step():
         if not db_mode:
             eng.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), 0, sptr)
+            # reads the kernel flagged (more than 64 targets) take the dense path INSIDE the step: part of the timed work
+            n_flagged[0] = eng.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), d_res.data_ptr(), 0, sptr)
             return
         # table-sharded: local sparse rows -> all_to_all by read range -> merge (sum by target) -> best/second
         eng.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), d_rows.data_ptr(), sptr)
+        n_flagged[0] = eng.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), d_res.data_ptr(), d_rows.data_ptr(), sptr)
         if args.backend == "nccl":
             multi.exchange_rows(d_rows, world, out=d_recv)
         else:
@@ -393,7 +427,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -415,7 +449,7 @@ def main():
         step()
         kernel_ms.append(eng.last_query_ms())
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -424,14 +458,16 @@ def main():
     value = total_reads / (elapsed / args.steps) / 1e6
 
     # ---- bookkeeping for the roofline: measured k-mers, hit rate, probed-bucket length (product-side kernel)
-    flagged = eng.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), d_res.data_ptr(), d_rows.data_ptr() if db_mode else 0, sptr)
+    flagged = n_flagged[0]
     st = eng.probe_stats_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads)
     kern_s = float(np.mean(kernel_ms)) / 1e3
     h = st["hits"] / max(st["probed"], 1)
     lam_q = st["bucket_len_sum"] / max(st["probed"], 1)
     key_b = w["key_bytes"]
     bytes_per_kmer = 8 + key_b * lam_q + 2 * h                      # bucket begin/end + keys of the bucket + label on hit
-    in_bytes = 2 * (d_cont.numel() - 64) / n_reads + 4              # packed read + pointer as laid out in HBM
+    # packed read + pointer as the packer emits them and the kernel addresses them (40 B + 4 B for 150 bp): one
+    # length slot + ceil(L / 8) containers + the pointer - not the generator's allocated pitch (76 B, mostly never touched)
+    in_bytes = 2 * (1 + (obj_len + 7) // 8) + 4
     alg_bytes = st["probed"] * bytes_per_kmer + n_reads * (in_bytes + 32)
     achieved = alg_bytes / kern_s / 1e9
     # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, tools/profile_bench.sh); the
@@ -441,9 +477,11 @@ def main():
     kname = {1: "query_kernel<", 2: "query_kernel_m<", 3: "query_kernel_s<", 4: "query_kernel_s<"}[info["layout"]]
     if info["layout"] in (3, 4):      # the instantiation the launcher picks (mic_kernels.hip: mic_launch_query)
         km = (k, info["minimizer_len"]) if (k in (31, 27, 32) and info["minimizer_len"] == 20) else (0, 0)
-        kname = f"query_kernel_s<{km[0]}, {km[1]}, {'true' if db_mode else 'false'}, {'true' if info['layout'] == 4 else 'false'}>"
-        if not db_mode and not os.environ.get("MIC_S_PER_KMER") and 32 < 2 * k - info["minimizer_len"] <= 48:
-            kname = f"query_kernel_r<{km[0]}, {km[1]}, {'true' if info['layout'] == 4 else 'false'}>"   # super-k-mer tables are probed per run
+        parted = info["n_parts"] > 1
+        two = info["layout"] == 4
+        kname = f"query_kernel_s<{km[0]}, {km[1]}, {'true' if parted else 'false'}, {'true' if two else 'false'}>"
+        if not os.environ.get("MIC_S_PER_KMER") and (two or 32 < 2 * k - info["minimizer_len"] <= 48):
+            kname = f"query_kernel_r<{km[0]}, {km[1]}, {'true' if two else 'false'}, {'true' if parted else 'false'}>"   # super-k-mer tables are probed per run
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_query_kernel.json")), reverse=True):
         try:
             pj = json.load(open(f))
@@ -507,7 +545,7 @@ def main():
 
     # ---- CPU baseline (rank 0, N=1): the oracle on this box's host cores, bounded sample; doubles as parity check
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not db_mode and not args.no_cpu:
         from oracle.binding import Oracle
         o = Oracle()
         t0 = time.time()
@@ -547,17 +585,71 @@ def main():
         assert equal, "GPU results differ from the CPU oracle on the sample"
 
     # ---- N = 1: the pipeline through the batch API and the end-to-end run through the CLI (SURVEY.md 8d ii, iii) -------
-    pipeline, e2e = None, None
-    if rank == 0 and world == 1:
+    pipeline, e2e, proxy, default_layout = None, None, None, None
+    if rank == 0 and world == 1 and not db_mode:
         if not args.no_pipeline:
             try:
                 pipeline = pipeline_leg(eng, L, d_rp, d_cont, n_reads, res, max(2, min(args.steps, 5)), PIPE_BATCHES)
             except Exception as ex:
                 pipeline = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             log("pipeline:", json.dumps(pipeline))
+        eng.close()
+        torch.cuda.empty_cache()
+
+        def kernel_ms_of(e, reps=3):
+            """HIP-event time of the query kernel of engine e on the bench's reads (mean of reps after one warm-up)"""
+            ms = []
+            for i in range(reps + 1):
+                e.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), 0, sptr)
+                e.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), d_res.data_ptr(), 0, sptr)
+                if i:
+                    ms.append(e.last_query_ms())
+            return float(np.mean(ms))
+        if not args.no_parts_proxy and info["layout"] in (3, 4):
+            # BASELINE config 4 on one GPU: what ONE rank of an N-GPU table-sharded run does - part 0 of N of the table
+            # (mic_db_set_part: a slot range of the resident table), ALL reads.  Per-rank kernel time is what the exchange and
+            # the merges are added to (DESIGN.md 6); hits_share says the part really answers for ~1/N of the k-mers.
+            try:
+                proxy = {"what": "HIP-event time of the query kernel of ONE rank of an N-way table-sharded run (part 0 of N of the table, "
+                                 "all reads), next to the whole table's", "whole_table_ms": round(kern_s * 1e3, 3), "parts": {}}
+                hits_whole = int(res[:, 0].astype(np.int64).sum())
+                for n_parts in (2, 4, 8):
+                    with MiClarkDB(k, T, device=local_rank, row_words=row_words, layout=layout) as ep:
+                        ep.set_part(0, n_parts)
+                        t0 = time.time()
+                        ep.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr())
+                        tb = time.time() - t0
+                        ms = kernel_ms_of(ep)
+                        pi = ep.info()
+                        hits = int(d_res[:, 0].to(torch.int64).sum().item())
+                    proxy["parts"][str(n_parts)] = {"kernel_ms": round(ms, 3), "vs_whole": round(ms / (kern_s * 1e3), 3),
+                                                     "part_hbm_GB": round(pi["hbm_bytes"] / 1e9, 2), "part_build_s": round(tb, 1),
+                                                     "hits_share": round(hits / max(hits_whole, 1), 4)}
+                    torch.cuda.empty_cache()
+            except Exception as ex:
+                proxy = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            log("table_sharded_proxy:", json.dumps(proxy))
+        if info["layout"] == 4 and not os.environ.get("MIC_LAYOUT"):
+            # `value` is quoted on the two-strand table; the command line (the end_to_end leg) builds the engine's AUTO layout,
+            # the one-strand table: its kernel on the same reads, so both legs of this line can be read against their own kernel
+            try:
+                with MiClarkDB(k, T, device=local_rank, row_words=row_words, layout=0) as ed:
+                    t0 = time.time()
+                    ed.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr())
+                    tb = time.time() - t0
+                    ms = kernel_ms_of(ed)
+                    di = ed.info()
+                    same = bool((d_res[:, :5].cpu().numpy().view(np.uint32) == res[:, :5]).all())
+                default_layout = {"layout": {1: "direct", 2: "minimizer", 3: "super (one strand)", 4: "super2"}[di["layout"]],
+                                  "value": round(n_reads / ms / 1e3, 1), "unit": "Mreads/s", "kernel_ms": round(ms, 3),
+                                  "hbm_GB": round(di["hbm_bytes"] / 1e9, 2), "table_build_s": round(tb, 1),
+                                  "results_equal_headline_table": same}
+            except Exception as ex:
+                default_layout = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            log("default_layout:", json.dumps(default_layout))
+            torch.cuda.empty_cache()
         if not args.no_e2e:
             try:
-                eng.close()              # the CLI builds its own resident table from the files
                 del d_res, d_cont, d_rp
                 torch.cuda.empty_cache()
                 e2e = end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res, truth, args.e2e_threads, paired=paired)
@@ -575,9 +667,9 @@ def main():
             del d_res
             torch.cuda.empty_cache()
             eng2 = MiClarkDB(k, T, device=local_rank, row_words=row_words, layout=layout)
+            eng2.set_part(rank, world)
             t0 = time.time()
-            eng2.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr(),
-                             shard=multi.shard_range(w["htsize"], world, rank))
+            eng2.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr())
             t_build2 = time.time() - t0
             info2 = eng2.info()
             rc = L.mic_synth_reads_device2(C.byref(spec), 5, n_reads, read_len, int(paired), 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
@@ -593,6 +685,7 @@ def main():
 
             def step_db():
                 eng2.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, r_res.data_ptr(), r_rows.data_ptr(), sptr)
+                eng2.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), r_res.data_ptr(), r_rows.data_ptr(), sptr)
                 if args.backend == "nccl":
                     multi.exchange_rows(r_rows, world, out=r_recv)
                 else:
@@ -625,7 +718,8 @@ def main():
             ok2 = (truth2[g2, 1] == 0) | ((allres[g2, 1] == truth2[g2, 0]) & (allres[g2, 2] >= truth2[g2, 1]))
             table_sharded = {"value": round(n_reads / (el2 / steps2) / 1e6, 3), "unit": "Mreads/s", "scaling": "strong",
                              "steps": steps2, "ms_per_step": round(el2 / steps2 * 1e3, 3),
-                             "mode": "table-sharded by bucket range + all_to_all of sparse rows + merge", "reads_total": n_reads,
+                             "mode": PART_MODE[info2["layout"]] + " + all_to_all of sparse rows + merge", "reads_total": n_reads,
+                             "kernel_ms_this_rank": round(eng2.last_query_ms(), 3),
                              "shard_hbm_GB": round(info2["hbm_bytes"] / 1e9, 2), "shard_build_s": round(t_build2, 1),
                              "exchange_MB_per_rank": round(r_rows.numel() * 4 * (world - 1) / world / 1e6, 1),
                              "known_answer": {"label_and_count_ok": float(ok2.mean()) if g2.any() else 1.0,
@@ -635,12 +729,12 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": f"Mreads/sec (10M x {'2x' if paired else ''}{read_len}bp{' pairs' if paired else ''}, k=31)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
+            "metric": f"Mreads/sec (10M x {'2x' if paired else ''}{read_len}bp{' pairs' if paired else ''}, k={k})", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if db_mode else "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": w["name"], "reads_per_gpu": n_reads, "read_len": read_len, "k": k,
-                       "mode": ("table-sharded by bucket range + all_to_all of sparse rows" if db_mode else
+                       "mode": (PART_MODE[info["layout"]] + " + all_to_all of sparse rows" if db_mode else
                                 ("read-sharded, table replicated" if world > 1 else "single GPU, table resident")),
                        "table": {"htsize": info["htsize"], "kmers": info["n_elems"], "slot_class": info["slot_class"],
                                  "layout": {1: "direct: one 64-B slot per on-disk bucket", 2: "minimizer-keyed 128-B slots", 3: "super-k-mer 128-B slots",
@@ -649,17 +743,22 @@ def main():
                                  "hbm_GB": round(info["hbm_bytes"] / 1e9, 2), "overflow_slots": info["n_overflow"],
                                  "max_bucket": info["max_bucket"], "on_disk_equiv_GB": round((info["htsize"] + n_el * (key_b + 2)) / 1e9, 2)},
                        "flagged_reads_dense_path": flagged,
-                       "setup_s": {"synth_db": round(t_gen, 1), "table_build": round(t_build, 1)}},
+                       "setup_s": {"synth_db": round(t_gen, 1), "table_build": round(t_build, 1), "table_build_stages": build_stages},
+                       "library": lib_id},
             "roofline": roofline, "cpu_baseline": cpu, "known_answer": known,
         }
         if pipeline is not None:
             out["pipeline"] = pipeline
         if e2e is not None:
             out["end_to_end"] = e2e
+        if proxy is not None:
+            out["table_sharded_proxy"] = proxy
+        if default_layout is not None:
+            out["default_layout"] = default_layout
         if table_sharded is not None:
             out["table_sharded"] = table_sharded
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

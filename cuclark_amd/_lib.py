@@ -36,7 +36,9 @@ class MicDbInfo(C.Structure):
                 ("n_elems", C.c_uint64), ("n_elems_file", C.c_uint64), ("n_slots", C.c_uint64),
                 ("n_overflow", C.c_uint64), ("hbm_bytes", C.c_uint64), ("key_bytes", C.c_int32),
                 ("slot_class", C.c_int32), ("max_bucket", C.c_uint32), ("sampling", C.c_uint32), ("layout", C.c_int32),
-                ("minimizer_len", C.c_int32), ("max_chain", C.c_uint32), ("reserved", C.c_uint32), ("n_entries", C.c_uint64)]
+                ("minimizer_len", C.c_int32), ("max_chain", C.c_uint32), ("reserved", C.c_uint32), ("n_entries", C.c_uint64),
+                ("part", C.c_uint32), ("n_parts", C.c_uint32), ("part_slot_lo", C.c_uint64), ("part_slot_hi", C.c_uint64),
+                ("n_slots_whole", C.c_uint64)]
 
 
 class MicSynthSpec(C.Structure):
@@ -62,8 +64,10 @@ SYMBOLS = [
     ("mic_db_load_files", C.c_int, [_VP, C.c_char_p, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64]),
     ("mic_db_load_host", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_int, _VP, C.c_uint32, C.c_uint64, C.c_uint64]),
     ("mic_db_load_device", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_int, _VP, C.c_uint32, C.c_uint64, C.c_uint64]),
+    ("mic_db_set_part", C.c_int, [_VP, C.c_uint32, C.c_uint32]),
     ("mic_db_get_info", C.c_int, [_VP, C.POINTER(MicDbInfo)]),
     ("mic_db_unload", C.c_int, [_VP]),
+    ("mic_db_last_build_report", C.c_char_p, []),
     ("mic_batches_alloc", C.c_int, [_VP, _SZ, _SZ, _SZ, _U32P, C.c_int, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP),
                                     C.POINTER(_VP)]),
     ("mic_batch_ready", C.c_int, [_VP, _SZ, _SZ, _SZ]),

@@ -787,11 +787,12 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   MBuildArgs a;
   const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
   struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
-  auto lap = [&](const char* what) {
-    if (!timing) return;
+  auto lap = [&](const char* what) {     // stage times: always into the build report (mic_db_last_build_report), on stderr with MIC_LOAD_TIMING
     hipStreamSynchronize(s);
     struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
-    fprintf(stderr, "[load]   %s: %.3f s\n", what, (t.tv_sec - t_prev.tv_sec) + (t.tv_nsec - t_prev.tv_nsec) / 1e9);
+    const double dt = (t.tv_sec - t_prev.tv_sec) + (t.tv_nsec - t_prev.tv_nsec) / 1e9;
+    mic_build_report_add(what, dt);
+    if (timing) fprintf(stderr, "[load]   %s: %.3f s\n", what, dt);
     t_prev = t;
   };
   HIPCK(hipMalloc(&d_a, sizeof(TileA) * n_tiles));
@@ -921,10 +922,16 @@ static hipError_t scan_u32_to_u64(const uint32_t* in, unsigned long long* out, u
 
 int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
                      int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
-                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap, int allow_fallback, int both_strands) {
+                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap, int allow_fallback, int both_strands,
+                     uint32_t part, uint32_t n_parts) {
   int rc = 0;
   const unsigned n_tiles = (unsigned)((n_buckets + TILE - 1) / TILE);
   TileA* d_a = nullptr; uint32_t* d_cnt = nullptr; uint32_t* d_cur = nullptr; unsigned long long* d_off = nullptr;
+  // Slot-range part (table-sharded runs): the table is sized from the WHOLE database - every engine of a
+  // sharded run computes the same n_slots - but only the main slots [part_lo, part_hi) and their continuation slots are
+  // built and kept.  Slot indices stay global ("virtual": the slot pointer handed out is the allocation minus part_lo
+  // slots), so the query kernels need nothing but the range test.
+  uint64_t part_lo = 0, part_hi = 0, n_part = 0; unsigned long long off_lo = 0, off_hi = 0;
   unsigned long long* d_coff = nullptr; unsigned long long* d_scal = nullptr; uint32_t* d_max = nullptr;
   unsigned long long* d_ck = nullptr; uint32_t* d_cm = nullptr; uint32_t* slots = nullptr; uint32_t* d_dem = nullptr;
   std::vector<TileA> h_a(n_tiles);
@@ -935,11 +942,12 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   MBuildArgs a;
   const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
   struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
-  auto lap = [&](const char* what) {
-    if (!timing) return;
+  auto lap = [&](const char* what) {     // stage times: always into the build report (mic_db_last_build_report), on stderr with MIC_LOAD_TIMING
     hipStreamSynchronize(s);
     struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
-    fprintf(stderr, "[load]   %s: %.3f s\n", what, (t.tv_sec - t_prev.tv_sec) + (t.tv_nsec - t_prev.tv_nsec) / 1e9);
+    const double dt = (t.tv_sec - t_prev.tv_sec) + (t.tv_nsec - t_prev.tv_nsec) / 1e9;
+    mic_build_report_add(what, dt);
+    if (timing) fprintf(stderr, "[load]   %s: %.3f s\n", what, dt);
     t_prev = t;
   };
 #define BY_RAW(KERN, ...) do { if (key_bytes == 8) KERN<uint64_t><<<n_tiles, TILE, 0, s>>>(__VA_ARGS__); \
@@ -1001,6 +1009,13 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     HIPCK(hipMemcpy(&last_cnt, d_cnt + n_slots - 1, 4, hipMemcpyDeviceToHost));
     n_cand = last_off + last_cnt;
   }
+  if (n_parts > 1) {
+    part_lo = (uint64_t)((unsigned __int128)n_slots * part / n_parts);
+    part_hi = (uint64_t)((unsigned __int128)n_slots * (part + 1) / n_parts);
+    HIPCK(hipMemcpy(&off_lo, d_off + part_lo, 8, hipMemcpyDeviceToHost));
+    if (part_hi < n_slots) HIPCK(hipMemcpy(&off_hi, d_off + part_hi, 8, hipMemcpyDeviceToHost)); else off_hi = n_cand;
+  } else { part_lo = 0; part_hi = n_slots; off_lo = 0; off_hi = n_cand; }
+  n_part = part_hi - part_lo;
   {
     // What must fit next to what is resident already: the table (128 B per slot, ~1 % continuation slots), 32 B of per-slot
     // arrays, and a staging area of 12 B per candidate.  When all candidates do not fit at once the staging area takes what
@@ -1012,18 +1027,19 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       const double lim = atof(env) * 1e9;
       if (lim > 0 && avail_b > lim) avail_b = lim;
     }
-    const double fixed = (double)n_slots * (128 * 1.02 + 24) + 64e6;    // table + chain offsets / cursors / entry counts (counts and offsets exist already)
+    const double fixed = (double)n_part * (128 * 1.02) + (double)n_slots * 24 + 64e6;    // table + chain offsets / cursors / entry counts (counts and offsets exist already)
     double budget = avail_b - fixed;
     if (const char* env = getenv("MIC_S_STAGING_LIMIT_MB")) {           // test hook: a small staging area forces several passes
       const double lim = atof(env) * 1e6;
       if (lim > 0 && budget > lim) budget = lim;
     }
-    if (budget < (double)n_cand * 12 / 16 || budget < 4096) {
+    const uint64_t n_cand_part = off_hi - off_lo;
+    if (budget < (double)n_cand_part * 12 / 16 || budget < 4096) {
       snprintf(err, err_cap, "the super-k-mer table and its build need at least %.3f GB, %.3f GB of HBM are available",
-               (fixed + (double)n_cand * 12 / 16) / 1e9, avail_b / 1e9);
+               (fixed + (double)n_cand_part * 12 / 16) / 1e9, avail_b / 1e9);
       rc = -3; goto done;
     }
-    stage_cap = (double)n_cand * 12 <= budget ? n_cand : (uint64_t)(budget / 12);
+    stage_cap = (double)n_cand_part * 12 <= budget ? n_cand_part : (uint64_t)(budget / 12);
   }
   {
     // slot ranges whose candidates fit the staging area: boundaries at multiples of G slots (2^16 for a large table), from a
@@ -1034,20 +1050,21 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     std::vector<unsigned long long> samp(n_samples);
     HIPCK(hipMemcpy2D(samp.data(), 8, d_off, 8 * G, 8, n_samples, hipMemcpyDeviceToHost));
     range_lo.clear(); range_base.clear();
-    uint64_t lo = 0; unsigned long long lo_off = 0;
-    while (lo < n_slots) {
-      // largest multiple of G (or the end) whose offset stays within the staging capacity
-      uint64_t hi = n_slots;
-      if (n_cand - lo_off > stage_cap) {
+    uint64_t lo = part_lo; unsigned long long lo_off = off_lo;
+    while (lo < part_hi) {
+      // largest multiple of G below the end of the part (or that end) whose offset stays within the staging capacity
+      uint64_t hi = part_hi; unsigned long long hi_off = off_hi;
+      if (off_hi - lo_off > stage_cap) {
         uint64_t g = lo / G + 1;
-        while (g < n_samples && samp[g] - lo_off <= stage_cap) ++g;
+        while (g < n_samples && g * G < part_hi && samp[g] - lo_off <= stage_cap) ++g;
         hi = (g - 1) * G;
         if (hi <= lo) { snprintf(err, err_cap, "a block of %llu slots holds more candidates than the staging area", (unsigned long long)G); rc = -3; goto done; }
+        hi_off = samp[g - 1];
       }
       range_lo.push_back(lo); range_base.push_back(lo_off);
-      lo = hi; lo_off = hi < n_slots ? samp[hi / G] : n_cand;
+      lo = hi; lo_off = hi_off;
     }
-    range_lo.push_back(n_slots); range_base.push_back(n_cand);
+    range_lo.push_back(part_hi); range_base.push_back(off_hi);
     n_ranges = range_lo.size() - 1;
     uint64_t biggest = 0;
     for (size_t r = 0; r < n_ranges; ++r) biggest = std::max<uint64_t>(biggest, range_base[r + 1] - range_base[r]);
@@ -1061,6 +1078,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   HIPCK(hipMalloc(&d_cur, n_slots * 4));      // scatter cursors
   HIPCK(hipMalloc(&d_nent, n_slots * 4));     // entries per slot
   HIPCK(hipMemsetAsync(d_cur, 0, n_slots * 4, s));
+  if (n_part != n_slots) HIPCK(hipMemsetAsync(d_nent, 0, n_slots * 4, s));   // slots of other parts: no entries, no chains
   HIPCK(hipMemsetAsync(d_max, 0, 4, s));
   // One pass when it works: the table is allocated with a pool of continuation slots (2 % of the main slots; Poisson(1.5)
   // entries per slot needs 0.1 %) and every range is scattered, sorted, merged and WRITTEN in one go - no counting merge, and
@@ -1068,25 +1086,26 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   // minimizers, which the rule below hands to the minimizer layout anyway) or an allocation that fails falls back to the
   // two-pass form: count the entries, size the chains exactly, write.  MIC_S_TWO_PASS=1 forces that form.
   if (!getenv("MIC_S_TWO_PASS")) {
-    uint64_t pool_cap = n_slots / 50 + 65536;
+    uint64_t pool_cap = n_part / 50 + 65536;
     if (const char* env = getenv("MIC_S_POOL_SLOTS")) { long v = atol(env); if (v > 0) pool_cap = (uint64_t)v; }   // test hook: a pool that runs out
-    if (n_slots + pool_cap > 0xFFFFFF00ull) pool_cap = 0xFFFFFF00ull > n_slots ? 0xFFFFFF00ull - n_slots : 0;
+    if (part_hi + pool_cap > 0xFFFFFF00ull) pool_cap = 0xFFFFFF00ull > part_hi ? 0xFFFFFF00ull - part_hi : 0;
     uint32_t* d_pool = nullptr;
-    hipError_t e_ = pool_cap ? hipMalloc(&slots, (size_t)(n_slots + pool_cap + 1) * 128) : hipErrorOutOfMemory;
+    hipError_t e_ = pool_cap ? hipMalloc(&slots, (size_t)(n_part + pool_cap + 1) * 128) : hipErrorOutOfMemory;
     if (e_ == hipSuccess) e_ = hipMalloc(&d_pool, 8);
     if (e_ == hipSuccess) e_ = hipMemsetAsync(d_pool, 0, 8, s);
+    lap("offsets scan + staging / cursor / table allocations (hipMalloc waits for the driver's wipe of freed pages)");
     if (e_ == hipSuccess) {
       for (size_t r = 0; r < n_ranges && e_ == hipSuccess; ++r) {
         const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
         BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
-        s_merge_kernel<2><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_nent, nullptr, slots,
+        s_merge_kernel<2><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, nullptr, slots - part_lo * 32,
                                                                            d_max, lo, hi, range_base[r], 1, d_pool, (uint32_t)pool_cap);
         e_ = hipGetLastError();
       }
       uint32_t h_pool[2] = {0, 0};
       if (e_ == hipSuccess) e_ = hipMemcpyAsync(h_pool, d_pool, 8, hipMemcpyDeviceToHost, s);
       if (e_ == hipSuccess) e_ = hipStreamSynchronize(s);
-      if (e_ == hipSuccess && !h_pool[1]) { one_pass = true; n_chain = h_pool[0]; alloc_slots = n_slots + pool_cap + 1; }
+      if (e_ == hipSuccess && !h_pool[1]) { one_pass = true; n_chain = h_pool[0]; alloc_slots = n_part + pool_cap + 1; }
     }
     if (d_pool) hipFree(d_pool);
     if (!one_pass) {
@@ -1102,7 +1121,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
     BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
     HIPCK(hipGetLastError());
-    s_merge_kernel<0><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_nent, nullptr,
+    s_merge_kernel<0><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, nullptr,
                                                                        nullptr, d_max, lo, hi, range_base[r], 1, nullptr, 0);
     HIPCK(hipGetLastError());
   }
@@ -1117,7 +1136,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     s_walk_kernel<<<4096, 256, 0, s>>>(d_cnt, d_nent, n_slots, d_scal);
     HIPCK(hipMemcpyAsync(&h_walk, d_scal, 8, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
-    const double walk = n_cand ? (double)h_walk / (double)n_cand : 0.0;
+    const double walk = off_hi > off_lo ? (double)h_walk / (double)(off_hi - off_lo) : 0.0;
     out->walk_ppm = walk * 1e6 > 4e9 ? 4000000000u : (uint32_t)(walk * 1e6);
     // A table whose stored k-mers sit, on average, behind more than this many continuation slots is answered faster by the
     // minimizer layout (fan-out-12 trees: logarithmic in the bucket size): measured with tandem repeats in the targets,
@@ -1153,13 +1172,13 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     HIPCK(e);
     n_chain = last_off + last_dem;
   }
-  if (n_slots + n_chain > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many S-slots"); rc = -1; goto done; }
+  if (part_hi + n_chain > 0xFFFFFF00ull) { snprintf(err, err_cap, "too many S-slots"); rc = -1; goto done; }
   if (!one_pass) {
-    hipError_t e_ = hipMalloc(&slots, (size_t)(n_slots + n_chain + 1) * 128);
+    hipError_t e_ = hipMalloc(&slots, (size_t)(n_part + n_chain + 1) * 128);
     if (e_ != hipSuccess) {
       (void)hipGetLastError();
       snprintf(err, err_cap, "hipMalloc of %.2f GB for the super-k-mer table failed: %s",
-               (double)(n_slots + n_chain + 1) * 128 / 1e9, hipGetErrorString(e_));
+               (double)(n_part + n_chain + 1) * 128 / 1e9, hipGetErrorString(e_));
       rc = -3; goto done;
     }
   }
@@ -1171,15 +1190,16 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
       HIPCK(hipGetLastError());
     }
-    s_merge_kernel<1><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, n_slots, d_ck, d_cm, k, m, d_nent, d_coff,
-                                                                       slots, d_max, lo, hi, range_base[r], n_ranges > 1 ? 1 : 0, nullptr, 0);
+    s_merge_kernel<1><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, d_coff,
+                                                                       slots - part_lo * 32, d_max, lo, hi, range_base[r], n_ranges > 1 ? 1 : 0, nullptr, 0);
     HIPCK(hipGetLastError());
   }
-  HIPCK(hipMemsetAsync(slots + (size_t)(n_slots + n_chain) * 32, 0xFF, 128, s));   // the spare slot after the table: empty
+  HIPCK(hipMemsetAsync(slots + (size_t)(n_part + n_chain) * 32, 0xFF, 128, s));   // the spare slot after the table: empty
   HIPCK(hipStreamSynchronize(s));
   if (!one_pass) lap("merge (write)");
 #undef BY_RAW
   out->slots = (uint4*)slots; slots = nullptr;
+  out->part_lo = part_lo; out->part_hi = part_hi;
   out->n_main = n_slots; out->n_overflow = n_chain; out->n_elems = h_scal[0]; out->n_elems_file = tot_elems;
   out->max_bucket = 0; out->max_chain = h_max; out->n_entries = h_entries; out->alloc_slots = alloc_slots;
 done:

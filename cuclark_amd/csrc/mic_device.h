@@ -166,20 +166,42 @@ __device__ __forceinline__ void s_candidates_fwd(uint64_t c, int k, int m, F&& f
   }
 }
 
-// sequential lookup (dense fallback, statistics, tests of the build): label + 1 or 0
-__device__ inline uint32_t s_probe(const uint4* __restrict__ slots, uint32_t n_slots, uint64_t c, int k, int m, bool fwd = false) {
-  uint64_t K = 0, x = 0; int j = -1;
-  if (fwd) s_candidates_fwd(c, k, m, [&](uint64_t kk, int jj, uint64_t xx) { if (j < 0) { K = kk; j = jj; x = xx; } });
-  else s_candidates(c, k, m, [&](uint64_t kk, int jj, uint64_t xx) { if (j < 0) { K = kk; j = jj; x = xx; } });
+// The lookup the QUERY KERNELS perform for the k-mer K that reads at nucleotide `tpos` of its read part, done sequentially
+// (dense fallback, statistics).  The kernels' sliding minimum runs over keys order27 << 5 | strand << 4 | position & 15, so
+// m-mers that tie on the 27 bits are resolved by strand and position (mod 16; the window holds at most 16 m-mers and chunks
+// start at multiples of 128, so the key is a function of tpos + i).  The table stores a k-mer under EVERY tied position, so
+// any choice finds it; but in a table-sharded run the tied positions may hash to slots of DIFFERENT parts, and the parts'
+// counts only add up if every path - per-run kernel, per-k-mer kernel, this one - makes the same choice.
+//   parted: only the main slots [slot_lo, slot_lo + slot_cnt) are resident (slots = allocation - slot_lo slots); *mine tells
+//   whether the chosen slot is.
+__device__ inline uint32_t s_probe_read(const uint4* __restrict__ slots, uint32_t n_slots, bool parted, uint32_t slot_lo,
+                                        uint32_t slot_cnt, uint64_t K, uint32_t tpos, int k, int m, bool fwd, bool* mine) {
   const int w = k - m + 1;
+  const uint64_t mask = (1ULL << (2 * m)) - 1;
+  const uint64_t rc = fwd ? 0 : revcomp_bits(K, k);
+  uint32_t best = 0xFFFFFFFFu; int bi = 0; uint64_t x = 0; bool rev = false;
+  for (int i = 0; i < w; ++i) {
+    const uint64_t mf = (K >> (2 * (k - m - i))) & mask;
+    uint64_t u = mf; uint32_t sb = 0;
+    if (!fwd) {
+      const uint64_t mr = (rc >> (2 * i)) & mask;          // reverse complement of m-mer i = m-mer w-1-i of rc(K)
+      if (!(mf < mr)) { u = mr; sb = 16u; }
+    }
+    const uint32_t key = (mmer_order_key_canon(u) & ~31u) | sb | ((tpos + (uint32_t)i) & 15u);
+    if (key < best) { best = key; bi = i; x = u; rev = sb != 0; }
+  }
+  const uint64_t Kq = rev ? rc : K;
+  const int j = rev ? w - 1 - bi : bi;
   uint64_t slot = sslot_of_x(x, n_slots);
+  if (parted && (uint32_t)slot - slot_lo >= slot_cnt) { *mine = false; return 0; }
+  *mine = true;
   for (;;) {
     const uint32_t* q = (const uint32_t*)(slots + slot * 8);
     for (int e = 0; e < MIC_S_CAP; ++e) {
       if (q[e] != (uint32_t)x) continue;
       const uint32_t pl = q[24 + e];
       if (!((pl >> (16 + j)) & 1)) continue;
-      if (s_extract(q[6 + 3 * e], q[7 + 3 * e], q[8 + 3 * e], w - 1 - j, k) == K) return (pl & 0xFFFFu) + 1;
+      if (s_extract(q[6 + 3 * e], q[7 + 3 * e], q[8 + 3 * e], w - 1 - j, k) == Kq) return (pl & 0xFFFFu) + 1;
     }
     if (!(q[30] & MIC_S_NEXT)) return 0;
     slot = q[31];

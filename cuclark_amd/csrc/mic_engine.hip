@@ -34,6 +34,9 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+std::mutex g_report_mu;
+std::string g_report;     // stage times of the last table build of this process, one "name: seconds" per line
+
 #define HIPTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     return fail(e_ == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 
@@ -78,6 +81,7 @@ struct mic_engine {
   bool timed = false;
   size_t last_n_reads = 0;
   void* ingest = nullptr;      // device-side ingest state (mic_ingest.hip)
+  uint32_t part = 0, n_parts = 0;   // mic_db_set_part: this engine answers for part `part` of `n_parts` of the database
 };
 
 namespace {
@@ -92,7 +96,11 @@ int set_device(const mic_engine* e) {
 void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s0, uint64_t s1, int key_bytes,
                 uint32_t sampling, int layout, int m) {
   e->slots = b.slots;
-  e->table.slots = b.slots;
+  const bool parted = (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2) && (b.part_lo != 0 || b.part_hi != b.n_main);
+  // a slot-range part is addressed by GLOBAL slot indices: the table pointer is the allocation minus the slots in front of it
+  e->table.slots = parted ? b.slots - (ptrdiff_t)b.part_lo * 8 : b.slots;
+  e->table.slot_lo = parted ? (uint32_t)b.part_lo : 0; e->table.slot_cnt = parted ? (uint32_t)(b.part_hi - b.part_lo) : 0;
+  e->table.parted = parted ? 1 : 0;
   e->table.n_main = b.n_main;
   e->table.shard_start = s0;
   e->table.shard_end = s1;
@@ -106,8 +114,11 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   mic_db_info& i = e->info;
   i.htsize = htsize; i.shard_start = s0; i.shard_end = s1;
   i.n_elems = b.n_elems; i.n_elems_file = b.n_elems_file;
-  i.n_slots = b.n_main + b.n_overflow; i.n_overflow = b.n_overflow;
-  i.hbm_bytes = (b.alloc_slots ? b.alloc_slots : b.n_main + b.n_overflow + 1) * (uint64_t)(layout != MIC_LAYOUT_DIRECT ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
+  const uint64_t n_res = parted ? b.part_hi - b.part_lo : b.n_main;    // main slots resident here
+  i.n_slots = n_res + b.n_overflow; i.n_overflow = b.n_overflow;
+  i.part = e->n_parts > 1 ? e->part : 0; i.n_parts = e->n_parts > 1 ? e->n_parts : 0;
+  i.part_slot_lo = parted ? b.part_lo : 0; i.part_slot_hi = parted ? b.part_hi : 0; i.n_slots_whole = b.n_main;
+  i.hbm_bytes = (b.alloc_slots ? b.alloc_slots : n_res + b.n_overflow + 1) * (uint64_t)(layout != MIC_LAYOUT_DIRECT ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
   i.key_bytes = key_bytes; i.slot_class = layout != MIC_LAYOUT_DIRECT ? 128 : e->slot_class; i.max_bucket = b.max_bucket;
   i.sampling = sampling; i.layout = layout; i.minimizer_len = layout != MIC_LAYOUT_DIRECT ? m : 0;
   i.max_chain = layout != MIC_LAYOUT_DIRECT ? b.max_chain : 0; i.reserved = (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2) ? b.walk_ppm : 0;
@@ -174,16 +185,10 @@ int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStrea
   return rc;
 }
 
-int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsize, uint64_t s0, uint64_t s1,
-                      const void* d_keys_shard, int key_bytes, const uint16_t* d_labels_shard, uint32_t sampling,
-                      uint64_t rank_base) {
-  e->slot_class = key_bytes == 8 ? 64 : 32;
-  MicBuildOut b;
-  memset(&b, 0, sizeof(b));
-  char err[256] = "";
-  // layout: explicit request, else the environment (MIC_LAYOUT=direct|minimizer), else by k
-  int layout = (int)e->cfg.layout;
-  bool by_default = false;   // nobody asked for this layout: a table that does not fit may fall back to the other one
+// layout: explicit request, else the environment (MIC_LAYOUT=direct|minimizer|super|super2), else by k
+void decide_layout(const mic_engine* e, int& layout, bool& by_default, int& m, int& m0) {
+  layout = (int)e->cfg.layout;
+  by_default = false;   // nobody asked for this layout: a table that does not fit may fall back to the other one
   if (layout == MIC_LAYOUT_AUTO) {
     const char* env = getenv("MIC_LAYOUT");
     if (env && !strcmp(env, "direct")) layout = MIC_LAYOUT_DIRECT;
@@ -192,16 +197,48 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
     else if (env && !strcmp(env, "super2")) layout = MIC_LAYOUT_SUPER2;
     else { layout = e->cfg.k >= 24 ? MIC_LAYOUT_SUPER : MIC_LAYOUT_DIRECT; by_default = true; }  // measured: DESIGN.md §3
   }
-  int m = 20;   // measured best for k = 31: minimizers long enough to be nearly unique in the table
+  m = 20;   // measured best for k = 31: minimizers long enough to be nearly unique in the table
   if (const char* env = getenv("MIC_MINIMIZER_LEN")) m = atoi(env);
   if (m > e->cfg.k - 4) m = e->cfg.k - 4;   // window w = k-m+1 >= 5
   if (m > 31) m = 31;
   if (layout == MIC_LAYOUT_MINIMIZER && (m < 8 || e->cfg.k - m + 1 > 64)) layout = MIC_LAYOUT_DIRECT;
-  const int m0 = m;
+  m0 = m;
   if (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2) {          // the super-k-mer entries hold windows of at most 16 m-mers
     if (m < e->cfg.k - 15) m = e->cfg.k - 15;
     if (m < 8 || m > 31 || e->cfg.k - m + 1 < 2) layout = MIC_LAYOUT_DIRECT;
   }
+  // parts of a table-sharded run: every engine must arrive at the same layout, so nothing depends on what fits where
+  if (e->n_parts > 1) by_default = false;
+}
+
+// mic_db_set_part: the super-k-mer layouts split their RESIDENT table by slot range inside the build (the images stay whole);
+// the other layouts answer for the part's share of the on-disk buckets, the reference's split (CuClarkDB.cu:566-574)
+int apply_part(const mic_engine* e, uint64_t htsize, uint64_t& s0, uint64_t& s1) {
+  if (e->n_parts <= 1) return MIC_OK;
+  if (s0 != 0 || s1 != htsize) return fail(MIC_E_INVALID, "mic_db_set_part and an explicit bucket range exclude each other");
+  int layout, m, m0; bool by_default;
+  decide_layout(e, layout, by_default, m, m0);
+  if (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2) return MIC_OK;
+  if (htsize < e->n_parts) return fail(MIC_E_INVALID, "more parts (%u) than buckets (%llu)", e->n_parts, (unsigned long long)htsize);
+  s0 = (uint64_t)((unsigned __int128)htsize * e->part / e->n_parts);
+  s1 = (uint64_t)((unsigned __int128)htsize * (e->part + 1) / e->n_parts);
+  return MIC_OK;
+}
+
+int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsize, uint64_t s0, uint64_t s1,
+                      const void* d_keys_shard, int key_bytes, const uint16_t* d_labels_shard, uint32_t sampling,
+                      uint64_t rank_base) {
+  e->slot_class = key_bytes == 8 ? 64 : 32;
+  MicBuildOut b;
+  memset(&b, 0, sizeof(b));
+  char err[256] = "";
+  { std::lock_guard<std::mutex> lk(g_report_mu); g_report.clear(); }
+  struct timespec t_b0; clock_gettime(CLOCK_MONOTONIC, &t_b0);
+  int layout, m, m0; bool by_default;
+  decide_layout(e, layout, by_default, m, m0);
+  // slot-range part (mic_db_set_part) of a super-k-mer table; the other layouts were given their bucket range by the caller
+  const bool slot_part = e->n_parts > 1 && (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2);
+  const uint32_t part = slot_part ? e->part : 0, n_parts = slot_part ? e->n_parts : 0;
   if (e->d_sizes) { hipFree(e->d_sizes); e->d_sizes = nullptr; }
   if (hipMalloc(&e->d_sizes, s1 - s0) == hipSuccess)
     hipMemcpyAsync(e->d_sizes, d_sizes_shard, s1 - s0, hipMemcpyDeviceToDevice, e->stream);
@@ -211,13 +248,13 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   if (layout == MIC_LAYOUT_SUPER2) {
     // both strands stored: the fastest kernel, twice the entries; falls back to the one-strand table when it does not fit
     rc = mic_build_stable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
-                          e->cfg.k, m, e->stream, &b, err, sizeof(err), by_default ? 1 : 0, 1);
-    if (rc == -3 && (by_default || getenv("MIC_SUPER2_MAY_FALL_BACK"))) { layout = MIC_LAYOUT_SUPER; memset(&b, 0, sizeof(b)); }
+                          e->cfg.k, m, e->stream, &b, err, sizeof(err), by_default ? 1 : 0, 1, part, n_parts);
+    if (rc == -3 && !slot_part && (by_default || getenv("MIC_SUPER2_MAY_FALL_BACK"))) { layout = MIC_LAYOUT_SUPER; memset(&b, 0, sizeof(b)); }
     else if (rc == -5 && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; }
   }
   if (layout == MIC_LAYOUT_SUPER) {
     rc = mic_build_stable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
-                          e->cfg.k, m, e->stream, &b, err, sizeof(err), by_default ? 1 : 0, 0);
+                          e->cfg.k, m, e->stream, &b, err, sizeof(err), by_default ? 1 : 0, 0, part, n_parts);
     // -3: does not fit; -5: crowded minimizers (tandem repeats): the minimizer layout's trees answer those faster
     if ((rc == -3 || rc == -5) && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; }
   }
@@ -232,6 +269,8 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
                          e->slot_class, e->stream, &b, err, sizeof(err));
   if (rc != 0) return fail(rc, "table build: %s", err);
   fill_table(e, b, htsize, s0, s1, key_bytes, sampling, layout, m);
+  { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    mic_build_report_add("table build, total", (t.tv_sec - t_b0.tv_sec) + (t.tv_nsec - t_b0.tv_nsec) / 1e9); }
   return MIC_OK;
 }
 
@@ -370,6 +409,13 @@ int mic_engine_table(mic_engine* e, MicTable* t, int* slot_class, int* n_cu, int
 void** mic_engine_ingest_slot(mic_engine* e) { return &e->ingest; }
 void mic_engine_copy_streams(mic_engine* e, hipStream_t* up, hipStream_t* down) { *up = e->up_stream; *down = e->down_stream; }
 
+void mic_build_report_add(const char* what, double seconds) {
+  char line[256];
+  snprintf(line, sizeof(line), "%s: %.4f\n", what, seconds);
+  std::lock_guard<std::mutex> lk(g_report_mu);
+  g_report += line;
+}
+
 extern "C" {
 
 const char* mic_last_error(void) { return g_err; }
@@ -457,6 +503,22 @@ int mic_db_get_info(const mic_engine* e, mic_db_info* info) {
   return MIC_OK;
 }
 
+const char* mic_db_last_build_report(void) {
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> lk(g_report_mu);
+  copy = g_report;
+  return copy.c_str();
+}
+
+int mic_db_set_part(mic_engine* e, uint32_t part, uint32_t n_parts) {
+  if (!e) return fail(MIC_E_INVALID, "null engine");
+  if (n_parts > 1 && part >= n_parts) return fail(MIC_E_INVALID, "part %u of %u", part, n_parts);
+  if (n_parts > 65536) return fail(MIC_E_INVALID, "too many parts");
+  if (e->db_loaded) return fail(MIC_E_STATE, "set the part before the database is loaded");
+  e->part = n_parts > 1 ? part : 0; e->n_parts = n_parts > 1 ? n_parts : 0;
+  return MIC_OK;
+}
+
 int mic_db_load_device(mic_engine* e, const uint8_t* d_sizes, uint64_t htsize, const void* d_keys, int key_bytes,
                        const uint16_t* d_labels, uint32_t sampling, uint64_t s0, uint64_t s1) {
   if (!e || !d_sizes || !d_keys || !d_labels) return fail(MIC_E_INVALID, "null argument");
@@ -464,6 +526,7 @@ int mic_db_load_device(mic_engine* e, const uint8_t* d_sizes, uint64_t htsize, c
   int rc = set_device(e);
   if (rc) return rc;
   if ((rc = check_shard(htsize, s0, s1))) return rc;
+  if ((rc = apply_part(e, htsize, s0, s1))) return rc;
   if (e->db_loaded) mic_db_unload(e);
   uint64_t base_elems = 0, base_rank = 0;
   if (s0 > 0 && mic_reduce_sizes(d_sizes, s0, &base_elems, &base_rank, e->stream) != 0)
@@ -479,6 +542,7 @@ int mic_db_load_host(mic_engine* e, const uint8_t* sizes, uint64_t htsize, const
   int rc = set_device(e);
   if (rc) return rc;
   if ((rc = check_shard(htsize, s0, s1))) return rc;
+  if ((rc = apply_part(e, htsize, s0, s1))) return rc;
   if (e->db_loaded) mic_db_unload(e);
   uint64_t base_elems = 0, base_rank = 0, n_el = 0;
   for (uint64_t i = 0; i < s0; ++i) { base_elems += sizes[i]; base_rank += sizes[i] > 0; }
@@ -524,6 +588,7 @@ int mic_db_load_files(mic_engine* e, const char* prefix, int key_bytes, uint32_t
     uint64_t htsize = (uint64_t)ftello(fs);
     fseeko(fs, 0, SEEK_SET);
     if ((rc = check_shard(htsize, s0, s1))) break;
+    if ((rc = apply_part(e, htsize, s0, s1))) break;
     if (key_bytes == 0) key_bytes = mic_key_bytes_rule(htsize, e->cfg.k);
     if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) { rc = fail(MIC_E_INVALID, "key_bytes must be 2, 4 or 8"); break; }
     h_sz = (uint8_t*)malloc(htsize);

@@ -95,6 +95,11 @@ struct MicTable {
   int m;                 // minimizer length (layout 1)
   int sharded;           // 1 if [shard_start, shard_end) is a strict subset of the table
   int fwd;               // layout 2: both strands stored under forward-strand minimizers (mic_device.h: s_candidates_fwd)
+  // layout 2, slot-range part (table-sharded runs): only the main slots [slot_lo, slot_lo + slot_cnt) of the n_main the
+  // minimizer hash spreads over are resident; `slots` is then the allocation MINUS slot_lo slots, so global slot indices
+  // (and the continuation indices stored in word 31) address it directly.  slot_cnt == 0: the whole table is here.
+  uint32_t slot_lo, slot_cnt;
+  int parted;            // 1: slot-range part as above (slot_cnt may be 0: an empty part answers nothing)
   const uint8_t* sizes;  // kept copy of the shard's on-disk bucket sizes (statistics only)
 };
 
@@ -109,6 +114,9 @@ struct MicQueryArgs {
   uint32_t* flagged;    // [0] = count, [1..] = read ids needing the dense path (or nullptr)
   uint32_t flagged_cap;
 };
+
+// stage times of the table build in progress (mic_engine.hip; read back with mic_db_last_build_report)
+void mic_build_report_add(const char* what, double seconds);
 
 // launchers (mic_kernels.hip)
 hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hipStream_t s);
@@ -133,6 +141,7 @@ struct MicBuildOut {
   uint32_t max_chain;   // layout 1: entries in the fullest slot chain
   uint32_t walk_ppm;    // super-k-mer table: mean continuation slots in front of a stored k-mer, x 1e6
   uint64_t n_entries;   // super-k-mer table: entries (super-k-mers) stored; other layouts: 0 (= one entry per k-mer)
+  uint64_t part_lo, part_hi; // super-k-mer table built as a slot-range part: the main slots [part_lo, part_hi) of n_main are resident (else 0, n_main)
   uint64_t alloc_slots; // slots allocated when that is more than n_main + n_overflow + 1 (one-pass super-k-mer build: the unused part of its continuation pool), else 0
 };
 // d_sizes/d_keys/d_labels point at the first bucket / first element of the shard.
@@ -147,7 +156,10 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
 // Super-k-mer table (layout 3, mic_device.h) from the same inputs.
 int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const void* d_keys,
                      int key_bytes, const uint16_t* d_labels, uint32_t sampling, uint64_t rank_base, int k, int m,
-                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap, int allow_fallback, int both_strands);
+                     hipStream_t s, MicBuildOut* out, char* err, size_t err_cap, int allow_fallback, int both_strands,
+                     uint32_t part, uint32_t n_parts);
+// (part of n_parts > 1: only the main slots [n_slots * part / n_parts, n_slots * (part + 1) / n_parts) of the table sized for the
+// whole input are built; out->slots is the allocation, slot s of the table lives at out->slots + (s - out->part_lo) * 8)
 // (allow_fallback: return -5 instead of building a table whose minimizers are crowded: see s_walk_kernel)
 // sums over d_sizes[0..n): total elements and non-empty buckets
 int mic_reduce_sizes(const uint8_t* d_sizes, uint64_t n, uint64_t* total, uint64_t* nonzero, hipStream_t s);

@@ -884,12 +884,14 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
             uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kp));
             const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
-            MicDiv dv; dv.d = kc->t.div.d; dv.magic = kc->t.div.magic; dv.shift = kc->t.div.shift; dv.add = kc->t.div.add;
-            const uint64_t s_lo = kc->t.shard_start, s_hi = kc->t.shard_end;
-            const uint64_t cc = kmer < rck ? kmer : rck;
-            uint64_t q = mic_div(cc, dv);
-            uint64_t rem = cc - q * dv.d;
-            act[h] = act[h] && rem >= s_lo && rem < s_hi;
+            if (!kc->t.parted) {   // (a slot-range part is filtered below, by the slot)
+              MicDiv dv; dv.d = kc->t.div.d; dv.magic = kc->t.div.magic; dv.shift = kc->t.div.shift; dv.add = kc->t.div.add;
+              const uint64_t s_lo = kc->t.shard_start, s_hi = kc->t.shard_end;
+              const uint64_t cc = kmer < rck ? kmer : rck;
+              uint64_t q = mic_div(cc, dv);
+              uint64_t rem = cc - q * dv.d;
+              act[h] = act[h] && rem >= s_lo && rem < s_hi;
+            }
           }
           // m-mer at this position = first m nt of the k-mer; its reverse complement = last m nt of rc(k-mer)
           const uint64_t mf = kmer >> (2 * (k - m));
@@ -931,6 +933,12 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
           const uint64_t x = (ko[h] >> (2 * ao[h])) & ((1ULL << (2 * m)) - 1);
           tk32[h] = (uint32_t)x;
           sl[h] = act[h] ? sslot_of_x(x, (uint32_t)t.n_main) : 0xFFFFFFFFu;
+          if (SHARDED) {   // slot-range part: the k-mer is this engine's iff its slot is resident here (slots are global indices)
+            uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+            if (kc->t.parted && sl[h] - kc->t.slot_lo >= kc->t.slot_cnt) sl[h] = 0xFFFFFFFFu;
+          }
         }
         uint32_t sl0 = sl[0], sl1 = sl[1];
         uint32_t res0 = 0, res1 = 0;   // label + 1 of the hit
@@ -1112,7 +1120,7 @@ __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cb
 #ifndef MIC_R_EAGER_ENTRY
 #define MIC_R_EAGER_ENTRY 1
 #endif
-template <int KK, int MM, bool FWD>
+template <int KK, int MM, bool FWD, bool PART>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r(const MicQueryArgs a) {
   // staged slots: 8 per LDS-DMA instruction, 128 bytes apart (the DMA's own layout: lane L lands at base + 16 L); each
   // group of 8 starts MIC_R_SKEW uint4 further so that the run lanes' reads of the same word of their slots spread over
@@ -1303,7 +1311,20 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
           const int jmaxf = qa - i0, jminf = jmaxf - n + 1;
           const int jmax = rev ? ctx - jminf : jmaxf, jmin = rev ? ctx - jmaxf : jminf;
           uint32_t cur = vr ? sslot_of_x(x, (uint32_t)t.n_main) : 0xFFFFFFFFu;
-          int remaining = vr ? n : 0;
+          bool mine = vr;
+          if (PART) {
+            // Slot-range part of a table-sharded run: a run (one minimizer occurrence -> one slot) belongs to exactly one
+            // part, so the filter is ONE compare per run in front of the slot load; slot indices are global, the table
+            // pointer is the allocation minus the slots in front of this part (mic_engine.hip: fill_table).  The bounds are
+            // re-read from the kernarg segment: the kernel has no scalar registers to spare.
+            uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+            mine = vr && cur - kc->t.slot_lo < kc->t.slot_cnt;
+            cur = mine ? cur : 0xFFFFFFFFu;
+          }
+          int remaining = mine ? n : 0;
+          if (PART && !wballot(mine)) continue;     // no run of this round is ours: nothing to load
           do {
             uint32_t sidx[MIC_RMAX / 8];
             // the list of slots to load sits in the stage area itself: it is consumed before the DMA lands.  (Handing the
@@ -1494,15 +1515,26 @@ __device__ inline uint32_t probe_scalar_m(const MicTable& t, uint64_t kmer) {
   }
 }
 
+// kmer = the k-mer as it reads, tpos = its first nucleotide's position in its read part (the super-k-mer tables resolve
+// tied minimizers by position, s_probe_read); *mine (optional) = this engine answers for the k-mer
 template <bool KEY64>
-__device__ inline uint32_t probe_any(const MicTable& t, uint64_t kmer) {
+__device__ inline uint32_t probe_any(const MicTable& t, uint64_t kmer, uint32_t tpos, bool* mine = nullptr) {
+  if (mine) *mine = true;
   if (t.layout == 2) {
-    const uint64_t c = canonical(kmer, t.k);
     if (t.sharded) {
+      const uint64_t c = canonical(kmer, t.k);
       const uint64_t q = mic_div(c, t.div), rem = c - q * t.div.d;
-      if (rem < t.shard_start || rem >= t.shard_end) return 0;
+      if (rem < t.shard_start || rem >= t.shard_end) { if (mine) *mine = false; return 0; }
     }
-    return s_probe(t.slots, (uint32_t)t.n_main, c, t.k, t.m, t.fwd != 0);
+    bool in_part = true;
+    const uint32_t r = s_probe_read(t.slots, (uint32_t)t.n_main, t.parted != 0, t.slot_lo, t.slot_cnt, kmer, tpos, t.k, t.m, t.fwd != 0, &in_part);
+    if (mine && !in_part) *mine = false;
+    return r;
+  }
+  if (mine && (t.sharded || t.layout == 0)) {
+    const uint64_t c = canonical(kmer, t.k);
+    const uint64_t q = mic_div(c, t.div), rem = c - q * t.div.d;
+    *mine = rem >= t.shard_start && rem < t.shard_end;
   }
   return t.layout ? probe_scalar_m(t, kmer) : probe_scalar<KEY64>(t, kmer);
 }
@@ -1534,7 +1566,7 @@ __global__ void __launch_bounds__(256) dense_count_kernel(const MicTable t, cons
       int s = 2 * (pos & 7);
       uint64_t x = s ? ((hi << s) | ((uint64_t)lo >> (16 - s))) : hi;
       uint64_t kmer = x >> (64 - 2 * k);
-      uint32_t m = probe_any<KEY64>(t, kmer);
+      uint32_t m = probe_any<KEY64>(t, kmer, pos);
       if (m && m - 1 < n_targets) atomicAdd(&row[m - 1], 1u);
     }
   }
@@ -1620,10 +1652,13 @@ __global__ void __launch_bounds__(256) probe_stats_kernel(const MicTable t, cons
         uint64_t q = mic_div(c, t.div);
         uint64_t rem = c - q * t.div.d;
         if (rem < t.shard_start || rem >= t.shard_end) continue;
+        bool mine = true;
+        const bool hit = probe_any<KEY64>(t, kmer, i + 1 - (uint32_t)k, &mine) != 0;
+        if (!mine) continue;     // a slot-range part: the k-mer's slot is resident on another engine
         ++np;
         nb += t.layout ? (t.sizes ? t.sizes[rem - t.shard_start] : 0)
                                                : (t.slots[(rem - t.shard_start) * 4].w & 0xFF);
-        nh += probe_any<KEY64>(t, kmer) != 0;
+        nh += hit;
       }
     }
   }
@@ -1643,6 +1678,8 @@ hipError_t mic_launch_probe_stats(const MicTable& t, int slot_class, const uint3
   else probe_stats_kernel<false><<<blocks, 256, 0, s>>>(t, reads_ptr, cont, (uint32_t)n_reads, d_out);
   return hipGetLastError();
 }
+
+static bool per_kmer_env() { static const bool v = getenv("MIC_S_PER_KMER") != nullptr; return v; }
 
 hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hipStream_t s) {
   if (a.n_reads == 0) return hipSuccess;
@@ -1664,18 +1701,20 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   if (a.t.layout == 2) {
     const unsigned g = (blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, b = 64 * MIC_M_WPB;
     static const bool generic = getenv("MIC_S_GENERIC") != nullptr;
-    const bool sh = a.t.sharded != 0, fw = a.t.fwd != 0;
+    // pt: slot-range part (one compare per run in query_kernel_r; the per-k-mer kernel filters in its `sharded` instantiation)
+    const bool pt = a.t.parted != 0, fw = a.t.fwd != 0;
+    const bool sh = a.t.sharded != 0 || (pt && (per_kmer_env() || (!fw && !(2 * a.t.k - a.t.m > 32 && 2 * a.t.k - a.t.m <= 48))));
     // instantiations: k and m as constants for cuCLARK's 31, cuCLARK-l's 27 and k = 32 with m = 20; the table-sharded filter
     // and the two-strand table each in their own (the common kernel carries neither's scalars)
     // the two-strand table is probed per run (query_kernel_r); MIC_S_PER_KMER=1 keeps the per-k-mer kernel for comparison
-    static const bool per_kmer = getenv("MIC_S_PER_KMER") != nullptr;
+    const bool per_kmer = per_kmer_env();
     // the one-strand table's per-run kernel reverse-complements a region of 2k - m nucleotides inside three words: its
     // realignment is a single funnel shift when the region is longer than 32 nucleotides (always for cuCLARK's k and m)
     const bool run_ok = 2 * a.t.k - a.t.m > 32 && 2 * a.t.k - a.t.m <= 48;
     static const unsigned extra_lds = [] { const char* e = getenv("MIC_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();   // occupancy experiments
 #define LAUNCH_S(KK_, MM_) do { \
-      if (fw && !sh && !per_kmer) query_kernel_r<KK_, MM_, true><<<g, b, extra_lds, s>>>(a); \
-      else if (!fw && !sh && !per_kmer && run_ok) query_kernel_r<KK_, MM_, false><<<g, b, extra_lds, s>>>(a); \
+      if (fw && !sh && !per_kmer) { if (pt) query_kernel_r<KK_, MM_, true, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, true, false><<<g, b, extra_lds, s>>>(a); } \
+      else if (!fw && !sh && !per_kmer && run_ok) { if (pt) query_kernel_r<KK_, MM_, false, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, false, false><<<g, b, extra_lds, s>>>(a); } \
       else if (fw) { if (sh) query_kernel_s<KK_, MM_, true, true><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, true><<<g, b, 0, s>>>(a); } \
       else { if (sh) query_kernel_s<KK_, MM_, true, false><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, false><<<g, b, 0, s>>>(a); } } while (0)
     if (!generic && a.t.k == 31 && a.t.m == 20) LAUNCH_S(31, 20);

@@ -75,6 +75,11 @@ class MiClarkDB:
         check(self.L.mic_db_load_device(self.h, d_sizes, int(htsize), d_keys, int(key_bytes), d_labels, int(sampling),
                                         int(shard[0]), int(shard[1])))
 
+    def set_part(self, part, n_parts):
+        """Table-sharded runs (CuClarkDB.cu:566-574): answer for part `part` of `n_parts` of the database; call before
+        read*().  Super-k-mer layouts cut the resident table by slot range, the others by on-disk bucket range."""
+        check(self.L.mic_db_set_part(self.h, int(part), int(n_parts)))
+
     def swapDbParts(self):
         """The table is fully resident: there is never another part to swap in (CuClarkDB.cu:813-858)."""
         return False

@@ -83,6 +83,10 @@ typedef struct mic_db_info {
   uint32_t max_chain;      /* entries in the fullest slot chain (MINIMIZER, SUPER)      */
   uint32_t reserved;       /* SUPER: mean number of continuation slots in front of a stored k-mer, x 1e6 (crowded minimizers) */
   uint64_t n_entries;      /* entries stored: super-k-mers (SUPER: several k-mers each), else = n_elems */
+  uint32_t part, n_parts;  /* mic_db_set_part (0, 0 when the engine holds the whole database)     */
+  uint64_t part_slot_lo;   /* SUPER / SUPER2 with a part: the resident main slots [lo, hi) ...     */
+  uint64_t part_slot_hi;
+  uint64_t n_slots_whole;  /* ... of this many the whole table has (identical on every part)       */
 } mic_db_info;
 
 /* ---- engine lifetime: CuClarkDB ctor/dtor (CuClarkDB.cu:85-253) ----------------------------- */
@@ -105,8 +109,23 @@ int mic_db_load_host(mic_engine* e, const uint8_t* sizes, uint64_t htsize, const
 /* Same from device memory images (d_keys/d_labels hold the WHOLE table's elements). */
 int mic_db_load_device(mic_engine* e, const uint8_t* d_sizes, uint64_t htsize, const void* d_keys, int key_bytes,
                        const uint16_t* d_labels, uint32_t sampling, uint64_t shard_start, uint64_t shard_end);
+/* Table-sharded runs (the reference's multi-device mode: m_partPointer ranges, CuClarkDB.cu:566-574, every device
+ * queried with all reads :886-890, partial rows summed :934-1001).  Call BEFORE mic_db_load_* (whole table: shard_start
+ * = shard_end = 0): the engine then answers for part `part` of `n_parts` of the database, and the per-read rows of the
+ * n_parts engines sum to the whole table's (mic_merge_rows_device / mic_batch_merge_shards).  HOW the database is cut
+ * follows the resident layout.  The super-k-mer layouts cut their resident table by SLOT range: a slot is chosen by
+ * the minimizer, so all k-mers of a run of a read (one super-k-mer) belong to one part - a part loads and searches
+ * 1/n_parts of the slots and the per-run kernel keeps its form (one compare per run).  The bucket cut of the on-disk
+ * hash (c mod HTSIZE) would scatter the k-mers of one super-k-mer over all parts.  The other layouts keep the
+ * reference's cut: part p answers for the buckets [HTSIZE p / n, HTSIZE (p + 1) / n).  Each part is built from the
+ * whole .sz/.ky/.lb images (all parts size the table identically); n_parts <= 1 clears the setting.
+ * shard_start / shard_end of mic_db_load_* remain the explicit bucket-range form (not combinable with a part). */
+int mic_db_set_part(mic_engine* e, uint32_t part, uint32_t n_parts);
 int mic_db_get_info(const mic_engine* e, mic_db_info* info);
 int mic_db_unload(mic_engine* e);
+/* Stage times of the last table build of this process, one "<stage>: <seconds>" per line (what MIC_LOAD_TIMING=1 prints on
+ * stderr); valid until the calling thread asks again.  The reference prints its load time, CuCLARK_hh.hh:610-625. */
+const char* mic_db_last_build_report(void);
 
 /* ---- batch API: the calls CuCLARK_hh.hh makes on CuClarkDB ----------------------------------
  * mic_batches_alloc   = CuClarkDB::malloc        (CuClarkDB.cu:317-419;  caller CuCLARK_hh.hh:1600-1606)

@@ -26,8 +26,8 @@ class _OrcIndex(C.Structure):
 
 def build(force=False):
     """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
-    src = os.path.join(_HERE, "clark_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("clark_oracle.c", "part_rule.c", "clark_oracle.h")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
     return _LIB
 
@@ -95,6 +95,11 @@ class Oracle:
                                         C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                         C.POINTER(C.c_void_p)]
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_part_slot_of_kmer.restype = C.c_uint32
+        L.orc_part_slot_of_kmer.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.orc_query_batch_slot_part.restype = C.c_uint64
+        L.orc_query_batch_slot_part.argtypes = [C.POINTER(_OrcDb), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
 
     # -- codec
     def revcomp(self, x, k):
@@ -282,6 +287,17 @@ class OracleDb:
         pe = self.htsize if part[1] is None else part[1]
         bad = self.orc.L.orc_query_batch(self.p, k, rp.ctypes.data, ct.ctypes.data, n, int(part[0]), int(pe), n_targets,
                                          counts.ctypes.data)
+        return counts, int(bad)
+
+    def query_batch_slot_part(self, k, m, both_strands, n_slots, part, n_parts, reads_pointer, containers, n_targets):
+        """dense counts of the k-mer occurrences that part `part` of `n_parts` of the product's resident slot range answers for
+        (part_rule.c); the parts sum to query_batch's counts"""
+        rp = np.ascontiguousarray(reads_pointer, np.uint32)
+        ct = np.concatenate([np.ascontiguousarray(containers, np.uint16), np.zeros(8, np.uint16)])
+        n = rp.size - 1
+        counts = np.zeros((n, n_targets), np.uint32)
+        bad = self.orc.L.orc_query_batch_slot_part(self.p, k, m, int(bool(both_strands)), int(n_slots), int(part), int(n_parts),
+                                                   rp.ctypes.data, ct.ctypes.data, n, n_targets, counts.ctypes.data)
         return counts, int(bad)
 
     def classify_batch(self, k, reads_pointer, containers, n_targets, threads=0):

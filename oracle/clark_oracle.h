@@ -188,6 +188,15 @@ long orc_classify_file(const orc_db* db, int k, const uint8_t* map, size_t nb, c
                        uint32_t n_targets, int paired, int extended, char** csv, size_t* csv_len,
                        uint32_t** results);
 
+/* ---- the product's table partition for table-sharded runs (part_rule.c; NOT a rule of the reference) ----------
+ * Slot, out of n_slots, of the minimizer of the k-mer that reads at nucleotide tpos of its read part; and the dense counts of
+ * a packed batch restricted to the k-mer occurrences whose slot lies in part `part` of `n_parts` of the slots.  The sum of
+ * the parts' counts is orc_query_batch's. */
+uint32_t orc_part_slot_of_kmer(uint64_t kmer, uint32_t tpos, int k, int m, int both_strands, uint32_t n_slots);
+uint64_t orc_query_batch_slot_part(const orc_db* db, int k, int m, int both_strands, uint32_t n_slots, uint32_t part,
+                                   uint32_t n_parts, const uint32_t* reads_pointer, const uint16_t* containers, size_t n_reads,
+                                   uint32_t n_targets, uint32_t* counts);
+
 void orc_free(void* p);
 
 #ifdef __cplusplus
