@@ -284,6 +284,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the batch-API pipeline leg (N=1)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-in, CSV-out leg through exe/cuCLARK (N=1)")
     ap.add_argument("--e2e-threads", type=int, default=12, help="-n of the end-to-end run")
+    ap.add_argument("--parts", type=int, default=0,
+                    help="--mode db: parts the table is cut into (default: one per rank = the reference's mode).  With fewer parts than "
+                         "ranks the ranks form N / parts groups that split the reads (2-D layout, DESIGN.md 6)")
+    ap.add_argument("--chunks", type=int, default=4, help="--mode db: read chunks per pass (the row exchange of a chunk overlaps the next chunk's kernel)")
     ap.add_argument("--no-parts-proxy", action="store_true",
                     help="N=1: skip \"table_sharded_proxy\" (kernel time of part 0 of 2/4/8 of the table against all reads)")
     ap.add_argument("--allow-variant-lib", action="store_true",
@@ -356,8 +360,13 @@ def main():
     layout = 0 if os.environ.get("MIC_LAYOUT") else LAYOUTS[args.layout]      # MIC_LAYOUT (tools/, tests) wins over the flag
     os.environ.setdefault("MIC_SUPER2_MAY_FALL_BACK", "1")
     eng = MiClarkDB(k, T, num_batches=PIPE_BATCHES, device=local_rank, row_words=row_words, layout=layout)
-    if db_mode and world > 1:
-        eng.set_part(rank, world)       # this rank's part of the table (super-k-mer layouts: a slot range of the resident table)
+    P = (args.parts or world) if db_mode else 1
+    part_i, group_i, n_groups, group_ranks = multi.grid(world, rank, P)
+    groups = None
+    if db_mode and P < world:          # every rank creates every group, in the same order
+        groups = [dist.new_group(list(range(g * P, (g + 1) * P))) for g in range(n_groups)]
+    if db_mode and P > 1:
+        eng.set_part(part_i, P)        # this rank's part of the table (super-k-mer layouts: a slot range of the resident table)
     t0 = time.time()
     eng.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr())
     info = eng.info()
@@ -377,53 +386,66 @@ def main():
     torch.cuda.synchronize()
     d_res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
     n_flagged = [0]
-    if db_mode:
-        per_r = multi.read_range(n_reads, world, rank)[2]
-        d_rows = multi.padded_rows(n_reads, world, row_words, dev)
-        d_recv = torch.zeros((world, per_r, row_words), dtype=torch.int32, device=dev)
-        d_acc = torch.zeros((2, per_r, row_words), dtype=torch.int32, device=dev)
-        d_res_part = torch.zeros((per_r, 8), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
 
-    def complete_rows(engine, cur, res_part):
-        """table-sharded: reads whose merged row does not fit get their dense counts summed over the ranks (flagged reads only)"""
+    def sharded_ops(engine, res_all):
+        """device work of a table-sharded pass (cuclark_amd/multi.py: ShardedPass) bound to one engine"""
+        staged = args.backend != "nccl"
+
+        def query(first, count, rows):
+            engine.query_device(d_rp.data_ptr() + 4 * first, d_cont.data_ptr(), count, res_all.data_ptr() + 32 * first, rows.data_ptr(), sptr)
+            n_flagged[0] += engine.resolve_flagged_device(d_rp.data_ptr() + 4 * first, d_cont.data_ptr(), res_all.data_ptr() + 32 * first,
+                                                          rows.data_ptr(), sptr)
+
         def count_dense(ids):
             d_ids = ids.to(torch.int32).to(dev)
             d_counts = torch.zeros((ids.numel(), T), dtype=torch.int32, device=dev)
             engine.count_dense_device(d_rp.data_ptr(), d_cont.data_ptr(), d_ids.data_ptr(), ids.numel(), d_counts.data_ptr(), sptr)
             torch.cuda.synchronize()
-            return d_counts if args.backend == "nccl" else d_counts.cpu()
-        rows_view = cur if args.backend == "nccl" else cur.cpu()
-        idx, counts = multi.complete_overflowed(rows_view, world, rank, n_reads, count_dense)
-        if idx is not None and idx.numel():
+            return d_counts.cpu() if staged else d_counts
+
+        def result_from_dense(counts, idx, res):
             d_idx = idx.to(torch.int32).to(dev)
             d_cnt = counts.to(dev).contiguous()
-            engine.result_from_dense_device(d_cnt.data_ptr(), d_idx.data_ptr(), idx.numel(), res_part.data_ptr(), 0, sptr)
+            engine.result_from_dense_device(d_cnt.data_ptr(), d_idx.data_ptr(), idx.numel(), res.data_ptr(), 0, sptr)
             torch.cuda.synchronize()
-        return 0 if idx is None else int(idx.numel())
+        return dict(query=query, count_dense=count_dense, result_from_dense=result_from_dense,
+                    merge=lambda a, b, out, n: engine.merge_rows_device(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, sptr),
+                    result=lambda rows, res, n: engine.result_from_rows_device(rows.data_ptr(), res.data_ptr(), n, sptr))
+
+    def sharded_pass(engine, res_all, P_, group_index, n_groups_, group, group_rank):
+        lo, hi, _ = multi.read_range(n_reads, n_groups_, group_index)          # this group's reads
+        return multi.ShardedPass(sharded_ops(engine, res_all), lo, hi - lo, row_words, dev, group, P_, group_rank, chunks=args.chunks,
+                                 staged=args.backend != "nccl")
+
+    def sharded_known_answer(sp, truth_all):
+        """constructive known answer over the reads of this rank's group, summed over the groups"""
+        got = sp.gather().cpu().numpy().view(np.uint32)
+        tr = truth_all[sp.first:sp.first + sp.n]
+        g = tr[:, 0] > 0
+        ok = (tr[g, 1] == 0) | ((got[g, 1] == tr[g, 0]) & (got[g, 2] >= tr[g, 1]))
+        v = torch.tensor([float(ok.sum()), float(g.sum()), float((got[~g, 0] == 0).sum()), float((~g).sum()),
+                          float(((got[:, 2] == got[:, 4]) & (got[:, 2] > 0)).sum()), float(sp.n)], dtype=torch.float64,
+                         device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(v)
+        v = (v / sp.P).tolist()                    # every rank of a group reported the group's reads
+        return {"genome_reads": int(v[1]), "label_and_count_ok": v[0] / v[1] if v[1] else 1.0,
+                "random_reads_no_hit": v[2] / v[3] if v[3] else 1.0, "tie_rate": v[4] / max(v[5], 1.0)}
+
+    sp = None
+    if db_mode:
+        sp = sharded_pass(eng, d_res, P, group_i, n_groups, groups[group_i] if groups else None, part_i)
 
     def step():
+        n_flagged[0] = 0
         if not db_mode:
             eng.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), 0, sptr)
             # reads the kernel flagged (more than 64 targets) take the dense path INSIDE the step: part of the timed work
             n_flagged[0] = eng.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), d_res.data_ptr(), 0, sptr)
             return
-        # table-sharded: local sparse rows -> all_to_all by read range -> merge (sum by target) -> best/second
-        eng.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), d_rows.data_ptr(), sptr)
-        n_flagged[0] = eng.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), d_res.data_ptr(), d_rows.data_ptr(), sptr)
-        if args.backend == "nccl":
-            multi.exchange_rows(d_rows, world, out=d_recv)
-        else:
-            torch.cuda.synchronize()
-            d_recv.copy_(multi.exchange_rows(d_rows.cpu(), world))
-        cur = d_recv[0]
-        for r in range(1, world):
-            out = d_acc[r & 1]
-            eng.merge_rows_device(cur.data_ptr(), d_recv[r].data_ptr(), out.data_ptr(), per_r, sptr)
-            cur = out
-        eng.result_from_rows_device(cur.data_ptr(), d_res_part.data_ptr(), per_r, sptr)
-        complete_rows(eng, cur, d_res_part)
+        # table-sharded: per chunk local sparse rows -> all_to_all by read range -> merge (sum by target) -> best/second
+        sp.step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -445,8 +467,12 @@ def main():
     elapsed = time.perf_counter() - t0
     # mean duration of the query kernel alone (HIP events recorded around it on its own stream), sampled
     # outside the timed loop so the event reads do not serialise it
+    q_first, q_n = (sp.first, sp.n) if db_mode else (0, n_reads)       # the reads this rank's kernel sees in one pass
     for _ in range(min(args.steps, 5)):
-        step()
+        if db_mode:      # the pass launches the kernel per chunk: time ONE launch over all of this rank's reads instead
+            eng.query_device(d_rp.data_ptr() + 4 * q_first, d_cont.data_ptr(), q_n, d_res.data_ptr() + 32 * q_first, 0, sptr)
+        else:
+            step()
         kernel_ms.append(eng.last_query_ms())
     torch.cuda.synchronize()
     if use_dist:
@@ -459,7 +485,7 @@ def main():
 
     # ---- bookkeeping for the roofline: measured k-mers, hit rate, probed-bucket length (product-side kernel)
     flagged = n_flagged[0]
-    st = eng.probe_stats_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads)
+    st = eng.probe_stats_device(d_rp.data_ptr() + 4 * q_first, d_cont.data_ptr(), q_n)
     kern_s = float(np.mean(kernel_ms)) / 1e3
     h = st["hits"] / max(st["probed"], 1)
     lam_q = st["bucket_len_sum"] / max(st["probed"], 1)
@@ -468,7 +494,7 @@ def main():
     # packed read + pointer as the packer emits them and the kernel addresses them (40 B + 4 B for 150 bp): one
     # length slot + ceil(L / 8) containers + the pointer - not the generator's allocated pitch (76 B, mostly never touched)
     in_bytes = 2 * (1 + (obj_len + 7) // 8) + 4
-    alg_bytes = st["probed"] * bytes_per_kmer + n_reads * (in_bytes + 32)
+    alg_bytes = st["probed"] * bytes_per_kmer + q_n * (in_bytes + 32)
     achieved = alg_bytes / kern_s / 1e9
     # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, tools/profile_bench.sh); the
     # counters cannot be read from inside this process, so the committed summary of the same workload is used.
@@ -534,14 +560,9 @@ def main():
                  "random_reads_no_hit": float((res[~gmask, 0] == 0).mean()) if (~gmask).any() else 1.0,
                  "tie_rate": float(((res[:, 2] == res[:, 4]) & (res[:, 2] > 0)).mean())}
     else:
-        # table-sharded: every rank finalised 1/N of the reads; gather them in read order and apply the same check
+        # table-sharded: every rank finalised its sub-ranges; gather inside the group in read order and apply the same check
         torch.cuda.synchronize()
-        part = d_res_part if args.backend == "nccl" else d_res_part.cpu()
-        allres = multi.gather_results(part, world)[:n_reads].cpu().numpy().view(np.uint32)
-        ok = (truth[gmask, 1] == 0) | ((allres[gmask, 1] == truth[gmask, 0]) & (allres[gmask, 2] >= truth[gmask, 1]))
-        known = {"genome_reads": int(gmask.sum()), "label_and_count_ok": float(ok.mean()) if gmask.any() else 1.0,
-                 "random_reads_no_hit": float((allres[~gmask, 0] == 0).mean()) if (~gmask).any() else 1.0,
-                 "tie_rate": float(((allres[:, 2] == allres[:, 4]) & (allres[:, 2] > 0)).mean())}
+        known = sharded_known_answer(sp, truth)
 
     # ---- CPU baseline (rank 0, N=1): the oracle on this box's host cores, bounded sample; doubles as parity check
     cpu = None
@@ -662,68 +683,57 @@ def main():
     # sparse rows are exchanged with all_to_all by read range, merged and finalised.  Fixed total work: "strong".
     table_sharded = None
     if world > 1 and not db_mode and not args.no_db_leg:
+        def sharded_leg(P2):
+            """the table cut into P2 parts, world // P2 groups of ranks splitting the SAME 10 M reads (P2 = world: the reference's mode)"""
+            part2, group2, n_groups2, _ = multi.grid(world, rank, P2)
+            grps = [dist.new_group(list(range(g * P2, (g + 1) * P2))) for g in range(n_groups2)] if P2 < world else None
+            eng2 = MiClarkDB(k, T, device=local_rank, row_words=row_words, layout=layout)
+            try:
+                if P2 > 1:
+                    eng2.set_part(part2, P2)
+                t0 = time.time()
+                eng2.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr())
+                t_build2 = time.time() - t0
+                info2 = eng2.info()
+                r_res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
+                sp2 = sharded_pass(eng2, r_res, P2, group2, n_groups2, grps[group2] if grps else None, part2)
+                steps2 = max(1, min(args.steps, 5))
+                for _ in range(min(args.warmup, 2)):
+                    sp2.step()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(steps2):
+                    sp2.step()
+                torch.cuda.synchronize()
+                barrier()
+                el2 = time.perf_counter() - t0
+                t = torch.tensor([el2], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el2 = float(t.item())
+                truth2 = d_truth.cpu().numpy().view(np.uint32).reshape(-1, 2)
+                ka2 = sharded_known_answer(sp2, truth2)
+                eng2.query_device(d_rp.data_ptr() + 4 * sp2.first, d_cont.data_ptr(), sp2.n, r_res.data_ptr() + 32 * sp2.first, 0, sptr)
+                k_ms = eng2.last_query_ms()
+                return {"value": round(n_reads / (el2 / steps2) / 1e6, 3), "unit": "Mreads/s", "scaling": "strong",
+                        "steps": steps2, "ms_per_step": round(el2 / steps2 * 1e3, 3), "parts": P2, "read_groups": n_groups2,
+                        "mode": (PART_MODE[info2["layout"]] if P2 > 1 else "table replicated") + " + all_to_all of sparse rows + merge", "reads_total": n_reads,
+                        "kernel_ms_this_rank_all_its_reads": round(k_ms, 3), "reads_this_rank": sp2.n,
+                        "shard_hbm_GB": round(info2["hbm_bytes"] / 1e9, 2), "shard_build_s": round(t_build2, 1), "chunks": len(sp2.per),
+                        "exchange_MB_per_rank": round(sp2.n * row_words * 4 * (P2 - 1) / P2 / 1e6, 1), "known_answer": ka2}
+            finally:
+                eng2.close()
+                torch.cuda.empty_cache()
         try:
             eng.close()
             del d_res
             torch.cuda.empty_cache()
-            eng2 = MiClarkDB(k, T, device=local_rank, row_words=row_words, layout=layout)
-            eng2.set_part(rank, world)
-            t0 = time.time()
-            eng2.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr())
-            t_build2 = time.time() - t0
-            info2 = eng2.info()
             rc = L.mic_synth_reads_device2(C.byref(spec), 5, n_reads, read_len, int(paired), 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
                                            d_cont.numel(), d_truth.data_ptr(), None)   # the same reads on every rank
             assert rc == 0
             torch.cuda.synchronize()
-            per2 = multi.read_range(n_reads, world, rank)[2]
-            r_res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
-            r_rows = multi.padded_rows(n_reads, world, row_words, dev)
-            r_recv = torch.zeros((world, per2, row_words), dtype=torch.int32, device=dev)
-            r_acc = torch.zeros((2, per2, row_words), dtype=torch.int32, device=dev)
-            r_part = torch.zeros((per2, 8), dtype=torch.int32, device=dev)
-
-            def step_db():
-                eng2.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, r_res.data_ptr(), r_rows.data_ptr(), sptr)
-                eng2.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), r_res.data_ptr(), r_rows.data_ptr(), sptr)
-                if args.backend == "nccl":
-                    multi.exchange_rows(r_rows, world, out=r_recv)
-                else:
-                    torch.cuda.synchronize()
-                    r_recv.copy_(multi.exchange_rows(r_rows.cpu(), world))
-                cur = r_recv[0]
-                for r in range(1, world):
-                    o2 = r_acc[r & 1]
-                    eng2.merge_rows_device(cur.data_ptr(), r_recv[r].data_ptr(), o2.data_ptr(), per2, sptr)
-                    cur = o2
-                eng2.result_from_rows_device(cur.data_ptr(), r_part.data_ptr(), per2, sptr)
-                complete_rows(eng2, cur, r_part)
-            steps2 = max(1, min(args.steps, 5))
-            for _ in range(min(args.warmup, 2)):
-                step_db()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(steps2):
-                step_db()
-            torch.cuda.synchronize()
-            barrier()
-            el2 = time.perf_counter() - t0
-            t = torch.tensor([el2], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el2 = float(t.item())
-            part = r_part if args.backend == "nccl" else r_part.cpu()
-            allres = multi.gather_results(part, world)[:n_reads].cpu().numpy().view(np.uint32)
-            truth2 = d_truth.cpu().numpy().view(np.uint32).reshape(-1, 2)
-            g2 = truth2[:, 0] > 0
-            ok2 = (truth2[g2, 1] == 0) | ((allres[g2, 1] == truth2[g2, 0]) & (allres[g2, 2] >= truth2[g2, 1]))
-            table_sharded = {"value": round(n_reads / (el2 / steps2) / 1e6, 3), "unit": "Mreads/s", "scaling": "strong",
-                             "steps": steps2, "ms_per_step": round(el2 / steps2 * 1e3, 3),
-                             "mode": PART_MODE[info2["layout"]] + " + all_to_all of sparse rows + merge", "reads_total": n_reads,
-                             "kernel_ms_this_rank": round(eng2.last_query_ms(), 3),
-                             "shard_hbm_GB": round(info2["hbm_bytes"] / 1e9, 2), "shard_build_s": round(t_build2, 1),
-                             "exchange_MB_per_rank": round(r_rows.numel() * 4 * (world - 1) / world / 1e6, 1),
-                             "known_answer": {"label_and_count_ok": float(ok2.mean()) if g2.any() else 1.0,
-                                              "random_reads_no_hit": float((allres[~g2, 0] == 0).mean()) if (~g2).any() else 1.0}}
+            table_sharded = sharded_leg(world)
+            if world >= 4:      # the 2-D layout for a table that needs two GPUs: 2 parts x world / 2 read groups
+                table_sharded["two_parts_2d"] = sharded_leg(2)
         except Exception as ex:   # the headline line must not depend on this leg
             table_sharded = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
@@ -734,7 +744,8 @@ def main():
             "scaling": "strong" if db_mode else "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": w["name"], "reads_per_gpu": n_reads, "read_len": read_len, "k": k,
-                       "mode": (PART_MODE[info["layout"]] + " + all_to_all of sparse rows" if db_mode else
+                       "mode": (f"{P} part(s) x {n_groups} read group(s): " + (PART_MODE[info["layout"]] if P > 1 else "table replicated") +
+                                " + all_to_all of sparse rows" if db_mode else
                                 ("read-sharded, table replicated" if world > 1 else "single GPU, table resident")),
                        "table": {"htsize": info["htsize"], "kmers": info["n_elems"], "slot_class": info["slot_class"],
                                  "layout": {1: "direct: one 64-B slot per on-disk bucket", 2: "minimizer-keyed 128-B slots", 3: "super-k-mer 128-B slots",

@@ -1128,6 +1128,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
   __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE + (MIC_RMAX / 8 - 1) * MIC_R_SKEW];
   __shared__ uint16_t s_rec[MIC_M_WPB][132];              // runs of a chunk: minimizer position | first k-mer << 8
   __shared__ uint32_t s_ahead[MIC_M_WPB][2][64];
+  __shared__ uint32_t s_part[PART ? MIC_M_WPB : 1][2];     // slot-range part: first resident slot, number of resident slots
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint4* stage = s_stage[wv];
@@ -1135,6 +1136,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * MIC_M_WPB + wv);
   const uint32_t n_waves = gridDim.x * MIC_M_WPB;
   const MicTable& t = a.t;
+  if (PART) { if (lane == 0) { s_part[wv][0] = t.slot_lo; s_part[wv][1] = t.slot_cnt; } __builtin_amdgcn_wave_barrier(); }
   const int k = KK ? KK : t.k, m = MM ? MM : t.m, w = k - m + 1, ctx = k - m;
   const uint4* __restrict__ slots = t.slots;
   const uint16_t* __restrict__ cont = a.cont;
@@ -1315,16 +1317,13 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
           if (PART) {
             // Slot-range part of a table-sharded run: a run (one minimizer occurrence -> one slot) belongs to exactly one
             // part, so the filter is ONE compare per run in front of the slot load; slot indices are global, the table
-            // pointer is the allocation minus the slots in front of this part (mic_engine.hip: fill_table).  The bounds are
-            // re-read from the kernarg segment: the kernel has no scalar registers to spare.
-            uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(kp));
-            const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
-            mine = vr && cur - kc->t.slot_lo < kc->t.slot_cnt;
+            // pointer is the allocation minus the slots in front of this part (mic_engine.hip: fill_table).  The bounds sit in
+            // LDS (the kernel has no scalar registers to spare, and a scalar load here would wait in front of the slot
+            // loads): they arrive with the run records the lane reads anyway.
+            mine = vr && cur - s_part[wv][0] < s_part[wv][1];
             cur = mine ? cur : 0xFFFFFFFFu;
           }
           int remaining = mine ? n : 0;
-          if (PART && !wballot(mine)) continue;     // no run of this round is ours: nothing to load
           do {
             uint32_t sidx[MIC_RMAX / 8];
             // the list of slots to load sits in the stage area itself: it is consumed before the DMA lands.  (Handing the

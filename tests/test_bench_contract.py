@@ -94,6 +94,27 @@ def test_bench_paired_config5_shape():
         assert gz[kind]["csv_equals_plain_run"] is True and gz[kind]["Mpairs_s"] > 0, gz
 
 
+@pytest.mark.gpu
+def test_bench_table_sharded_mode_under_rccl_on_one_gpu():
+    """--mode db at N = 1 with the nccl backend: RCCL is initialised and the table-sharded pass runs through its collectives
+    (a degenerate all_to_all_single per chunk on device tensors, asynchronous, the overflow all-gather, the in-group gather) -
+    the code path the driver launches on eight GPUs, executed once on one."""
+    d = _bench("--workload", "tiny", "--mode", "db", "--backend", "nccl", "--steps", "2", "--warmup", "1")
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong"
+    assert d["known_answer"]["label_and_count_ok"] == 1.0 and d["known_answer"]["random_reads_no_hit"] == 1.0
+    assert "1 part(s) x 1 read group(s)" in d["config"]["mode"]
+
+
+@pytest.mark.gpu
+def test_bench_light27_config2_proper():
+    """SURVEY.md 8d config 2 as cuCLARK-l builds it: HTSIZE 57 777 779, k = 27, u32 keys, ~90 M k-mers, 10 M reads."""
+    d = _bench("--workload", "light27", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000")
+    _check_config(d, 10_000_000)
+    t = d["config"]["table"]
+    assert t["htsize"] == 57777779 and d["config"]["k"] == 27 and 80_000_000 < t["kmers"] < 95_000_000
+    assert "k=27" in d["metric"]
+
+
 def test_bench_has_the_contract_flags():
     src = open(os.path.join(gu.ROOT, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup"):
@@ -102,23 +123,28 @@ def test_bench_has_the_contract_flags():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["db", "read"])
+@pytest.mark.parametrize("mode", ["db", "db_2d", "read"])
 def test_bench_two_ranks_on_one_gpu(mode):
     """The N>1 code paths of bench.py with two ranks sharing cuda:0 (rows exchanged through host memory with gloo):
     table-sharded mode must reproduce the constructive known answer after exchange + merge + gather."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29533", os.path.join(gu.ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-                        "--warmup", "1", "--workload", "tiny", "--mode", mode, "--backend", "gloo"],
+                        "--warmup", "1", "--workload", "tiny", "--mode", mode[:2] if mode != "read" else mode, "--backend", "gloo",
+                        *(["--parts", "1"] if mode == "db_2d" else [])],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2
-    assert d["scaling"] == ("strong" if mode == "db" else "weak")
+    assert d["scaling"] == ("weak" if mode == "read" else "strong")
     assert d["known_answer"]["label_and_count_ok"] == 1.0 and d["known_answer"]["random_reads_no_hit"] == 1.0
     per = d["config"]["reads_per_gpu"]
     total = per * (2 if mode == "read" else 1)
     assert abs(d["value"] - total / d["ms_per_step"] / 1e3) / d["value"] < 0.02
+    if mode == "db":
+        assert "2 part(s) x 1 read group(s)" in d["config"]["mode"]
+    if mode == "db_2d":      # one part per group: the ranks split the reads, the exchange is degenerate
+        assert "1 part(s) x 2 read group(s)" in d["config"]["mode"]
     if mode == "read":   # the extra table-sharded leg rides along and must reproduce the known answer too
         ts = d["table_sharded"]
         assert "error" not in ts, ts

@@ -137,6 +137,95 @@ def _overflow_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _sharded_pass_worker(rank, world, port, ret):
+    """cuclark_amd/multi.py: ShardedPass on two gloo ranks: reads cut into chunks, rows of every chunk exchanged, merged, finished,
+    overflowed rows completed from dense counts - with the per-rank rows computed by the oracle under the product's partition
+    (slot range of the resident table: oracle/part_rule.c) instead of the HIP kernel."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuclark_amd import multi
+        o = gu.oracle()
+        rng = np.random.default_rng(22)
+        k, T, RW, htsize = 27, 40, 16, 4099
+        sizes, keys, labels, canon = gu.random_db(rng, htsize, 3000, k, 8, T)
+        odb = o.db_from_arrays(sizes, keys, labels, 1)
+        by_label = {t: [c for c, l in zip(canon, labels) if l == t] for t in range(T)}
+        recs = []
+        for i, n_t in enumerate([3, 40, 14, 15, 16, 17, 30, 2, 25, 16, 9, 40, 1, 0, 5, 33, 2]):
+            parts = [gu.kmer_to_ascii(by_label[t][(i + j) % len(by_label[t])], k) for j, t in enumerate(rng.permutation(T)[:n_t])]
+            recs.append(f">r{i}\n" + ("N".join(parts) if parts else "ACGT" * 10) + "\n")
+        data = "".join(recs).encode()
+        ix = o.index_reads(data)
+        rp, ct = o.pack_batch(data, ix["seq_s"], ix["seq_e"], ix["length"], k)
+        n = rp.size - 1
+        whole, _ = odb.query_batch(k, rp, ct, T)
+        expect = o.result_from_counts(whole)
+        mine, _ = odb.query_batch_slot_part(k, 20, True, 1000, rank, world, rp, ct, T)          # this rank's part of the table
+        other, _ = odb.query_batch_slot_part(k, 20, True, 1000, 1 - rank, world, rp, ct, T)
+        assert (mine + other == whole).all() and mine.sum() > 0 and other.sum() > 0
+
+        def query(first, count, rows):
+            rows[:count] = torch.from_numpy(_rows_u32_or_invalid(o, mine[first:first + count], RW).view(np.int32))
+
+        def merge(a, b, out, nn):
+            out[:nn] = torch.from_numpy(_merge_u32_or_invalid(a[:nn].numpy().view(np.uint32), b[:nn].numpy().view(np.uint32)).view(np.int32))
+
+        def result(rows, res, nn):
+            m = rows.numpy().view(np.uint32)
+            for i in range(nn):
+                if m[i, 0] == INVALID:
+                    continue
+                row16 = np.zeros(2 * RW, np.uint16)
+                row16[0] = m[i, 0]
+                row16[1:1 + 2 * m[i, 0]:2] = m[i, 1:1 + m[i, 0]] & 0xFFFF
+                row16[2:2 + 2 * m[i, 0]:2] = m[i, 1:1 + m[i, 0]] >> 16
+                res[i, :5] = torch.from_numpy(o.result_from_row(row16).astype(np.int64)).to(torch.int32)
+
+        def result_from_dense(counts, idx, res):
+            res[idx, :5] = torch.from_numpy(o.result_from_counts(counts.numpy().view(np.uint32)).astype(np.int64)).to(torch.int32)
+        ops = dict(query=query, merge=merge, result=result, result_from_dense=result_from_dense,
+                   count_dense=lambda ids: torch.from_numpy(mine[ids.numpy()].astype(np.int32)))
+        ok = True
+        for chunks in (1, 3):
+            sp = multi.ShardedPass(ops, 0, n, RW, "cpu", None, world, rank, chunks=chunks, staged=False)
+            sp.step()
+            got = sp.gather().numpy().view(np.uint32)
+            t = torch.tensor([sp.completed])
+            dist.all_reduce(t)
+            ok = ok and bool((got[:, :5] == expect).all()) and int(t.item()) == int((np.count_nonzero(whole, axis=1) > RW - 1).sum())
+            ok = ok and len(sp.per) == chunks
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sharded_pass_in_chunks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_pass_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_grid_of_parts_and_read_groups():
+    from cuclark_amd import multi
+    for world, parts in ((8, 8), (8, 2), (8, 1), (4, 2), (2, 2), (1, 1)):
+        seen = set()
+        for rank in range(world):
+            p, g, ng, ranks = multi.grid(world, rank, parts)
+            assert ng == world // parts and rank in ranks and len(ranks) == parts and ranks.index(rank) == p
+            seen.add((p, g))
+        assert len(seen) == world
+
+
 def test_two_ranks_complete_overflowed_rows():
     world = 2
     ctx = mp.get_context("spawn")
