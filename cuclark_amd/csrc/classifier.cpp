@@ -477,7 +477,7 @@ class PairedSource : public Classifier::SegmentSource {
   bool next(Classifier::Segment& s) override {
     if (done_) return false;
     std::string out;
-    out.reserve(seg_ + (1u << 16));
+    out.reserve(std::min<size_t>(seg_, (size_t)64 << 20) + (1u << 16));
     std::string l1, l2;
     const std::string seps = " /\t@";
     while (out.size() < seg_) {
@@ -858,6 +858,21 @@ std::string merge_paired(const std::string& file1, const std::string& file2) {
   std::string out;
   while (src.next(s)) out += s.own;
   return out;
+}
+
+bool merge_paired_parallel(const std::string& file1, const std::string& file2, unsigned threads, size_t batch_bytes, std::string& out) {
+  PairedFileFeeder feed(file1, file2, threads);
+  if (!feed.ok()) return false;
+  out.clear();
+  Classifier::Range r;
+  std::string piece;
+  try {
+    while (feed.assign(batch_bytes, batch_bytes * 4 + 4096, r)) { feed.text(r, piece); out += piece; }
+  } catch (const std::runtime_error&) {
+    if (feed.gave_up()) return false;
+    throw;
+  }
+  return !feed.gave_up();
 }
 
 void Classifier::run(const std::string& objects, const std::string& results) {

@@ -102,6 +102,10 @@ class Classifier {
 
 // file.cc:205-268: merged FASTA text of two FASTQ mates ("seq1" + 'N' + "seq2").
 std::string merge_paired(const std::string& file1, const std::string& file2);
+// The same text from the loaders' parallel merger (PairedFileFeeder: line counts, then batches of `batch_bytes` merged
+// independently); false when the files are not what it can cut (the caller then runs merge_paired, which ends the way
+// the reference ends on such files).
+bool merge_paired_parallel(const std::string& file1, const std::string& file2, unsigned threads, size_t batch_bytes, std::string& out);
 
 }  // namespace mic
 #endif

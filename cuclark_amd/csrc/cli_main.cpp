@@ -56,6 +56,26 @@ int main(int argc, char** argv) {
       return 0;
     }
   }
+  // cuCLARK --merge-pairs <file1> <file2> <out.fa> [serial|parallel [threads [batch_bytes]]]: the paired-end merge alone
+  // (file.cc:205-268: the reference writes <file1>_ConcatenatedByCLARK.fa and classifies that), no device involved.
+  // "parallel" prints "gave up" and exits 3 when the loaders' merger hands the files to the serial reader.
+  if (argc >= 5 && std::string(argv[1]) == "--merge-pairs") {
+    try {
+      std::string text;
+      const bool par = argc > 5 && std::string(argv[5]) == "parallel";
+      if (par) {
+        const unsigned th = argc > 6 ? (unsigned)atoi(argv[6]) : 4u;
+        const size_t bb = argc > 7 ? (size_t)strtoull(argv[7], nullptr, 10) : (size_t)1 << 20;
+        if (!mic::merge_paired_parallel(argv[2], argv[3], th ? th : 1u, bb ? bb : 1, text)) { std::cerr << "gave up" << std::endl; return 3; }
+      } else text = mic::merge_paired(argv[2], argv[3]);
+      FILE* f = fopen(argv[4], "wb");
+      if (!f || fwrite(text.data(), 1, text.size(), f) != text.size() || fclose(f) != 0) { std::cerr << "Failed to write " << argv[4] << std::endl; return 1; }
+      return 0;
+    } catch (const std::exception& ex) {
+      std::cerr << ex.what() << std::endl;
+      return 1;
+    }
+  }
   if (argc < 6) {
     std::cerr << "To run " << argv[0] << ", at least four  parameters are necessary:\n";
     std::cerr << "filename of the targets definition, directory of database, filename for objects, filename for results." << std::endl;

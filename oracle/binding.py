@@ -45,6 +45,8 @@ class Oracle:
         L.orc_nt_code.argtypes = [C.c_uint8]
         L.orc_revcomp.restype = C.c_uint64
         L.orc_revcomp.argtypes = [C.c_uint64, C.c_int]
+        L.orc_kmer_from_ascii.restype = C.c_uint64
+        L.orc_kmer_from_ascii.argtypes = [C.c_char_p, C.c_int]
         L.orc_canonical.restype = C.c_uint64
         L.orc_canonical.argtypes = [C.c_uint64, C.c_int]
         L.orc_key_bytes_rule.restype = C.c_int

@@ -19,6 +19,11 @@
 //   ref_table_X query <k> <key_bytes> <prefix> <kmers.txt> [sampling] [mmap]
 //         kmers.txt: one forward-strand k-mer value (decimal u64) per line
 //         prints "<kmer> <found 0/1> <label>" per line
+//   ref_table_X merge <file1.fq> <file2.fq> <out.fa>
+//         the reference's mergePairedFiles (file.cc:205-268) on the two files; its exits (perror + exit(1)) are the process's
+//   ref_table_X codec <k> <kmers_ascii.txt>
+//         per line of k nucleotides: "<getKmers value> <getReverse of it>" (kmersConversion.cc:39-68: the codec and the
+//         reverse complement every other piece of the reference builds on)
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +38,11 @@
 #endif
 
 #include "HashTableStorage_hh.hh"
+#include "file.hh"
+
+// defined in the reference's kmersConversion.cc (not declared in its header)
+void getKmers(const std::string& c, uint64_t& _km_f, uint8_t k);
+void getReverse(uint64_t& _km_r, uint8_t k);
 
 static int code_of(unsigned char c) {
   switch (c) {
@@ -131,7 +141,25 @@ int main(int argc, char** argv) {
     if (kb == 4) return do_query<T32>(k, argv[4], argv[5], s, mm);
     if (kb == 8) return do_query<T64>(k, argv[4], argv[5], s, mm);
   }
-  fprintf(stderr, "usage: %s info | build <k> <key_bytes> <out_prefix> <targets.tsv> [min_count] [light_gap] | "
+  if (argc >= 5 && std::string(argv[1]) == "merge") {
+    mergePairedFiles(argv[2], argv[3], argv[4]);
+    return 0;
+  }
+  if (argc >= 4 && std::string(argv[1]) == "codec") {
+    const int k = atoi(argv[2]);
+    std::ifstream in(argv[3]);
+    std::string line;
+    while (std::getline(in, line)) {
+      if ((int)line.size() < k) continue;
+      uint64_t f = 0;
+      getKmers(line, f, (uint8_t)k);
+      uint64_t r = f;
+      getReverse(r, (uint8_t)k);
+      printf("%llu %llu\n", (unsigned long long)f, (unsigned long long)r);
+    }
+    return 0;
+  }
+  fprintf(stderr, "usage: %s info | merge <f1> <f2> <out> | codec <k> <kmers_ascii.txt> | build <k> <key_bytes> <out_prefix> <targets.tsv> [min_count] [light_gap] | "
                   "query <k> <key_bytes> <prefix> <kmers.txt> [sampling] [mmap]\n", argv[0]);
   return 1;
 }

@@ -724,7 +724,7 @@ def test_table_adapts_to_the_free_hbm(monkeypatch):
 
 
 def test_properties_at_scale():
-    """200 M-k-mer table, 2 M reads (a scale the oracle cannot sweep in a test): the two table layouts give identical
+    """200 M-k-mer table, 2 M reads (a scale the oracle cannot sweep in a test): the four table layouts give identical
     result rows and sparse rows; two bucket-range shards merged on the device equal the whole table; a second pass is
     bit-identical; the oracle agrees on a 20 000-read sample; the constructive known answer holds."""
     if os.environ["MIC_LAYOUT"] != "minimizer":
@@ -774,11 +774,23 @@ def test_properties_at_scale():
     res_m, rows_m, _ = run(2)
     res_d, rows_d, _ = run(1)
     res_s, rows_s, _ = run(3)
+    res_t, rows_t, _ = run(4)                                   # the two-strand table: the layout the headline is quoted on
     assert torch.equal(res_m[:, :6], res_d[:, :6])              # words 0..5: sum, best/second, targets hit
     assert torch.equal(res_s[:, :6], res_d[:, :6])
+    assert torch.equal(res_t[:, :6], res_d[:, :6])
     valid = (rows_m[:, 0] != -1) & (rows_d[:, 0] != -1)
     assert valid.float().mean() > 0.999 and torch.equal(rows_m[valid], rows_d[valid])
     assert torch.equal(rows_s[valid], rows_d[valid])
+    assert torch.equal(rows_t[valid], rows_d[valid])
+    _, rows_ta, _ = run(4, (0, htsize // 3))                    # ... and sharded by on-disk bucket range (per-k-mer kernel)
+    _, rows_tb, _ = run(4, (htsize // 3, htsize))
+    with MiClarkDB(k, T) as e:
+        merged_t = torch.zeros_like(rows_ta)
+        torch.cuda.synchronize()
+        e.merge_rows_device(rows_ta.data_ptr(), rows_tb.data_ptr(), merged_t.data_ptr(), n_reads)
+        e.sync()
+    ok_t = (merged_t[:, 0] != -1) & valid
+    assert ok_t.float().mean() > 0.999 and torch.equal(merged_t[ok_t], rows_m[ok_t])
     _, rows_sa, _ = run(3, (0, htsize // 3))                    # the super-k-mer table sharded by on-disk bucket range
     _, rows_sb, _ = run(3, (htsize // 3, htsize))
     # two shards merged on the device == the whole table
