@@ -65,6 +65,7 @@ SYMBOLS = [
     ("mic_db_load_host", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_int, _VP, C.c_uint32, C.c_uint64, C.c_uint64]),
     ("mic_db_load_device", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_int, _VP, C.c_uint32, C.c_uint64, C.c_uint64]),
     ("mic_db_set_part", C.c_int, [_VP, C.c_uint32, C.c_uint32]),
+    ("mic_db_reserve_hbm", C.c_int, [_VP, C.c_uint64]),
     ("mic_db_get_info", C.c_int, [_VP, C.POINTER(MicDbInfo)]),
     ("mic_db_unload", C.c_int, [_VP]),
     ("mic_db_last_build_report", C.c_char_p, []),

@@ -158,11 +158,17 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
     engines_.push_back(e);
   }
   // the ingest slots (pinned and device buffers of the streaming path) are set up while the database loads
+  // The slots' device memory is announced to the engines first (mic_db_reserve_hbm): the table build sizes its staging area
+  // from the free HBM, and what it sees must not depend on how far the side thread has got.
   std::thread slots;
   if (device_ingest() && !opt_.objects.empty()) {
     size_t bytes = ~(size_t)0 >> 1;
     struct stat st;
     if (opt_.objects2.empty() && !is_gzip(opt_.objects) && stat(opt_.objects.c_str(), &st) == 0) bytes = (size_t)st.st_size;
+    size_t slot_bytes = 0, workers = 0;
+    ingest_geometry(bytes, slot_bytes, workers);
+    const size_t per_engine = (workers + engines_.size() - 1) / engines_.size();
+    for (mic_engine* e : engines_) mic_db_reserve_hbm(e, (uint64_t)per_engine * slot_bytes * 7);   // ~6.1 x the slot size per slot (mic_ingest.hip)
     slots = std::thread([this, bytes] { try { ensure_ingest(bytes); } catch (const std::exception&) { release_ingest(); } });
   }
   std::string load_err;
@@ -172,11 +178,20 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
     if (rc != MIC_OK) load_err = std::string("Failed to load the database: ") + mic_last_error();
   }
   if (slots.joinable()) slots.join();
+  for (mic_engine* e : engines_) mic_db_reserve_hbm(e, 0);
   if (!load_err.empty()) die(load_err);
+  {  // a default layout that was given up for another one is said, with the reason (the rate depends on it: DESIGN.md 5.3)
+    std::istringstream rep(mic_db_last_build_report());
+    std::string ln;
+    while (std::getline(rep, ln))
+      if (ln.compare(0, 9, "fallback:") == 0) std::cerr << "Note: resident table " << ln.substr(0, ln.rfind(':')) << std::endl;
+  }
   mic_db_info info;
   check(mic_db_get_info(engines_[0], &info), "db info");
+  static const char* const layout_name[] = {"?", "direct", "minimizer-keyed", "super-k-mer", "super-k-mer, both strands"};
   std::cerr << "Total DB size in HBM:\t" << info.hbm_bytes / 1000000 / 1000.0 << " GB (" << info.n_elems << " k-mers, "
-            << info.n_overflow << " overflow slots) on " << use << " device(s)\n";
+            << info.n_overflow << " overflow slots, " << layout_name[info.layout >= 1 && info.layout <= 4 ? info.layout : 0]
+            << " table) on " << use << " device(s)\n";
 }
 
 Classifier::~Classifier() {
@@ -1040,19 +1055,27 @@ void Classifier::release_ingest() {
   ingest_bytes_ = ingest_workers_ = 0;
 }
 
-void Classifier::ensure_ingest(size_t total_bytes) {
+// slot size and number of slots of the streaming path for an input of total_bytes
+void Classifier::ingest_geometry(size_t total_bytes, size_t& bytes, size_t& workers) const {
   // one worker (host thread + slot + stream) moves ~30 Mreads/s; eight saturate the link
-  // slots: one per host thread and half as many again in the queues between the stages
-  size_t workers = std::min<size_t>(std::max<size_t>(opt_.threads, 1), 48);
+  // slots: one per host thread and half as many again in the queues between the stages - at most 16 (6 GB of HBM and 2 GB of
+  // pinned memory at the default slot size): more slots only deepen the queues
+  workers = std::min<size_t>(std::max<size_t>(opt_.threads, 1), 48);
   workers += workers / 2;
+  if (workers > 16) workers = 16;
   if (const char* env = getenv("MIC_INGEST_SLOTS")) { long v = atol(env); if (v >= 1 && v <= 96) workers = (size_t)v; }
-  size_t bytes = 64u << 20;
-  if (const char* env = getenv("MIC_INGEST_MB")) { long v = atol(env); if (v >= 1 && v <= 1024) bytes = (size_t)v << 20; }
+  bytes = 64u << 20;
+  if (const char* env = getenv("MIC_INGEST_MB")) { long v = atol(env); if (v >= 1 && v <= 128) bytes = (size_t)v << 20; }
   if (const char* env = getenv("MIC_INGEST_KB")) { long v = atol(env); if (v >= 4) bytes = (size_t)v << 10; }
   if (const char* env = getenv("MIC_INGEST_WORKERS")) { long v = atol(env); if (v >= 1 && v <= 64) workers = (size_t)v; }
   // small inputs: do not pin more than the input needs
   while (bytes > (1u << 20) && total_bytes / workers < bytes / 2) bytes /= 2;
   if (total_bytes < bytes) workers = 1;
+}
+
+void Classifier::ensure_ingest(size_t total_bytes) {
+  size_t bytes = 0, workers = 0;
+  ingest_geometry(total_bytes, bytes, workers);
   if (!ingest_raw_.empty() && bytes <= ingest_bytes_ && workers <= ingest_workers_) return;
   release_ingest();
   const size_t n_eng = engines_.size();
@@ -1190,7 +1213,7 @@ bool Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
           const uint64_t left = feed.remaining();
           size_t w = (size_t)((double)want * ramp);
           if (left / NL < w) w = (size_t)(left / NL);
-          want = std::max<size_t>(std::min(w, want), (size_t)1 << 20);
+          want = std::max<size_t>(std::min(w, want), std::min<size_t>((size_t)1 << 20, want));   // (a floor above `want` would not fit the slot)
         }
         try { more = feed.assign(want, cap, it.r); } catch (const std::exception& ex) { fail(ex.what()); }
         if (!more) {

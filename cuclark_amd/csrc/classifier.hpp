@@ -80,6 +80,7 @@ class Classifier {
   void parse_targets();  // getTargetsData, CuCLARK_hh.hh:1795-1906
   size_t process_segment(const uint8_t* map, size_t nb, bool paired, FILE* fout);   // returns the number of objects
   bool device_ingest() const;                 // is the streaming path usable for this run?
+  void ingest_geometry(size_t total_bytes, size_t& slot_bytes, size_t& slots) const;
   void ensure_ingest(size_t total_bytes);     // slots sized for the input at hand
   void release_ingest();
   std::vector<std::vector<uint8_t*>> ingest_raw_;   // [engine][slot]: pinned input buffers lent by the engines

@@ -850,7 +850,7 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       size_t free_b = 0, total_b = 0;
       HIPCK(hipMemGetInfo(&free_b, &total_b));
       // room for the slots = free HBM minus the two per-slot cursors of the scatter and the query batches afterwards
-      double avail = (double)free_b - (double)n_mslots * 8 - 1.5e9;
+      double avail = (double)free_b - (double)n_mslots * 8 - 1.5e9 - (double)mic_build_reserved_hbm;
       if (const char* env = getenv("MIC_HBM_LIMIT_GB")) {   // test hook: pretend only this much is available for the slots
         const double lim = atof(env) * 1e9;
         if (lim > 0 && avail > lim) avail = lim;
@@ -1022,7 +1022,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     // is left and the table is built in several passes over slot ranges (each pass scatters only its range's candidates).
     size_t free_b = 0, total_b = 0;
     HIPCK(hipMemGetInfo(&free_b, &total_b));
-    avail_b = (double)free_b - 1.5e9;
+    avail_b = (double)free_b - 1.5e9 - (double)mic_build_reserved_hbm;
     if (const char* env = getenv("MIC_HBM_LIMIT_GB")) {   // test hook: pretend only this much is available
       const double lim = atof(env) * 1e9;
       if (lim > 0 && avail_b > lim) avail_b = lim;

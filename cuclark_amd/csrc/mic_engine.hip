@@ -34,6 +34,9 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+}  // namespace
+thread_local uint64_t mic_build_reserved_hbm = 0;
+namespace {
 std::mutex g_report_mu;
 std::string g_report;     // stage times of the last table build of this process, one "name: seconds" per line
 
@@ -81,6 +84,7 @@ struct mic_engine {
   bool timed = false;
   size_t last_n_reads = 0;
   void* ingest = nullptr;      // device-side ingest state (mic_ingest.hip)
+  uint64_t reserve_hbm = 0;         // mic_db_reserve_hbm: device memory the caller is allocating while the table builds
   uint32_t part = 0, n_parts = 0;   // mic_db_set_part: this engine answers for part `part` of `n_parts` of the database
 };
 
@@ -211,6 +215,14 @@ void decide_layout(const mic_engine* e, int& layout, bool& by_default, int& m, i
   if (e->n_parts > 1) by_default = false;
 }
 
+// a default layout that was given up for another one: said in the build report ("fallback: ..." lines; the CLI prints them)
+void note_fallback(const char* from, const char* to, const char* why) {
+  char line[400];
+  snprintf(line, sizeof(line), "fallback: %s -> %s (%s)", from, to, why);
+  for (char* c = line; *c; ++c) if (*c == ':' && c > line + 8) *c = ';';      // one "name: seconds" pair per line
+  mic_build_report_add(line, 0.0);
+}
+
 // mic_db_set_part: the super-k-mer layouts split their RESIDENT table by slot range inside the build (the images stay whole);
 // the other layouts answer for the part's share of the on-disk buckets, the reference's split (CuClarkDB.cu:566-574)
 int apply_part(const mic_engine* e, uint64_t htsize, uint64_t& s0, uint64_t& s1) {
@@ -233,6 +245,7 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   memset(&b, 0, sizeof(b));
   char err[256] = "";
   { std::lock_guard<std::mutex> lk(g_report_mu); g_report.clear(); }
+  mic_build_reserved_hbm = e->reserve_hbm;       // the builders size their staging areas from the free HBM minus this
   struct timespec t_b0; clock_gettime(CLOCK_MONOTONIC, &t_b0);
   int layout, m, m0; bool by_default;
   decide_layout(e, layout, by_default, m, m0);
@@ -249,20 +262,20 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
     // both strands stored: the fastest kernel, twice the entries; falls back to the one-strand table when it does not fit
     rc = mic_build_stable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
                           e->cfg.k, m, e->stream, &b, err, sizeof(err), by_default ? 1 : 0, 1, part, n_parts);
-    if (rc == -3 && !slot_part && (by_default || getenv("MIC_SUPER2_MAY_FALL_BACK"))) { layout = MIC_LAYOUT_SUPER; memset(&b, 0, sizeof(b)); }
-    else if (rc == -5 && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; }
+    if (rc == -3 && !slot_part && (by_default || getenv("MIC_SUPER2_MAY_FALL_BACK"))) { layout = MIC_LAYOUT_SUPER; memset(&b, 0, sizeof(b)); note_fallback("two-strand super-k-mer table", "one-strand super-k-mer table", err); }
+    else if (rc == -5 && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; note_fallback("two-strand super-k-mer table", "minimizer table", err); }
   }
   if (layout == MIC_LAYOUT_SUPER) {
     rc = mic_build_stable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
                           e->cfg.k, m, e->stream, &b, err, sizeof(err), by_default ? 1 : 0, 0, part, n_parts);
     // -3: does not fit; -5: crowded minimizers (tandem repeats): the minimizer layout's trees answer those faster
-    if ((rc == -3 || rc == -5) && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; }
+    if ((rc == -3 || rc == -5) && by_default) { layout = MIC_LAYOUT_MINIMIZER; memset(&b, 0, sizeof(b)); m = m0; note_fallback("super-k-mer table", "minimizer table", err); }
   }
   if (layout == MIC_LAYOUT_MINIMIZER) {
     rc = mic_build_mtable(d_sizes_shard, s1 - s0, s0, htsize, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
                           e->cfg.k, m, e->stream, &b, err, sizeof(err));
     // -3: even the densest minimizer table exceeds the free HBM; the direct layout is ~40 % smaller (64 B per bucket)
-    if (rc == -3 && by_default) { layout = MIC_LAYOUT_DIRECT; memset(&b, 0, sizeof(b)); }
+    if (rc == -3 && by_default) { layout = MIC_LAYOUT_DIRECT; memset(&b, 0, sizeof(b)); note_fallback("minimizer table", "direct table", err); }
   }
   if (layout == MIC_LAYOUT_DIRECT)
     rc = mic_build_table(d_sizes_shard, s1 - s0, d_keys_shard, key_bytes, d_labels_shard, sampling, rank_base,
@@ -508,6 +521,12 @@ const char* mic_db_last_build_report(void) {
   std::lock_guard<std::mutex> lk(g_report_mu);
   copy = g_report;
   return copy.c_str();
+}
+
+int mic_db_reserve_hbm(mic_engine* e, uint64_t bytes) {
+  if (!e) return fail(MIC_E_INVALID, "null engine");
+  e->reserve_hbm = bytes;
+  return MIC_OK;
 }
 
 int mic_db_set_part(mic_engine* e, uint32_t part, uint32_t n_parts) {

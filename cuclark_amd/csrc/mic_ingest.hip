@@ -290,8 +290,12 @@ __global__ void __launch_bounds__(256) csv_len_kernel(CsvArgs a, uint32_t* __res
   const int g = mic_fmt_gamma(total, norm, a.k, tmp);
   const int c = mic_fmt_conf(best, sbest, tmp);
   if (g < 0) atomicOr(&hdr[H_STATUS], (uint32_t)MIC_INGEST_ODD_RECORD);
-  line_len[r] = nl + 1 + digits_u32(norm) + 1 + (uint32_t)(g < 0 ? 1 : g) + 1 + tname_len(a, ib) + 1 + digits_u32(best) + 1 + tname_len(a, is) + 1 +
+  uint32_t ll = nl + 1 + digits_u32(norm) + 1 + (uint32_t)(g < 0 ? 1 : g) + 1 + tname_len(a, ib) + 1 + digits_u32(best) + 1 + tname_len(a, is) + 1 +
                 digits_u32(sbest) + 1 + (uint32_t)c + 1;
+  // a line this long (target names of hundreds of characters) goes through the host path: with every line below the bound the
+  // 32-bit sum of a slot's line lengths cannot wrap (mic_ingest_alloc limits the slot size accordingly)
+  if (ll > 768u) { atomicOr(&hdr[H_STATUS], (uint32_t)MIC_INGEST_TOO_MANY); ll = 0; }
+  line_len[r] = ll;
 }
 
 #define CSV_LDS 24576
@@ -464,7 +468,8 @@ extern "C" {
 int mic_ingest_alloc(mic_engine* e, size_t n_slots, size_t max_bytes, const char* const* target_names, uint32_t n_targets,
                      int want_results, uint8_t** raw) {
   if (!e || !raw || n_slots == 0 || n_slots > 64) return mic_set_error(MIC_E_INVALID, "bad argument");
-  if (max_bytes < 4096 || max_bytes > ((size_t)1 << 30)) return mic_set_error(MIC_E_INVALID, "ingest slots hold 4 KiB .. 1 GiB of input");
+  // at most 128 MiB: with the per-line bound of csv_len_kernel (768 bytes) the 32-bit scan of the CSV line lengths cannot wrap
+  if (max_bytes < 4096 || max_bytes > ((size_t)128 << 20)) return mic_set_error(MIC_E_INVALID, "ingest slots hold 4 KiB .. 128 MiB of input");
   MicTable t; int sc, ncu, dev, k; uint32_t nt;
   int rc = mic_engine_table(e, &t, &sc, &ncu, &dev, &k, &nt);
   if (rc) return rc;
@@ -476,7 +481,8 @@ int mic_ingest_alloc(mic_engine* e, size_t n_slots, size_t max_bytes, const char
   g->max_tiles = g->max_bytes / ING_TILE;
   g->max_lines = g->max_bytes / 16 + 64;          // fewer than 16 bytes per line on average: host path
   g->max_reads = g->max_bytes / 32 + 16;          // fewer than 32 bytes per record on average: host path
-  g->cont_cap = g->max_bytes / 8 + g->max_bytes / 8 + 10 * g->max_reads + 64;   // sum of the per-read reservations (record_kernel)
+  // sum of the per-read reservations of record_kernel: nbytes / 8 + 2 (nbytes / (k + 1) + 1) + 8 containers per read
+  g->cont_cap = g->max_bytes / 8 + 2 * (g->max_bytes / (size_t)(k + 1)) + 10 * g->max_reads + 64;
   g->csv_cap = g->max_bytes;
   g->want_results = want_results;
   g->n_targets = n_targets;

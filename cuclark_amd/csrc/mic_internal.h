@@ -117,6 +117,8 @@ struct MicQueryArgs {
 
 // stage times of the table build in progress (mic_engine.hip; read back with mic_db_last_build_report)
 void mic_build_report_add(const char* what, double seconds);
+// device memory the engine's caller is allocating concurrently with the build (mic_db_reserve_hbm): not available to it
+extern thread_local uint64_t mic_build_reserved_hbm;
 
 // launchers (mic_kernels.hip)
 hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hipStream_t s);

@@ -121,6 +121,10 @@ int mic_db_load_device(mic_engine* e, const uint8_t* d_sizes, uint64_t htsize, c
  * whole .sz/.ky/.lb images (all parts size the table identically); n_parts <= 1 clears the setting.
  * shard_start / shard_end of mic_db_load_* remain the explicit bucket-range form (not combinable with a part). */
 int mic_db_set_part(mic_engine* e, uint32_t part, uint32_t n_parts);
+/* Device memory the caller is about to allocate on this engine's device WHILE the next mic_db_load_* runs (e.g. the ingest
+ * slots, set up on a side thread): the table builders size their staging areas from the free HBM minus this, so the layout
+ * and the number of build passes do not depend on which allocation comes first.  0 clears it. */
+int mic_db_reserve_hbm(mic_engine* e, uint64_t bytes);
 int mic_db_get_info(const mic_engine* e, mic_db_info* info);
 int mic_db_unload(mic_engine* e);
 /* Stage times of the last table build of this process, one "<stage>: <seconds>" per line (what MIC_LOAD_TIMING=1 prints on
@@ -217,7 +221,7 @@ int mic_last_query_ms(mic_engine* e, float* ms);
  * the host only moves bytes.  Output is byte-identical to mic_index_reads + mic_pack_reads + mic_batch_query +
  * mic_csv_line on the same bytes.
  *
- * mic_ingest_alloc    engine-owned pinned input buffers (raw[i], max_bytes each) lent to the caller, as
+ * mic_ingest_alloc    engine-owned pinned input buffers (raw[i], max_bytes each, 4 KiB .. 128 MiB) lent to the caller, as
  *                     CuClarkDB::malloc lends its batch buffers (CuClarkDB.cu:355-360); target_names as in mic_csv_line.
  * mic_ingest_classify blocking; slot-private stream: call it from one host thread per slot to keep the device busy.
  *                     The slot's first byte must be '>' (FASTA, also the merged paired-end text of file.cc:205-268 with

@@ -1,0 +1,121 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer (and ThreadSanitizer) runs of the HOST code of the command line: classifier.cpp
+(loaders, strip_fastq, the paired-end mergers, the gzip / BGZF inflate streams, the three thread pools of run_stream and their
+queues), cli_main.cpp and mic_host.cpp (indexer, packer, CSV), linked against a mock of the device entry points
+(tools/sanitize/mock_engine.cpp: every slot "classified" on the CPU into one "<name>,<length>" line per record).  The checks:
+no sanitizer report, and every record of the input arrives exactly once and in file order.  CPU only - GPU sanitizers are not
+available on this pool."""
+import gzip
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+CSRC = os.path.join(gu.ROOT, "cuclark_amd", "csrc")
+SRCS = [os.path.join(CSRC, f) for f in ("classifier.cpp", "cli_main.cpp", "mic_host.cpp")] + [os.path.join(gu.ROOT, "tools", "sanitize", "mock_engine.cpp")]
+
+
+def _build(tmp, flavour):
+    exe = os.path.join(tmp, f"cuCLARK_{flavour}")
+    san = {"asan": "-fsanitize=address,undefined", "tsan": "-fsanitize=thread"}[flavour]
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fopenmp", *san.split(), "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined",
+                        f"-I{os.path.join(gu.ROOT, 'include')}", f"-I{CSRC}", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                        "-o", exe, *SRCS, "-lz", "-lpthread"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.fixture(scope="module")
+def rig(tmp_path_factory):
+    tmp = str(tmp_path_factory.mktemp("san"))
+    rng = np.random.default_rng(9)
+    nt = np.frombuffer(b"ACGTN", np.uint8)
+
+    def seq(n):
+        return nt[rng.choice(5, n, p=[0.245, 0.245, 0.245, 0.245, 0.02])].tobytes().decode()
+    recs = [(f"read{i}_{'x' * int(rng.integers(0, 50))}", seq(int(rng.integers(1, 400)))) for i in range(30000)]
+    fq = "".join(f"@{n} extra words\n{s}\n+\n{'I' * len(s)}\n" for n, s in recs).encode()
+    fa = "".join(f">{n}\tdesc\n" + "\n".join(s[i:i + 70] for i in range(0, len(s), 70)) + "\n" for n, s in recs).encode()
+    mates = [seq(len(s)) for _, s in recs]
+    fq1 = "".join(f"@{n}/1\n{s}\n+\n{'F' * len(s)}\n" for n, s in recs).encode()
+    fq2 = "".join(f"@{n}/2\n{s}\n+\n{'F' * len(s)}\n" for (n, _), s in zip(recs, mates)).encode()
+    files = {}
+    for name, data in (("r.fq", fq), ("r.fa", fa), ("p_1.fq", fq1), ("p_2.fq", fq2)):
+        files[name] = os.path.join(tmp, name)
+        open(files[name], "wb").write(data)
+    with gzip.open(os.path.join(tmp, "r.fq.gz"), "wb", compresslevel=1) as f:          # several members, like `cat a.gz b.gz`
+        f.write(fq[:len(fq) // 2])
+    with gzip.open(os.path.join(tmp, "r.fq.gz"), "ab", compresslevel=6) as f:
+        f.write(fq[len(fq) // 2:])
+    with open(os.path.join(tmp, "r.bgzf.fq.gz"), "wb") as f:                            # block gzip (BGZF)
+        for o in range(0, len(fq), 0xFF00):
+            blk = fq[o:o + 0xFF00]
+            c = zlib.compressobj(1, zlib.DEFLATED, -15)
+            body = c.compress(blk) + c.flush()
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(blk), len(blk)))
+        f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")
+    for i, (a, b) in enumerate(((fq1, "p_1.fq.gz"), (fq2, "p_2.fq.gz"))):
+        with gzip.open(os.path.join(tmp, b), "wb", compresslevel=1) as f:
+            f.write(a)
+    # a database that only has to exist (the mock engine loads nothing)
+    db = os.path.join(tmp, "DB")
+    os.makedirs(db)
+    genome = os.path.join(tmp, "g.fa")
+    open(genome, "w").write(">g\nACGT\n")
+    open(os.path.join(tmp, "targets.txt"), "w").write(f"{genome} T0\n{genome} T1\n")
+    base = os.path.join(db, "db_central_k31_t2_s64_m0.tsk")
+    open(base + ".sz", "wb").write(bytes(64))
+    open(base + ".ky", "wb").write(b"")
+    open(base + ".lb", "wb").write(b"")
+    single = "".join(f"{n[:39]},{len(s)}\n" for n, s in recs)
+    pairs = "".join(f"{n[:39]},{len(s) + len(m)}\n" for (n, s), m in zip(recs, mates))
+    return dict(tmp=tmp, single=single, pairs=pairs)
+
+
+def _run(exe, rig, objects, env_extra=(), threads="4"):
+    tmp = rig["tmp"]
+    out = os.path.join(tmp, "out")
+    if os.path.exists(out + ".csv"):
+        os.remove(out + ".csv")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1",
+               **dict(env_extra))
+    cmd = [exe, "-k", "31", "--htsize", "64", "-T", os.path.join(tmp, "targets.txt"), "-D", os.path.join(tmp, "DB"),
+           *objects, "-R", out, "-n", threads]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    lines = open(out + ".csv").read().split("\n", 1)
+    return lines[1] if len(lines) > 1 else ""
+
+
+CASES = [
+    ("fastq", ["-O", "r.fq"], "single", {"MIC_INGEST_MB": "4"}),
+    ("fastq_tiny_slots", ["-O", "r.fq"], "single", {"MIC_INGEST_MB": "2"}),
+    ("fasta_multiline", ["-O", "r.fa"], "single", {"MIC_INGEST_MB": "2"}),
+    ("gzip_two_members", ["-O", "r.fq.gz"], "single", {"MIC_INGEST_MB": "2"}),
+    ("bgzf", ["-O", "r.bgzf.fq.gz"], "single", {"MIC_INGEST_MB": "2"}),
+    ("pairs_parallel_merge", ["-P", "p_1.fq", "p_2.fq"], "pairs", {"MIC_INGEST_MB": "2"}),
+    ("pairs_serial_reader", ["-P", "p_1.fq", "p_2.fq"], "pairs", {"MIC_SERIAL_PAIRS": "1", "MIC_INGEST_MB": "2"}),
+    ("pairs_gzip", ["-P", "p_1.fq.gz", "p_2.fq.gz"], "pairs", {"MIC_INGEST_MB": "2"}),
+]
+
+
+@pytest.mark.parametrize("flavour", ["asan", "tsan"])
+def test_host_pipeline_under_sanitizers(flavour, rig):
+    exe = _build(rig["tmp"], flavour)
+    for name, objects, want, env in CASES:
+        objects = [o if o.startswith("-") else os.path.join(rig["tmp"], o) for o in objects]
+        for threads in (("1", "7") if flavour == "asan" else ("5",)):
+            got = _run(exe, rig, objects, env.items(), threads)
+            assert got == rig[want], (flavour, name, threads, got[:200], rig[want][:200])
+    # the merge verb (no engine at all), golden pair files
+    f1, f2 = (os.path.join(gu.GOLDEN, f"pairs_k31_{i}.fq") for i in (1, 2))
+    out = os.path.join(rig["tmp"], "m.fa")
+    want = open(os.path.join(gu.GOLDEN, "pairs_k31_merged.fa"), "rb").read()
+    for mode in ([], ["parallel", "6", "300"]):
+        r = subprocess.run([exe, "--merge-pairs", f1, f2, out, *mode], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and open(out, "rb").read() == want, r.stderr[-2000:]

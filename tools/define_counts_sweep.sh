@@ -6,5 +6,5 @@ for d in "$@"; do
   i=$((i+1))
   make -C $R/cuclark_amd/csrc variant VARIANT_FLAGS="$d" 2>&1 | grep -E "error" -A3
   echo "== $d"
-  MIC_LIB_PATH=$R/cuclark_amd/lib/libmi_clark_var.so bash $R/tools/quick_counts.sh v$i
+  MIC_LIB_PATH=$R/cuclark_amd/csrc/obj_var/libmi_clark_var.so bash $R/tools/quick_counts.sh v$i
 done
