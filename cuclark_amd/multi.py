@@ -111,7 +111,7 @@ class ShardedPass:
     all_to_all of the sparse rows by read sub-range (asynchronous: it overlaps the next chunk's query) -> P-1 merges ->
     best / second -> completion of overflowed rows.  Group rank j ends up with the results of sub-range j of every chunk.
 
-    ops (device work, supplied by the caller - bench.py binds them to an engine, the CPU tests to the oracle):
+    ops (device work, supplied by the caller - bench.py binds them to an engine, the CPU tests to a reference implementation):
       query(first, count, rows)            rows[:count] <- sparse rows of reads [first, first + count) against this rank's part
       merge(a, b, out, n)                  out[:n] <- a (+) b   (mergeKernel, CuClarkDB.cu:1321-1415)
       result(rows, res, n)                 res[:n] <- best / second of rows   (resultKernel, CuClarkDB.cu:1421-1471)
