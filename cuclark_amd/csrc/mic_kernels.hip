@@ -1324,6 +1324,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             cur = mine ? cur : 0xFFFFFFFFu;
           }
           int remaining = mine ? n : 0;
+          uint32_t run_lab = 0, run_cnt = 0;        // label + 1 and hits of this lane's run so far
           do {
             uint32_t sidx[MIC_RMAX / 8];
             // the list of slots to load sits in the stage area itself: it is consumed before the DMA lands.  (Handing the
@@ -1374,7 +1375,13 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
               const int hi = left < jmax ? left : jmax, lo = ctx - right > jmin ? ctx - right : jmin;
               const uint32_t range = ((2u << (hi & 31)) - 1u) & (~0u << (lo & 31));         // empty when hi < lo
               const uint32_t hits = (same && mineq) ? (uint32_t)__popc((pl >> 16) & range) : 0u;
-              tally_counts(hits ? (pl & 0xFFFFu) + 1u : 0u, hits, cbits, acc, n_ent, overflow, total, lane);
+              // The run's hits are tallied ONCE per round: a lane keeps (label, count) of its run; a second entry with ANOTHER
+              // label (the same minimizer in two targets' genomes, both contexts matching parts of the run) is tallied on the
+              // spot - a wave-uniform branch that is virtually never taken.
+              const uint32_t lab_new = (pl & 0xFFFFu) + 1u;
+              const bool other = hits != 0 && run_lab != 0 && run_lab != lab_new;
+              if (wballot(other)) tally_counts(other ? lab_new : 0u, other ? hits : 0u, cbits, acc, n_ent, overflow, total, lane);
+              if (hits != 0 && !other) { run_lab = lab_new; run_cnt += hits; }
               remaining -= (int)hits;
               more = same && remaining > 0 && e < 5;                        // another entry of the same minimizer?
               e += more ? 1u : 0u;
@@ -1385,6 +1392,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             cur = 0xFFFFFFFFu;
             if (wballot(nx)) { if (nx && q[5] <= key) cur = q[31]; }
           } while (wballot(cur != 0xFFFFFFFFu));
+          tally_counts(run_lab, run_cnt, cbits, acc, n_ent, overflow, total, lane);
         }
       }
     }

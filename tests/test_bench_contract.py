@@ -47,11 +47,12 @@ def _bench(*args, timeout=1500):
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
-def _check_config(d, n_reads):
+def _check_config(d, n_reads, random_hits_possible=False):
     assert d["config"]["reads_per_gpu"] == n_reads
     assert d["cpu_baseline"]["parity_with_gpu_on_sample"] is True           # bit-exact vs the oracle on the sample
     ka = d["known_answer"]
-    assert ka["label_and_count_ok"] == 1.0 and ka["random_reads_no_hit"] == 1.0
+    # (k = 27: 1.8e8 stored 27-mers of 1.8e16 - a few of the 2 M random reads do meet one; k = 31: none in 1e12 draws)
+    assert ka["label_and_count_ok"] == 1.0 and (ka["random_reads_no_hit"] == 1.0 or (random_hits_possible and ka["random_reads_no_hit"] > 0.99999))
     assert d["config"]["flagged_reads_dense_path"] == 0
     assert d["pipeline"]["results_equal_device_path"] is True
     e2e = d["end_to_end"]
@@ -109,7 +110,7 @@ def test_bench_table_sharded_mode_under_rccl_on_one_gpu():
 def test_bench_light27_config2_proper():
     """SURVEY.md 8d config 2 as cuCLARK-l builds it: HTSIZE 57 777 779, k = 27, u32 keys, ~90 M k-mers, 10 M reads."""
     d = _bench("--workload", "light27", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000")
-    _check_config(d, 10_000_000)
+    _check_config(d, 10_000_000, random_hits_possible=True)
     t = d["config"]["table"]
     assert t["htsize"] == 57777779 and d["config"]["k"] == 27 and 80_000_000 < t["kmers"] < 95_000_000
     assert "k=27" in d["metric"]
