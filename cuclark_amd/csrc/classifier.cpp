@@ -5,6 +5,7 @@
 // Multi-device: one engine per GPU with the whole table resident; batches are dealt round-robin (reads are
 // independent), results are written in file order.
 #include "classifier.hpp"
+#include "pgz.hpp"
 
 #include <fcntl.h>
 #include <stdlib.h>
@@ -298,7 +299,8 @@ class InflateStream {
       gzbuffer(gz_, 1 << 20);
     }
     ok_ = true;
-    producer_ = std::thread([this] { bgzf_ ? produce_bgzf() : produce_gz(); });
+    path_ = path;
+    producer_ = std::thread([this] { bgzf_ ? produce_bgzf() : (threads_ > 1 && !getenv("MIC_SERIAL_GZIP") ? produce_gz_parallel() : produce_gz()); });
   }
   ~InflateStream() {
     { std::lock_guard<std::mutex> g(m_); stop_ = true; }
@@ -355,6 +357,30 @@ class InflateStream {
       if (!push(chunk)) return;
     }
   }
+  // ordinary gzip, inflated by threads_ threads at once (pgz.hpp); anything it cannot map falls back to the zlib stream
+  void produce_gz_parallel() {
+    int fd = open(path_.c_str(), O_RDONLY);
+    struct stat st;
+    if (fd == -1 || fstat(fd, &st) != 0 || st.st_size < 18) { if (fd != -1) close(fd); produce_gz(); return; }
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { produce_gz(); return; }
+    if (((const uint8_t*)m)[0] != 0x1f || ((const uint8_t*)m)[1] != 0x8b) {       // a plain file: zlib passes it through
+      munmap(m, (size_t)st.st_size);
+      produce_gz();
+      return;
+    }
+    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    bool stopped = false;
+    auto sink = pgz::piece_sink([&](pgz::Bytes&& b) {
+      std::vector<char> chunk((const char*)b.p, (const char*)b.p + b.n);
+      if (!push(chunk)) { stopped = true; return false; }
+      return true;
+    });
+    const int rc = pgz::inflate_all((const uint8_t*)m, (size_t)st.st_size, threads_, (size_t)512 << 10, sink);
+    munmap(m, (size_t)st.st_size);
+    if (!stopped) finish(rc != 0);
+  }
   void produce_bgzf() {
     struct Blk { size_t off, csize, isize, out; };
     std::vector<unsigned char> in;
@@ -409,6 +435,7 @@ class InflateStream {
 
   bool ok_ = false, bgzf_ = false;
   unsigned threads_ = 1;
+  std::string path_;
   gzFile gz_ = nullptr; FILE* raw_ = nullptr;
   std::thread producer_;
   std::mutex m_; std::condition_variable cv_data_, cv_space_;
@@ -458,6 +485,88 @@ class GzSource : public Classifier::SegmentSource {
  private:
   InflateStream in_; std::string carry_; bool eof_ = false; size_t seg_;
 };
+
+// ---- compressed input, inflated up front ---------------------------------------------------------------------------------
+// The reference's script copies a .gz input, gunzips the copy and classifies the plain file (classify_metagenome.sh:116-142).
+// The same here, in memory: the file is inflated by many threads at once (pgz.hpp; block gzip block-parallel) straight into
+// an anonymous memory file (memfd), and the plain-file path then runs on that file: its loaders cut, strip and - for a pair of
+// files - merge in parallel, which no reader of an inflate stream can.  Only when the inflated text would not fit in half of
+// the available memory does the input stay a stream (GzSource / PairedSource over InflateStream).
+class InflatedFile {
+ public:
+  ~InflatedFile() { if (fd_ != -1) close(fd_); }
+  int fd() const { return fd_; }
+  uint64_t size() const { return size_; }
+  std::string path() const { return "/proc/self/fd/" + std::to_string(fd_); }
+  // 0: inflated; 1: not attempted (does not fit in memory, or MIC_GZ_STREAM); -1: the file is damaged
+  int inflate(const std::string& src, unsigned threads) {
+    if (getenv("MIC_GZ_STREAM")) return 1;
+    int in = open(src.c_str(), O_RDONLY);
+    struct stat st;
+    if (in == -1 || fstat(in, &st) != 0 || st.st_size < 18) { if (in != -1) close(in); return 1; }
+    {  // room for the text?  (deflate of sequence data: 3 - 6 x; 10 x to be safe)
+      uint64_t avail_kb = 0;
+      if (FILE* f = fopen("/proc/meminfo", "r")) {
+        char line[128];
+        while (fgets(line, sizeof(line), f)) if (sscanf(line, "MemAvailable: %llu kB", (unsigned long long*)&avail_kb) == 1) break;
+        fclose(f);
+      }
+      if (avail_kb && (uint64_t)st.st_size * 10 > avail_kb * 1024 / 2) { close(in); return 1; }
+    }
+    fd_ = memfd_create("mic_inflated", MFD_CLOEXEC);
+    if (fd_ == -1) { close(in); return 1; }
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, in, 0);
+    close(in);
+    if (m == MAP_FAILED) { close(fd_); fd_ = -1; return 1; }
+    const uint8_t* h = (const uint8_t*)m;
+    const bool bgzf = h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C';
+    int rc;
+    if (!bgzf) {
+      struct FdSink {
+        int fd; uint64_t size = 0; uint8_t* map = nullptr; size_t map_len = 0;
+        uint8_t* reserve(size_t n) {
+          const uint64_t a = size & ~(uint64_t)4095;
+          map_len = (size_t)(size - a) + n;
+          if (ftruncate(fd, (off_t)(size + n)) != 0) return nullptr;
+          void* p = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)a);
+          if (p == MAP_FAILED) return nullptr;
+          map = (uint8_t*)p;
+          return map + (size - a);
+        }
+        bool commit(size_t n) { munmap(map, map_len); size += n; return true; }
+      } sink{fd_};
+      rc = pgz::inflate_all(h, (size_t)st.st_size, threads, (size_t)1 << 20, sink);
+      size_ = sink.size;
+      munmap(m, (size_t)st.st_size);
+      if (rc == 1) { close(fd_); fd_ = -1; return 1; }           // out of memory for the text: stream instead
+    } else {
+      munmap(m, (size_t)st.st_size);
+      InflateStream is(src, threads);
+      std::vector<char> buf((size_t)16 << 20);
+      rc = 0;
+      for (;;) {
+        const long n = is.read(buf.data(), buf.size());
+        if (n < 0) { rc = -1; break; }
+        if (n == 0) break;
+        size_t w = 0;
+        while (w < (size_t)n) { const ssize_t k = write(fd_, buf.data() + w, (size_t)n - w); if (k <= 0) { rc = 1; break; } w += (size_t)k; }
+        if (rc) break;
+        size_ += (uint64_t)n;
+      }
+      if (rc == 1) { close(fd_); fd_ = -1; return 1; }
+    }
+    return rc == 0 ? 0 : -1;
+  }
+ private:
+  int fd_ = -1; uint64_t size_ = 0;
+};
+
+static unsigned inflate_threads(size_t cli_threads, unsigned files) {
+  unsigned hw = std::thread::hardware_concurrency();
+  unsigned t = std::max<unsigned>((unsigned)cli_threads, std::min(hw ? hw : 1u, 32u));
+  if (const char* env = getenv("MIC_INFLATE_THREADS")) { long v = atol(env); if (v >= 1 && v <= 256) t = (unsigned)v; }
+  return std::max(1u, t / std::max(1u, files));
+}
 
 // line reader over zlib (plain files are read transparently)
 class GzLines {
@@ -892,6 +1001,26 @@ bool merge_paired_parallel(const std::string& file1, const std::string& file2, u
 
 void Classifier::run(const std::string& objects, const std::string& results) {
   auto simple = [&](const std::string& obj, const std::string& res) {
+    if (is_gzip(obj) && device_ingest()) {
+      // inflate up front (all threads), then the plain-file path on the inflated text
+      struct timeval ta, tb;
+      gettimeofday(&ta, nullptr);
+      InflatedFile inf;
+      const int rc = inf.inflate(obj, inflate_threads(opt_.threads, 1));
+      if (rc < 0) die("Failed to uncompress input objects.");
+      if (rc == 0) {
+        gettimeofday(&tb, nullptr);
+        prelude_s_ = (tb.tv_sec - ta.tv_sec) + (tb.tv_usec - ta.tv_usec) / 1e6;
+        if (getenv("MIC_CLI_TIMING")) std::cerr << "[timing] inflate: " << inf.size() / 1e6 << " MB of text in " << prelude_s_ * 1e3 << " ms" << std::endl;
+        if (inf.size() == 0) { prelude_s_ = 0; std::cerr << "Failed to open " << obj << std::endl; return; }
+        FileFeeder feed(inf.path());
+        if (!feed.ok()) { prelude_s_ = 0; std::cerr << "Failed to open " << obj << std::endl; return; }
+        if (feed.first_byte() != '>' && feed.first_byte() != '@') { std::cerr << "Failed to recognize the format of the file." << std::endl; exit(-1); }
+        run_stream(feed, res, false, (size_t)feed.size());
+        prelude_s_ = 0;
+        return;
+      }
+    }
     if (is_gzip(obj)) {
       GzSource src(obj, segment_bytes_);
       if (!src.ok()) { std::cerr << "Failed to uncompress input objects." << std::endl; return; }
@@ -942,6 +1071,30 @@ void Classifier::run_paired(const std::string& f1, const std::string& f2, const 
     if (list_mode) std::cout << "> Processing file: '" << merged_name << "' in " << opt_.batches << " batches." << std::endl;
     else std::cout << "Processing file: '" << merged_name << "' in " << opt_.batches << " batches using " << opt_.threads
                    << " CPU thread(s)." << std::endl;
+    if (device_ingest() && (is_gzip(a) || is_gzip(b)) && !getenv("MIC_SERIAL_PAIRS")) {
+      // compressed mates: both inflated up front and at the same time, then merged by the loaders like plain files
+      struct timeval ta, tb;
+      gettimeofday(&ta, nullptr);
+      InflatedFile ia, ib;
+      int ra = 1, rb = 1;
+      const bool ga = is_gzip(a), gb = is_gzip(b);
+      const unsigned th = inflate_threads(opt_.threads, (ga ? 1u : 0u) + (gb ? 1u : 0u));
+      std::thread tb_thread;
+      if (gb) tb_thread = std::thread([&] { rb = ib.inflate(b, th); });
+      if (ga) ra = ia.inflate(a, th);
+      if (tb_thread.joinable()) tb_thread.join();
+      if ((ga && ra < 0) || (gb && rb < 0)) die("Failed to uncompress input objects.");
+      if ((!ga || ra == 0) && (!gb || rb == 0)) {
+        gettimeofday(&tb, nullptr);
+        prelude_s_ = (tb.tv_sec - ta.tv_sec) + (tb.tv_usec - ta.tv_usec) / 1e6;
+        if (getenv("MIC_CLI_TIMING")) std::cerr << "[timing] inflate: " << ((ga ? ia.size() : 0) + (gb ? ib.size() : 0)) / 1e6 << " MB of text in " << prelude_s_ * 1e3
+                                                << " ms (" << th << " threads per file)" << std::endl;
+        PairedFileFeeder feed(ga ? ia.path() : a, gb ? ib.path() : b, (unsigned)opt_.threads);
+        const bool done = feed.ok() && run_stream(feed, res, true, (size_t)feed.merged_estimate());
+        prelude_s_ = 0;
+        if (done) return;
+      }
+    }
     if (device_ingest() && !is_gzip(a) && !is_gzip(b) && !getenv("MIC_SERIAL_PAIRS")) {
       // two plain FASTQ files: the loaders merge the pair in parallel; files that need the reference's line-by-line
       // treatment come back here
@@ -1349,7 +1502,8 @@ bool Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
   if (feed.gave_up()) { unlink(csv.c_str()); return false; }
   if (!err.empty()) die(err);
   gettimeofday(&t1, nullptr);
-  const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
+  // (the time it took to inflate a compressed input up front belongs to the assignment time)
+  const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0 + prelude_s_;
   if (timing) std::cerr << "[timing] device ingest: " << n_batches << " batches of <= " << (cap >> 10) << " KB on " << S
                         << " slot(s), " << n_fallback << " through the host path; threads: " << NL << " load, " << ND << " device, " << NW
                         << " write; thread-seconds: load " << us_load / 1e6 << ", device " << us_dev / 1e6 << ", write " << us_write / 1e6

@@ -99,6 +99,7 @@ class Classifier {
   std::vector<std::string> labels_, labels_c_, names_;
   std::vector<mic_engine*> engines_;
   std::atomic<size_t> n_objects_{0};
+  double prelude_s_ = 0;                      // seconds spent inflating a compressed input before the streaming path started
 };
 
 // file.cc:205-268: merged FASTA text of two FASTQ mates ("seq1" + 'N' + "seq2").

@@ -27,6 +27,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -120,20 +123,50 @@ static const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12
 
 // Reads the header of a dynamic block (after BFINAL / BTYPE) into the two codes.  strict: everything a real encoder emits
 // must hold (used by the block finder); returns false on anything invalid.
+// Kraft sum of a set of code lengths (in units of 2^-15): 1 << 15 for a complete code
+static inline uint32_t kraft(const uint8_t* len, int n) {
+  uint32_t sum = 0;
+  for (int i = 0; i < n; ++i) if (len[i]) sum += 1u << (15 - len[i]);
+  return sum;
+}
+
+// Reads the header of a dynamic block (after BFINAL / BTYPE) into the two codes.  strict: what a real encoder emits must
+// hold - every code complete (used by the block finder, where the cheap tests come first: of the bit offsets that are not
+// block starts almost none survives the code-length code's Kraft sum, so the finder costs tens of nanoseconds per offset).
 static inline bool read_dynamic(Bits& b, Huff& lit, Huff& dist, bool strict) {
   const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
   if (hlit > 286 || hdist > 30) return false;
   uint8_t cl[19]; memset(cl, 0, sizeof(cl));
   for (int i = 0; i < hclen; ++i) cl[kClOrder[i]] = (uint8_t)b.get(3);
-  Huff pre;
-  const int pr = pre.build(cl, 19);
-  if (pr < 0 || (pr > 0 && strict)) return false;
-  if (pr > 0) { int used = 0; for (int i = 0; i < 19; ++i) used += cl[i] != 0; if (used != 1) return false; }
+  const uint32_t ks = kraft(cl, 19);
+  if (ks > (1u << 15)) return false;
+  if (ks < (1u << 15)) {                                       // incomplete: legal only as one single code (zlib's rule), never from an encoder
+    if (strict) return false;
+    int used = 0; for (int i = 0; i < 19; ++i) used += cl[i] != 0;
+    if (used != 1) return false;
+  }
+  // the code-length code has at most 7 bits: a 128-entry table
+  uint8_t pre[128];
+  {
+    memset(pre, 0, sizeof(pre));
+    uint32_t code = 0;
+    for (int l = 1; l <= 7; ++l) {
+      for (int sym = 0; sym < 19; ++sym) {
+        if (cl[sym] != l) continue;
+        uint32_t r = 0;
+        for (int q = 0; q < l; ++q) r |= ((code >> q) & 1u) << (l - 1 - q);
+        for (uint32_t v = r; v < 128; v += 1u << l) pre[v] = (uint8_t)((l << 5) | sym);
+        ++code;
+      }
+      code <<= 1;
+    }
+  }
   uint8_t len[320]; int n = 0;
   while (n < hlit + hdist) {
-    if (b.over) return false;
-    const int s = pre.decode(b);
-    if (s < 0) return false;
+    const uint8_t e = pre[b.peek(7)];
+    if (!e) return false;
+    b.drop(e >> 5);
+    const int s = e & 31;
     if (s < 16) { len[n++] = (uint8_t)s; continue; }
     int rep, val = 0;
     if (s == 16) { if (n == 0) return false; val = len[n - 1]; rep = 3 + (int)b.get(2); }
@@ -142,17 +175,17 @@ static inline bool read_dynamic(Bits& b, Huff& lit, Huff& dist, bool strict) {
     if (n + rep > hlit + hdist) return false;
     while (rep--) len[n++] = (uint8_t)val;
   }
-  if (len[256] == 0) return false;                            // no end-of-block code
-  const int lr = lit.build(len, hlit);
-  if (lr < 0 || (lr > 0 && strict)) return false;
-  if (lr > 0) return false;                                    // zlib rejects incomplete literal/length codes (more than one code)
-  const int dr = dist.build(len + hlit, hdist);
-  if (dr < 0) return false;
-  if (dr > 0) {                                                // incomplete distance code: only a single code (or none) is legal
+  if (b.over || len[256] == 0) return false;                   // no end-of-block code
+  if (kraft(len, hlit) != (1u << 15)) return false;            // zlib rejects over-subscribed and incomplete literal/length codes
+  const uint32_t kd = kraft(len + hlit, hdist);
+  if (kd > (1u << 15)) return false;
+  if (kd < (1u << 15)) {                                       // incomplete distance code: a single code (or none) is legal
     int used = 0; for (int i = 0; i < hdist; ++i) used += len[hlit + i] != 0;
     if (used > 1) return false;
   }
-  return !b.over;
+  lit.build(len, hlit);
+  dist.build(len + hlit, hdist);
+  return true;
 }
 
 static inline void fixed_codes(Huff& lit, Huff& dist) {
@@ -332,13 +365,47 @@ static inline bool find_block(const uint8_t* data, size_t n, uint64_t from, uint
   return false;
 }
 
-template <typename F>
-static inline void run_parallel(unsigned threads, F&& f) {
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < threads; ++t) pool.emplace_back(f);
-  f();
-  for (auto& t : pool) t.join();
-}
+// A pool that lives as long as one file: the phases of a round are short, thread creation per phase would show.
+class Pool {
+ public:
+  explicit Pool(unsigned threads) {
+    for (unsigned t = 1; t < threads; ++t) th_.emplace_back([this] { loop(); });
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  // f() is run by every thread of the pool and by the caller; returns when all are done
+  void run(const std::function<void()>& f) {
+    { std::lock_guard<std::mutex> g(m_); job_ = &f; left_ = th_.size(); ++gen_; }
+    cv_.notify_all();
+    f();
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [&] { return left_ == 0; });
+    job_ = nullptr;
+  }
+ private:
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void()>* f;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        f = job_;
+      }
+      (*f)();
+      { std::lock_guard<std::mutex> g(m_); --left_; }
+      done_.notify_one();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_; std::condition_variable cv_, done_;
+  const std::function<void()>* job_ = nullptr; size_t left_ = 0; uint64_t gen_ = 0; bool stop_ = false;
+};
 
 // ---- the whole file -------------------------------------------------------------------------------------------------
 // One round's output: a plain array (no value-initialisation of tens of megabytes) handed to the consumer by move.
@@ -352,9 +419,20 @@ struct Bytes {
   ~Bytes() { free(p); }
 };
 
-// Inflates a gzip file held in memory (all members), `threads` at a time, handing the output over in order, one piece per
-// round, through sink(Bytes&&) -> bool (false: stop).  Returns 0 on success, -1 on a damaged file (as zlib would report),
-// 1 if the consumer stopped.  chunk_bytes: compressed bytes per chunk.
+// sink that hands every round's bytes to f(Bytes&&) -> bool
+template <typename F>
+struct PieceSink {
+  F f; Bytes cur;
+  explicit PieceSink(F fn) : f(fn) {}
+  uint8_t* reserve(size_t n) { cur = Bytes(); cur.p = (uint8_t*)malloc(n ? n : 1); cur.n = n; return cur.p; }
+  bool commit(size_t) { return f(std::move(cur)); }
+};
+template <typename F> static inline PieceSink<F> piece_sink(F f) { return PieceSink<F>(f); }
+
+// Inflates a gzip file held in memory (all members), `threads` at a time.  The output of every round goes where the sink
+// says: uint8_t* sink.reserve(size_t n) hands out room for the round's n bytes (nullptr: stop), the chunks of the round are
+// written into it in parallel, bool sink.commit(size_t n) takes it over (false: stop).  Returns 0 on success, -1 on a damaged
+// file (as zlib would report), 1 if the sink stopped.  chunk_bytes: compressed bytes per chunk.
 template <typename Sink>
 int inflate_all(const uint8_t* data, size_t n, unsigned threads, size_t chunk_bytes, Sink&& sink) {
   if (threads < 1) threads = 1;
@@ -369,6 +447,7 @@ int inflate_all(const uint8_t* data, size_t n, unsigned threads, size_t chunk_by
   uint64_t member_len = 0;
   // chunk slots live as long as the file: their symbol arrays keep their capacity from round to round
   std::vector<Chunk> ch(round_chunks), redo(round_chunks + 2);
+  Pool pool(threads);
   const bool debug = getenv("PGZ_DEBUG") != nullptr;
   for (;;) {
     // chunk starts of this round (compressed byte offsets), then their block starts
@@ -384,19 +463,21 @@ int inflate_all(const uint8_t* data, size_t n, unsigned threads, size_t chunk_by
     const uint64_t round_end = (uint64_t)std::min(n, base + n_ch * chunk_bytes) * 8;
     {
       std::atomic<size_t> next{1};
-      run_parallel(threads, [&] {
+      pool.run([&] {
         for (;;) {
           const size_t i = next.fetch_add(1);
           if (i >= n_ch) return;
-          const uint64_t limit = i + 1 < n_ch ? ch[i + 1].start_bit : round_end;
+          // (the search range comes from the nominal cuts: a neighbour's start_bit is being rewritten by its own finder)
+          const uint64_t from = (uint64_t)(base + i * chunk_bytes) * 8;
+          const uint64_t limit = i + 1 < n_ch ? (uint64_t)(base + (i + 1) * chunk_bytes) * 8 : round_end;
           uint64_t at = 0;
-          if (find_block(data, n, ch[i].start_bit, limit, at)) { ch[i].start_bit = at; ch[i].found = true; }
+          if (find_block(data, n, from, limit, at)) { ch[i].start_bit = at; ch[i].found = true; }
         }
       });
     }
     {
       std::atomic<size_t> next{0};
-      run_parallel(threads, [&] {
+      pool.run([&] {
         for (;;) {
           const size_t i = next.fetch_add(1);
           if (i >= n_ch) return;
@@ -454,14 +535,12 @@ int inflate_all(const uint8_t* data, size_t n, unsigned threads, size_t chunk_by
       }
       window.swap(nw);
     }
-    Bytes out;
-    out.n = (size_t)total;
-    out.p = (uint8_t*)malloc(out.n ? out.n : 1);
-    if (!out.p) return -1;
+    uint8_t* out_p = total ? sink.reserve((size_t)total) : nullptr;
+    if (total && !out_p) return 1;
     // phase 4 in parallel: markers -> bytes into the round's output, CRC-32 of the pieces between member ends
     {
       std::atomic<size_t> next{0};
-      run_parallel(threads, [&] {
+      pool.run([&] {
         for (;;) {
           const size_t i = next.fetch_add(1);
           if (i >= order.size()) return;
@@ -469,7 +548,7 @@ int inflate_all(const uint8_t* data, size_t n, unsigned threads, size_t chunk_by
           const uint8_t* w = win[i].data();
           const size_t m = c.n_sym;
           const uint16_t* s = c.sym;
-          uint8_t* o = out.p + c.out_off;
+          uint8_t* o = out_p + c.out_off;
           for (size_t q = 0; q < m; ++q) o[q] = s[q] < 256 ? (uint8_t)s[q] : w[s[q] & 0x7FFF];
           uint64_t a = 0;
           for (size_t e = 0; e <= c.ends.size(); ++e) {
@@ -494,7 +573,7 @@ int inflate_all(const uint8_t* data, size_t n, unsigned threads, size_t chunk_by
         }
       }
     }
-    if (out.n && !sink(std::move(out))) return 1;
+    if (total && !sink.commit((size_t)total)) return 1;
     if (eof) return 0;
     if (pos >= (uint64_t)n * 8) return -1;        // the data ended inside a member
     cur_bit = pos;

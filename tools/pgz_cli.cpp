@@ -20,10 +20,11 @@ int main(int argc, char** argv) {
   FILE* o = std::string(argv[2]) == "-" ? nullptr : fopen(argv[2], "wb");
   size_t total = 0;
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = pgz::inflate_all(gz.data(), gz.size(), th, cb, [&](pgz::Bytes&& b) {
+  auto sink = pgz::piece_sink([&](pgz::Bytes&& b) {
     total += b.n;
     return !o || fwrite(b.p, 1, b.n, o) == b.n;
   });
+  const int rc = pgz::inflate_all(gz.data(), gz.size(), th, cb, sink);
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (o) fclose(o);
   fprintf(stderr, "rc=%d %zu bytes in %.3f s = %.1f MB/s on %u threads\n", rc, total, dt, total / dt / 1e6, th);
