@@ -282,8 +282,8 @@ class MmapSource : public Classifier::SegmentSource {
 class InflateStream {
  public:
   explicit InflateStream(const std::string& path, unsigned threads = 0) {
-    unsigned hw = std::thread::hardware_concurrency();
-    threads_ = threads ? threads : std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
+    const unsigned hw = pgz::usable_cpus();
+    threads_ = threads ? threads : std::max(1u, std::min(8u, hw / 2));
     if (const char* env = getenv("MIC_INFLATE_THREADS")) { long v = atol(env); if (v >= 1 && v <= 64) threads_ = (unsigned)v; }
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return;
@@ -562,8 +562,9 @@ class InflatedFile {
 };
 
 static unsigned inflate_threads(size_t cli_threads, unsigned files) {
-  unsigned hw = std::thread::hardware_concurrency();
-  unsigned t = std::max<unsigned>((unsigned)cli_threads, std::min(hw ? hw : 1u, 32u));
+  // all the CPUs the process may use (the cgroup's quota, not the host's thread count), at least what -n asks for
+  const unsigned hw = pgz::usable_cpus();
+  unsigned t = std::max<unsigned>((unsigned)cli_threads, std::min(hw, 64u));
   if (const char* env = getenv("MIC_INFLATE_THREADS")) { long v = atol(env); if (v >= 1 && v <= 256) t = (unsigned)v; }
   return std::max(1u, t / std::max(1u, files));
 }

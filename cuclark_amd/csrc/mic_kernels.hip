@@ -1120,6 +1120,9 @@ __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cb
 #ifndef MIC_R_EAGER_ENTRY
 #define MIC_R_EAGER_ENTRY 1
 #endif
+#ifndef MIC_R_TALLY_PER_ROUND
+#define MIC_R_TALLY_PER_ROUND 1   // 0: a tally per entry iteration (round 2's form), for comparison
+#endif
 template <int KK, int MM, bool FWD, bool PART>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r(const MicQueryArgs a) {
   // staged slots: 8 per LDS-DMA instruction, 128 bytes apart (the DMA's own layout: lane L lands at base + 16 L); each
@@ -1379,9 +1382,13 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
               // label (the same minimizer in two targets' genomes, both contexts matching parts of the run) is tallied on the
               // spot - a wave-uniform branch that is virtually never taken.
               const uint32_t lab_new = (pl & 0xFFFFu) + 1u;
+#if MIC_R_TALLY_PER_ROUND
               const bool other = hits != 0 && run_lab != 0 && run_lab != lab_new;
               if (wballot(other)) tally_counts(other ? lab_new : 0u, other ? hits : 0u, cbits, acc, n_ent, overflow, total, lane);
               if (hits != 0 && !other) { run_lab = lab_new; run_cnt += hits; }
+#else
+              tally_counts(hits ? lab_new : 0u, hits, cbits, acc, n_ent, overflow, total, lane);
+#endif
               remaining -= (int)hits;
               more = same && remaining > 0 && e < 5;                        // another entry of the same minimizer?
               e += more ? 1u : 0u;
