@@ -290,6 +290,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=4, help="--mode db: read chunks per pass (the row exchange of a chunk overlaps the next chunk's kernel)")
     ap.add_argument("--no-parts-proxy", action="store_true",
                     help="N=1: skip \"table_sharded_proxy\" (kernel time of part 0 of 2/4/8 of the table against all reads)")
+    ap.add_argument("--no-default-layout", action="store_true", help="N=1: skip the kernel leg on the engine's default (one-strand) table")
     ap.add_argument("--allow-variant-lib", action="store_true",
                     help="accept MIC_LIB_PATH (a measuring build of the library, tools/*_sweep.sh); refused otherwise: the line must "
                          "describe the product library")
@@ -650,7 +651,7 @@ def main():
             except Exception as ex:
                 proxy = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             log("table_sharded_proxy:", json.dumps(proxy))
-        if info["layout"] == 4 and not os.environ.get("MIC_LAYOUT"):
+        if info["layout"] == 4 and not os.environ.get("MIC_LAYOUT") and not args.no_default_layout:
             # `value` is quoted on the two-strand table; the command line (the end_to_end leg) builds the engine's AUTO layout,
             # the one-strand table: its kernel on the same reads, so both legs of this line can be read against their own kernel
             try:

@@ -6,7 +6,7 @@ cd $R/cuclark_amd/csrc
 for v in ${@:-0 1 2 3 6}; do
   make variant VARIANT_FLAGS="-DMIC_ABLATE=$v" 2>&1 | grep -E "error" -A3   # a measuring build: obj_var/, libmi_clark_var.so (csrc/Makefile)
   OUT=$R/gpurun_out/ablate_$v; mkdir -p $OUT
-  ( cd /tmp && TMPDIR=/tmp timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --allow-variant-lib --no-parts-proxy --no-cpu --no-pipeline --no-e2e --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/err.txt )
+  ( cd /tmp && TMPDIR=/tmp timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --allow-variant-lib --no-parts-proxy --no-default-layout --no-cpu --no-pipeline --no-e2e --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/err.txt )
   python3 - <<PY
 import csv, glob, collections, json
 agg = collections.defaultdict(list)

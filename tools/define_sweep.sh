@@ -7,6 +7,6 @@ export MIC_LIB_PATH=$R/cuclark_amd/csrc/obj_var/libmi_clark_var.so
 for d in "$@"; do
   make -C $R/cuclark_amd/csrc variant VARIANT_FLAGS="$d" 2>&1 | grep -E "error" -A3
   for i in 1 2; do
-    python $R/bench.py --allow-variant-lib --no-parts-proxy --no-cpu --no-pipeline --no-e2e --steps 10 --warmup 2 $BENCH_ARGS 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$d', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
+    python $R/bench.py --allow-variant-lib --no-parts-proxy --no-default-layout --no-cpu --no-pipeline --no-e2e --steps 10 --warmup 2 $BENCH_ARGS 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$d', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
   done
 done
