@@ -288,6 +288,9 @@ def main():
                     help="--mode db: parts the table is cut into (default: one per rank = the reference's mode).  With fewer parts than "
                          "ranks the ranks form N / parts groups that split the reads (2-D layout, DESIGN.md 6)")
     ap.add_argument("--chunks", type=int, default=4, help="--mode db: read chunks per pass (the row exchange of a chunk overlaps the next chunk's kernel)")
+    ap.add_argument("--single-part", type=int, default=0,
+                    help="N=1, profiling only: load part 0 of this many parts of the table (mic_db_set_part) and time its kernel on all reads - "
+                         "the instantiation one rank of a table-sharded run executes; results are partial, the checks that need the whole table are skipped")
     ap.add_argument("--no-parts-proxy", action="store_true",
                     help="N=1: skip \"table_sharded_proxy\" (kernel time of part 0 of 2/4/8 of the table against all reads)")
     ap.add_argument("--no-default-layout", action="store_true", help="N=1: skip the kernel leg on the engine's default (one-strand) table")
@@ -368,6 +371,9 @@ def main():
         groups = [dist.new_group(list(range(g * P, (g + 1) * P))) for g in range(n_groups)]
     if db_mode and P > 1:
         eng.set_part(part_i, P)        # this rank's part of the table (super-k-mer layouts: a slot range of the resident table)
+    if args.single_part > 1 and world == 1 and not db_mode:
+        eng.set_part(0, args.single_part)
+        args.no_cpu = args.no_pipeline = args.no_e2e = args.no_parts_proxy = args.no_default_layout = True
     t0 = time.time()
     eng.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr())
     info = eng.info()
@@ -554,7 +560,9 @@ def main():
     res = d_res.cpu().numpy().view(np.uint32)
     truth = d_truth.cpu().numpy().view(np.uint32).reshape(-1, 2)
     gmask = truth[:, 0] > 0
-    if not db_mode:
+    if args.single_part > 1 and not db_mode:
+        known = {"partial_table": f"part 0 of {args.single_part}", "hits": int(res[:, 0].astype(np.int64).sum())}
+    elif not db_mode:
         # a genome read with w unmodified windows must report its genome's label with >= w hits (w = 0: no claim)
         ok = (truth[gmask, 1] == 0) | ((res[gmask, 1] == truth[gmask, 0]) & (res[gmask, 2] >= truth[gmask, 1]))
         known = {"genome_reads": int(gmask.sum()), "label_and_count_ok": float(ok.mean()) if gmask.any() else 1.0,
