@@ -514,7 +514,8 @@ def main():
         two = info["layout"] == 4
         kname = f"query_kernel_s<{km[0]}, {km[1]}, {'true' if parted else 'false'}, {'true' if two else 'false'}>"
         if not os.environ.get("MIC_S_PER_KMER") and (two or 32 < 2 * k - info["minimizer_len"] <= 48):
-            kname = f"query_kernel_r<{km[0]}, {km[1]}, {'true' if two else 'false'}, {'true' if parted else 'false'}>"   # super-k-mer tables are probed per run
+            kname = (f"query_kernel_r<{km[0]}, {km[1]}, {'true' if two else 'false'}, {'true' if parted else 'false'}, "
+                     f"{'true' if info['side_kmers'] else 'false'}>")   # super-k-mer tables are probed per run
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_query_kernel.json")), reverse=True):
         try:
             pj = json.load(open(f))

@@ -38,7 +38,7 @@ class MicDbInfo(C.Structure):
                 ("slot_class", C.c_int32), ("max_bucket", C.c_uint32), ("sampling", C.c_uint32), ("layout", C.c_int32),
                 ("minimizer_len", C.c_int32), ("max_chain", C.c_uint32), ("reserved", C.c_uint32), ("n_entries", C.c_uint64),
                 ("part", C.c_uint32), ("n_parts", C.c_uint32), ("part_slot_lo", C.c_uint64), ("part_slot_hi", C.c_uint64),
-                ("n_slots_whole", C.c_uint64)]
+                ("n_slots_whole", C.c_uint64), ("side_kmers", C.c_uint64), ("side_bytes", C.c_uint64)]
 
 
 class MicSynthSpec(C.Structure):

@@ -614,6 +614,13 @@ __global__ void s_sum_kernel(const uint32_t* __restrict__ v, uint64_t n, unsigne
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
 }
 
+__global__ void s_max_kernel(const uint32_t* __restrict__ v, uint64_t n, uint32_t* __restrict__ out) {
+  uint32_t mine = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mine = v[i] > mine ? v[i] : mine;
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(mine, off); mine = o > mine ? o : mine; }
+  if ((threadIdx.x & 63) == 0 && mine) atomicMax(out, mine);
+}
+
 // How far lookups have to walk: sum over the slots of (candidates staged for the slot) x (continuation slots behind it).
 // Divided by the number of candidates this is the mean number of EXTRA slots a stored k-mer sits behind - the cost of
 // crowded minimizers (tandem repeats, low complexity: one minimizer value in thousands of contexts).
@@ -769,6 +776,127 @@ __global__ void __launch_bounds__(256) s_merge_kernel(const unsigned long long* 
 __global__ void s_chain_demand_kernel(const uint32_t* __restrict__ n_ent, uint64_t n, uint32_t* __restrict__ demand) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const uint32_t e = n_ent[i]; demand[i] = e > MIC_S_CAP ? (e - 1) / MIC_S_CAP : 0; }
+}
+
+// ---- crowded minimizers: a side table keyed by the whole k-mer ------------------------------------------------------------
+// A minimizer value that sits in thousands of contexts (the m-mers of a microsatellite: every flank of every occurrence is a
+// context of its own) gives a chain of thousands of entries under ONE sort key, which a lookup can only walk
+// slot by slot.  After the table is built, the groups of more than MIC_S_CROWD entries with the same minimizer value are
+// taken OUT of their chains: their k-mers go into an open-addressing hash table keyed by the oriented k-mer itself (16-byte
+// cells {k-mer lo, hi, label + 1, 0}, at most half full), and ONE marker entry (presence mask 0) stays behind.  A query run
+// that meets the marker looks its k-mers up one by one in the side table (query_kernel_r<.., SIDE>: a wave-uniform rare
+// path); every other run of the table is as fast as before.  Exact: a k-mer is in exactly one of the two places.
+#ifndef MIC_S_CROWD
+#define MIC_S_CROWD 12
+#endif
+
+struct SChain {      // entries of a slot's chain, in order
+  const uint32_t* slots; uint64_t slot; uint32_t e, n_here; bool valid;
+  __device__ SChain(const uint32_t* sl, uint64_t s) : slots(sl), slot(s), e(0) { n_here = sl[s * 32 + 30] & 0xFFu; valid = true; settle(); }
+  __device__ void settle() {
+    while (valid && e >= n_here) {
+      const uint32_t* q = slots + slot * 32;
+      if (q[30] & MIC_S_NEXT) { slot = q[31]; n_here = slots[slot * 32 + 30] & 0xFFu; e = 0; } else valid = false;
+    }
+  }
+  __device__ void next() { ++e; settle(); }
+  __device__ const uint32_t* q() const { return slots + slot * 32; }
+};
+
+__device__ inline uint64_t s_entry_x(const uint32_t* q, uint32_t e, int k, int m) {
+  const u128 S = ((u128)q[6 + 3 * e] << 64) | ((u128)q[7 + 3 * e] << 32) | q[8 + 3 * e];
+  const int ctx = k - m;
+  return (uint64_t)(S >> (96 - 2 * (ctx + m))) & ((1ULL << (2 * m)) - 1);
+}
+
+// out[0] += k-mers of crowded groups, out[1] += crowded groups
+__global__ void __launch_bounds__(256) s_crowd_count_kernel(const uint32_t* __restrict__ slots, uint64_t slot_lo, uint64_t slot_hi, int k, int m,
+                                                            unsigned long long* __restrict__ out) {
+  const uint64_t s = slot_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= slot_hi) return;
+  if ((slots[s * 32 + 30] & 0xFFu) < MIC_S_CAP || !(slots[s * 32 + 30] & MIC_S_NEXT)) return;   // a chain of one slot holds no crowded group
+  SChain c(slots, s);
+  while (c.valid) {
+    const uint64_t x = s_entry_x(c.q(), c.e, k, m);
+    uint32_t n = 0, kmers = 0;
+    while (c.valid && s_entry_x(c.q(), c.e, k, m) == x) { ++n; kmers += __popc(c.q()[24 + c.e] >> 16); c.next(); }
+    if (n > MIC_S_CROWD) { atomicAdd(&out[0], (unsigned long long)kmers); atomicAdd(&out[1], 1ull); }
+  }
+}
+
+__device__ inline void s_side_insert(uint4* __restrict__ side, uint32_t mask, uint64_t K, uint32_t label1) {
+  uint32_t h = (uint32_t)((K * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+  for (;;) {
+    uint32_t* cell = (uint32_t*)(side + h);
+    if (atomicCAS(&cell[2], 0u, label1) == 0u) { cell[0] = (uint32_t)K; cell[1] = (uint32_t)(K >> 32); return; }
+    h = (h + 1) & mask;
+  }
+}
+
+// moves the crowded groups of every chain into the side table and compacts the chain in place (one thread per main slot)
+__global__ void __launch_bounds__(256) s_crowd_move_kernel(uint32_t* __restrict__ slots, uint64_t slot_lo, uint64_t slot_hi, int k, int m,
+                                                           uint4* __restrict__ side, uint32_t side_mask, uint32_t* __restrict__ n_ent,
+                                                           uint32_t* __restrict__ max_ent) {
+  const uint64_t s = slot_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= slot_hi) return;
+  if ((slots[s * 32 + 30] & 0xFFu) < MIC_S_CAP || !(slots[s * 32 + 30] & MIC_S_NEXT)) return;
+  {  // anything to do here?
+    SChain c(slots, s);
+    bool any = false;
+    while (c.valid && !any) {
+      const uint64_t x = s_entry_x(c.q(), c.e, k, m);
+      uint32_t n = 0;
+      while (c.valid && s_entry_x(c.q(), c.e, k, m) == x) { ++n; c.next(); }
+      any = n > MIC_S_CROWD;
+    }
+    if (!any) return;
+  }
+  const int w = k - m + 1, ctx = k - m;
+  SChain rd(slots, s);
+  uint64_t w_slot = s; uint32_t w_e = 0, total = 0;      // write position: never ahead of the read position
+  auto put = [&](uint32_t key, uint32_t S0, uint32_t S1, uint32_t S2, uint32_t pl) {
+    if (w_e == MIC_S_CAP) { w_slot = slots[w_slot * 32 + 31]; w_e = 0; }       // the chain's own next slot (it had more entries before)
+    uint32_t* q = slots + w_slot * 32;
+    q[w_e] = key; q[6 + 3 * w_e] = S0; q[7 + 3 * w_e] = S1; q[8 + 3 * w_e] = S2; q[24 + w_e] = pl;
+    ++w_e; ++total;
+  };
+  while (rd.valid) {
+    const uint64_t x = s_entry_x(rd.q(), rd.e, k, m);
+    uint32_t n = 0;
+    { SChain la = rd; while (la.valid && s_entry_x(la.q(), la.e, k, m) == x) { ++n; la.next(); } }
+    if (n > MIC_S_CROWD) {
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t* q = rd.q();
+        const uint32_t S0 = q[6 + 3 * rd.e], S1 = q[7 + 3 * rd.e], S2 = q[8 + 3 * rd.e], pl = q[24 + rd.e];
+        for (int j = 0; j < w; ++j)
+          if ((pl >> (16 + j)) & 1u) s_side_insert(side, side_mask, s_extract(S0, S1, S2, w - 1 - j, k), (pl & 0xFFFFu) + 1u);
+        rd.next();
+      }
+      const u128 v = (u128)x << (96 - 2 * (ctx + m));                       // the marker: the minimizer alone, presence mask 0
+      put((uint32_t)x, (uint32_t)(v >> 64), (uint32_t)(v >> 32), (uint32_t)v, 0xFFFFu);
+    } else {
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t* q = rd.q();
+        const uint32_t key = q[rd.e], S0 = q[6 + 3 * rd.e], S1 = q[7 + 3 * rd.e], S2 = q[8 + 3 * rd.e], pl = q[24 + rd.e];
+        rd.next();                                                          // (read before the write below may overwrite it)
+        put(key, S0, S1, S2, pl);
+      }
+    }
+  }
+  // close the chain behind the last entry written: counts, unused keys, the continuation flag
+  {
+    uint64_t sl = s; uint32_t left = total;
+    for (;;) {
+      uint32_t* q = slots + sl * 32;
+      const uint32_t here = left > MIC_S_CAP ? MIC_S_CAP : left;
+      left -= here;
+      for (uint32_t e = here; e < MIC_S_CAP; ++e) { q[e] = 0xFFFFFFFFu; q[6 + 3 * e] = q[7 + 3 * e] = q[8 + 3 * e] = 0; q[24 + e] = 0; }
+      const uint32_t nxt = q[31];
+      if (left) { q[30] = here | MIC_S_NEXT; sl = nxt; } else { q[30] = here; q[31] = 0; break; }
+    }
+  }
+  n_ent[s] = total;
+  atomicMax(max_ent, total);
 }
 
 }  // namespace
@@ -932,6 +1060,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   // built and kept.  Slot indices stay global ("virtual": the slot pointer handed out is the allocation minus part_lo
   // slots), so the query kernels need nothing but the range test.
   uint64_t part_lo = 0, part_hi = 0, n_part = 0; unsigned long long off_lo = 0, off_hi = 0;
+  uint4* side = nullptr; uint64_t side_cells = 0, side_kmers = 0;
   unsigned long long* d_coff = nullptr; unsigned long long* d_scal = nullptr; uint32_t* d_max = nullptr;
   unsigned long long* d_ck = nullptr; uint32_t* d_cm = nullptr; uint32_t* slots = nullptr; uint32_t* d_dem = nullptr;
   std::vector<TileA> h_a(n_tiles);
@@ -1127,6 +1256,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   }
   if (!one_pass) lap("scatter of the candidates + sort + merge (count)");
   HIPCK(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
+  HIPCK(hipStreamSynchronize(s));
   HIPCK(hipMemsetAsync(d_scal + 1, 0, 8, s));
   s_sum_kernel<<<4096, 256, 0, s>>>(d_nent, n_slots, d_scal + 1);       // entries = super-k-mers stored (statistics)
   HIPCK(hipMemcpyAsync(&h_entries, d_scal + 1, 8, hipMemcpyDeviceToHost, s));
@@ -1143,11 +1273,14 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     // profiles/r02_nonideal_databases.json, DESIGN.md 5.3.  Only when the layout was not asked for explicitly.
     // Measured (2 G k-mers, 4 M reads): 0.0046 random genomes and 0.0060 with 10 % homologous segments (super-k-mer layout
     // 1 300 Mreads/s, minimizer layout 930); 0.0148 with 2 % tandem repeats (790 vs 945) and 0.0192 with 5 % (550 vs 925).
-    double limit = 0.010;
-    if (const char* env = getenv("MIC_S_WALK_LIMIT")) limit = atof(env);
-    if (allow_fallback && limit > 0 && walk > limit) {
-      snprintf(err, err_cap, "crowded minimizers: a stored k-mer sits behind %.4f continuation slots on average (limit %.4f)", walk, limit);
-      rc = -5; goto done;
+    // (Until round 3 a table whose walk exceeded 0.010 was abandoned for the minimizer layout when nobody had asked for this one;
+    // the crowded minimizers now leave their chains for a side table below, and the walk of what remains is ~0.)
+    if (const char* env = getenv("MIC_S_WALK_LIMIT")) {
+      const double limit = atof(env);
+      if (allow_fallback && limit > 0 && walk > limit && getenv("MIC_S_NO_SIDE")) {
+        snprintf(err, err_cap, "crowded minimizers: a stored k-mer sits behind %.4f continuation slots on average (limit %.4f)", walk, limit);
+        rc = -5; goto done;
+      }
     }
     // ... and a database whose k-mers do not overlap (cuCLARK-l's sampled blocks: one k-mer per entry) gains nothing from
     // super-k-mers: the minimizer layout holds it in a quarter of the memory and answers 10 % faster (1 360 vs 1 240)
@@ -1197,9 +1330,50 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   HIPCK(hipMemsetAsync(slots + (size_t)(n_part + n_chain) * 32, 0xFF, 128, s));   // the spare slot after the table: empty
   HIPCK(hipStreamSynchronize(s));
   if (!one_pass) lap("merge (write)");
+  // Crowded minimizers (one minimizer value in more than MIC_S_CROWD contexts): out of the chains, into a side table keyed by
+  // the k-mer (see s_crowd_move_kernel).  Only the one-pass / two-pass builds that left the table in `slots` can be
+  // post-processed here, i.e. always; a side table that cannot be allocated leaves the chains as they are (slower, exact).
+  if (h_max > MIC_S_CROWD && !getenv("MIC_S_NO_SIDE")) {
+    unsigned long long h_crowd[2] = {0, 0};
+    HIPCK(hipMemsetAsync(d_scal, 0, 16, s));
+    s_crowd_count_kernel<<<(unsigned)((n_part + 255) / 256), 256, 0, s>>>(slots - part_lo * 32, part_lo, part_hi, k, m, d_scal);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(h_crowd, d_scal, 16, hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    if (h_crowd[1] > 0) {
+      uint64_t cells = 1024;
+      while (cells < 2 * h_crowd[0]) cells <<= 1;
+      if (cells <= 0x80000000ull && hipMalloc(&side, cells * 16) == hipSuccess) {
+        HIPCK(hipMemsetAsync(side, 0, cells * 16, s));
+        HIPCK(hipMemsetAsync(d_max, 0, 4, s));
+        s_crowd_move_kernel<<<(unsigned)((n_part + 255) / 256), 256, 0, s>>>(slots - part_lo * 32, part_lo, part_hi, k, m, side, (uint32_t)(cells - 1),
+                                                                           d_nent, d_max);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemsetAsync(d_max, 0, 4, s));
+        s_max_kernel<<<4096, 256, 0, s>>>(d_nent, n_slots, d_max);
+        HIPCK(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+        side_cells = cells; side_kmers = h_crowd[0];
+        // the statistics of what stays in the chains
+        unsigned long long h_walk = 0;
+        HIPCK(hipMemsetAsync(d_scal, 0, 16, s));
+        s_sum_kernel<<<4096, 256, 0, s>>>(d_nent, n_slots, d_scal + 1);
+        s_walk_kernel<<<4096, 256, 0, s>>>(d_cnt, d_nent, n_slots, d_scal);
+        HIPCK(hipMemcpyAsync(&h_entries, d_scal + 1, 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipMemcpyAsync(&h_walk, d_scal, 8, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+        { const double walk = off_hi > off_lo ? (double)h_walk / (double)(off_hi - off_lo) : 0.0; out->walk_ppm = (uint32_t)(walk * 1e6); }
+        lap("crowded minimizers moved to the side table");
+      } else {
+        (void)hipGetLastError();
+        side = nullptr;
+      }
+    }
+  }
 #undef BY_RAW
   out->slots = (uint4*)slots; slots = nullptr;
   out->part_lo = part_lo; out->part_hi = part_hi;
+  out->side = side; side = nullptr; out->side_cells = side_cells; out->side_kmers = side_kmers;
   out->n_main = n_slots; out->n_overflow = n_chain; out->n_elems = h_scal[0]; out->n_elems_file = tot_elems;
   out->max_bucket = 0; out->max_chain = h_max; out->n_entries = h_entries; out->alloc_slots = alloc_slots;
 done:
@@ -1215,5 +1389,6 @@ done:
   if (d_dem) hipFree(d_dem);
   if (d_nent) hipFree(d_nent);
   if (slots) hipFree(slots);
+  if (side) hipFree(side);
   return rc;
 }

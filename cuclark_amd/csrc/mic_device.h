@@ -166,6 +166,18 @@ __device__ __forceinline__ void s_candidates_fwd(uint64_t c, int k, int m, F&& f
   }
 }
 
+// Side table of the crowded minimizers' k-mers (mic_build.hip: s_crowd_move_kernel): cells {k-mer lo, hi, label + 1, 0}, linear probing
+__device__ __forceinline__ uint32_t s_side_hash(uint64_t K, uint32_t mask) { return (uint32_t)((K * 0x9E3779B97F4A7C15ull) >> 32) & mask; }
+__device__ inline uint32_t s_side_probe(const uint4* __restrict__ side, uint32_t mask, uint64_t K) {
+  uint32_t h = s_side_hash(K, mask);
+  for (;;) {
+    const uint4 c = side[h];
+    if (c.z == 0) return 0;
+    if (c.x == (uint32_t)K && c.y == (uint32_t)(K >> 32)) return c.z;
+    h = (h + 1) & mask;
+  }
+}
+
 // The lookup the QUERY KERNELS perform for the k-mer K that reads at nucleotide `tpos` of its read part, done sequentially
 // (dense fallback, statistics).  The kernels' sliding minimum runs over keys order27 << 5 | strand << 4 | position & 15, so
 // m-mers that tie on the 27 bits are resolved by strand and position (mod 16; the window holds at most 16 m-mers and chunks
@@ -175,7 +187,8 @@ __device__ __forceinline__ void s_candidates_fwd(uint64_t c, int k, int m, F&& f
 //   parted: only the main slots [slot_lo, slot_lo + slot_cnt) are resident (slots = allocation - slot_lo slots); *mine tells
 //   whether the chosen slot is.
 __device__ inline uint32_t s_probe_read(const uint4* __restrict__ slots, uint32_t n_slots, bool parted, uint32_t slot_lo,
-                                        uint32_t slot_cnt, uint64_t K, uint32_t tpos, int k, int m, bool fwd, bool* mine) {
+                                        uint32_t slot_cnt, uint64_t K, uint32_t tpos, int k, int m, bool fwd, bool* mine,
+                                        const uint4* __restrict__ side = nullptr, uint32_t side_mask = 0) {
   const int w = k - m + 1;
   const uint64_t mask = (1ULL << (2 * m)) - 1;
   const uint64_t rc = fwd ? 0 : revcomp_bits(K, k);
@@ -200,6 +213,8 @@ __device__ inline uint32_t s_probe_read(const uint4* __restrict__ slots, uint32_
     for (int e = 0; e < MIC_S_CAP; ++e) {
       if (q[e] != (uint32_t)x) continue;
       const uint32_t pl = q[24 + e];
+      // a marker (presence mask 0) with this very minimizer: its k-mers live in the side table
+      if ((pl >> 16) == 0 && side && s_extract(q[6 + 3 * e], q[7 + 3 * e], q[8 + 3 * e], w - 1, m) == x) return s_side_probe(side, side_mask, Kq);
       if (!((pl >> (16 + j)) & 1)) continue;
       if (s_extract(q[6 + 3 * e], q[7 + 3 * e], q[8 + 3 * e], w - 1 - j, k) == Kq) return (pl & 0xFFFFu) + 1;
     }

@@ -68,6 +68,7 @@ struct mic_engine {
   // table
   bool db_loaded = false;
   uint4* slots = nullptr;
+  uint4* side = nullptr;       // super-k-mer tables: the k-mers of crowded minimizers (or null)
   uint8_t* d_sizes = nullptr;  // the shard's on-disk bucket sizes (statistics)
   MicTable table;
   int slot_class = 32;
@@ -105,6 +106,8 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   e->table.slots = parted ? b.slots - (ptrdiff_t)b.part_lo * 8 : b.slots;
   e->table.slot_lo = parted ? (uint32_t)b.part_lo : 0; e->table.slot_cnt = parted ? (uint32_t)(b.part_hi - b.part_lo) : 0;
   e->table.parted = parted ? 1 : 0;
+  e->side = b.side;
+  e->table.side = b.side; e->table.side_mask = b.side ? (uint32_t)(b.side_cells - 1) : 0;
   e->table.n_main = b.n_main;
   e->table.shard_start = s0;
   e->table.shard_end = s1;
@@ -122,7 +125,8 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   i.n_slots = n_res + b.n_overflow; i.n_overflow = b.n_overflow;
   i.part = e->n_parts > 1 ? e->part : 0; i.n_parts = e->n_parts > 1 ? e->n_parts : 0;
   i.part_slot_lo = parted ? b.part_lo : 0; i.part_slot_hi = parted ? b.part_hi : 0; i.n_slots_whole = b.n_main;
-  i.hbm_bytes = (b.alloc_slots ? b.alloc_slots : n_res + b.n_overflow + 1) * (uint64_t)(layout != MIC_LAYOUT_DIRECT ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
+  i.side_kmers = b.side ? b.side_kmers : 0; i.side_bytes = b.side ? b.side_cells * 16 : 0;
+  i.hbm_bytes = (b.side ? b.side_cells * 16 : 0) + (b.alloc_slots ? b.alloc_slots : n_res + b.n_overflow + 1) * (uint64_t)(layout != MIC_LAYOUT_DIRECT ? MIC_MSLOT_BYTES : MIC_SLOT_BYTES);
   i.key_bytes = key_bytes; i.slot_class = layout != MIC_LAYOUT_DIRECT ? 128 : e->slot_class; i.max_bucket = b.max_bucket;
   i.sampling = sampling; i.layout = layout; i.minimizer_len = layout != MIC_LAYOUT_DIRECT ? m : 0;
   i.max_chain = layout != MIC_LAYOUT_DIRECT ? b.max_chain : 0; i.reserved = (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2) ? b.walk_ppm : 0;
@@ -486,6 +490,7 @@ int mic_destroy(mic_engine* e) {
   mic_ingest_free(e);
   free_batches(e);
   if (e->slots) hipFree(e->slots);
+  if (e->side) hipFree(e->side);
   if (e->d_sizes) hipFree(e->d_sizes);
   if (e->d_flagged) hipFree(e->d_flagged);
   if (e->ev0) hipEventDestroy(e->ev0);
@@ -503,8 +508,9 @@ int mic_db_unload(mic_engine* e) {
   if (rc) return rc;
   hipDeviceSynchronize();
   if (e->slots) hipFree(e->slots);
+  if (e->side) hipFree(e->side);
   if (e->d_sizes) hipFree(e->d_sizes);
-  e->slots = nullptr; e->d_sizes = nullptr; e->db_loaded = false;
+  e->slots = nullptr; e->side = nullptr; e->d_sizes = nullptr; e->db_loaded = false;
   memset(&e->info, 0, sizeof(e->info));
   return MIC_OK;
 }

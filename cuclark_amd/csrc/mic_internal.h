@@ -99,6 +99,9 @@ struct MicTable {
   // minimizer hash spreads over are resident; `slots` is then the allocation MINUS slot_lo slots, so global slot indices
   // (and the continuation indices stored in word 31) address it directly.  slot_cnt == 0: the whole table is here.
   uint32_t slot_lo, slot_cnt;
+  // layout 2: the k-mers of crowded minimizers, keyed by the oriented k-mer: cells {lo, hi, label + 1, 0}, label + 1 == 0 is
+  // empty, linear probing, side_mask + 1 cells (a power of two); null when the table has none
+  const uint4* side; uint32_t side_mask;
   int parted;            // 1: slot-range part as above (slot_cnt may be 0: an empty part answers nothing)
   const uint8_t* sizes;  // kept copy of the shard's on-disk bucket sizes (statistics only)
 };
@@ -143,6 +146,7 @@ struct MicBuildOut {
   uint32_t max_chain;   // layout 1: entries in the fullest slot chain
   uint32_t walk_ppm;    // super-k-mer table: mean continuation slots in front of a stored k-mer, x 1e6
   uint64_t n_entries;   // super-k-mer table: entries (super-k-mers) stored; other layouts: 0 (= one entry per k-mer)
+  uint4* side; uint64_t side_cells, side_kmers;   // super-k-mer table: the k-mers of crowded minimizers (mic_build.hip: s_crowd_move_kernel), or null
   uint64_t part_lo, part_hi; // super-k-mer table built as a slot-range part: the main slots [part_lo, part_hi) of n_main are resident (else 0, n_main)
   uint64_t alloc_slots; // slots allocated when that is more than n_main + n_overflow + 1 (one-pass super-k-mer build: the unused part of its continuation pool), else 0
 };

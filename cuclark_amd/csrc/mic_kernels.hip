@@ -1010,6 +1010,20 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
                 const bool m1 = same1 && ((p1 >> (16 + (w - 1) - ao[1])) & 1) && s_extract(a1, b1, c1, (int)ao[1], k) == ko[1];
                 if (m0) hit0 = (p0 & 0xFFFFu) + 1;
                 if (m1) hit1 = (p1 & 0xFFFFu) + 1;
+                {
+                  // a marker entry (presence mask 0) of this very minimizer: the minimizer is crowded, its k-mers are in the
+                  // side table (mic_build.hip: s_crowd_move_kernel).  Rare: a wave-uniform branch around the probes.
+                  const bool cr0 = same0 && (p0 >> 16) == 0, cr1 = same1 && (p1 >> 16) == 0;
+                  if (__ballot(cr0) | __ballot(cr1)) {
+                    uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(kp));
+                    const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+                    const uint4* side = kc->t.side; const uint32_t smask = kc->t.side_mask;
+                    const uint64_t mm = (1ULL << (2 * m)) - 1;
+                    if (side && cr0 && s_extract(a0, b0, c0, w - 1, m) == ((ko[0] >> (2 * ao[0])) & mm)) hit0 = s_side_probe(side, smask, ko[0]);
+                    if (side && cr1 && s_extract(a1, b1, c1, w - 1, m) == ((ko[1] >> (2 * ao[1])) & mm)) hit1 = s_side_probe(side, smask, ko[1]);
+                  }
+                }
                 more0 = same0 && !m0 && e0 < 5; more1 = same1 && !m1 && e1 < 5;     // another entry of the same minimizer?
                 e0 += more0 ? 1u : 0u; e1 += more1 ? 1u : 0u;
                 if (!(__ballot(more0) | __ballot(more1))) break;
@@ -1124,7 +1138,7 @@ __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cb
 #define MIC_R_TALLY_PER_ROUND 0   // 1: a lane keeps (label, count) of its run and the wave tallies once per round instead of once per entry
                                   // iteration: 2 VGPRs and a ballot more, ~0.3 tally calls per read fewer - measured 1.5 % SLOWER (6.10 vs 6.00 ms)
 #endif
-template <int KK, int MM, bool FWD, bool PART>
+template <int KK, int MM, bool FWD, bool PART, bool SIDE>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r(const MicQueryArgs a) {
   // staged slots: 8 per LDS-DMA instruction, 128 bytes apart (the DMA's own layout: lane L lands at base + 16 L); each
   // group of 8 starts MIC_R_SKEW uint4 further so that the run lanes' reads of the same word of their slots spread over
@@ -1328,7 +1342,10 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             cur = mine ? cur : 0xFFFFFFFFu;
           }
           int remaining = mine ? n : 0;
+#if MIC_R_TALLY_PER_ROUND
           uint32_t run_lab = 0, run_cnt = 0;        // label + 1 and hits of this lane's run so far
+#endif
+          bool crowded = false;                     // SIDE: the run's minimizer is a crowded one (marker entry): its k-mers are in the side table
           do {
             uint32_t sidx[MIC_RMAX / 8];
             // the list of slots to load sits in the stage area itself: it is consumed before the DMA lands.  (Handing the
@@ -1379,6 +1396,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
               const int hi = left < jmax ? left : jmax, lo = ctx - right > jmin ? ctx - right : jmin;
               const uint32_t range = ((2u << (hi & 31)) - 1u) & (~0u << (lo & 31));         // empty when hi < lo
               const uint32_t hits = (same && mineq) ? (uint32_t)__popc((pl >> 16) & range) : 0u;
+              if (SIDE && same && mineq && (pl >> 16) == 0) { crowded = true; remaining = 0; }     // the marker: nothing of this minimizer is in the chains
               // The run's hits are tallied ONCE per round: a lane keeps (label, count) of its run; a second entry with ANOTHER
               // label (the same minimizer in two targets' genomes, both contexts matching parts of the run) is tallied on the
               // spot - a wave-uniform branch that is virtually never taken.
@@ -1400,7 +1418,55 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             cur = 0xFFFFFFFFu;
             if (wballot(nx)) { if (nx && q[5] <= key) cur = q[31]; }
           } while (wballot(cur != 0xFFFFFFFFu));
+#if MIC_R_TALLY_PER_ROUND
           tally_counts(run_lab, run_cnt, cbits, acc, n_ent, overflow, total, lane);
+#endif
+          if (SIDE && wballot(crowded)) {
+            // Rare path (a database with microsatellites, a read that overlaps one): the k-mers of the crowded runs are looked
+            // up ONE BY ONE in the side table, keyed by the k-mer as the table stores it (as it reads; the one-strand table: in
+            // the strand of its run).  Two bitmaps over the chunk's 128 k-mers are built in the (idle) stage area: which k-mers,
+            // and which of them are taken as the reverse complement.
+            __builtin_amdgcn_wave_barrier();
+            uint32_t* bm = (uint32_t*)stage;
+            if (ln < 8) bm[lane] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (crowded) {
+              for (int bpos = i0; bpos < i0 + n; ++bpos) {
+                atomicOr(&bm[bpos >> 5], 1u << (bpos & 31));
+                if (!FWD && rev) atomicOr(&bm[4 + (bpos >> 5)], 1u << (bpos & 31));
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+            const uint4* __restrict__ side = kc->t.side;
+            const uint32_t smask = kc->t.side_mask;
+            uint32_t sres[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint32_t pos = 64u * h + (uint32_t)lane;
+              bool go = (bm[pos >> 5] >> (pos & 31)) & 1u;
+              const bool rv = !FWD && ((bm[4 + (pos >> 5)] >> (pos & 31)) & 1u);
+              const int idx = 4 * h + (lane >> 4);
+              const uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
+              uint64_t K = kmer_from_dwords(d0, d1, d2, ln & 15, k);
+              if (rv) K = revcomp_bits(K, k);
+              uint32_t hsh = s_side_hash(K, smask), got = 0;
+              while (wballot(go)) {
+                uint4 c = make_uint4(0, 0, 0, 0);
+                if (go) c = load_slot_quarter(side + hsh);
+                if (go) {
+                  if (c.z == 0) go = false;
+                  else if (c.x == (uint32_t)K && c.y == (uint32_t)(K >> 32)) { got = c.z; go = false; }
+                  else hsh = (hsh + 1) & smask;
+                }
+              }
+              sres[h] = got;
+            }
+            __builtin_amdgcn_wave_barrier();
+            tally2(sres[0], sres[1], acc, n_ent, overflow, total, lane);
+          }
         }
       }
     }
@@ -1542,7 +1608,8 @@ __device__ inline uint32_t probe_any(const MicTable& t, uint64_t kmer, uint32_t 
       if (rem < t.shard_start || rem >= t.shard_end) { if (mine) *mine = false; return 0; }
     }
     bool in_part = true;
-    const uint32_t r = s_probe_read(t.slots, (uint32_t)t.n_main, t.parted != 0, t.slot_lo, t.slot_cnt, kmer, tpos, t.k, t.m, t.fwd != 0, &in_part);
+    const uint32_t r = s_probe_read(t.slots, (uint32_t)t.n_main, t.parted != 0, t.slot_lo, t.slot_cnt, kmer, tpos, t.k, t.m, t.fwd != 0, &in_part,
+                                    t.side, t.side_mask);
     if (mine && !in_part) *mine = false;
     return r;
   }
@@ -1727,9 +1794,13 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     // realignment is a single funnel shift when the region is longer than 32 nucleotides (always for cuCLARK's k and m)
     const bool run_ok = 2 * a.t.k - a.t.m > 32 && 2 * a.t.k - a.t.m <= 48;
     static const unsigned extra_lds = [] { const char* e = getenv("MIC_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();   // occupancy experiments
+    const bool sd = a.t.side != nullptr;    // crowded minimizers in a side table: the instantiation with the rare per-k-mer path
+#define LAUNCH_R(KK_, MM_, FW_) do { \
+      if (pt) { if (sd) query_kernel_r<KK_, MM_, FW_, true, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, FW_, true, false><<<g, b, extra_lds, s>>>(a); } \
+      else { if (sd) query_kernel_r<KK_, MM_, FW_, false, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, FW_, false, false><<<g, b, extra_lds, s>>>(a); } } while (0)
 #define LAUNCH_S(KK_, MM_) do { \
-      if (fw && !sh && !per_kmer) { if (pt) query_kernel_r<KK_, MM_, true, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, true, false><<<g, b, extra_lds, s>>>(a); } \
-      else if (!fw && !sh && !per_kmer && run_ok) { if (pt) query_kernel_r<KK_, MM_, false, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, false, false><<<g, b, extra_lds, s>>>(a); } \
+      if (fw && !sh && !per_kmer) LAUNCH_R(KK_, MM_, true); \
+      else if (!fw && !sh && !per_kmer && run_ok) LAUNCH_R(KK_, MM_, false); \
       else if (fw) { if (sh) query_kernel_s<KK_, MM_, true, true><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, true><<<g, b, 0, s>>>(a); } \
       else { if (sh) query_kernel_s<KK_, MM_, true, false><<<g, b, 0, s>>>(a); else query_kernel_s<KK_, MM_, false, false><<<g, b, 0, s>>>(a); } } while (0)
     if (!generic && a.t.k == 31 && a.t.m == 20) LAUNCH_S(31, 20);
@@ -1737,6 +1808,7 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     else if (!generic && a.t.k == 32 && a.t.m == 20) LAUNCH_S(32, 20);
     else LAUNCH_S(0, 0);
 #undef LAUNCH_S
+#undef LAUNCH_R
 #ifdef MIC_PHASE_TIMING
     unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipStreamSynchronize(s);

@@ -87,6 +87,9 @@ typedef struct mic_db_info {
   uint64_t part_slot_lo;   /* SUPER / SUPER2 with a part: the resident main slots [lo, hi) ...     */
   uint64_t part_slot_hi;
   uint64_t n_slots_whole;  /* ... of this many the whole table has (identical on every part)       */
+  uint64_t side_kmers;     /* SUPER / SUPER2: k-mers of crowded minimizers (one minimizer value in more than 12 contexts: microsatellites),
+                              kept in a side table keyed by the whole k-mer instead of in slot chains */
+  uint64_t side_bytes;     /* HBM of that side table (part of hbm_bytes)                            */
 } mic_db_info;
 
 /* ---- engine lifetime: CuClarkDB ctor/dtor (CuClarkDB.cu:85-253) ----------------------------- */

@@ -1,0 +1,137 @@
+"""Crowded minimizers: databases in which ONE minimizer value sits in hundreds of contexts - the flanks of
+microsatellites.  The super-k-mer layouts move such a minimizer's k-mers out of its slot chain into a side table keyed by the
+whole k-mer and leave a marker behind; a query run that meets the marker looks its k-mers up one by one.  Everything must stay
+bit-exact against the oracle: whole table, parts of the table, the per-k-mer kernel, the dense path."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from test_gpu_parity import _canonical_np, _oracle_results
+
+pytestmark = pytest.mark.gpu
+
+
+def _microsatellite_db(rng, k, htsize, T, n_sites=900):
+    """n_sites occurrences of short tandem repeats, each between its own random flanks, spread over T targets, plus plain
+    random sequence; the database = every k-mer (labelled by the first sequence it occurs in)"""
+    units = ["AC", "AG", "AAT", "ACG", "AAAC", "ACAG", "A", "AGC"]
+    seqs, lab = [], []
+    for i in range(n_sites):
+        u = units[int(rng.integers(0, len(units)))]
+        rep = (u * 40)[: int(rng.integers(30, 70))]
+        fl = "".join(rng.choice(list("ACGT"), 90))
+        seqs.append(fl[:45] + rep + fl[45:])
+        lab.append(i % T)
+    for i in range(60):
+        seqs.append("".join(rng.choice(list("ACGT"), 400)))
+        lab.append(i % T)
+    code = {"A": 3, "C": 2, "G": 1, "T": 0}
+    first = {}
+    for s, l in zip(seqs, lab):
+        v = 0
+        for i, ch in enumerate(s):
+            v = ((v << 2) | code[ch]) & ((1 << (2 * k)) - 1)
+            if i >= k - 1:
+                first.setdefault(int(_canonical_np(np.array([v], np.uint64), k)[0]), l)
+    canon = sorted(first, key=lambda c: (c % htsize, c // htsize))
+    sizes = np.zeros(htsize, np.int64)
+    keep = []
+    for c in canon:
+        if sizes[c % htsize] < 255:
+            sizes[c % htsize] += 1
+            keep.append(c)
+    keys = np.array([c // htsize for c in keep], dtype=np.uint64)
+    labels = np.array([first[c] for c in keep], dtype=np.uint16)
+    return seqs, sizes.astype(np.uint8), keys, labels
+
+
+def _reads(rng, seqs, n):
+    comp = str.maketrans("ACGT", "TGCA")
+    out = []
+    for i in range(n):
+        if rng.random() < 0.15:
+            s = "".join(rng.choice(list("ACGT"), 150))
+        else:
+            src = seqs[int(rng.integers(0, len(seqs)))]
+            a = int(rng.integers(0, max(1, len(src) - 120)))
+            s = list(src[a:a + int(rng.integers(60, 151))])
+            for p in range(len(s)):
+                if rng.random() < 0.01:
+                    s[p] = "ACGTN"[int(rng.integers(0, 5))]
+            s = "".join(s)
+            if i % 2:
+                s = s[::-1].translate(comp)
+        out.append(f">r{i}\n{s}\n")
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("layout", ["direct", "minimizer", "super", "super2"])
+def test_crowded_minimizers_go_to_the_side_table(layout, monkeypatch):
+    from cuclark_amd import MiClarkDB, host
+    import torch
+    monkeypatch.setenv("MIC_LAYOUT", layout)
+    rng = np.random.default_rng(41)
+    k, T, htsize = 31, 12, 1 << 18
+    seqs, sizes, keys, labels = _microsatellite_db(rng, k, htsize, T)
+    data = _reads(rng, seqs, 3000)
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    n = rp.size - 1
+    odb = gu.oracle().db_from_arrays(sizes, keys, labels)
+    counts, expect = _oracle_results(odb, k, rp, cont, T)
+    assert (expect[:, 0] > 0).mean() > 0.5
+    with MiClarkDB(k, T, row_words=16) as e:
+        e.read_arrays(sizes, keys, labels)
+        info = e.info()
+        res, rows = e.classify_packed(rp, cont, extended=True)
+    assert (res[:, :5] == expect).all()
+    if layout not in ("super", "super2"):
+        assert info["side_kmers"] == 0
+        return
+    assert info["side_kmers"] > 500 and info["side_bytes"] >= 32 * info["side_kmers"] and info["max_chain"] <= 40, info
+    # the same table with its chains left alone: same answers, far longer chains
+    monkeypatch.setenv("MIC_S_NO_SIDE", "1")
+    with MiClarkDB(k, T, row_words=16) as e:
+        e.read_arrays(sizes, keys, labels)
+        info0 = e.info()
+        res0 = e.classify_packed(rp, cont)
+    monkeypatch.delenv("MIC_S_NO_SIDE")
+    assert info0["side_kmers"] == 0 and info0["max_chain"] > 3 * info["max_chain"] and (res0[:, :5] == expect).all()
+    assert info0["n_elems"] == info["n_elems"]
+    # the per-k-mer kernel, the dense path (rows of 2 entries overflow), and 3 parts of the table merged
+    monkeypatch.setenv("MIC_S_PER_KMER", "1")
+    with MiClarkDB(k, T) as e:
+        e.read_arrays(sizes, keys, labels)
+        assert (e.classify_packed(rp, cont)[:, :5] == expect).all()
+    monkeypatch.delenv("MIC_S_PER_KMER")
+    with MiClarkDB(k, T, row_words=3) as e:
+        e.read_arrays(sizes, keys, labels)
+        res3, rows3 = e.classify_packed(rp, cont, extended=True)
+    assert (res3[:, :5] == expect).all() and (res3[:, 6] & 2).sum() > 10          # dense path taken, same results
+    dev = torch.device("cuda:0")
+    hits, side_total, acc = np.zeros(n, np.int64), 0, None
+    with MiClarkDB(k, T, row_words=16) as m:
+        for p in range(3):
+            with MiClarkDB(k, T, row_words=16) as e:
+                e.set_part(p, 3)
+                e.read_arrays(sizes, keys, labels)
+                side_total += e.info()["side_kmers"]
+                r, rw = e.classify_packed(rp, cont, extended=True)
+            hits += r[:, 0]
+            cur = torch.from_numpy(rw.astype(np.int64)).to(dev).to(torch.int32).contiguous()
+            if acc is None:
+                acc = cur
+            else:
+                out = torch.empty_like(acc)
+                torch.cuda.synchronize()
+                m.merge_rows_device(acc.data_ptr(), cur.data_ptr(), out.data_ptr(), n)
+                m.sync()
+                acc = out
+        results = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+        m.result_from_rows_device(acc.data_ptr(), results.data_ptr(), n)
+        m.sync()
+    assert (hits == expect[:, 0]).all() and side_total == info["side_kmers"]
+    fits = acc[:, 0].cpu().numpy() != -1
+    assert (results.cpu().numpy().view(np.uint32)[fits, :5] == expect[fits]).all() and fits.mean() > 0.9
