@@ -1445,6 +1445,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             uint32_t sres[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+              sres[h] = 0;
+              if (__builtin_amdgcn_readfirstlane(bm[2 * h] | bm[2 * h + 1]) == 0) continue;      // no crowded k-mer in this half of the chunk
               const uint32_t pos = 64u * h + (uint32_t)lane;
               bool go = (bm[pos >> 5] >> (pos & 31)) & 1u;
               const bool rv = !FWD && ((bm[4 + (pos >> 5)] >> (pos & 31)) & 1u);
