@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <immintrin.h>
+#include <pthread.h>
 #include <sched.h>
 #include <zlib.h>
 
@@ -484,7 +485,33 @@ static inline unsigned usable_cpus() {
 class Pool {
  public:
   explicit Pool(unsigned threads) {
-    for (unsigned t = 1; t < threads; ++t) th_.emplace_back([this] { loop(); });
+    // MIC_PIN_THREADS=1 (experiment): one worker per PHYSICAL core.  Under a CPU-time quota the scheduler is free to put two
+    // workers on the two hardware threads of one core, where each runs at about half speed.
+    std::vector<int> cores;
+    if (getenv("MIC_PIN_THREADS")) cores = physical_cores();
+    for (unsigned t = 1; t < threads; ++t) {
+      th_.emplace_back([this] { loop(); });
+      if (!cores.empty()) {
+        cpu_set_t set; CPU_ZERO(&set); CPU_SET(cores[(pin_base() + t) % cores.size()], &set);
+        pthread_setaffinity_np(th_.back().native_handle(), sizeof(set), &set);
+      }
+    }
+  }
+  static unsigned pin_base() { static std::atomic<unsigned> next{0}; return next.fetch_add(17); }
+  static std::vector<int> physical_cores() {          // the first hardware thread of every core this process may run on
+    std::vector<int> out;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) != 0) return out;
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+      if (!CPU_ISSET(c, &set)) continue;
+      char path[128];
+      snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+      FILE* f = fopen(path, "r");
+      int first = c;
+      if (f) { if (fscanf(f, "%d", &first) != 1) first = c; fclose(f); }
+      if (first == c) out.push_back(c);
+    }
+    return out;
   }
   ~Pool() {
     { std::lock_guard<std::mutex> g(m_); stop_ = true; ++gen_; }
