@@ -26,6 +26,7 @@
 #include <immintrin.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -322,10 +323,15 @@ struct Chunk {
   void reset() { start_bit = end_bit = 0; found = ok = at_eof = false; n_sym = 0; ends.clear(); piece_crc.clear(); piece_len.clear(); out_off = 0; }
   bool room(size_t w, size_t need) {
     if (w + need <= cap) return true;
-    const size_t nc = std::max(cap * 2, w + need + (1u << 16));
-    uint16_t* p = (uint16_t*)realloc(sym, nc * sizeof(uint16_t));
-    if (!p) return false;
-    sym = p; cap = nc;
+    // 2-MiB aligned and advised as huge pages: a chunk's symbols are tens of megabytes of fresh memory in the first round, and
+    // taking them in 4-KiB page faults costs as much as decoding them
+    const size_t nc = (std::max(cap * 2, w + need + (1u << 16)) * sizeof(uint16_t) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    void* p = nullptr;
+    if (posix_memalign(&p, (size_t)2 << 20, nc) != 0 || !p) return false;
+    madvise(p, nc, MADV_HUGEPAGE);
+    if (w) memcpy(p, sym, w * sizeof(uint16_t));
+    free(sym);
+    sym = (uint16_t*)p; cap = nc / sizeof(uint16_t);
     return true;
   }
 };
@@ -485,33 +491,9 @@ static inline unsigned usable_cpus() {
 class Pool {
  public:
   explicit Pool(unsigned threads) {
-    // MIC_PIN_THREADS=1 (experiment): one worker per PHYSICAL core.  Under a CPU-time quota the scheduler is free to put two
-    // workers on the two hardware threads of one core, where each runs at about half speed.
-    std::vector<int> cores;
-    if (getenv("MIC_PIN_THREADS")) cores = physical_cores();
-    for (unsigned t = 1; t < threads; ++t) {
-      th_.emplace_back([this] { loop(); });
-      if (!cores.empty()) {
-        cpu_set_t set; CPU_ZERO(&set); CPU_SET(cores[(pin_base() + t) % cores.size()], &set);
-        pthread_setaffinity_np(th_.back().native_handle(), sizeof(set), &set);
-      }
-    }
-  }
-  static unsigned pin_base() { static std::atomic<unsigned> next{0}; return next.fetch_add(17); }
-  static std::vector<int> physical_cores() {          // the first hardware thread of every core this process may run on
-    std::vector<int> out;
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) != 0) return out;
-    for (int c = 0; c < CPU_SETSIZE; ++c) {
-      if (!CPU_ISSET(c, &set)) continue;
-      char path[128];
-      snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
-      FILE* f = fopen(path, "r");
-      int first = c;
-      if (f) { if (fscanf(f, "%d", &first) != 1) first = c; fclose(f); }
-      if (first == c) out.push_back(c);
-    }
-    return out;
+    // (pinning one worker per physical core - the scheduler may put two on the hardware threads of one core under a CPU-time
+    // quota - was measured on the GPU box: 5-15 % SLOWER; the workers float)
+    for (unsigned t = 1; t < threads; ++t) th_.emplace_back([this] { loop(); });
   }
   ~Pool() {
     { std::lock_guard<std::mutex> g(m_); stop_ = true; ++gen_; }
@@ -627,6 +609,7 @@ int inflate_all(const uint8_t* data, size_t n, unsigned threads, size_t chunk_by
           if (!c.found) continue;
           uint64_t stop = round_end;
           for (size_t j = i + 1; j < n_ch; ++j) if (ch[j].found) { stop = ch[j].start_bit; break; }
+          if (!c.room(0, chunk_bytes * 6)) { c.ok = false; continue; }
           c.ok = i == 0 ? decode_blocks(data, n, c.start_bit, stop, file_start ? nullptr : window.data(), file_start, c, (size_t)-1 >> 2)
                         : decode_blocks(data, n, c.start_bit, stop, nullptr, false, c, max_out);
         }
