@@ -153,3 +153,24 @@ def test_bench_two_ranks_on_one_gpu(mode):
         assert ts["known_answer"]["label_and_count_ok"] == 1.0 and ts["known_answer"]["random_reads_no_hit"] == 1.0
     else:
         assert "table_sharded" not in d
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_two_dimensional_layout():
+    """Four ranks sharing cuda:0 over gloo, read mode: the headline leg, then the table-sharded legs - 4 parts x 1 group (the
+    reference's mode) and 2 parts x 2 read groups (the 2-D layout, exchange inside process subgroups) - each must reproduce the
+    constructive known answer on all reads."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                        "127.0.0.1", "--master-port", "29537", os.path.join(gu.ROOT, "bench.py"), "--gpus", "4", "--steps", "2",
+                        "--warmup", "1", "--workload", "tiny", "--mode", "read", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["scaling"] == "weak"
+    ts = d["table_sharded"]
+    assert "error" not in ts, ts
+    assert ts["parts"] == 4 and ts["read_groups"] == 1 and ts["known_answer"]["label_and_count_ok"] == 1.0
+    td = ts["two_parts_2d"]
+    assert td["parts"] == 2 and td["read_groups"] == 2 and td["reads_this_rank"] == d["config"]["reads_per_gpu"] // 2
+    assert td["known_answer"]["label_and_count_ok"] == 1.0 and td["known_answer"]["random_reads_no_hit"] == 1.0
