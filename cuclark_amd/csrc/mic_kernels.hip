@@ -1134,6 +1134,12 @@ __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cb
 #ifndef MIC_R_EAGER_ENTRY
 #define MIC_R_EAGER_ENTRY 1
 #endif
+#ifndef MIC_R_BPERM_WRAP
+#define MIC_R_BPERM_WRAP 1        // 0: the four window words of a run's region with explicitly wrapped lane numbers (round 2's form)
+#endif
+#ifndef MIC_R_AHEAD_MASK
+#define MIC_R_AHEAD_MASK 0        // 1: mask the read-ahead window to the part's containers (round 2's form)
+#endif
 #ifndef MIC_R_TALLY_PER_ROUND
 #define MIC_R_TALLY_PER_ROUND 0   // 1: a lane keeps (label, count) of its run and the wave tallies once per round instead of once per entry
                                   // iteration: 2 VGPRs and a ballot more, ~0.3 tally calls per read fewer - measured 1.5 % SLOWER (6.10 vs 6.00 ms)
@@ -1232,8 +1238,18 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         // the kernel they cost scalar register pairs the kernel does not have (34 -> 15 spill moves, +4 VALU, -6 SALU per read)
         int ln = lane;
         asm volatile("" : "+v"(ln));
+#if MIC_R_AHEAD_MASK
         const uint32_t wd = window_word_w(cont, first, cend, base, ln, use_ahead,
                                           use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp) : 0u);
+#else
+        // The first window of a part comes out of the read-ahead entry AS IT IS: what lies behind the part's last nucleotide
+        // (the next part's header, the next read, lanes 12+ of the entry) is never part of a k-mer that is counted - the active
+        // k-mers end inside the part, the keys of m-mers behind them only reach lanes that are not active, and a run's region is
+        // compared within the run's own k-mers only - so the two compares, two selects and the masks of window_word_w are spared
+        // (8 VALU per read).  Later chunks are loaded container by container and stay bounded by the part's end.
+        const uint32_t wd = use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp)
+                                      : window_word_w(cont, first, cend, base, ln, false, 0u);
+#endif
         // order keys of the m-mers at positions 64h + lane: order (27 bits) | position & 15
         uint32_t hk0, hk1;
         const bool past = nk - base > (uint32_t)(129 - w);     // the last k-mers' windows reach m-mers past position 127
@@ -1309,7 +1325,15 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
           const int s1 = qa - ctx - 1;
           const int D = s1 >> 4;                                  // -1 (the region starts in front of the chunk) .. 8
           const uint32_t tsh = 30u - 2u * (uint32_t)(s1 & 15);
+#if MIC_R_BPERM_WRAP
+          // ds_bpermute takes its lane from bits 7..2 of the byte address: D = -1 (the region starts in front of the chunk) wraps
+          // to lane 63 by itself, and D + 1 .. D + 3 are the same address plus 4, 8, 12 - no masking, one shift
+          const int a0 = D << 2;
+          const uint32_t W0 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0, (int)wd), W1 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 4, (int)wd),
+                         W2 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 8, (int)wd), W3 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 12, (int)wd);
+#else
           const uint32_t W0 = bperm((D) & 63, wd), W1 = bperm((D + 1) & 63, wd), W2 = bperm((D + 2) & 63, wd), W3 = bperm((D + 3) & 63, wd);
+#endif
           uint32_t G0 = __builtin_amdgcn_alignbit(W0, W1, tsh), G1 = __builtin_amdgcn_alignbit(W1, W2, tsh), G2 = __builtin_amdgcn_alignbit(W2, W3, tsh);
           if (!FWD) {
             // a run on the reverse strand is looked up as the reverse complement of the SAME region (the minimizer sits ctx

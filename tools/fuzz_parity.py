@@ -42,6 +42,8 @@ def fuzz(budget, seed0=1, verbose=True):
         n = rp.size - 1
         for layout in (1, 2, 3, 4):
             tag = f"seed={seed} layout={layout} k={k} htsize={htsize} n={n_elems} T={T} L={L}"
+            if os.environ.get("MIC_FUZZ_TRACE"):
+                print(tag, flush=True)
             with MiClarkDB(k, T, layout=layout) as e:
                 e.read_arrays(sizes, keys, labels)
                 res, rows = e.classify_packed(rp, cont, extended=True)
@@ -57,6 +59,8 @@ def fuzz(budget, seed0=1, verbose=True):
                 cuts = [dict(part=(p, np_)) for p in range(np_)]
             else:
                 continue
+            if os.environ.get("MIC_FUZZ_TRACE"):
+                print("   cuts", cuts, flush=True)
             engines = [MiClarkDB(k, T, layout=layout) for _ in cuts]
             try:
                 for e, c in zip(engines, cuts):
