@@ -102,11 +102,78 @@ __device__ __forceinline__ uint32_t mslot_of_kmer(uint64_t kmer, int k, int m, u
 #define MIC_S_CAP 6
 #define MIC_S_NEXT 0x100u
 
-__device__ __forceinline__ uint32_t s_order27(uint64_t x) { return mmer_order_key_canon(x) >> 5; }
+// Which m-mer of a k-mer is "its minimizer" (round 4): MOD-SAMPLING (Groot Koerkamp & Pibiri, "The mod-minimizer", WABI 2024).
+// Take t = m - j w with the largest j that keeps t >= 7 (t = m when there is none: the plain random minimizer).  Among the
+// W = k - t + 1 = (j + 1) w t-mers of the k-mer find the one with the smallest order, at position i; the sampled m-mer is the one
+// at position p = i mod w.  Consecutive k-mers of a read keep the same sampled m-mer for longer than under the plain minimizer:
+// density 0.120 instead of 0.154 for k = 31, m = 20 (t = 8, W = 24), i.e. ~15 instead of ~19.5 runs per 150-bp read, 21 % fewer
+// entries in the table, and the query computes orders of 16-bit values (one 24-bit multiply-add) instead of 40-bit ones.
+// p is a function of the k-mer alone, so everything else - entries, presence masks, slots, exactness - is as before.
+//   one-strand table: the order is taken of the CANONICAL t-mer (min of the t-mer and its reverse complement); because
+//   t = m (mod w) the positions of rc(K) mirror those of K (p -> w-1-p), and the strand is that of the sampled m-mer;
+//   ties (the same t-mer twice in the window, or 27-bit collisions) are resolved by the position bits of the query's key;
+//   the build stores a k-mer under EVERY tied position.
+#ifndef MIC_S_MOD
+#define MIC_S_MOD 1      /* 0: t = m, the plain minimizer of rounds 1-3 through the same code (ablation) */
+#endif
+__host__ __device__ __forceinline__ int s_tlen(int k, int m) {
+  int t = m;
+#if MIC_S_MOD
+  const int w = k - m + 1;
+  while (t - w >= 7) t -= w;
+#endif
+  return t;
+}
+// order of a t-mer value (the top 27 bits count): t <= 12 is one full-rate 24-bit multiply-add
+__device__ __forceinline__ uint32_t s_torder(uint64_t tv) {
+  uint32_t h = __umul24((uint32_t)tv & 0xFFFFFFu, 0x9E3779u) + 0x27D4EB2Fu;
+  const uint32_t hi = (uint32_t)(tv >> 24);
+  if (hi) h += hi * 0x85EBCA77u + (uint32_t)(tv >> 56) * 0xC2B2AE3Du;
+  return h;
+}
+__device__ __forceinline__ uint32_t s_torder24(uint32_t tv) { return __umul24(tv, 0x9E3779u) + 0x27D4EB2Fu; }   // tv < 2^24
+// reverse complement of a t-mer of at most 16 nucleotides
+__device__ __forceinline__ uint32_t revcomp_bits32(uint32_t x, int t) {
+  uint32_t r = __builtin_bitreverse32(x) >> (32 - 2 * t);
+  r = ((r >> 1) & 0x55555555u) | ((r << 1) & ~0x55555555u);
+  return ~r & (t >= 16 ? 0xFFFFFFFFu : (1u << (2 * t)) - 1u);
+}
+// sequential form: f(p) for every position p (0 .. w-1) the query may sample for the k-mer K as it reads (every tie)
+template <typename F>
+__device__ __forceinline__ void s_sampled(uint64_t K, int k, int m, bool canon, F&& f) {
+  const int w = k - m + 1, t = s_tlen(k, m), W = k - t + 1;
+  const uint64_t tmask = t >= 32 ? ~0ULL : (1ULL << (2 * t)) - 1;
+  uint32_t hmin = 0xFFFFFFFFu;
+  for (int i = 0; i < W; ++i) {
+    uint64_t tv = (K >> (2 * (k - t - i))) & tmask;
+    if (canon) { const uint64_t tr = revcomp_bits(tv, t); tv = tr < tv ? tr : tv; }
+    const uint32_t h = s_torder(tv) >> 5;
+    hmin = h < hmin ? h : hmin;
+  }
+  uint32_t done = 0;
+  for (int i = 0; i < W; ++i) {
+    uint64_t tv = (K >> (2 * (k - t - i))) & tmask;
+    if (canon) { const uint64_t tr = revcomp_bits(tv, t); tv = tr < tv ? tr : tv; }
+    if ((s_torder(tv) >> 5) != hmin) continue;
+    const int p = i % w;
+    if ((done >> p) & 1u) continue;
+    done |= 1u << p;
+    f(p);
+  }
+}
 
 __device__ __forceinline__ uint32_t sslot_of_x(uint64_t x, uint32_t n_slots) {
   const uint32_t hi = (uint32_t)(x >> 32);
   uint32_t h = (uint32_t)x * 0x85EBCA77u + __umul24(hi ^ (hi >> 24), 0xC2B2AFu);
+#if !(MIC_HASH_LITE & 2)
+  h ^= h >> 15; h *= 0x165667B1u;
+#endif
+  return __umulhi(h, n_slots);
+}
+
+// the same function of x given as (low word, bits above it): 32-bit operations only (query_kernel_r)
+__device__ __forceinline__ uint32_t sslot_of_x32(uint32_t lo, uint32_t hi, uint32_t n_slots) {
+  uint32_t h = lo * 0x85EBCA77u + __umul24(hi ^ (hi >> 24), 0xC2B2AFu);
 #if !(MIC_HASH_LITE & 2)
   h ^= h >> 15; h *= 0x165667B1u;
 #endif
@@ -127,42 +194,25 @@ __device__ __forceinline__ void s_candidates(uint64_t c, int k, int m, F&& f) {
   const int w = k - m + 1;
   const uint64_t mask = (1ULL << (2 * m)) - 1;
   const uint64_t rc = revcomp_bits(c, k);
-  uint32_t hmin = 0xFFFFFFFFu;
-  for (int i = 0; i < w; ++i) {
-    const uint64_t mf = (c >> (2 * (k - m - i))) & mask, mr = revcomp_bits(mf, m);
-    const uint32_t h = s_order27(mf < mr ? mf : mr);
-    hmin = h < hmin ? h : hmin;
-  }
-  for (int i = 0; i < w; ++i) {
-    const uint64_t mf = (c >> (2 * (k - m - i))) & mask, mr = revcomp_bits(mf, m);
-    if (s_order27(mf < mr ? mf : mr) != hmin) continue;
-    if (mf <= mr) f(c, i, mf);
-    if (mf >= mr) f(rc, w - 1 - i, mr);
-  }
+  s_sampled(c, k, m, true, [&](int p) {
+    const uint64_t mf = (c >> (2 * (k - m - p))) & mask, mr = revcomp_bits(mf, m);
+    if (mf <= mr) f(c, p, mf);
+    if (mf >= mr) f(rc, w - 1 - p, mr);
+  });
 }
 
 // Two-strand form of the same table ("S2", MIC_LAYOUT_SUPER2): BOTH orientations of every database k-mer are stored,
-// each under the minimizer of its own m-mers AS THEY READ (no canonical m-mer).  A query k-mer is then looked up exactly as
-// it stands in the read: no reverse complement, no canonical m-mer and no strand bookkeeping in the query kernel (60 of
-// its 414 VALU instructions per 150-bp read) at the price of twice the entries.  A k-mer that is its own reverse
-// complement is stored once.
+// each under the sampled m-mer of its own t-mers AS THEY READ (no canonical form).  A query k-mer is then looked up exactly as
+// it stands in the read: no reverse complement and no strand bookkeeping in the query kernel, at the price of twice the
+// entries.  A k-mer that is its own reverse complement is stored once.
 template <typename F>
 __device__ __forceinline__ void s_candidates_fwd(uint64_t c, int k, int m, F&& f) {
-  const int w = k - m + 1;
   const uint64_t mask = (1ULL << (2 * m)) - 1;
   const uint64_t rc = revcomp_bits(c, k);
   for (int strand = 0; strand < 2; ++strand) {
     if (strand && rc == c) break;
     const uint64_t K = strand ? rc : c;
-    uint32_t hmin = 0xFFFFFFFFu;
-    for (int i = 0; i < w; ++i) {
-      const uint32_t h = s_order27((K >> (2 * (k - m - i))) & mask);
-      hmin = h < hmin ? h : hmin;
-    }
-    for (int i = 0; i < w; ++i) {
-      const uint64_t mf = (K >> (2 * (k - m - i))) & mask;
-      if (s_order27(mf) == hmin) f(K, i, mf);
-    }
+    s_sampled(K, k, m, false, [&](int p) { f(K, p, (K >> (2 * (k - m - p))) & mask); });
   }
 }
 
@@ -179,32 +229,34 @@ __device__ inline uint32_t s_side_probe(const uint4* __restrict__ side, uint32_t
 }
 
 // The lookup the QUERY KERNELS perform for the k-mer K that reads at nucleotide `tpos` of its read part, done sequentially
-// (dense fallback, statistics).  The kernels' sliding minimum runs over keys order27 << 5 | strand << 4 | position & 15, so
-// m-mers that tie on the 27 bits are resolved by strand and position (mod 16; the window holds at most 16 m-mers and chunks
-// start at multiples of 128, so the key is a function of tpos + i).  The table stores a k-mer under EVERY tied position, so
-// any choice finds it; but in a table-sharded run the tied positions may hash to slots of DIFFERENT parts, and the parts'
-// counts only add up if every path - per-run kernel, per-k-mer kernel, this one - makes the same choice.
+// (dense fallback, statistics).  The kernels' sliding minimum runs over keys order27 << 5 | position & 31 of the t-mers, so
+// t-mers that tie on the 27 bits are resolved by the position (mod 32; the window holds at most 26 t-mers and chunks start at
+// multiples of 128, so the key is a function of tpos + i).  The table stores a k-mer under EVERY tied position, so any choice
+// finds it; but in a table-sharded run the tied positions may hash to slots of DIFFERENT parts, and the parts' counts only add
+// up if every path - per-run kernel, per-k-mer kernel, this one - makes the same choice.  One-strand table: the k-mer is looked
+// up in the strand in which the sampled m-mer is the smaller of itself and its reverse complement (forward when they are equal).
 //   parted: only the main slots [slot_lo, slot_lo + slot_cnt) are resident (slots = allocation - slot_lo slots); *mine tells
 //   whether the chosen slot is.
 __device__ inline uint32_t s_probe_read(const uint4* __restrict__ slots, uint32_t n_slots, bool parted, uint32_t slot_lo,
                                         uint32_t slot_cnt, uint64_t K, uint32_t tpos, int k, int m, bool fwd, bool* mine,
                                         const uint4* __restrict__ side = nullptr, uint32_t side_mask = 0) {
-  const int w = k - m + 1;
+  const int w = k - m + 1, t = s_tlen(k, m), W = k - t + 1;
   const uint64_t mask = (1ULL << (2 * m)) - 1;
-  const uint64_t rc = fwd ? 0 : revcomp_bits(K, k);
-  uint32_t best = 0xFFFFFFFFu; int bi = 0; uint64_t x = 0; bool rev = false;
-  for (int i = 0; i < w; ++i) {
-    const uint64_t mf = (K >> (2 * (k - m - i))) & mask;
-    uint64_t u = mf; uint32_t sb = 0;
-    if (!fwd) {
-      const uint64_t mr = (rc >> (2 * i)) & mask;          // reverse complement of m-mer i = m-mer w-1-i of rc(K)
-      if (!(mf < mr)) { u = mr; sb = 16u; }
-    }
-    const uint32_t key = (mmer_order_key_canon(u) & ~31u) | sb | ((tpos + (uint32_t)i) & 15u);
-    if (key < best) { best = key; bi = i; x = u; rev = sb != 0; }
+  const uint64_t tmask = t >= 32 ? ~0ULL : (1ULL << (2 * t)) - 1;
+  uint32_t best = 0xFFFFFFFFu; int bi = 0;
+  for (int i = 0; i < W; ++i) {
+    uint64_t tv = (K >> (2 * (k - t - i))) & tmask;
+    if (!fwd) { const uint64_t tr = revcomp_bits(tv, t); tv = tr < tv ? tr : tv; }
+    const uint32_t key = (s_torder(tv) & ~31u) | ((tpos + (uint32_t)i) & 31u);
+    if (key < best) { best = key; bi = i; }
   }
-  const uint64_t Kq = rev ? rc : K;
-  const int j = rev ? w - 1 - bi : bi;
+  const int p = bi % w;
+  const uint64_t mf = (K >> (2 * (k - m - p))) & mask;
+  const uint64_t mr = fwd ? 0 : revcomp_bits(mf, m);
+  const bool rev = !fwd && mr < mf;
+  const uint64_t x = rev ? mr : mf;
+  const uint64_t Kq = rev ? revcomp_bits(K, k) : K;
+  const int j = rev ? w - 1 - p : p;
   uint64_t slot = sslot_of_x(x, n_slots);
   if (parted && (uint32_t)slot - slot_lo >= slot_cnt) { *mine = false; return 0; }
   *mine = true;

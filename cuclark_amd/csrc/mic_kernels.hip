@@ -397,6 +397,86 @@ __device__ __forceinline__ uint32_t row_prefix_min(uint32_t t) {
   return t;
 }
 
+__device__ __forceinline__ uint32_t row_suffix_min(uint32_t t) {
+  uint32_t x;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)t, 0x101, 0xF, 0xF, false); t = x < t ? x : t;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)t, 0x102, 0xF, 0xF, false); t = x < t ? x : t;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)t, 0x104, 0xF, 0xF, false); t = x < t ? x : t;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)t, 0x108, 0xF, 0xF, false); t = x < t ? x : t;
+  return t;
+}
+
+// Sliding minimum over windows of 16 <= W <= 32 positions, positions 64 h + lane in a_h: afterwards a0, a1 = min over
+// [position, position + W).  Rows of 16 lanes are scanned from both sides by DPP (full-rate v_min_u32_dpp, no LDS):
+// P = prefix minimum, S = suffix minimum inside the row; a window of 16 that starts at x is S(x) and P(x + 15) (the next
+// row, or the same one when x starts a row), and a window of W is two windows of 16, at x and at x + W - 16.  Two rounds of
+// ds_bpermute instead of the five of the doubling form (sliding_min3), which serves W < 16.
+__device__ __forceinline__ void sliding_min_rows(uint32_t& a0, uint32_t& a1, uint32_t a2, int W, int lane) {
+  const uint32_t P0 = row_prefix_min(a0), P1 = row_prefix_min(a1), P2 = row_prefix_min(a2);
+  const uint32_t S0 = row_suffix_min(a0), S1 = row_suffix_min(a1), S2 = row_suffix_min(a2);
+  const int at = lane << 2;                                       // ds_bpermute wraps the lane number by itself
+  const uint32_t x0 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + 60, (int)P0), x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + 60, (int)P1),
+                 x2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + 60, (int)P2);
+  const bool wr = lane >= 49;
+  const uint32_t n0 = wr ? x1 : x0, n1 = wr ? x2 : x1;
+  uint32_t M0 = n0 < S0 ? n0 : S0, M1 = n1 < S1 ? n1 : S1;
+  if (W > 16) {
+    const uint32_t M2 = x2 < S2 ? x2 : S2;                        // exact for lanes < 49: lanes < W - 16 are read
+    const int sh = (W - 16) << 2;
+    const uint32_t y0 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + sh, (int)M0), y1 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + sh, (int)M1),
+                   y2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + sh, (int)M2);
+    const bool wy = lane >= 80 - W;                               // lane + W - 16 >= 64
+    const uint32_t v0 = wy ? y1 : y0, v1 = wy ? y2 : y1;
+    M0 = v0 < M0 ? v0 : M0; M1 = v1 < M1 ? v1 : M1;
+  }
+  a0 = M0; a1 = M1;
+}
+
+// Front half of the super-k-mer kernels: where in the chunk the SAMPLED m-mer (mic_device.h: mod-sampling) of the k-mers at
+// chunk positions lane and 64 + lane sits.  wd: window dword `lane` of the chunk (16 nucleotides); `past`: windows of counted
+// k-mers reach t-mers behind position 127 (a third pass of keys).  CANON: one-strand table, canonical t-mers.
+template <bool CANON>
+__device__ __forceinline__ void sampled_positions(uint32_t wd, int ln, int k, int m, bool past, uint32_t& qa0, uint32_t& qa1) {
+  const int w = k - m + 1, t = s_tlen(k, m), W = k - t + 1;
+  const uint32_t pb = (uint32_t)ln & 31u;                           // chunks start at multiples of 128: position & 31 = lane & 31 in every pass
+  uint32_t a0, a1, a2 = 0xFFFFFFFFu;
+  if (t <= 16) {
+    // the t-mer at position P = 64 h + lane: 16 nucleotides from P on are one funnel shift of window dwords (P - 1) / 16 and
+    // the next (the shift stays below 32 this way; P = 0 reads lane 63 and shifts it out)
+    const int s1 = ln - 1;
+    const int ad = (s1 >> 4) << 2;
+    const uint32_t tsh = 30u - 2u * (uint32_t)(s1 & 15);
+    auto tkey = [&](int h) {
+      const uint32_t W0 = (uint32_t)__builtin_amdgcn_ds_bpermute(ad + 16 * h, (int)wd), W1 = (uint32_t)__builtin_amdgcn_ds_bpermute(ad + 16 * h + 4, (int)wd);
+      uint32_t tv = __builtin_amdgcn_alignbit(W0, W1, tsh) >> (32 - 2 * t);
+      if (CANON) { const uint32_t tr = revcomp_bits32(tv, t); tv = tr < tv ? tr : tv; }
+      return ((t <= 12 ? s_torder24(tv) : s_torder(tv)) & ~31u) | pb;
+    };
+    a0 = tkey(0); a1 = tkey(1);
+    if (past) a2 = tkey(2);
+  } else {
+    auto tkey = [&](int h) {
+      const int idx = 4 * h + (ln >> 4);
+      const uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
+      uint64_t tv = kmer_from_dwords(d0, d1, d2, ln & 15, t);
+      if (CANON) { const uint64_t tr = revcomp_bits(tv, t); tv = tr < tv ? tr : tv; }
+      return (s_torder(tv) & ~31u) | pb;
+    };
+    a0 = tkey(0); a1 = tkey(1);
+    if (past) a2 = tkey(2);
+  }
+  if (W >= 16) sliding_min_rows(a0, a1, a2, W, ln);
+  else sliding_min3(a0, a1, a2, W, ln);
+  // position of the minimal t-mer inside the k-mer, then of the sampled m-mer: i mod w
+  uint32_t d0 = (a0 - (uint32_t)ln) & 31u, d1 = (a1 - (uint32_t)ln) & 31u;
+  if (W == 2 * w) { const uint32_t e0 = d0 - (uint32_t)w, e1 = d1 - (uint32_t)w; d0 = e0 < d0 ? e0 : d0; d1 = e1 < d1 ? e1 : d1; }
+  else if (W != w) {
+    const uint32_t rcp = (1024u + (uint32_t)w - 1u) / (uint32_t)w;      // d < 32, w <= 16: (d * rcp) >> 10 = d / w exactly
+    d0 -= (uint32_t)w * ((d0 * rcp) >> 10); d1 -= (uint32_t)w * ((d1 * rcp) >> 10);
+  }
+  qa0 = (uint32_t)ln + d0; qa1 = 64u + (uint32_t)ln + d1;
+}
+
 // -DMIC_PHASE_TIMING: per-phase cycle sums of query_kernel_m (s_memtime around each phase, one atomicAdd per wave),
 // printed by the launcher.  A measuring build only: the counter reads themselves cost ~5 %.
 // -DMIC_PERTURB: sensitivity analysis.  MIC_PERTURB_VALU / _LDS / _SALU = number of 8-instruction groups of dummy
@@ -864,19 +944,17 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
         const bool use_ahead = ahead_ok && base == 0;
         const uint32_t wd = window_word_w(cont, first, cend, base, lane, use_ahead,
                                           use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp) : 0u);
-        // k-mers of the two passes and the keys of the m-mers at positions base+64h+lane: order (27 bits) | strand | pos & 15
-        uint64_t km[2], rk[2]; bool act[2]; uint32_t hk0, hk1;
+        // k-mers of the two passes
+        uint64_t km[2], rk[2]; bool act[2];
         int ln = lane;
         asm volatile("" : "+v"(ln));   // lane-derived shift counts and positions are recomputed per chunk, not kept in VGPRs
-        const bool past = nk - base > (uint32_t)(129 - w);     // see query_kernel_m: the tail keys come out of pass 1
-        uint32_t tail = 0xFFFFFFFFu;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int idx = 4 * h + (lane >> 4);
           uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
           uint64_t kmer = kmer_from_dwords(d0, d1, d2, ln & 15, k);
-          // the reverse complement is needed for the canonical m-mers and the orientation (one-strand table) and for the
-          // bucket filter of the table-sharded mode (the buckets are those of the canonical k-mer)
+          // the reverse complement is needed for the orientation (one-strand table) and for the bucket filter of the
+          // table-sharded mode (the buckets are those of the canonical k-mer)
           const uint64_t rck = (!FWD || SHARDED) ? revcomp_bits(kmer, k) : 0;
           km[h] = kmer; rk[h] = rck;
           act[h] = base + 64 * h + lane < nk;
@@ -893,44 +971,27 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
               act[h] = act[h] && rem >= s_lo && rem < s_hi;
             }
           }
-          // m-mer at this position = first m nt of the k-mer; its reverse complement = last m nt of rc(k-mer)
-          const uint64_t mf = kmer >> (2 * (k - m));
-          uint32_t key;
-          if (FWD) key = (mmer_order_key_canon(mf) & ~31u) | (uint32_t)(ln & 15);
-          else {
-            const uint64_t mr = rck & ((1ULL << (2 * m)) - 1);
-            const bool fw = mf < mr;
-            key = (mmer_order_key_canon(fw ? mf : mr) & ~31u) | (fw ? 0u : 16u) | (uint32_t)(ln & 15);
-          }
-          if (h == 0) hk0 = key; else hk1 = key;
-          if (h == 1 && past) {
-            // last m-mer of the k-mer (position 64 + lane + w - 1) = its last m nt; reverse complement = first m nt of rc(k-mer)
-            const uint64_t tf = kmer & ((1ULL << (2 * m)) - 1);
-            uint32_t tk;
-            if (FWD) tk = (mmer_order_key_canon(tf) & ~31u) | (uint32_t)((ln + w - 1) & 15);
-            else {
-              const uint64_t tr = rck >> (2 * (k - m));
-              const bool tfw = tf < tr;
-              tk = (mmer_order_key_canon(tfw ? tf : tr) & ~31u) | (tfw ? 0u : 16u) | (uint32_t)((ln + w - 1) & 15);
-            }
-            tail = row_prefix_min(ln >= 65 - w ? tk : 0xFFFFFFFFu);
-          }
         }
-        sliding_min2(hk0, hk1, w, lane);
-        hk1 = tail < hk1 ? tail : hk1;
-        // every k-mer now knows its minimizer: strand and position -> oriented k-mer, nucleotide offset in the entry,
-        // minimizer value x -> slot and sort key
+        // where the sampled m-mer of every k-mer sits (mod-sampling, mic_device.h; shared with query_kernel_r)
+        const uint32_t n_act = nk - base < 128u ? nk - base : 128u;
+        const bool past = n_act + (uint32_t)(k - s_tlen(k, m)) >= 129u;
+        uint32_t qa[2];
+        sampled_positions<!FWD>(wd, ln, k, m, past, qa[0], qa[1]);
+        // every k-mer now knows its m-mer: position -> strand (the smaller of the m-mer and its reverse complement), oriented
+        // k-mer, nucleotide offset in the entry, minimizer value x -> slot and sort key
         uint64_t ko[2]; uint32_t ao[2], tk32[2], sl[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const uint32_t mk = h == 0 ? hk0 : hk1;
-          const uint32_t j = (mk - (uint32_t)ln) & 15;
-          const bool rev = !FWD && (mk & 16u) != 0;
+          const uint32_t j = qa[h] - (uint32_t)(64 * h + ln);                 // 0 .. w - 1
+          const uint64_t mm = (1ULL << (2 * m)) - 1;
+          const uint64_t xf = (km[h] >> (2 * ((uint32_t)(w - 1) - j))) & mm;
+          const uint64_t xr = FWD ? 0 : (rk[h] >> (2 * j)) & mm;               // its reverse complement = m-mer w-1-j of rc(k-mer)
+          const bool rev = !FWD && xr < xf;
           ko[h] = rev ? rk[h] : km[h];
           // minimizer position in the oriented k-mer: jo = rev ? w-1-j : j; offset of the k-mer in the super-k-mer:
           // w-1-jo; and because k-m = w-1 that offset is also the number of nucleotides to the right of the minimizer
           ao[h] = rev ? j : (uint32_t)(w - 1) - j;
-          const uint64_t x = (ko[h] >> (2 * ao[h])) & ((1ULL << (2 * m)) - 1);
+          const uint64_t x = rev ? xr : xf;
           tk32[h] = (uint32_t)x;
           sl[h] = act[h] ? sslot_of_x(x, (uint32_t)t.n_main) : 0xFFFFFFFFu;
           if (SHARDED) {   // slot-range part: the k-mer is this engine's iff its slot is resident here (slots are global indices)
@@ -1120,14 +1181,31 @@ __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cb
     mm &= ~wballot(mine);
     const uint32_t c = mine ? cnt : 0u;
     uint32_t sum = 0;
+#if MIC_R_TALLY_DPP
+    // runs sit in lanes 0 .. MIC_RMAX - 1 = the first two rows of 16: an inclusive row scan by DPP (4 full-rate adds) leaves the
+    // rows' sums in lanes 15 and 31 - against one and-compare pair and three scalar operations per count bit
+    {
+      uint32_t v = c;
+      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+      sum = __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31);
+    }
+#else
 #pragma unroll
     for (int b = 0; b < 5; ++b)
       if (b < cbits) sum += (uint32_t)__popcll(wballot((c & (1u << b)) != 0)) << b;
+#endif
     total += sum;
     row_add(acc, n_ent, overflow, l1, sum, lane);
   }
 }
 
+#ifndef MIC_R_TALLY_DPP
+#define MIC_R_TALLY_DPP 1      // 0: a run's hits summed with one ballot per count bit (rounds 2-3)
+#endif
+static_assert(MIC_RMAX == 32, "tally_counts sums the first two rows of lanes");
 #ifndef MIC_R_LINEAR
 #define MIC_R_LINEAR 1      // 0: three-step binary search over the six keys (three dependent LDS reads): 1.2 % slower
 #endif
@@ -1250,45 +1328,13 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         const uint32_t wd = use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp)
                                       : window_word_w(cont, first, cend, base, ln, false, 0u);
 #endif
-        // order keys of the m-mers at positions 64h + lane: order (27 bits) | position & 15
-        uint32_t hk0, hk1;
-        const bool past = nk - base > (uint32_t)(129 - w);     // the last k-mers' windows reach m-mers past position 127
-        uint32_t tail = 0xFFFFFFFFu;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int idx = 4 * h + (lane >> 4);
-          const uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
-          const uint64_t kmer = kmer_from_dwords(d0, d1, d2, ln & 15, k);
-          // one-strand table: the m-mer counts in its canonical form and the key carries the strand (bit 4), as in query_kernel_s
-          const uint64_t rck = FWD ? 0 : revcomp_bits(kmer, k);
-          const uint64_t mf = kmer >> (2 * (k - m));
-          uint32_t key;
-          if (FWD) key = (mmer_order_key_canon(mf) & ~31u) | (uint32_t)(ln & 15);
-          else {
-            const uint64_t mr = rck & ((1ULL << (2 * m)) - 1);
-            const bool fw = mf < mr;
-            key = (mmer_order_key_canon(fw ? mf : mr) & ~31u) | (fw ? 0u : 16u) | (uint32_t)(ln & 15);
-          }
-          if (h == 0) hk0 = key; else hk1 = key;
-          if (h == 1 && past) {   // m-mer 64 + lane + w - 1 = the last m nucleotides of this k-mer (see query_kernel_s)
-            const uint64_t tf = kmer & ((1ULL << (2 * m)) - 1);
-            uint32_t tk;
-            if (FWD) tk = (mmer_order_key_canon(tf) & ~31u) | (uint32_t)((ln + w - 1) & 15);
-            else {
-              const uint64_t tr = rck >> (2 * (k - m));
-              const bool tfw = tf < tr;
-              tk = (mmer_order_key_canon(tfw ? tf : tr) & ~31u) | (tfw ? 0u : 16u) | (uint32_t)((ln + w - 1) & 15);
-            }
-            tail = row_prefix_min(ln >= 65 - w ? tk : 0xFFFFFFFFu);
-          }
-        }
-        sliding_min2(hk0, hk1, w, ln);
-        hk1 = tail < hk1 ? tail : hk1;
-        // runs: k-mers next to each other whose minimizer sits at the same position of the chunk
+        // position in the chunk of the sampled m-mer of the k-mers at positions lane and 64 + lane (mod-sampling, mic_device.h)
         const uint32_t n_act = nk - base < 128u ? nk - base : 128u;
-        // position of the minimizer in the chunk, | strand << 8 for the one-strand table (a run has one strand)
-        const uint32_t qa0 = (uint32_t)ln + ((hk0 - (uint32_t)ln) & 15u) + (FWD ? 0u : (hk0 & 16u) << 4);
-        const uint32_t qa1 = 64u + (uint32_t)ln + ((hk1 - (uint32_t)ln) & 15u) + (FWD ? 0u : (hk1 & 16u) << 4);
+        const bool past = n_act + (uint32_t)(k - s_tlen(k, m)) >= 129u;   // the last k-mers' windows reach t-mers past position 127
+        uint32_t qa0, qa1;
+        sampled_positions<!FWD>(wd, ln, k, m, past, qa0, qa1);
+        // runs: k-mers next to each other whose sampled m-mer sits at the same position of the chunk (one-strand table: the
+        // strand is that of the m-mer, so a run has one)
         const uint32_t last0 = __builtin_amdgcn_readlane(qa0, 63);
         uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)qa0, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 keeps -1
         uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)last0, (int)qa1, 0x138, 0xF, 0xF, false);
@@ -1300,16 +1346,10 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         const uint64_t b0 = wballot(f0), b1 = wballot(f1);
         const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1);
         __builtin_amdgcn_wave_barrier();
-        // record: minimizer position (8 bits) | first k-mer (7 bits) | strand; the closing record holds n_act mod 128
-        if (FWD) {      // no strand: the first k-mer has all eight bits, the closing record holds n_act itself
-          if (f0) rec[below(b0)] = (uint16_t)(qa0 | ((uint32_t)lane << 8));
-          if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
-          if (ln == 0) rec[R] = (uint16_t)(n_act << 8);
-        } else {
-          if (f0) rec[below(b0)] = (uint16_t)((qa0 & 255u) | ((uint32_t)lane << 8) | ((qa0 >> 8) << 15));
-          if (f1) rec[R0 + below(b1)] = (uint16_t)((qa1 & 255u) | ((64u + (uint32_t)lane) << 8) | ((qa1 >> 8) << 15));
-          if (ln == 0) rec[R] = (uint16_t)((n_act & 127u) << 8);
-        }
+        // record: position of the sampled m-mer (8 bits) | first k-mer << 8; the closing record holds n_act
+        if (f0) rec[below(b0)] = (uint16_t)(qa0 | ((uint32_t)lane << 8));
+        if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
+        if (ln == 0) rec[R] = (uint16_t)(n_act << 8);
         __builtin_amdgcn_wave_barrier();
 
         for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
@@ -1317,9 +1357,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
           const bool vr = (uint32_t)lane < nrun;
           const uint32_t ri = vr ? rbase + (uint32_t)lane : 0u;
           const uint32_t rc0 = rec[ri], rc1 = rec[ri + 1];
-          const int qa = (int)(rc0 & 255u), i0 = FWD ? (int)(rc0 >> 8) : (int)((rc0 >> 8) & 127u);
-          const int n = FWD ? (int)(rc1 >> 8) - i0 : (int)((((rc1 >> 8) - (rc0 >> 8) - 1u) & 127u) + 1u);
-          const bool rev = !FWD && (rc0 >> 15) != 0;
+          const int qa = (int)(rc0 & 255u), i0 = (int)(rc0 >> 8);
+          const int n = (int)(rc1 >> 8) - i0;
           // the region [qa - ctx, qa + k) of the chunk, left-aligned in three words like the entry's super-k-mer: it starts
           // off = 1..16 nucleotides into window dword D (off = 16 instead of 0 keeps the alignbit shift below 32)
           const int s1 = qa - ctx - 1;
@@ -1335,10 +1374,27 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
           const uint32_t W0 = bperm((D) & 63, wd), W1 = bperm((D + 1) & 63, wd), W2 = bperm((D + 2) & 63, wd), W3 = bperm((D + 3) & 63, wd);
 #endif
           uint32_t G0 = __builtin_amdgcn_alignbit(W0, W1, tsh), G1 = __builtin_amdgcn_alignbit(W1, W2, tsh), G2 = __builtin_amdgcn_alignbit(W2, W3, tsh);
+          // minimizer value x = nucleotides ctx .. ctx + m - 1 of the region: its low word is one funnel shift of (G0, G1), the
+          // bits above it (m > 16) one bit-field extract of G0 - 64-bit shifts run at half rate
+          // (k > 16: the region's first two words hold bits behind the minimizer; shorter k-mers take the 64-bit form)
+          const uint32_t xsh = (64u - 2u * (uint32_t)k) & 31u;                              // k > 16: 0 .. 30
+          auto region_x = [&](uint32_t A0, uint32_t A1, uint32_t& lo, uint32_t& hi) {
+            if (k > 16) {
+              lo = __builtin_amdgcn_alignbit(A0, A1, xsh) & (m >= 16 ? 0xFFFFFFFFu : (1u << ((2 * m) & 31)) - 1u);
+              hi = m > 16 ? (A0 >> xsh) & ((1u << ((2 * m - 32) & 31)) - 1u) : 0u;
+            } else {
+              const uint64_t x = ((((uint64_t)A0 << 32) | A1) << (2 * ctx)) >> (64 - 2 * m);
+              lo = (uint32_t)x; hi = (uint32_t)(x >> 32);
+            }
+          };
+          uint32_t key, xhi;
+          region_x(G0, G1, key, xhi);
+          bool rev = false;
           if (!FWD) {
-            // a run on the reverse strand is looked up as the reverse complement of the SAME region (the minimizer sits ctx
-            // nucleotides from either end): reverse the 96 bits, drop the 96 - 2 (k + ctx) bits that were behind the region,
-            // swap the two bits of every nucleotide back, complement - once per run, not twice per k-mer
+            // One-strand table: the run is looked up in the strand in which its sampled m-mer is the smaller of itself and its
+            // reverse complement - as the reverse complement of the SAME region (the m-mer sits ctx nucleotides from either
+            // end): reverse the 96 bits, drop the 96 - 2 (k + ctx) bits that were behind the region, swap the two bits of every
+            // nucleotide back, complement - once per run, not twice per k-mer; the m-mer of that region is the reverse complement
             const uint32_t sh = 96u - 2u * (uint32_t)(k + ctx);                  // 0 .. 31 (the launcher checks)
             const uint32_t r0 = __builtin_bitreverse32(G2), r1 = __builtin_bitreverse32(G1), r2 = __builtin_bitreverse32(G0);
             uint32_t q0 = sh ? __builtin_amdgcn_alignbit(r0, r1, 32u - sh) : r0;
@@ -1347,14 +1403,16 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             q0 = ~(((q0 >> 1) & 0x55555555u) | ((q0 << 1) & 0xAAAAAAAAu));
             q1 = ~(((q1 >> 1) & 0x55555555u) | ((q1 << 1) & 0xAAAAAAAAu));
             q2 = ~(((q2 >> 1) & 0x55555555u) | ((q2 << 1) & 0xAAAAAAAAu));
+            uint32_t kr, hr;
+            region_x(q0, q1, kr, hr);
+            rev = hr < xhi || (hr == xhi && kr < key);
             G0 = rev ? q0 : G0; G1 = rev ? q1 : G1; G2 = rev ? q2 : G2;
+            key = rev ? kr : key; xhi = rev ? hr : xhi;
           }
-          const uint64_t x = ((((uint64_t)G0 << 32) | G1) << (2 * ctx)) >> (64 - 2 * m);
-          const uint32_t key = (uint32_t)x;
           // minimizer position inside the run's first / last k-mer; in the reverse complement position j becomes ctx - j
           const int jmaxf = qa - i0, jminf = jmaxf - n + 1;
           const int jmax = rev ? ctx - jminf : jmaxf, jmin = rev ? ctx - jmaxf : jminf;
-          uint32_t cur = vr ? sslot_of_x(x, (uint32_t)t.n_main) : 0xFFFFFFFFu;
+          uint32_t cur = vr ? sslot_of_x32(key, xhi, (uint32_t)t.n_main) : 0xFFFFFFFFu;
           bool mine = vr;
           if (PART) {
             // Slot-range part of a table-sharded run: a run (one minimizer occurrence -> one slot) belongs to exactly one
@@ -1404,17 +1462,22 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             bool more = vl && e < 6;
             e = e < 5 ? e : 5;
             for (;;) {
-              uint32_t g = q[e], S0 = q[6 + 3 * e], S1 = q[7 + 3 * e], S2 = q[8 + 3 * e], pl = q[24 + e];
+              uint32_t e3 = e + (e << 1);
+              asm volatile("" : "+v"(e3));     // (the compiler would turn 3 e into a 64-bit multiply-add of the LDS address: quarter rate)
+              uint32_t g = q[e], S0 = q[6 + e3], S1 = q[7 + e3], S2 = q[8 + e3], pl = q[24 + e];
 #if MIC_R_EAGER_ENTRY
               asm volatile("" : "+v"(S2));     // read with the others: the compiler would sink it into the branch below, one more LDS round trip
 #endif
               const bool same = more && g == key;
               const uint32_t d0 = G0 ^ S0, d1 = G1 ^ S1, d2 = G2 ^ S2;
-              const uint64_t dtop = ((uint64_t)d0 << 32) | d1;
-              const bool mineq = ((dtop << (2 * ctx)) >> (64 - 2 * m)) == 0;                 // the whole minimizer, not only its low 32 bits
-              const uint32_t dl = (uint32_t)((uint64_t)d0 >> (32 - 2 * ctx));               // left context, nucleotide ctx-1 in the low bits
-              const uint32_t dr = 2 * k >= 32 ? (uint32_t)(((((uint64_t)d1 << 32) | d2) << (2 * k - 32)) >> 32)
-                                              : (uint32_t)((dtop << (2 * k)) >> 32);       // right context, its first nucleotide on top
+              // the whole minimizer, not only its low 32 bits: its nucleotides are the low 32 - 2 ctx bits of word 0 and the top
+              // 2 (ctx + m) - 32 bits of word 1 (32-bit operations: the 64-bit form shifts and compares at half rate)
+              const bool mineq = k > 16
+                                     ? ((d0 & ((1u << ((32 - 2 * ctx) & 31)) - 1u)) | (d1 >> xsh)) == 0
+                                     : (((((uint64_t)d0 << 32) | d1) << (2 * ctx)) >> (64 - 2 * m)) == 0;
+              const uint32_t dl = d0 >> (32 - 2 * ctx);                                      // left context, nucleotide ctx-1 in the low bits
+              const uint32_t dr = k > 16 ? __builtin_amdgcn_alignbit(d1, d2, xsh)
+                                              : (uint32_t)((((((uint64_t)d0 << 32) | d1)) << (2 * k)) >> 32);   // right context, its first nucleotide on top
               const int left = __builtin_ctz(dl | (1u << (2 * ctx))) >> 1;                   // equal nucleotides next to the minimizer
               const int right = __builtin_clz(dr | (1u << (31 - 2 * ctx))) >> 1;
               const int hi = left < jmax ? left : jmax, lo = ctx - right > jmin ? ctx - right : jmin;

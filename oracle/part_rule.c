@@ -6,12 +6,13 @@
  * (CuClarkDB.cu:566-574, filter :1272-1274); per-target counts are additive over ANY partition of the k-mer occurrences
  * (mergeKernel sums, CuClarkDB.cu:1385-1388), so the result of the whole run does not depend on how the table is cut.  The
  * product's super-k-mer layouts cut the RESIDENT table by slot range: a k-mer occurrence belongs to the part that holds the
- * slot of its minimizer.  That rule is restated here from its description (cuclark_amd/csrc/mic_device.h: s_probe_read,
- * mmer_order_key_canon, sslot_of_x), independently of the HIP code:
- *   - the k-mer that reads at nucleotide tpos of its read part has w = k - m + 1 m-mers; m-mer i gets the key
- *     order27(u) << 5 | strand << 4 | (tpos + i) & 15, where (one-strand table) u = min(m-mer, its reverse complement) and
- *     strand = 0 iff the m-mer itself is the smaller, or (two-strand table) u = the m-mer as it reads and strand = 0;
- *   - the minimizer is the m-mer with the smallest key; its value u is hashed to a slot in [0, n_slots);
+ * slot of its sampled m-mer.  That rule is restated here from its description (cuclark_amd/csrc/mic_device.h: s_tlen, s_torder,
+ * s_probe_read, sslot_of_x), independently of the HIP code:
+ *   - mod-sampling: t = m - j w (w = k - m + 1) with the largest j that keeps t >= 7, t = m when there is none; the k-mer that
+ *     reads at nucleotide tpos of its read part has W = k - t + 1 t-mers; t-mer i gets the key order27(u) << 5 | (tpos + i) & 31,
+ *     where u = the t-mer as it reads (two-strand table) or the smaller of the t-mer and its reverse complement (one-strand);
+ *   - the t-mer with the smallest key, at position i, samples the m-mer at position p = i mod w; its value (one-strand table:
+ *     the smaller of the m-mer and its reverse complement) is hashed to a slot in [0, n_slots);
  *   - part p of n answers for the slots [n_slots p / n, n_slots (p + 1) / n).
  * Whether the k-mer is in the database, and with which label, is orc_db_find's business as for every other count.
  */
@@ -21,12 +22,18 @@
 
 static uint32_t umul24(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)); }
 
-/* 32-bit order key of a (canonical) m-mer value; the top 27 bits order the m-mers */
-static uint32_t mmer_order_key(uint64_t u) {
-  const uint32_t hi = (uint32_t)(u >> 32);
-  uint32_t h = ((uint32_t)u * 0x9E3779B1u) ^ (umul24(hi ^ (hi >> 24), 0xEBCA77u) + 0x27D4EB2Fu);
-  h ^= h >> 15;
-  h *= 0x2C1B3C6Du;
+static int tmer_len(int k, int m) {
+  const int w = k - m + 1;
+  int t = m;
+  while (t - w >= 7) t -= w;
+  return t;
+}
+
+/* 32-bit order key of a t-mer value; the top 27 bits order the t-mers */
+static uint32_t tmer_order_key(uint64_t tv) {
+  uint32_t h = umul24((uint32_t)tv, 0x9E3779u) + 0x27D4EB2Fu;
+  const uint32_t hi = (uint32_t)(tv >> 24);
+  if (hi) h += hi * 0x85EBCA77u + (uint32_t)(tv >> 56) * 0xC2B2AE3Du;
   return h;
 }
 
@@ -37,20 +44,24 @@ static uint32_t slot_of_minimizer(uint64_t x, uint32_t n_slots) {
 }
 
 uint32_t orc_part_slot_of_kmer(uint64_t kmer, uint32_t tpos, int k, int m, int both_strands, uint32_t n_slots) {
-  const int w = k - m + 1;
+  const int w = k - m + 1, t = tmer_len(k, m), W = k - t + 1;
   const uint64_t mask = (1ULL << (2 * m)) - 1;
+  const uint64_t tmask = t >= 32 ? ~0ULL : (1ULL << (2 * t)) - 1;
   uint32_t best = 0xFFFFFFFFu;
-  uint64_t x = 0;
-  for (int i = 0; i < w; ++i) {
-    const uint64_t mf = (kmer >> (2 * (k - m - i))) & mask;
-    uint64_t u = mf;
-    uint32_t strand = 0;
+  int bi = 0;
+  for (int i = 0; i < W; ++i) {
+    uint64_t tv = (kmer >> (2 * (k - t - i))) & tmask;
     if (!both_strands) {
-      const uint64_t mr = orc_revcomp(mf, m);
-      if (!(mf < mr)) { u = mr; strand = 16u; }
+      const uint64_t tr = orc_revcomp(tv, t);
+      if (tr < tv) tv = tr;
     }
-    const uint32_t key = (mmer_order_key(u) & ~31u) | strand | ((tpos + (uint32_t)i) & 15u);
-    if (key < best) { best = key; x = u; }
+    const uint32_t key = (tmer_order_key(tv) & ~31u) | ((tpos + (uint32_t)i) & 31u);
+    if (key < best) { best = key; bi = i; }
+  }
+  uint64_t x = (kmer >> (2 * (k - m - bi % w))) & mask;
+  if (!both_strands) {
+    const uint64_t xr = orc_revcomp(x, m);
+    if (xr < x) x = xr;
   }
   return slot_of_minimizer(x, n_slots);
 }
