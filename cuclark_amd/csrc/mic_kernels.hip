@@ -212,13 +212,15 @@ __device__ __forceinline__ void tally3(uint32_t r0, uint32_t r1, uint32_t r2, Ro
 template <typename ARGS>   // MicQueryArgs, or the cold fields re-read from the kernarg segment (query_kernel_m)
 __device__ __forceinline__ void finish_read(const RowAcc& acc, uint32_t n_ent, uint32_t total, uint32_t overflow,
                                             uint32_t r, const ARGS& a, int lane) {
-  uint64_t best = 0, second = 0;
+  // (count, label + 1) pairs compared as 32-bit scalars: a 64-bit key has no scalar compare and went through the vector unit
+  uint32_t bc = 0, bl = 0, sc = 0, sl = 0;       // best and second: count, label + 1 (0 = none)
   for (uint32_t i = 0; i < n_ent; ++i) {
-    uint32_t l1 = __builtin_amdgcn_readlane(acc.label1, i);
-    uint32_t c = __builtin_amdgcn_readlane(acc.count, i);
-    uint64_t key = ((uint64_t)c << 16) | (uint64_t)(0x10000u - l1);  // 0xFFFF - label
-    if (key > best) { second = best; best = key; }
-    else if (key > second) second = key;
+    const uint32_t l1 = __builtin_amdgcn_readlane(acc.label1, i);
+    const uint32_t c = __builtin_amdgcn_readlane(acc.count, i);
+    const bool over_best = c > bc || (c == bc && l1 < bl);
+    const bool over_second = c > sc || (c == sc && l1 < sl);
+    if (over_best) { sc = bc; sl = bl; bc = c; bl = l1; }
+    else if (over_second) { sc = c; sl = l1; }
   }
   uint32_t flags = 0;
   if (a.rows) {
@@ -243,10 +245,10 @@ __device__ __forceinline__ void finish_read(const RowAcc& acc, uint32_t n_ent, u
   if (lane == 0) {
     uint4 lo, hi;
     lo.x = total;
-    lo.y = best ? 0x10000u - (uint32_t)(best & 0xFFFF) : 0;   // label+1
-    lo.z = (uint32_t)(best >> 16);
-    lo.w = second ? 0x10000u - (uint32_t)(second & 0xFFFF) : 0;
-    hi.x = (uint32_t)(second >> 16);
+    lo.y = bl;   // label+1
+    lo.z = bc;
+    lo.w = sl;
+    hi.x = sc;
     hi.y = n_ent; hi.z = flags; hi.w = 0;
     uint4* out = (uint4*)(a.results + (size_t)r * 8);
     out[0] = lo; out[1] = hi;
@@ -411,8 +413,46 @@ __device__ __forceinline__ uint32_t row_suffix_min(uint32_t t) {
 // P = prefix minimum, S = suffix minimum inside the row; a window of 16 that starts at x is S(x) and P(x + 15) (the next
 // row, or the same one when x starts a row), and a window of W is two windows of 16, at x and at x + W - 16.  Two rounds of
 // ds_bpermute instead of the five of the doubling form (sliding_min3), which serves W < 16.
+#ifndef MIC_SLIDE_Q
+#define MIC_SLIDE_Q 1
+#endif
+template <int BANKS>
+__device__ __forceinline__ uint32_t with_row_in_front(uint32_t P) {     // min(P, lane 15 of the row in front) in the lanes of BANKS, rows 1-3
+  const uint32_t f = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)P, 0x142, 0xE, BANKS, false);      // row_bcast:15
+  return f < P ? f : P;
+}
 __device__ __forceinline__ void sliding_min_rows(uint32_t& a0, uint32_t& a1, uint32_t a2, int W, int lane) {
   const uint32_t P0 = row_prefix_min(a0), P1 = row_prefix_min(a1), P2 = row_prefix_min(a2);
+#if MIC_SLIDE_Q
+  if (W > 16 && ((W - 16) & 3) == 0) {
+    // One round of ds_bpermute: the window [x, x + W) is the rest of x's row, S(x), the prefix P(e) of the row of its last
+    // position e = x + W - 1, and - when that row is the next but one, which is when e sits in lanes 0 .. W-18 of its row -
+    // the whole row in between.  That row's minimum is lane 15 of its P: DPP row_bcast:15 hands it to the next row, the bank
+    // mask cuts it to lanes 0 .. W-17 (lane W-17 belongs to a window that starts its row: the row in front is part of it
+    // anyway); the first row of arrays 1 and 2 gets lane 63 of the array in front through a scalar.
+    const uint32_t S0 = row_suffix_min(a0), S1 = row_suffix_min(a1);
+    const int s = W - 16, bm = (1 << (s >> 2)) - 1;
+    uint32_t Q0, Q1, Q2;
+    // (the bank mask is an immediate of the instruction)
+    switch (bm) {
+      case 1: Q0 = with_row_in_front<1>(P0); Q1 = with_row_in_front<1>(P1); Q2 = with_row_in_front<1>(P2); break;
+      case 3: Q0 = with_row_in_front<3>(P0); Q1 = with_row_in_front<3>(P1); Q2 = with_row_in_front<3>(P2); break;
+      case 7: Q0 = with_row_in_front<7>(P0); Q1 = with_row_in_front<7>(P1); Q2 = with_row_in_front<7>(P2); break;
+      default: Q0 = with_row_in_front<15>(P0); Q1 = with_row_in_front<15>(P1); Q2 = with_row_in_front<15>(P2); break;
+    }
+    const uint32_t f0 = __builtin_amdgcn_readlane(P0, 63), f1 = __builtin_amdgcn_readlane(P1, 63);
+    const bool head = lane < s;
+    const uint32_t h1 = f0 < Q1 ? f0 : Q1, h2 = f1 < Q2 ? f1 : Q2;
+    Q1 = head ? h1 : Q1; Q2 = head ? h2 : Q2;
+    const int at = (lane << 2) + ((W - 1) << 2);
+    const uint32_t z0 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)Q0), z1 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)Q1),
+                   z2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)Q2);
+    const bool wz = lane >= 65 - W;                               // lane + W - 1 >= 64
+    const uint32_t v0 = wz ? z1 : z0, v1 = wz ? z2 : z1;
+    a0 = v0 < S0 ? v0 : S0; a1 = v1 < S1 ? v1 : S1;
+    return;
+  }
+#endif
   const uint32_t S0 = row_suffix_min(a0), S1 = row_suffix_min(a1), S2 = row_suffix_min(a2);
   const int at = lane << 2;                                       // ds_bpermute wraps the lane number by itself
   const uint32_t x0 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + 60, (int)P0), x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + 60, (int)P1),
@@ -1247,16 +1287,31 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
   // read-ahead through LDS: see query_kernel_s
   uint32_t* ahead0 = s_ahead[wv][0];
   uint32_t* ahead1 = s_ahead[wv][1];
+#ifndef MIC_R_AHEAD_SPLIT
+#define MIC_R_AHEAD_SPLIT 1
+#endif
   auto ahead_issue = [&](uint32_t* entry, uint32_t pp_w, uint32_t r_ptr) {
     const uint64_t abase = ((uint64_t)(cont + pp_w)) & ~3ULL;
     const uint32_t rr = r_ptr < a.n_reads ? r_ptr : a.n_reads - 1;
     const uint64_t pbase = (uint64_t)(a.reads_ptr + rr) - 48;
+#if MIC_R_AHEAD_SPLIT
+    // two LDS-DMA instructions under their lanes' masks, scalar base + 4 * lane each (lane L lands at entry + 4 L whatever
+    // the mask): 12 window dwords, 2 pointers - 14 loads instead of 64, and none of the selects of the one-instruction form
+    // (the pointers are loaded by lanes 0, 1 into entry + 12: with one destination the compiler merges the two loads again)
+    if (lane < 12)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const uint32_t*)abase + lane),
+                                       (__attribute__((address_space(3))) void*)entry, 4, 0, 0);
+    if (lane < 2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const uint32_t*)(pbase + 48) + lane),
+                                       (__attribute__((address_space(3))) void*)(entry + 12), 4, 0, 0);
+#else
     uint32_t lv = (uint32_t)lane;
     asm volatile("" : "+v"(lv));
     const uint32_t li = lv < 14 ? lv : 0u;
     const uint64_t addr = (li < 12 ? abase : pbase) + 4 * li;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
                                      (__attribute__((address_space(3))) void*)entry, 4, 0, 0);
+#endif
   };
   auto ahead_take = [&](const uint32_t* entry, uint32_t pp_w, uint32_t& hdr, uint32_t& npp, uint32_t& npe) {
     const uint32_t raw = entry[lane];
@@ -1335,12 +1390,34 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         sampled_positions<!FWD>(wd, ln, k, m, past, qa0, qa1);
         // runs: k-mers next to each other whose sampled m-mer sits at the same position of the chunk (one-strand table: the
         // strand is that of the m-mer, so a run has one)
+#ifndef MIC_R_SENTINEL
+#define MIC_R_SENTINEL 1
+#endif
+#if MIC_R_SENTINEL
+        // k-mers behind the last one of the chunk get a position no m-mer has: the first of them then "leads a run" whose record
+        // is exactly the closing record (first k-mer = n_act) - no compound predicates for the ballots, no extra write
+        qa0 = (uint32_t)lane < n_act ? qa0 : 0xFFu;
+        qa1 = 64u + (uint32_t)lane < n_act ? qa1 : 0xFFu;
+        const uint32_t last0 = __builtin_amdgcn_readlane(qa0, 63);
+        uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)qa0, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 keeps -1
+        uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)last0, (int)qa1, 0x138, 0xF, 0xF, false);
+        const bool f0 = qa0 != p0, f1 = qa1 != p1;
+        const uint64_t b0 = wballot(f0), b1 = wballot(f1);
+        const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1) - (n_act < 128u ? 1u : 0u);
+        __builtin_amdgcn_wave_barrier();
+        // record: position of the sampled m-mer (8 bits) | first k-mer << 8; the closing record holds n_act
+        if (f0) rec[below(b0)] = (uint16_t)(qa0 | ((uint32_t)lane << 8));
+        if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
+        if (__builtin_expect(n_act == 128u, 0)) {     // a full chunk has no k-mer behind its last one (reads longer than 157 nt)
+          asm volatile("" ::: "memory");              // (keeps the scalar test a branch of its own)
+          if (ln == 0) rec[R] = (uint16_t)(128u << 8);
+        }
+        __builtin_amdgcn_wave_barrier();
+#else
         const uint32_t last0 = __builtin_amdgcn_readlane(qa0, 63);
         uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)qa0, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 keeps -1
         uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)last0, (int)qa1, 0x138, 0xF, 0xF, false);
         const bool f0 = (uint32_t)lane < n_act && qa0 != p0, f1 = 64u + (uint32_t)lane < n_act && qa1 != p1;
-        // (a ballot of a compound predicate costs a select and a compare: the leaders' masks are the ballots of the plain
-        // comparisons cut to the active k-mers in scalar registers)
         // (the leaders' masks cut to the active k-mers in scalar registers instead of a ballot of the compound predicate:
         // 4 VALU fewer, 16 SALU more per read, measured 1.5 % slower - the scalar unit is as busy as the vector units)
         const uint64_t b0 = wballot(f0), b1 = wballot(f1);
@@ -1351,6 +1428,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
         if (ln == 0) rec[R] = (uint16_t)(n_act << 8);
         __builtin_amdgcn_wave_barrier();
+#endif
 
         for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
           const uint32_t nrun = R - rbase < MIC_RMAX ? R - rbase : MIC_RMAX;
@@ -1477,7 +1555,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
                                      : (((((uint64_t)d0 << 32) | d1) << (2 * ctx)) >> (64 - 2 * m)) == 0;
               const uint32_t dl = d0 >> (32 - 2 * ctx);                                      // left context, nucleotide ctx-1 in the low bits
               const uint32_t dr = k > 16 ? __builtin_amdgcn_alignbit(d1, d2, xsh)
-                                              : (uint32_t)((((((uint64_t)d0 << 32) | d1)) << (2 * k)) >> 32);   // right context, its first nucleotide on top
+                                              : (uint32_t)((((((uint64_t)d0 << 32) | d1)) << ((2 * k) & 63)) >> 32);   // right context, its first nucleotide on top
               const int left = __builtin_ctz(dl | (1u << (2 * ctx))) >> 1;                   // equal nucleotides next to the minimizer
               const int right = __builtin_clz(dr | (1u << (31 - 2 * ctx))) >> 1;
               const int hi = left < jmax ? left : jmax, lo = ctx - right > jmin ? ctx - right : jmin;
