@@ -421,7 +421,7 @@ __device__ __forceinline__ uint32_t with_row_in_front(uint32_t P) {     // min(P
   const uint32_t f = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)P, 0x142, 0xE, BANKS, false);      // row_bcast:15
   return f < P ? f : P;
 }
-__device__ __forceinline__ void sliding_min_rows(uint32_t& a0, uint32_t& a1, uint32_t a2, int W, int lane) {
+__device__ __forceinline__ void sliding_min_rows(uint32_t& a0, uint32_t& a1, uint32_t a2, int W, int lane, int lane_inv) {
   const uint32_t P0 = row_prefix_min(a0), P1 = row_prefix_min(a1), P2 = row_prefix_min(a2);
 #if MIC_SLIDE_Q
   if (W > 16 && ((W - 16) & 3) == 0) {
@@ -444,7 +444,7 @@ __device__ __forceinline__ void sliding_min_rows(uint32_t& a0, uint32_t& a1, uin
     const bool head = lane < s;
     const uint32_t h1 = f0 < Q1 ? f0 : Q1, h2 = f1 < Q2 ? f1 : Q2;
     Q1 = head ? h1 : Q1; Q2 = head ? h2 : Q2;
-    const int at = (lane << 2) + ((W - 1) << 2);
+    const int at = (lane_inv << 2) + ((W - 1) << 2);
     const uint32_t z0 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)Q0), z1 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)Q1),
                    z2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)Q2);
     const bool wz = lane >= 65 - W;                               // lane + W - 1 >= 64
@@ -454,7 +454,7 @@ __device__ __forceinline__ void sliding_min_rows(uint32_t& a0, uint32_t& a1, uin
   }
 #endif
   const uint32_t S0 = row_suffix_min(a0), S1 = row_suffix_min(a1), S2 = row_suffix_min(a2);
-  const int at = lane << 2;                                       // ds_bpermute wraps the lane number by itself
+  const int at = lane_inv << 2;                                   // ds_bpermute wraps the lane number by itself
   const uint32_t x0 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + 60, (int)P0), x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + 60, (int)P1),
                  x2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + 60, (int)P2);
   const bool wr = lane >= 49;
@@ -475,15 +475,18 @@ __device__ __forceinline__ void sliding_min_rows(uint32_t& a0, uint32_t& a1, uin
 // Front half of the super-k-mer kernels: where in the chunk the SAMPLED m-mer (mic_device.h: mod-sampling) of the k-mers at
 // chunk positions lane and 64 + lane sits.  wd: window dword `lane` of the chunk (16 nucleotides); `past`: windows of counted
 // k-mers reach t-mers behind position 127 (a third pass of keys).  CANON: one-strand table, canonical t-mers.
+// ln: the lane number as an opaque per-chunk copy (what is derived from it - compare masks - is recomputed per chunk: kept across
+// the kernel they would live in scalar register pairs the per-run kernel does not have); lane_inv: the lane number the compiler
+// may hoist from (vector registers are plentiful: shift counts and permute addresses stay resident, 8 VALU per chunk fewer).
 template <bool CANON>
-__device__ __forceinline__ void sampled_positions(uint32_t wd, int ln, int k, int m, bool past, uint32_t& qa0, uint32_t& qa1) {
+__device__ __forceinline__ void sampled_positions(uint32_t wd, int ln, int lane_inv, int k, int m, bool past, uint32_t& qa0, uint32_t& qa1) {
   const int w = k - m + 1, t = s_tlen(k, m), W = k - t + 1;
-  const uint32_t pb = (uint32_t)ln & 31u;                           // chunks start at multiples of 128: position & 31 = lane & 31 in every pass
+  const uint32_t pb = (uint32_t)lane_inv & 31u;                     // chunks start at multiples of 128: position & 31 = lane & 31 in every pass
   uint32_t a0, a1, a2 = 0xFFFFFFFFu;
   if (t <= 16) {
     // the t-mer at position P = 64 h + lane: 16 nucleotides from P on are one funnel shift of window dwords (P - 1) / 16 and
     // the next (the shift stays below 32 this way; P = 0 reads lane 63 and shifts it out)
-    const int s1 = ln - 1;
+    const int s1 = lane_inv - 1;
     const int ad = (s1 >> 4) << 2;
     const uint32_t tsh = 30u - 2u * (uint32_t)(s1 & 15);
     auto tkey = [&](int h) {
@@ -496,25 +499,25 @@ __device__ __forceinline__ void sampled_positions(uint32_t wd, int ln, int k, in
     if (past) a2 = tkey(2);
   } else {
     auto tkey = [&](int h) {
-      const int idx = 4 * h + (ln >> 4);
+      const int idx = 4 * h + (lane_inv >> 4);
       const uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
-      uint64_t tv = kmer_from_dwords(d0, d1, d2, ln & 15, t);
+      uint64_t tv = kmer_from_dwords(d0, d1, d2, lane_inv & 15, t);
       if (CANON) { const uint64_t tr = revcomp_bits(tv, t); tv = tr < tv ? tr : tv; }
       return (s_torder(tv) & ~31u) | pb;
     };
     a0 = tkey(0); a1 = tkey(1);
     if (past) a2 = tkey(2);
   }
-  if (W >= 16) sliding_min_rows(a0, a1, a2, W, ln);
+  if (W >= 16) sliding_min_rows(a0, a1, a2, W, ln, lane_inv);
   else sliding_min3(a0, a1, a2, W, ln);
   // position of the minimal t-mer inside the k-mer, then of the sampled m-mer: i mod w
-  uint32_t d0 = (a0 - (uint32_t)ln) & 31u, d1 = (a1 - (uint32_t)ln) & 31u;
+  uint32_t d0 = (a0 - pb) & 31u, d1 = (a1 - pb) & 31u;
   if (W == 2 * w) { const uint32_t e0 = d0 - (uint32_t)w, e1 = d1 - (uint32_t)w; d0 = e0 < d0 ? e0 : d0; d1 = e1 < d1 ? e1 : d1; }
   else if (W != w) {
     const uint32_t rcp = (1024u + (uint32_t)w - 1u) / (uint32_t)w;      // d < 32, w <= 16: (d * rcp) >> 10 = d / w exactly
     d0 -= (uint32_t)w * ((d0 * rcp) >> 10); d1 -= (uint32_t)w * ((d1 * rcp) >> 10);
   }
-  qa0 = (uint32_t)ln + d0; qa1 = 64u + (uint32_t)ln + d1;
+  qa0 = (uint32_t)lane_inv + d0; qa1 = 64u + (uint32_t)lane_inv + d1;
 }
 
 // -DMIC_PHASE_TIMING: per-phase cycle sums of query_kernel_m (s_memtime around each phase, one atomicAdd per wave),
@@ -1016,7 +1019,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
         const uint32_t n_act = nk - base < 128u ? nk - base : 128u;
         const bool past = n_act + (uint32_t)(k - s_tlen(k, m)) >= 129u;
         uint32_t qa[2];
-        sampled_positions<!FWD>(wd, ln, k, m, past, qa[0], qa[1]);
+        sampled_positions<!FWD>(wd, ln, ln, k, m, past, qa[0], qa[1]);
         // every k-mer now knows its m-mer: position -> strand (the smaller of the m-mer and its reverse complement), oriented
         // k-mer, nucleotide offset in the entry, minimizer value x -> slot and sort key
         uint64_t ko[2]; uint32_t ao[2], tk32[2], sl[2];
@@ -1387,7 +1390,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         const uint32_t n_act = nk - base < 128u ? nk - base : 128u;
         const bool past = n_act + (uint32_t)(k - s_tlen(k, m)) >= 129u;   // the last k-mers' windows reach t-mers past position 127
         uint32_t qa0, qa1;
-        sampled_positions<!FWD>(wd, ln, k, m, past, qa0, qa1);
+        sampled_positions<!FWD>(wd, ln, lane, k, m, past, qa0, qa1);
         // runs: k-mers next to each other whose sampled m-mer sits at the same position of the chunk (one-strand table: the
         // strand is that of the m-mer, so a run has one)
 #ifndef MIC_R_SENTINEL
