@@ -143,22 +143,28 @@ template <typename F>
 __device__ __forceinline__ void s_sampled(uint64_t K, int k, int m, bool canon, F&& f) {
   const int w = k - m + 1, t = s_tlen(k, m), W = k - t + 1;
   const uint64_t tmask = t >= 32 ? ~0ULL : (1ULL << (2 * t)) - 1;
-  uint32_t hmin = 0xFFFFFFFFu;
+  // one pass: the smallest order so far and the set of positions p = i mod w that reach it (w <= 16: a bit each)
+  uint32_t hmin = 0xFFFFFFFFu, set = 0;
+  int p = 0;
   for (int i = 0; i < W; ++i) {
-    uint64_t tv = (K >> (2 * (k - t - i))) & tmask;
-    if (canon) { const uint64_t tr = revcomp_bits(tv, t); tv = tr < tv ? tr : tv; }
-    const uint32_t h = s_torder(tv) >> 5;
-    hmin = h < hmin ? h : hmin;
+    uint32_t h;
+    if (t <= 12) {                       // 24-bit values: 32-bit arithmetic throughout (the build evaluates 2 x 24 of these per k-mer)
+      uint32_t tv = (uint32_t)(K >> (2 * (k - t - i))) & (uint32_t)tmask;
+      if (canon) { const uint32_t tr = revcomp_bits32(tv, t); tv = tr < tv ? tr : tv; }
+      h = s_torder24(tv) >> 5;
+    } else {
+      uint64_t tv = (K >> (2 * (k - t - i))) & tmask;
+      if (canon) { const uint64_t tr = revcomp_bits(tv, t); tv = tr < tv ? tr : tv; }
+      h = s_torder(tv) >> 5;
+    }
+    if (h < hmin) { hmin = h; set = 0; }
+    if (h == hmin) set |= 1u << p;
+    if (++p == w) p = 0;
   }
-  uint32_t done = 0;
-  for (int i = 0; i < W; ++i) {
-    uint64_t tv = (K >> (2 * (k - t - i))) & tmask;
-    if (canon) { const uint64_t tr = revcomp_bits(tv, t); tv = tr < tv ? tr : tv; }
-    if ((s_torder(tv) >> 5) != hmin) continue;
-    const int p = i % w;
-    if ((done >> p) & 1u) continue;
-    done |= 1u << p;
-    f(p);
+  while (set) {
+    const int q = __builtin_ctz(set);
+    set &= set - 1;
+    f(q);
   }
 }
 
