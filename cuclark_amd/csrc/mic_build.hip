@@ -1283,12 +1283,17 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       }
     }
     // ... and a database whose k-mers do not overlap (cuCLARK-l's sampled blocks: one k-mer per entry) gains nothing from
-    // super-k-mers: the minimizer layout holds it in a quarter of the memory and answers 10 % faster (1 360 vs 1 240)
-    double min_per_entry = 1.3;
+    // super-k-mers in MEMORY: the minimizer layout holds it in a quarter of the bytes.  Since the per-run kernel works on
+    // t-mers (round 3) the super-k-mer table answers faster even so (1 620 vs 1 480 Mreads/s on cuCLARK-l's blocks), so the
+    // minimizer layout is only taken when the table would be a large one (MIC_S_SMALL_TABLE_GB, default 16: cuCLARK-l's
+    // databases are made for 4-GB cards and stay far below)
+    double min_per_entry = 1.3, small_gb = 16.0;
     if (const char* env = getenv("MIC_S_MIN_KMERS_PER_ENTRY")) min_per_entry = atof(env);
+    if (const char* env = getenv("MIC_S_SMALL_TABLE_GB")) small_gb = atof(env);
     const double stored = (double)h_scal[0] * (both_strands ? 2.0 : 1.0);
-    if (allow_fallback && h_entries && stored / (double)h_entries < min_per_entry) {
-      snprintf(err, err_cap, "%.2f k-mers per super-k-mer entry (limit %.2f): no adjacency to exploit", stored / (double)h_entries, min_per_entry);
+    if (allow_fallback && h_entries && stored / (double)h_entries < min_per_entry && (double)n_slots * 128.0 / 1e9 > small_gb) {
+      snprintf(err, err_cap, "%.2f k-mers per super-k-mer entry (limit %.2f) in a table of %.1f GB: no adjacency to exploit", stored / (double)h_entries,
+               min_per_entry, (double)n_slots * 128.0 / 1e9);
       rc = -5; goto done;
     }
   }

@@ -548,10 +548,11 @@ def test_skewed_minimizer_bucket():
 
 
 def test_default_layout_follows_the_database(monkeypatch, table_layout):
-    """Nobody asks for a layout (MIC_LAYOUT unset, cfg.layout 0): adjacent k-mers of genomes -> super-k-mer slots;
-    unrelated k-mers (one per entry: cuCLARK-l's sampled blocks, or one low-complexity core in thousands of contexts with
-    unrelated labels) -> the minimizer layout.  Same answers either way.  (Crowded minimizers alone no longer
-    change the layout: their k-mers go to the side table, tests/test_crowded.py.)"""
+    """Nobody asks for a layout (MIC_LAYOUT unset, cfg.layout 0): super-k-mer slots - also for unrelated k-mers (one per entry:
+    cuCLARK-l's sampled blocks, or one low-complexity core in thousands of contexts with unrelated labels) as long as the table
+    is a small one; a LARGE table of unrelated k-mers (here: MIC_S_SMALL_TABLE_GB=0) -> the minimizer layout, a quarter of the
+    memory.  Same answers either way.  (Crowded minimizers alone do not change the layout: their k-mers go to
+    the side table, tests/test_crowded.py.)"""
     if table_layout != "super":
         pytest.skip("one run is enough")
     monkeypatch.delenv("MIC_LAYOUT")
@@ -565,7 +566,11 @@ def test_default_layout_follows_the_database(monkeypatch, table_layout):
     unrelated = [int(v) for v in rng.integers(0, 1 << 62, 40000, dtype=np.uint64)]
     core = "AT" * 12 + "A"                                      # a low-complexity stretch of 25 nt in 4096 contexts
     crowded = [code(core + "".join(t)) for t in itertools.product("ACGT", repeat=6)] + [code(genome[i:i + k]) for i in range(0, 3000)]
-    for name, kmers, want in (("genome", genome_kmers, 3), ("unrelated", unrelated, 2), ("crowded", crowded, 2)):
+    for name, kmers, want in (("genome", genome_kmers, 3), ("unrelated", unrelated, 3), ("crowded", crowded, 3),
+                              ("unrelated, large", unrelated, 2), ("genome, large", genome_kmers, 3)):
+        if name.endswith("large"):
+            monkeypatch.setenv("MIC_S_SMALL_TABLE_GB", "0")
+        name = name.split(",")[0]
         canon = sorted({o.canonical(v, k) for v in kmers}, key=lambda c: (c % htsize, c // htsize))
         sizes = np.zeros(htsize, np.int64)
         for c in canon:
