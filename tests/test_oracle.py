@@ -173,3 +173,57 @@ def test_fast_batch_classifier_equals_the_plain_one(orc):
     nd = orc.numa_db(sizes, keys, labels, threads=4)           # one replica per NUMA node, threads pinned
     assert (nd.classify_batch(k, rp, ct, T) == ref).all()
     nd.close()
+
+
+def test_mod_sampling_rule_of_the_partition_restatement():
+    """The sampling rule the table partition follows (oracle/part_rule.c restates mic_device.h: s_tlen, s_torder, s_probe_read;
+    DESIGN.md 3.6), on the CPU: (1) a k-mer and its reverse complement are answered by the same slot of the one-strand table
+    whatever their position in the read - the positions of rc(K) mirror those of K because t = m (mod w); (2) consecutive k-mers
+    of a random read keep their slot for 1 / 0.120 positions on average (the plain minimizer: 1 / 0.154), i.e. a 150-bp read
+    falls into 15-16 runs instead of 19-20."""
+    o = gu.oracle()
+    rng = np.random.default_rng(77)
+    n_slots = 1 << 30
+    for k, m in ((31, 20), (27, 20), (32, 20), (24, 20), (21, 17)):
+        seq = rng.integers(0, 4, 20000)
+        vals = []
+        v = 0
+        mask = (1 << (2 * k)) - 1
+        for i, c in enumerate(seq):
+            v = ((v << 2) | int(c)) & mask
+            if i >= k - 1:
+                vals.append(v)
+        # (1) strand symmetry of the one-strand rule: K at position p and rc(K) at any other position
+        w = k - m + 1
+        t = m
+        while t - w >= 7:
+            t -= w
+
+        def tied(K):      # the smallest 27-bit order of the canonical t-mers of K occurs more than once: either position may be taken
+            orders = []
+            for i in range(k - t + 1):
+                tv = (K >> (2 * (k - t - i))) & ((1 << (2 * t)) - 1)
+                tv = min(tv, o.revcomp(tv, t))
+                orders.append((((tv & 0xFFFFFF) * 0x9E3779 + 0x27D4EB2F + (tv >> 24) * 0x85EBCA77) & 0xFFFFFFFF) >> 5)
+            return orders.count(min(orders)) > 1
+
+        n_checked = 0
+        for j in range(0, 2000, 7):
+            K = vals[j]
+            if tied(K):
+                continue
+            a = o.L.orc_part_slot_of_kmer(K, j, k, m, 0, n_slots)
+            b = o.L.orc_part_slot_of_kmer(o.revcomp(K, k), (j * 5 + 3) % 977, k, m, 0, n_slots)
+            assert a == b, (k, m, j)
+            n_checked += 1
+        assert n_checked > 250
+        # (2) density of the two-strand rule (t-mers as they read)
+        slots = np.array([o.L.orc_part_slot_of_kmer(K, j, k, m, 1, n_slots) for j, K in enumerate(vals[:6000])])
+        density = (1 + np.count_nonzero(slots[1:] != slots[:-1])) / slots.size
+        plain = 2.0 / (w + 1)
+        if t < m:       # mod-sampling applies: clearly below the plain minimizer's density
+            assert density < 0.88 * plain, (k, m, t, density, plain)
+        else:
+            assert abs(density - plain) < 0.15 * plain, (k, m, t, density, plain)
+        if (k, m) == (31, 20):
+            assert 0.112 < density < 0.128, density
