@@ -1248,7 +1248,7 @@ void Classifier::ensure_ingest(size_t total_bytes) {
 // FASTQ: copy the header and the sequence line of every four-line record, drop the '+' and the quality line (nothing
 // reads them: CuCLARK_hh.hh:1496-1523 only steps over them).  `phase` = line of the record the input is in (0..3),
 // carried across calls; returns the bytes written.
-static size_t strip_fastq(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap, unsigned& phase) {   // (size_t)-1: dst is full
+static size_t strip_fastq_scalar(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap, unsigned& phase) {   // (size_t)-1: dst is full
   size_t pos = 0, w = 0;
   while (pos < n) {
     if (phase == 0) {   // common case: the record's four lines are all in this piece
@@ -1272,6 +1272,123 @@ static size_t strip_fastq(const uint8_t* src, size_t n, uint8_t* dst, size_t dst
     pos = end;
   }
   return w;
+}
+
+// The same with AVX2: the line ends of 64 input bytes are two compares and two move-masks; only two of a record's four line
+// ends do anything (the sequence line's end closes a span that is copied, the quality line's end opens the next one), and the
+// span - header + sequence, ~165 bytes - is copied 32 bytes at a time.  Byte-identical to the scalar form for every input and
+// every split of it into calls (tests/test_cli.py: --strip-fastq); 2-3 x its rate per thread, which is what the loaders of the
+// streaming command line spend their time in.
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2,bmi,bmi2")))
+static inline void copy_span_avx2(uint8_t* d_, const uint8_t* s_, size_t len) {
+  size_t i = 0;
+  for (; i + 32 <= len; i += 32) _mm256_storeu_si256((__m256i*)(d_ + i), _mm256_loadu_si256((const __m256i*)(s_ + i)));
+  if (i < len) memcpy(d_ + i, s_ + i, len - i);
+}
+__attribute__((target("avx2,bmi,bmi2")))
+static size_t strip_fastq_avx2(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap, unsigned& phase) {
+  const __m256i nl = _mm256_set1_epi8('\n');
+  size_t w = 0;
+  unsigned ph = phase;
+  size_t open = ph < 2 ? 0 : (size_t)-1;      // start of the span being kept ((size_t)-1: inside the dropped lines)
+#define copy(from, to) ((w + ((to) - (from)) > dst_cap) ? false : (copy_span_avx2(dst + w, src + (from), (to) - (from)), w += (to) - (from), true))
+  size_t pos = 0;
+  for (; pos + 64 <= n; pos += 64) {
+    const uint32_t lo = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(src + pos)), nl));
+    const uint32_t hi = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(src + pos + 32)), nl));
+    uint64_t m = ((uint64_t)hi << 32) | lo;
+    while (m) {
+      const size_t e = pos + (size_t)__builtin_ctzll(m) + 1;      // one past the line end
+      m &= m - 1;
+      if (ph == 1) { if (!copy(open, e)) return (size_t)-1; open = (size_t)-1; }
+      else if (ph == 3) open = e;
+      ph = (ph + 1) & 3;
+    }
+  }
+  for (; pos < n; ++pos) {
+    if (src[pos] != '\n') continue;
+    const size_t e = pos + 1;
+    if (ph == 1) { if (!copy(open, e)) return (size_t)-1; open = (size_t)-1; }
+    else if (ph == 3) open = e;
+    ph = (ph + 1) & 3;
+  }
+  if (open != (size_t)-1 && open < n) { if (!copy(open, n)) return (size_t)-1; }     // a kept line that continues in the next call
+#undef copy
+  phase = ph;
+  return w;
+}
+#endif
+
+static size_t strip_fastq(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap, unsigned& phase) {
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi") && !getenv("MIC_STRIP_SCALAR");
+  if (avx2) return strip_fastq_avx2(src, n, dst, dst_cap, phase);
+#endif
+  return strip_fastq_scalar(src, n, dst, dst_cap, phase);
+}
+
+// test hook (cuCLARK --strip-fastq): the whole input through strip_fastq in pieces of `piece` bytes
+std::string strip_fastq_text(const std::string& in, size_t piece, bool scalar, int reps) {
+  std::string out(in.size() + 64, '\0');
+  size_t w = 0;
+  for (int rep = 0; rep < reps; ++rep) {      // (reps > 1: timing runs over the same buffers)
+    unsigned phase = 0;
+    w = 0;
+    for (size_t o = 0; o < in.size(); o += piece) {
+      const size_t n = std::min(piece, in.size() - o);
+      const size_t got = scalar ? strip_fastq_scalar((const uint8_t*)in.data() + o, n, (uint8_t*)out.data() + w, out.size() - w, phase)
+                                : strip_fastq((const uint8_t*)in.data() + o, n, (uint8_t*)out.data() + w, out.size() - w, phase);
+      if (got == (size_t)-1) throw std::runtime_error("strip_fastq: destination full");
+      w += got;
+    }
+  }
+  out.resize(w);
+  return out;
+}
+
+// test hook (cuCLARK --strip-fastq <file> - <chunk> loaders <threads> [mmap]): what the loaders of run_stream do with a plain FASTQ
+// file, without the device: ranges of 32 MiB dealt to `threads`, each range read in chunks of `chunk` bytes (pread into a
+// stage buffer, or straight out of a mapping) and stripped into a slot-sized buffer.  Returns GB/s of input.
+double strip_fastq_loaders_rate(const std::string& path, size_t chunk, unsigned threads, bool use_mmap) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  struct stat st;
+  if (fd == -1 || fstat(fd, &st) != 0) throw std::runtime_error("cannot open " + path);
+  const size_t size = (size_t)st.st_size, RANGE = (size_t)32 << 20;
+  const uint8_t* map = nullptr;
+  if (use_mmap) {
+    map = (const uint8_t*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map == MAP_FAILED) throw std::runtime_error("mmap failed");
+  }
+  std::atomic<size_t> next{0};
+  struct timeval a, b;
+  gettimeofday(&a, nullptr);
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < threads; ++t)
+    pool.emplace_back([&] {
+      std::vector<uint8_t> stage(chunk), dst(RANGE + 64);
+      for (;;) {
+        const size_t o = next.fetch_add(RANGE);
+        if (o >= size) break;
+        const size_t len = std::min(RANGE, size - o);
+        unsigned phase = 0; size_t w = 0;       // (ranges are not cut at records here: the phase only has to be carried inside one)
+        for (size_t c = 0; c < len; c += chunk) {
+          const size_t n = std::min(chunk, len - c);
+          const uint8_t* src;
+          if (map) src = map + o + c;
+          else { if (pread(fd, stage.data(), n, (off_t)(o + c)) != (ssize_t)n) return; src = stage.data(); }
+          const size_t got = strip_fastq(src, n, dst.data() + w, dst.size() - w, phase);
+          if (got == (size_t)-1) return;
+          w += got;
+        }
+      }
+    });
+  for (auto& th : pool) th.join();
+  gettimeofday(&b, nullptr);
+  if (map) munmap((void*)map, size);
+  close(fd);
+  return (double)size / ((b.tv_sec - a.tv_sec) + (b.tv_usec - a.tv_usec) * 1e-6) / 1e9;
 }
 
 bool Classifier::run_stream(Feeder& feed, const std::string& results_base, bool paired, size_t total_bytes) {

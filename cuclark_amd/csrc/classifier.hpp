@@ -108,6 +108,9 @@ std::string merge_paired(const std::string& file1, const std::string& file2);
 // independently); false when the files are not what it can cut (the caller then runs merge_paired, which ends the way
 // the reference ends on such files).
 bool merge_paired_parallel(const std::string& file1, const std::string& file2, unsigned threads, size_t batch_bytes, std::string& out);
+// test hook: FASTQ text with the '+' and quality lines dropped, as the loaders hand it to the device (cuCLARK --strip-fastq)
+std::string strip_fastq_text(const std::string& in, size_t piece, bool scalar, int reps = 1);
+double strip_fastq_loaders_rate(const std::string& path, size_t chunk, unsigned threads, bool use_mmap);
 
 }  // namespace mic
 #endif

@@ -7,7 +7,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sys/time.h>
+
+#include <fstream>
 #include <iostream>
+#include <iterator>
 #include <string>
 
 #include "classifier.hpp"
@@ -70,6 +74,44 @@ int main(int argc, char** argv) {
       } else text = mic::merge_paired(argv[2], argv[3]);
       FILE* f = fopen(argv[4], "wb");
       if (!f || fwrite(text.data(), 1, text.size(), f) != text.size() || fclose(f) != 0) { std::cerr << "Failed to write " << argv[4] << std::endl; return 1; }
+      return 0;
+    } catch (const std::exception& ex) {
+      std::cerr << ex.what() << std::endl;
+      return 1;
+    }
+  }
+  // cuCLARK --strip-fastq <in.fq> <out> [piece_bytes [scalar|bench]]: the loaders' FASTQ stripper alone (header + sequence line
+  // of every record), fed in pieces; "bench" prints both forms' rates instead of writing
+  if (argc >= 4 && std::string(argv[1]) == "--strip-fastq") {
+    try {
+      const size_t piece = argc > 4 ? (size_t)strtoull(argv[4], nullptr, 10) : (size_t)1 << 20;
+      const std::string mode = argc > 5 ? argv[5] : "";
+      std::string in;
+      if (mode != "loaders") {
+        std::ifstream f(argv[2], std::ios::binary);
+        in.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+      }
+      if (mode == "loaders") {
+        const unsigned th = argc > 6 ? (unsigned)atoi(argv[6]) : 8u;
+        const bool mm = argc > 7 && std::string(argv[7]) == "mmap";
+        for (int rep = 0; rep < 3; ++rep)
+          std::cout << (mm ? "mmap" : "pread") << " chunk " << piece << " threads " << th << ": " << mic::strip_fastq_loaders_rate(argv[2], piece, th ? th : 1, mm) << " GB/s" << std::endl;
+        return 0;
+      }
+      if (mode == "bench") {
+        for (int sc = 1; sc >= 0; --sc) {
+          struct timeval a, b; gettimeofday(&a, nullptr);
+          size_t tot = 0;
+          tot = 5 * mic::strip_fastq_text(in, piece ? piece : 1, sc != 0, 5).size();
+          gettimeofday(&b, nullptr);
+          const double sec = (b.tv_sec - a.tv_sec) + (b.tv_usec - a.tv_usec) * 1e-6;
+          std::cout << (sc ? "scalar" : "vector") << ": " << 5.0 * in.size() / sec / 1e9 << " GB/s in (" << tot / 5 << " bytes out)" << std::endl;
+        }
+        return 0;
+      }
+      const std::string out = mic::strip_fastq_text(in, piece ? piece : 1, mode == "scalar");
+      FILE* o = fopen(argv[3], "wb");
+      if (!o || fwrite(out.data(), 1, out.size(), o) != out.size() || fclose(o) != 0) { std::cerr << "Failed to write " << argv[3] << std::endl; return 1; }
       return 0;
     } catch (const std::exception& ex) {
       std::cerr << ex.what() << std::endl;

@@ -113,3 +113,42 @@ def test_codec_vectors_through_the_gpu_query(layout, monkeypatch, orc):
         assert ((res[:, 0] == 1) == want_in).all()
         lab = np.array([min(v["fwd"], v["rev"]) % 7 + 1 for v in vs] * 2)
         assert (res[want_in, 1] == lab[want_in]).all()
+
+
+def _strip_reference(text):
+    """header + sequence line of every four-line record, the rest dropped - a trailing incomplete line is kept as it stands when
+    it is a header or a sequence line (CuCLARK_hh.hh:1496-1523 steps over the '+' and quality lines and reads nothing of them)"""
+    out = []
+    for i, line in enumerate(text.split(b"\n")[:-1]):
+        if i % 4 < 2:
+            out.append(line + b"\n")
+    tail = text.split(b"\n")[-1]
+    if tail and (text.count(b"\n") % 4) < 2:
+        out.append(tail)
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("piece", [1, 5, 31, 32, 33, 63, 64, 65, 127, 4096, 1 << 20])
+def test_fastq_stripper_vector_form_equals_scalar_form(tmp_path, piece):
+    """The loaders drop the '+' and quality lines while they copy FASTQ into the device's slots; the AVX2 form (64 bytes per step)
+    must produce the bytes of the scalar form for every split of the input into calls - lines longer than a step, empty reads,
+    CR LF line ends, a file cut inside any of the four lines."""
+    rng = np.random.default_rng(piece)
+    recs = []
+    for i in range(3000):
+        L = int(rng.choice([0, 1, 31, 32, 33, 63, 64, 65, 100, 150, 151, 300, 1000]))
+        seq = "".join(rng.choice(list("ACGTN"), L))
+        eol = "\r\n" if i % 97 == 0 else "\n"
+        recs.append(f"@r{i} d{'x' * int(rng.integers(0, 90))}{eol}{seq}{eol}+{eol}{'I' * L}{eol}")
+    text = "".join(recs).encode()
+    for cut in (len(text), len(text) - 1, len(text) - 160, len(text) // 2 + 7, 2, 0):
+        src = tmp_path / "in.fq"
+        src.write_bytes(text[:cut])
+        outs = []
+        for mode in ([], ["scalar"]):
+            out = tmp_path / ("o_" + "".join(mode))
+            r = subprocess.run([EXE, "--strip-fastq", str(src), str(out), str(piece), *mode], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr
+            outs.append(out.read_bytes())
+        assert outs[0] == outs[1], (piece, cut)
+        assert outs[0] == _strip_reference(text[:cut]), (piece, cut)

@@ -3,9 +3,12 @@
 layouts, the whole table, bucket-range shards and parts of the table (mic_db_set_part) merged through the batch API.
     python tools/fuzz_parity.py [seconds] [seed]
 tests/test_fuzz_slice.py runs a 60-second seeded slice of it under -m gpu."""
+import faulthandler
 import os
 import sys
 import time
+
+faulthandler.enable(all_threads=True)      # a native crash in a soak of hours must at least name the call it happened in
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -97,4 +100,4 @@ if __name__ == "__main__":
     except AssertionError as ex:
         print(ex)
         sys.exit(1)
-    print(f"fuzz ok: {n_cases} random configurations x 4 layouts, {n_reads} reads, seeds {seed0}..{seed0 + n_cases - 1}")
+    print(f"fuzz ok: {n_cases} random configurations x 4 layouts, {n_reads} reads, seeds {seed0}..{seed0 + n_cases - 1}", flush=True)
