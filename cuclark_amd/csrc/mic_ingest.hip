@@ -429,8 +429,12 @@ int alloc_slot(Ingest* g, Slot& s, size_t tmp, int device) {
   Arena dv2, hs2;
   dv2.base = (char*)d; hs2.base = (char*)h;
   carve_slot(g, s, dv2, hs2, tmp);
+  // The event a slot's host thread waits on (three times per batch) BLOCKS instead of spinning: the command line runs one such
+  // thread per slot next to its loaders, and a job that is allowed 16 CPUs (cgroup quota) has none to burn in 16 busy-waits -
+  // the loaders are what bounds the run.  MIC_INGEST_SPIN=1 restores the busy-wait (lowest latency on an idle host).
+  static const unsigned wait_flags = hipEventDisableTiming | (getenv("MIC_INGEST_SPIN") ? 0u : (unsigned)hipEventBlockingSync);
   if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&s.ev, wait_flags)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s.ev_k, hipEventDisableTiming)) != hipSuccess ||
       // the query kernel's read-ahead looks past the last read of a batch: no stale length slots there
