@@ -1580,6 +1580,7 @@ bool Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
     cv_write.notify_all();
   };
 
+  const bool discard_csv = getenv("MIC_CSV_DISCARD") != nullptr;
   auto writer = [&]() {
     mic_thread_bind_near_device(engines_[0], 1);
     for (;;) {
@@ -1591,7 +1592,7 @@ bool Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
         it = std::move(to_write.front()); to_write.pop_front();
       }
       const uint64_t ta = timing ? now_us() : 0;
-      size_t done = 0;
+      size_t done = discard_csv ? it.text_n : 0;      // MIC_CSV_DISCARD=1: a measuring run without the writes (what the other stages can do)
       while (done < it.text_n) {
         const ssize_t n = pwrite(out_fd, it.text + done, it.text_n - done, (off_t)(it.off + done));
         if (n <= 0) { fail("Failed to write the results file."); break; }
