@@ -9,8 +9,8 @@ per-target hit counts + best/second) over one batch of synthetic reads that is a
 Workloads, all synthetic, generated in HBM by libmi_clark.so's generators:
   full   config 3: 10 M x 150 bp reads (80 % sampled from the genomes with 1 % substitutions and 0.1 % N, 20 % random)
          vs. a 36 GB-on-disk-equivalent k=31 table: HTSIZE 1610612741, u32 keys, ~5.7e9 k-mers, 4096 targets,
-         resident as 150 GB of 128-byte super-k-mer slots, both strands stored (--layout super2, the bench's default; the
-         command line's default is the one-strand table, 75 GB: `default_layout` in the JSON line times its kernel too). [default]
+         resident as 119 GB of 128-byte super-k-mer slots, both strands stored (--layout super2, the bench's default; the
+         command line's default is the one-strand table, 59 GB: `default_layout` in the JSON line times its kernel too). [default]
   light27 config 2 proper: the CuCLARK-l table as cuCLARK-l builds it: HTSIZE 57777779, k=27 (forced, main.cc:241-249), u32 keys,
          ~90 M k-mers; 10 M x 150 bp reads.
   light  config 2, k=31 side variant: same reads vs. HTSIZE 57777779, k=31 (u64 keys), ~54 M k-mers (not reachable through the
