@@ -368,6 +368,30 @@ struct Ingest {
 
 const uint32_t kFlaggedCapI = 1024;
 
+// The wait of a slot's host thread for its stream (three times per batch) does not spin: the command line runs one such thread per
+// slot next to its loaders, and a job that is allowed 16 CPUs (cgroup quota) has none to burn in busy-waits - with
+// hipEventSynchronize's spinning one and the same box gave 108-195 Mreads/s from run to run, with this 189-194.
+// Polling with short sleeps, not hipEventBlockingSync: the interrupt-driven wait stalled once for minutes under rocprofv3 --pmc.
+// MIC_INGEST_SPIN=1 restores the busy-wait (lowest latency on an idle host).
+static hipError_t wait_event(hipEvent_t ev) {
+  static const bool spin = getenv("MIC_INGEST_SPIN") != nullptr;
+  if (spin) return hipEventSynchronize(ev);
+  // (hipErrorNotReady is recorded as the thread's last error like any other: an error of a launch before the wait is taken
+  // out first and returned, and the "not ready" answers are taken out behind the wait - hipGetLastError() keeps its meaning
+  // for the launches that follow)
+  hipError_t pending = hipGetLastError();
+  if (pending != hipSuccess) return pending;
+  struct timespec ts = {0, 30000};                     // 30 us: a batch takes ~1 ms on the device
+  hipError_t e;
+  for (int i = 0;; ++i) {
+    e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) break;
+    if (i >= 64) nanosleep(&ts, nullptr);              // a batch that is nearly done: a few microseconds of queries first
+  }
+  (void)hipGetLastError();
+  return e;
+}
+
 #define ITRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     return mic_set_error(e_ == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 
@@ -429,12 +453,8 @@ int alloc_slot(Ingest* g, Slot& s, size_t tmp, int device) {
   Arena dv2, hs2;
   dv2.base = (char*)d; hs2.base = (char*)h;
   carve_slot(g, s, dv2, hs2, tmp);
-  // The event a slot's host thread waits on (three times per batch) BLOCKS instead of spinning: the command line runs one such
-  // thread per slot next to its loaders, and a job that is allowed 16 CPUs (cgroup quota) has none to burn in 16 busy-waits -
-  // the loaders are what bounds the run.  MIC_INGEST_SPIN=1 restores the busy-wait (lowest latency on an idle host).
-  static const unsigned wait_flags = hipEventDisableTiming | (getenv("MIC_INGEST_SPIN") ? 0u : (unsigned)hipEventBlockingSync);
   if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreateWithFlags(&s.ev, wait_flags)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&s.ev_k, hipEventDisableTiming)) != hipSuccess ||
       // the query kernel's read-ahead looks past the last read of a batch: no stale length slots there
@@ -580,7 +600,7 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int flags
   }
   ITRY(hipMemcpyAsync(s.h_hdr, s.d_hdr, H_WORDS * 4, hipMemcpyDeviceToHost, st));
   ITRY(hipEventRecord(s.ev, st));
-  ITRY(hipEventSynchronize(s.ev));
+  ITRY(wait_event(s.ev));
   const double t1 = timing ? now_s() : 0;
   uint32_t n_reads = s.h_hdr[H_NREADS];
   out->n_lines = s.h_hdr[H_NLINES];
@@ -610,7 +630,7 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int flags
   csv_finish_kernel<<<1, 1, 0, st>>>(s.d_line_off, n_reads, s.d_flagged, s.d_rp, s.d_hdr);
   ITRY(hipMemcpyAsync(s.h_hdr, s.d_hdr, H_WORDS * 4, hipMemcpyDeviceToHost, st));
   ITRY(hipEventRecord(s.ev, st));
-  ITRY(hipEventSynchronize(s.ev));
+  ITRY(wait_event(s.ev));
   const double t2 = timing ? now_s() : 0;
   s.n_reads = n_reads; s.cont_used = s.h_hdr[H_CONT];
   const uint32_t csv_bytes = s.h_hdr[H_CSV_BYTES];
@@ -625,7 +645,7 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int flags
   ITRY(hipMemcpyAsync(s.h_csv, s.d_csv, csv_bytes, hipMemcpyDeviceToHost, down));
   if (g->want_results) ITRY(hipMemcpyAsync(s.h_results, s.d_results, (size_t)n_reads * 32, hipMemcpyDeviceToHost, down));
   ITRY(hipEventRecord(s.ev, down));
-  ITRY(hipEventSynchronize(s.ev));
+  ITRY(wait_event(s.ev));
   out->n_reads = n_reads; out->csv_bytes = csv_bytes; out->csv = s.h_csv; out->results = g->want_results ? s.h_results : nullptr;
   out->status = MIC_INGEST_OK;
   if (timing) {
