@@ -92,6 +92,9 @@ SYMBOLS = [
     ("mic_ingest_classify", C.c_int, [_VP, _SZ, _SZ, C.c_int, C.POINTER(MicIngestResult)]),
     ("mic_ingest_fetch_packed", C.c_int, [_VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("mic_ingest_free", C.c_int, [_VP]),
+    ("mic_gz_inflate_device", C.c_int, [_VP, _VP, _SZ, C.POINTER(_VP), C.POINTER(_SZ), C.POINTER(C.c_uint32)]),
+    ("mic_gz_copy_text", C.c_int, [_VP, _VP, _SZ, _SZ, _VP]),
+    ("mic_gz_free_text", C.c_int, [_VP, _VP]),
     ("mic_format_ratio_g", C.c_int, [C.c_uint32, C.c_uint32, C.c_char_p]),
     ("mic_key_bytes_rule", C.c_int, [C.c_uint64, C.c_int]),
     ("mic_index_reads", C.c_long, [_VP, _SZ, _SZ, _U64P, _U64P, _U64P, _U64P, _U64P]),

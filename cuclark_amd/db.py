@@ -14,6 +14,10 @@ from . import _lib
 from ._lib import MicConfig, MicDbInfo, MicError, check, MIC_RESULT_WORDS
 
 
+class MiClarkUnsupported(RuntimeError):
+    """mic_gz_*: an input the device path does not take (MIC_E_UNSUPPORTED); the caller uses its other path."""
+
+
 def _as_np(ptr, shape, dtype):
     n = int(np.prod(shape))
     if n == 0:
@@ -155,6 +159,24 @@ class MiClarkDB:
         rows = bufs["rows"].copy() if extended else None
         self.freeBatchMemory()
         return (res, rows) if extended else res
+
+    # -- compressed input: one gzip member inflated on the device (mic_gz_*)
+    def gunzip(self, gz_bytes):
+        """The text of a one-member .gz file, inflated on the device and copied back.  Returns (text bytes, crc32 of the
+        member's trailer), or raises MiClarkUnsupported when the file is not of the kind this path takes."""
+        buf = np.frombuffer(gz_bytes, np.uint8)
+        d_text, n, crc = C.c_void_p(), C.c_size_t(0), C.c_uint32(0)
+        rc = self.L.mic_gz_inflate_device(self.h, buf.ctypes.data, buf.size, C.byref(d_text), C.byref(n), C.byref(crc))
+        if rc == -7:
+            raise MiClarkUnsupported(self.L.mic_last_error().decode())
+        check(rc)
+        out = np.empty(n.value, np.uint8)
+        try:
+            if n.value:
+                check(self.L.mic_gz_copy_text(self.h, d_text, 0, n.value, out.ctypes.data))
+        finally:
+            self.L.mic_gz_free_text(self.h, d_text)
+        return out.tobytes(), int(crc.value)
 
     # -- device-side ingest: raw FASTA/FASTQ bytes -> CSV text (mic_ingest_*)
     def ingest_alloc(self, n_slots, max_bytes, target_names, want_results=False):

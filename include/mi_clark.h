@@ -40,6 +40,7 @@ extern "C" {
 #define MIC_E_HIP (-4)      /* HIP runtime error                              */
 #define MIC_E_STATE (-5)    /* call out of order (e.g. query before DB load)  */
 #define MIC_E_NODEVICE (-6) /* no usable gfx950 device / kernels not loadable */
+#define MIC_E_UNSUPPORTED (-7) /* mic_gz_*: an input this path does not take; the caller uses its other path   */
 
 #define MIC_RESULT_WORDS 8
 #define MIC_FLAG_ROW_OVERFLOW 1u /* sparse row did not fit; dense path was used */
@@ -260,6 +261,17 @@ int mic_ingest_classify(mic_engine* e, size_t slot, size_t n_bytes, int flags, m
 int mic_ingest_fetch_packed(mic_engine* e, size_t slot, uint32_t* reads_pointer, size_t rp_cap, uint16_t* containers,
                             size_t cont_cap, uint64_t* n_reads, uint64_t* n_containers);
 int mic_ingest_free(mic_engine* e);
+/* ---- compressed input: one gzip member inflated on the device ------------------------------------------------
+ * Replaces the `gunzip` the reference's scripts run in front of the classifier (classify_metagenome.sh:116-142) for the
+ * common case: ONE member, no preset dictionary.  `gz` = the whole .gz file in host memory.  On MIC_OK *d_text is a
+ * device buffer of *n_text bytes of text (mic_gz_free_text releases it, mic_gz_copy_text copies a piece to the host),
+ * the member's ISIZE has been checked and *crc32_expected is its CRC-32 for the caller to check on the copy it takes.
+ * MIC_E_UNSUPPORTED: several members, data behind the last block, or blocks that could not be found speculatively - the
+ * caller inflates on the CPU (csrc/pgz.hpp / zlib) as before; MIC_E_INVALID: the data is damaged (zlib would fail too). */
+int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_bytes, void** d_text, size_t* n_text, uint32_t* crc32_expected);
+int mic_gz_copy_text(mic_engine* e, const void* d_text, size_t offset, size_t n, void* host_dst);
+int mic_gz_free_text(mic_engine* e, void* d_text);
+
 /* "%g" of (double)num / den for 0 < num <= den, by the integer-only formatter the device CSV kernel uses
  * (csrc/mic_fmt.h); writes at most 14 characters and a terminator, returns the length. */
 int mic_format_ratio_g(uint32_t num, uint32_t den, char* out16);

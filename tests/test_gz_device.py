@@ -1,0 +1,104 @@
+"""gzip members inflated on the device (mic_gz_*, csrc/mic_gz.hip) against zlib: every kind of block, sizes from empty to tens of
+megabytes, every compression level; what the path does not take (several members, damage) must come back as "unsupported" or as an
+error - never as wrong text."""
+import gzip
+import io
+import zlib
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _fastq(rng, n, L=150):
+    nt = np.frombuffer(b"ACGT", np.uint8)
+    out = io.BytesIO()
+    for i in range(n):
+        s = nt[rng.integers(0, 4, L)].tobytes()
+        q = bytes(rng.choice(np.frombuffer(b"FFFFFFFF:,#", np.uint8), L))
+        out.write(b"@read_%09d/1 some description\n" % i + s + b"\n+\n" + q + b"\n")
+    return out.getvalue()
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from cuclark_amd import MiClarkDB
+    with MiClarkDB(31, 4) as e:
+        yield e
+
+
+def _gz(data, level=6, **kw):
+    buf = io.BytesIO()
+    with gzip.GzipFile(fileobj=buf, mode="wb", compresslevel=level, mtime=0, **kw) as f:
+        f.write(data)
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_fastq_text_of_many_blocks(engine, level):
+    rng = np.random.default_rng(level)
+    data = _fastq(rng, 60000)                       # ~20 MB of text, hundreds of deflate blocks
+    text, crc = engine.gunzip(_gz(data, level))
+    assert text == data
+    assert crc == zlib.crc32(data)
+
+
+@pytest.mark.parametrize("kind", ["empty", "one byte", "tiny (fixed codes)", "random (stored blocks)", "zeros", "period 3", "text 1 MB",
+                                  "binary mix", "long header"])
+def test_block_kinds_and_sizes(engine, kind):
+    rng = np.random.default_rng(7)
+    data = {"empty": b"", "one byte": b"x", "tiny (fixed codes)": b"hello, hello, hello world\n",
+            "random (stored blocks)": rng.integers(0, 256, 300000, dtype=np.uint8).tobytes(), "zeros": bytes(5_000_000),
+            "period 3": b"ACG" * 700000, "text 1 MB": _fastq(rng, 3000),
+            "binary mix": rng.integers(0, 256, 100000, dtype=np.uint8).tobytes() + _fastq(rng, 2000) + bytes(200000) +
+                          rng.integers(0, 4, 300000, dtype=np.uint8).tobytes(),
+            "long header": _fastq(rng, 500)}[kind]
+    gz = _gz(data, 6, filename="x" * 300 + ".fq") if kind == "long header" else _gz(data, 6)
+    text, crc = engine.gunzip(gz)
+    assert text == data and crc == zlib.crc32(data)
+
+
+def test_raw_deflate_with_fixed_and_stored_blocks_between_dynamic_ones(engine):
+    """a stream put together block by block: Z_FULL_FLUSH / Z_SYNC_FLUSH leave empty stored blocks, Z_FIXED forces fixed codes"""
+    rng = np.random.default_rng(11)
+    parts = []
+    body = b""
+    crc = 0
+    for i, (strategy, flush) in enumerate([(zlib.Z_DEFAULT_STRATEGY, zlib.Z_SYNC_FLUSH), (zlib.Z_FIXED, zlib.Z_FULL_FLUSH),
+                                           (zlib.Z_DEFAULT_STRATEGY, zlib.Z_NO_FLUSH), (zlib.Z_HUFFMAN_ONLY, zlib.Z_SYNC_FLUSH)] * 3):
+        parts.append(_fastq(rng, 2500))
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    for i, p in enumerate(parts):
+        body += c.compress(p) + c.flush(zlib.Z_FULL_FLUSH if i % 2 else zlib.Z_SYNC_FLUSH)
+    body += c.flush()
+    data = b"".join(parts)
+    gz = b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03" + body + zlib.crc32(data).to_bytes(4, "little") + (len(data) & 0xFFFFFFFF).to_bytes(4, "little")
+    assert zlib.decompress(gz, 31) == data
+    text, crc = engine.gunzip(gz)
+    assert text == data
+
+
+def test_what_the_path_does_not_take(engine):
+    from cuclark_amd.db import MiClarkUnsupported
+    from cuclark_amd import MicError
+    rng = np.random.default_rng(5)
+    data = _fastq(rng, 20000)
+    gz = _gz(data, 6)
+    with pytest.raises(MiClarkUnsupported):                       # two members
+        engine.gunzip(gz + gz)
+    with pytest.raises(MiClarkUnsupported):                       # not gzip at all
+        engine.gunzip(data[:100000])
+    bad = bytearray(gz)
+    bad[len(bad) // 2] ^= 0x55                                     # a damaged block: unsupported or an error, never wrong text passing as right
+    try:
+        text, crc = engine.gunzip(bytes(bad))
+        assert zlib.crc32(text) != crc or text == data
+    except (MiClarkUnsupported, MicError):
+        pass
+    bad = bytearray(gz)
+    bad[-2] ^= 1                                                   # ISIZE wrong
+    with pytest.raises((MiClarkUnsupported, MicError)):
+        engine.gunzip(bytes(bad))
