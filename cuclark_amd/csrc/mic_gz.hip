@@ -1,23 +1,31 @@
 // mic_gz.hip - one gzip member inflated ON THE DEVICE: the two-stage scheme of csrc/pgz.hpp (pugz / rapidgzip)
-// with thousands of decode units instead of sixteen threads.  BASELINE config 5 names gzip FASTQ; the reference's scripts gunzip
-// to a temporary file first (classify_metagenome.sh:116-142).  A job that is allowed 16 CPUs inflates 3 GB/s of text with all of
-// them (pgz.hpp); the device decodes one deflate block per wavefront, ~7 000 of them at once.
+// with one decode unit per deflate block - thousands of wavefronts - instead of sixteen threads.  BASELINE config 5 names gzip
+// FASTQ; the reference's scripts gunzip to a temporary file first (classify_metagenome.sh:116-142).  A LIBRARY ENTRY with its own
+// tests and timing tool (tests/test_gz_device.py, tools/gz_device_timing.py): 316 MB of FASTQ text out of 59 MB of gzip in 53 ms
+// (6 GB/s; pgz.hpp on the 16 allowed CPUs: 3 GB/s).  The command line does not call it yet: its loaders want the text in host
+// memory, and what the copy back and a second file in flight cost leaves 1.5 x - it pays once the ingest kernels read the
+// text where it is.
 //
-//   1  gz_find_kernel     one wavefront per 16 KiB of compressed data: the first bit offset at which a block with dynamic codes
+//   1  gz_find_kernel     one wavefront per 8 KiB of compressed data: the first bit offset at which a block with dynamic codes
 //                         starts - 64 offsets per step through the cheap tests (BFINAL / BTYPE bits, HLIT / HDIST in range, the
 //                         code-length code exactly complete), the survivors one by one through the whole header (every code
 //                         complete, an end-of-block code) and 300 symbols of trial decode;
 //   2  gz_decode_kernel   one wavefront per unit = from one found start to the first block boundary at or behind the next found
-//                         start: first a counting pass (symbols out, where it ended), the host stitches the units into a chain
-//                         (a unit whose start lies inside the unit in front of it was a false find and is dropped; a gap or an
-//                         error gives the file back to the caller's CPU inflater), then the same decode writing 16-bit symbols:
-//                         a byte, or a MARKER 0x8000 | i for a back-reference to position i of the 32 KiB in front of the unit;
+//                         start, into a region of the symbol buffer sized by the unit's compressed span: 16-bit symbols - a
+//                         byte, or a MARKER 0x8000 | i for a back-reference to position i of the 32 KiB in front of the unit.
+//                         The host stitches the units into a chain (a unit whose start lies inside the unit in front of it was a
+//                         false find and is dropped; a gap or an error gives the file back to the caller's CPU inflater); a
+//                         unit that outgrew its region was counted exactly and is decoded again into one that fits.
+//                         The decode itself is serial; all 64 lanes run it redundantly on state the compiler is told is uniform
+//                         (scalar registers, scalar branches) and are there for what is parallel: staging the input through
+//                         LDS, filling the decode tables, copying a match inside an LDS ring of the last 2 Ki symbols, writing
+//                         symbols out 64 at a time.  First-level literal table: one vector register, looked up by v_readlane;
 //   3  gz_window_kernel   in chain order the last 32 KiB of every unit are resolved against the window handed on (one block,
-//                         the window in LDS) and every unit's incoming window is kept;
+//                         the window in LDS, symbols loaded one unit ahead) and every unit's incoming window is kept;
 //   4  gz_resolve_kernel  all units at once: markers replaced, symbols narrowed to bytes at the unit's offset of the text.
-// The member's length is checked here (ISIZE); its CRC-32 is returned for the caller, who checks it on the copy it takes
-// (classifier.cpp, pgz::crc32_fast).  Stored and fixed-code blocks are decoded; several members, a preset dictionary or anything
-// that does not stitch: MIC_E_UNSUPPORTED, and the caller inflates on the CPU as before - a wrong speculation cannot pass.
+// The member's length is checked here (ISIZE); its CRC-32 is returned for the caller, who checks it on the copy it takes.
+// Stored and fixed-code blocks are decoded; several members, a preset dictionary or anything that does not stitch:
+// MIC_E_UNSUPPORTED, and the caller inflates on the CPU as before - a wrong speculation cannot pass.
 #include "mi_clark.h"
 #include "mic_internal.h"
 
@@ -36,7 +44,8 @@ void mic_engine_copy_streams(mic_engine* e, hipStream_t* up, hipStream_t* down);
 
 namespace {
 
-constexpr uint32_t GZ_CHUNK = 16384;      // compressed bytes per finder chunk
+constexpr uint32_t GZ_CHUNK = 8192;       // compressed bytes per finder chunk: below the size of a block (gzip: 16 Ki symbols, 10-30 KB), so that
+                                          // the first start of every chunk is every start and a unit is one block - the longest unit is the decode time
 constexpr int GZ_TRIAL = 300;             // symbols of trial decode behind a candidate header
 
 __constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -256,27 +265,241 @@ __global__ void __launch_bounds__(64) gz_find_kernel(const uint8_t* __restrict__
 // ---- 2: decode units ------------------------------------------------------------------------------------------------------
 struct GzUnit {
   unsigned long long start_bit, stop_bit;      // decode from start_bit to the first block boundary at or behind stop_bit
-  unsigned long long out_off;                  // WRITE pass: where its symbols go (in symbols)
+  unsigned long long sym_off, sym_cap;         // its region of the symbol buffer (in symbols)
+  unsigned long long out_off;                  // where its bytes go in the text (set once the chain is known)
   unsigned long long end_bit;                  // result: where it stopped
-  unsigned long long n_sym;                    // result: symbols produced
+  unsigned long long n_sym;                    // result: symbols produced (also when they did not fit: status GZ_ERR_ROOM)
   uint32_t status;                             // result: 0 ok, 1 ended with the member's last block, >= 2 error
   uint32_t pad;
 };
 enum { GZ_OK = 0, GZ_FINAL = 1, GZ_ERR_CODE = 2, GZ_ERR_OVER = 3, GZ_ERR_STORED = 4, GZ_ERR_DIST = 5, GZ_ERR_TYPE = 6, GZ_ERR_ROOM = 7 };
 
+// The decode of one unit is a serial thing; the wavefront runs it REDUNDANTLY in all 64 lanes (same addresses, same values, no
+// divergence) so that the lanes are there for what is parallel: staging the compressed bytes into LDS, filling the decode tables,
+// copying a match.  Bits come out of a 512-byte LDS window of the input; a symbol is one LDS lookup in a table of the codes of at
+// most 10 (distances: 8) bits - longer codes take the count / symbol walk.
+constexpr int GZ_FAST_LIT = 10, GZ_FAST_DIST = 8, GZ_STAGE = 512, GZ_RING = 2048;
+
+// Everything the decode decides on is the same in all lanes; the compiler cannot know that of a value that came out of memory, and
+// treats every branch on it as divergent (exec masks, both sides).  UNI() says it: the value goes through v_readfirstlane into a
+// scalar register, what is computed from it is scalar arithmetic, and the branches are scalar branches.
+__device__ __forceinline__ uint32_t UNI(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint64_t UNI64(uint64_t x) { return ((uint64_t)UNI((uint32_t)(x >> 32)) << 32) | UNI((uint32_t)x); }
+
+struct Fast {
+  Scratch sc;
+  uint16_t lit_fast[1 << GZ_FAST_LIT];        // len << 12 | symbol, 0 = longer code
+  uint16_t dist_fast[1 << GZ_FAST_DIST];
+  uint32_t stage[GZ_STAGE / 4 + 4];
+  uint32_t len_tab[32], dist_tab[32];         // base | extra bits << 16: the constant tables, here because a lookup with a vector index
+                                              // in constant memory is a global load (hundreds of cycles on the decode's critical path)
+  uint16_t ring[GZ_RING];                     // the unit's last GZ_RING symbols: literals land here, matches are copied inside it, and
+                                              // whole groups of 64 go out to the symbol buffer in one store - a match that reads the
+                                              // unit's own output from global memory waits for every store in flight first
+};
+
+struct WBits {                                 // the Bits of a whole wavefront: refills out of the LDS stage
+  const uint8_t* p; uint64_t n; uint64_t pos; uint64_t buf; int cnt; bool over;
+  uint64_t base;                               // the stage holds bytes [base, base + GZ_STAGE) of the data (base a multiple of 4)
+  uint32_t* stage; int lane;
+  __device__ void restage(uint64_t at) {
+    base = at & ~3ull;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < GZ_STAGE / 4 + 2; i += 64) {
+      const uint64_t byte = base + 4ull * (uint64_t)i;
+      stage[i] = byte + 4 <= n + 16 ? *(const uint32_t*)(p + byte) : 0u;       // p is 256-byte aligned, base a multiple of 4
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ void init(const uint8_t* d, uint64_t len, uint64_t bitpos, uint32_t* st, int ln) {
+    p = d; n = len; pos = bitpos >> 3; buf = 0; cnt = 0; over = false; stage = st; lane = ln;
+    restage(pos);
+    refill();
+    const int skip = (int)(bitpos & 7);
+    buf >>= skip; cnt -= skip;
+  }
+  __device__ void refill() {
+    if (pos >= n + 8) { over = true; const int add = (63 - cnt) >> 3; pos += (uint64_t)add; cnt += add * 8; return; }
+    if (pos < base || pos + 8 > base + GZ_STAGE) restage(pos);
+    const uint32_t o = (uint32_t)(pos - base);
+    const uint32_t w = o >> 2, sh = (o & 3u) * 8u;
+    const uint32_t s0 = UNI(stage[w]), s1 = UNI(stage[w + 1]), s2 = UNI(stage[w + 2]);
+    const uint64_t lo = (uint64_t)s0 | ((uint64_t)s1 << 32);
+    const uint64_t v = sh ? (lo >> sh) | ((uint64_t)s2 << (64 - sh)) : lo;
+    buf |= v << cnt;
+    const int add = (63 - cnt) >> 3;
+    pos += (uint64_t)add; cnt += add * 8;
+  }
+  __device__ uint32_t peek(int k) { if (cnt < k) refill(); return (uint32_t)(buf & ((1ull << k) - 1)); }
+  __device__ void drop(int k) { buf >>= k; cnt -= k; }
+  __device__ uint32_t get(int k) { const uint32_t v = peek(k); drop(k); return v; }
+  __device__ uint64_t bitpos() const { return pos * 8 - (uint64_t)cnt; }
+  __device__ void align() { drop(cnt & 7); }
+};
+
+// the same Huffman walk on the wavefront's bits
+__device__ int slow_decode(const Huff& h, WBits& b, int limit) {
+  const uint32_t v = b.peek(15);
+  int code = 0, first = 0, index = 0;
+  for (int l = 1; l <= 15; ++l) {
+    code |= (int)((v >> (l - 1)) & 1u);
+    const int c = (int)UNI(h.count[l]);
+    if (code - c < first) { b.drop(l); const int at = index + (code - first); return at < limit ? (int)UNI(h.symbol[at]) : -1; }
+    index += c; first += c; first <<= 1; code <<= 1;
+  }
+  return -1;
+}
+
+// direct table of the codes of at most FASTBITS bits out of a built Huff (count / symbol): all lanes fill
+template <int FASTBITS>
+__device__ void fill_fast(const Huff& h, const uint8_t* len, uint16_t* fast, int lane) {
+  for (int i = lane; i < (1 << FASTBITS); i += 64) fast[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  // first code and first sorted index of every length
+  int first_code[16], first_idx[16];
+  { int code = 0, idx = 0; for (int l = 1; l <= 15; ++l) { first_code[l] = code; first_idx[l] = idx; code = (code + h.count[l]) << 1; idx += h.count[l]; } }
+  int n_codes = 0;
+  for (int l = 1; l <= 15; ++l) n_codes += h.count[l];
+  for (int idx = lane; idx < n_codes; idx += 64) {
+    const int sym = h.symbol[idx];
+    const int l = len[sym] & 15;
+    if (l == 0 || l > FASTBITS) continue;
+    const uint32_t code = (uint32_t)(first_code[l] + (idx - first_idx[l]));
+    const uint32_t r = __builtin_bitreverse32(code) >> (32 - l);
+    const uint16_t e = (uint16_t)((l << 12) | sym);
+    for (uint32_t v = r; v < (1u << FASTBITS); v += 1u << l) fast[v] = e;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The first level of the literal decode lives in ONE vector register: lane i holds the entry of the 6-bit index i, and a lookup is
+// v_readlane with a scalar lane number - no LDS round trip on the critical path of the symbols that make up a FASTQ file
+// (nucleotides: codes of 2-3 bits, two of them in six).  Entry: bits used << 16 | second literal << 8 | first literal | count << 24
+// (count 1 or 2); 0 = the code is longer than six bits or no literal: the LDS tables decide.
+__device__ uint32_t first_level(const Fast& f, int lane) {
+  const uint32_t e1 = f.lit_fast[lane];
+  if (!e1 || (e1 & 0xFFFu) >= 256u || (e1 >> 12) > 6u) return 0u;
+  const uint32_t l1 = e1 >> 12;
+  const uint32_t e2 = f.lit_fast[(uint32_t)lane >> l1];
+  const uint32_t l2 = e2 >> 12;
+  if (e2 && (e2 & 0xFFFu) < 256u && l1 + l2 <= 6u) return (2u << 24) | ((l1 + l2) << 16) | ((e2 & 0xFFu) << 8) | (e1 & 0xFFu);
+  return (1u << 24) | (l1 << 16) | (e1 & 0xFFu);
+}
+
+// read_dynamic on the wavefront's bits (every lane the same), then the fast tables
+__device__ bool read_dynamic_w(WBits& b, Fast& f, int lane) {
+  Scratch& s = f.sc;
+  const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
+  if (hlit > 286 || hdist > 30) return false;
+  uint8_t cl[19];
+  for (int i = 0; i < 19; ++i) cl[i] = 0;
+  for (int i = 0; i < hclen; ++i) cl[c_cl_order[i]] = (uint8_t)b.get(3);
+  const uint32_t ks = kraft(cl, 19);
+  if (ks > (1u << 15)) return false;
+  if (ks < (1u << 15)) { int used = 0; for (int i = 0; i < 19; ++i) used += cl[i] != 0; if (used != 1) return false; }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    for (int i = 0; i < 128; ++i) s.pre[i] = 0;
+    uint32_t code = 0;
+    for (int l = 1; l <= 7; ++l) {
+      for (int sym = 0; sym < 19; ++sym) {
+        if (cl[sym] != l) continue;
+        const uint32_t r = __builtin_bitreverse32(code) >> (32 - l);
+        for (uint32_t v = r; v < 128; v += 1u << l) s.pre[v] = (uint8_t)((l << 5) | sym);
+        ++code;
+      }
+      code <<= 1;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  int n = 0;
+  const int total = hlit + hdist;
+  int prev = 0;
+  while (n < total) {
+    const uint32_t e = UNI(s.pre[b.peek(7)]);
+    if (!e) return false;
+    b.drop((int)(e >> 5));
+    const int sy = (int)(e & 31);
+    if (sy < 16) { if (lane == 0) s.len[n] = (uint8_t)sy; prev = sy; ++n; continue; }
+    int rep, val = 0;
+    if (sy == 16) { if (n == 0) return false; val = prev; rep = 3 + (int)b.get(2); }
+    else if (sy == 17) rep = 3 + (int)b.get(3);
+    else rep = 11 + (int)b.get(7);
+    if (n + rep > total) return false;
+    if (lane == 0) for (int i = 0; i < rep; ++i) s.len[n + i] = (uint8_t)val;
+    n += rep; prev = val;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (b.over || UNI(s.len[256]) == 0) return false;
+  {
+    // the two Kraft sums and the number of distance codes: 316 LDS reads, spread over the lanes and summed
+    uint32_t kl = 0, kd = 0, used = 0;
+    for (int i = lane; i < total; i += 64) {
+      const uint32_t l = s.len[i];
+      if (!l) continue;
+      if (i < hlit) kl += 1u << (15 - l); else { kd += 1u << (15 - l); ++used; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { kl += __shfl_xor(kl, o); kd += __shfl_xor(kd, o); used += __shfl_xor(used, o); }
+    kl = UNI(kl); kd = UNI(kd); used = UNI(used);
+    if (kl != (1u << 15)) return false;
+    if (kd > (1u << 15)) return false;
+    if (kd < (1u << 15) && used > 1) return false;
+  }
+  if (lane == 0) { s.lit.build(s.len, hlit); s.dist.build(s.len + hlit, hdist); }
+  __builtin_amdgcn_wave_barrier();
+  fill_fast<GZ_FAST_LIT>(s.lit, s.len, f.lit_fast, lane);
+  fill_fast<GZ_FAST_DIST>(s.dist, s.len + hlit, f.dist_fast, lane);
+  return true;
+}
+
+__device__ void fixed_codes_w(Fast& f, int lane) {
+  Scratch& s = f.sc;
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    for (int i = 0; i < 144; ++i) s.len[i] = 8;
+    for (int i = 144; i < 256; ++i) s.len[i] = 9;
+    for (int i = 256; i < 280; ++i) s.len[i] = 7;
+    for (int i = 280; i < 288; ++i) s.len[i] = 8;
+    for (int i = 0; i < 30; ++i) s.len[288 + i] = 5;
+    s.lit.build(s.len, 288);
+    s.dist.build(s.len + 288, 30);
+  }
+  __builtin_amdgcn_wave_barrier();
+  fill_fast<GZ_FAST_LIT>(s.lit, s.len, f.lit_fast, lane);
+  fill_fast<GZ_FAST_DIST>(s.dist, s.len + 288, f.dist_fast, lane);
+}
+
+// WRITE = false: the counting form (units that did not fit their region are counted exactly and decoded again)
 template <bool WRITE>
 __global__ void __launch_bounds__(64) gz_decode_kernel(const uint8_t* __restrict__ d, uint64_t n, GzUnit* __restrict__ units, uint32_t n_units,
-                                                      uint16_t* __restrict__ sym, int first_is_file_start) {
-  __shared__ Scratch sc;
-  const uint32_t u = blockIdx.x;
-  if (u >= n_units || threadIdx.x != 0) return;
+                                                      uint16_t* __restrict__ sym, const uint32_t* __restrict__ which) {
+  __shared__ Fast f;
+  const uint32_t u = which ? which[blockIdx.x] : blockIdx.x;
+  const int lane = threadIdx.x;
+  if (u >= n_units) return;
   GzUnit& U = units[u];
-  const bool known = first_is_file_start && u == 0;       // the member's first unit has no history in front of it: no markers possible
-  uint16_t* out = WRITE ? sym + U.out_off : nullptr;
-  const uint64_t room = WRITE ? U.n_sym : ~0ull;          // the counting pass said how many
-  uint64_t w = 0;
+  const bool known = u == 0;                              // the member's first unit has nothing in front of it: no markers possible
+  const uint64_t cyc0 = __builtin_readcyclecounter();
+  uint16_t* out = sym + UNI64(U.sym_off);
+  const uint64_t room = WRITE ? UNI64(U.sym_cap) : 0;
+  const uint64_t stop_bit = UNI64(U.stop_bit);
+  uint64_t w = 0, wf = 0;                                 // symbols produced / symbols that have left the ring for the symbol buffer
   uint32_t status = GZ_OK;
-  Bits b; b.init(d, n, U.start_bit);
+  constexpr uint32_t RM = GZ_RING - 1;
+  // symbols [wf, upto) out of the ring, 64 per store (only what fits the unit's region: the rest is counted, and decoded again)
+  auto flush = [&](uint64_t upto) {
+    __builtin_amdgcn_wave_barrier();
+    for (uint64_t g = wf; g < upto; g += 64) {
+      const uint64_t at = g + (uint64_t)lane;
+      if (at < upto && at < room) out[at] = f.ring[at & RM];
+    }
+    wf = upto;
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (lane < 29) f.len_tab[lane] = (uint32_t)c_len_base[lane] | ((uint32_t)c_len_extra[lane] << 16);
+  if (lane < 30) f.dist_tab[lane] = (uint32_t)c_dist_base[lane] | ((uint32_t)c_dist_extra[lane] << 16);
+  __builtin_amdgcn_wave_barrier();
+  WBits b; b.init(d, n, UNI64(U.start_bit), f.stage, lane);
   for (;;) {
     if (b.over) { status = GZ_ERR_OVER; break; }
     const uint32_t last = b.get(1), type = b.get(2);
@@ -284,73 +507,143 @@ __global__ void __launch_bounds__(64) gz_decode_kernel(const uint8_t* __restrict
       b.align();
       const uint32_t len = b.get(16), nlen = b.get(16);
       if ((len ^ 0xFFFFu) != nlen) { status = GZ_ERR_STORED; break; }
-      if (w + len > room) { status = GZ_ERR_ROOM; break; }
-      for (uint32_t i = 0; i < len; ++i) { const uint32_t c = b.get(8); if (WRITE) out[w] = (uint16_t)c; ++w; }
-      if (b.over) { status = GZ_ERR_OVER; break; }
+      // stored bytes: straight out of the data (the bit buffer is byte-aligned here), all lanes; the ring keeps their tail
+      const uint64_t from = b.bitpos() >> 3;
+      if (from + len > n) { status = GZ_ERR_OVER; break; }
+      flush(w);
+      for (uint32_t i = lane; i < len; i += 64) {
+        const uint16_t c = d[from + i];
+        if (w + i < room) out[w + i] = c;
+        if (len - i <= GZ_RING) f.ring[(w + i) & RM] = c;
+      }
+      w += len; wf = w;
+      __threadfence();                                     // (rare; the far path above counts on whole groups otherwise)
+      __builtin_amdgcn_wave_barrier();
+      b.pos = from + len; b.buf = 0; b.cnt = 0;
     } else if (type == 1 || type == 2) {
-      if (type == 1) fixed_codes(sc);
-      else if (!read_dynamic(b, sc, false)) { status = GZ_ERR_CODE; break; }
+      if (type == 1) fixed_codes_w(f, lane);
+      else if (!read_dynamic_w(b, f, lane)) { status = GZ_ERR_CODE; break; }
+      const uint32_t t6 = first_level(f, lane);
+      bool bad = false;
       for (;;) {
-        if (b.over) { status = GZ_ERR_OVER; break; }
-        int s = sc.lit.decode(b);
-        if (s < 0) { status = GZ_ERR_CODE; break; }
+        // (the loop-carried state, said uniform once per symbol: the compiler keeps it in scalar registers from here to the back edge)
+        b.buf = UNI64(b.buf); b.pos = UNI64(b.pos); b.cnt = (int)UNI((uint32_t)b.cnt); b.base = UNI64(b.base);
+        w = UNI64(w); wf = UNI64(wf);
+        if (b.over) { status = GZ_ERR_OVER; bad = true; break; }
+        const uint32_t v = b.peek(15);
+        {
+          const uint32_t q = __builtin_amdgcn_readlane(t6, (int)(v & 63u));
+          if (q) {                                        // one or two literals out of the register-resident first level
+            const uint32_t cnt2 = q >> 24;
+            b.drop((int)((q >> 16) & 0xFFu));
+            if (lane == 0) { f.ring[w & RM] = (uint16_t)(q & 0xFFu); if (cnt2 == 2) f.ring[(w + 1) & RM] = (uint16_t)((q >> 8) & 0xFFu); }
+            w += cnt2;
+            if ((w & 63u) < cnt2) {
+              if (w > (1ull << 28)) { status = GZ_ERR_ROOM; bad = true; break; }
+              if (w - wf >= 64) flush(w & ~63ull);
+            }
+            continue;
+          }
+        }
+        const uint32_t e = UNI(f.lit_fast[v & ((1u << GZ_FAST_LIT) - 1)]);
+        int s;
+        if (e) { b.drop((int)(e >> 12)); s = (int)(e & 0xFFF); }
+        else { s = slow_decode(f.sc.lit, b, 288); if (s < 0) { status = GZ_ERR_CODE; bad = true; break; } }
         if (s < 256) {
-          if (w >= room || w > (1ull << 28)) { status = GZ_ERR_ROOM; break; }
-          if (WRITE) out[w] = (uint16_t)s;
+          if (lane == 0) f.ring[w & RM] = (uint16_t)s;
           ++w;
+          if ((w & 63u) == 0) {
+            if (w > (1ull << 28)) { status = GZ_ERR_ROOM; bad = true; break; }       // (one wavefront would work for seconds: the CPU path)
+            if (w - wf >= 64) flush(w);
+          }
           continue;
         }
         if (s == 256) break;
         s -= 257;
-        if (s >= 29) { status = GZ_ERR_CODE; break; }
-        const uint32_t len = c_len_base[s] + b.get(c_len_extra[s]);
-        const int ds = sc.dist.decode(b);
-        if (ds < 0 || ds >= 30) { status = GZ_ERR_CODE; break; }
-        const uint32_t dist = c_dist_base[ds] + b.get(c_dist_extra[ds]);
-        if (w + len > room || w > (1ull << 28)) { status = GZ_ERR_ROOM; break; }      // (a unit of more than 2^28 symbols: one wavefront would work for seconds - the CPU path)
-        if (dist > w && (known || dist - w > 32768u)) { status = GZ_ERR_DIST; break; }
-        if (WRITE) {
-          for (uint32_t i = 0; i < len; ++i) {
-            // a reference that reaches in front of the unit: position 32768 - (dist - w) + i of the unknown window, as a marker
-            const uint64_t at = w + i;
-            out[at] = at >= dist ? out[at - dist] : (uint16_t)(0x8000u | (uint32_t)(32768u - (dist - at)));
-          }
+        if (s >= 29) { status = GZ_ERR_CODE; bad = true; break; }
+        const uint32_t lt = UNI(f.len_tab[s]);
+        const uint32_t len = (lt & 0xFFFFu) + b.get((int)(lt >> 16));
+        const uint32_t v2 = b.peek(15);
+        const uint32_t e2 = UNI(f.dist_fast[v2 & ((1u << GZ_FAST_DIST) - 1)]);
+        int ds;
+        if (e2) { b.drop((int)(e2 >> 12)); ds = (int)(e2 & 0xFFF); }
+        else { ds = slow_decode(f.sc.dist, b, 30); }
+        if (ds < 0 || ds >= 30) { status = GZ_ERR_CODE; bad = true; break; }
+        const uint32_t dt = UNI(f.dist_tab[ds]);
+        const uint32_t dist = (dt & 0xFFFFu) + b.get((int)(dt >> 16));
+        if (dist > w && (known || dist - w > 32768u)) { status = GZ_ERR_DIST; bad = true; break; }
+        // The match, one element per lane: element i comes from w - dist + i, or - where that is inside the match itself - from
+        // w - dist + (i mod dist).  In front of the unit: position 32768 - (dist - (w + i)) of the unknown window, as a marker; inside
+        // the ring (the last GZ_RING symbols, minus what this match overwrites): an LDS copy; further back: the symbol buffer, once
+        // everything the ring still holds has been written out and has arrived.
+        const bool far = dist > (uint32_t)GZ_RING - 258u;                     // some source symbol may have left the ring
+        if (far) {
+          // Its sources lie GZ_RING - 516 symbols or more behind w: they left the ring in groups of 64 at least
+          // (GZ_RING - 516 - 385) / 64 = 17 stores ago.  Memory operations of a wavefront complete in the order of their issue for
+          // the counter, so "at most 8 still in flight" means those stores have arrived - no flush, no full wait.
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < len; i += 64) {
+          uint32_t j = i;
+          if (j >= dist) j = dist == 1 ? 0u : j % dist;      // (len > dist: a run; dist 1 is the common one)
+          const int64_t rel = (int64_t)w - (int64_t)dist + (int64_t)j;
+          uint16_t x;
+          if (rel < 0) x = (uint16_t)(0x8000u | (uint32_t)(32768 + rel));
+          else if (far && (uint64_t)rel < wf) x = (uint64_t)rel < room ? __atomic_load_n(&out[rel], __ATOMIC_RELAXED) : (uint16_t)0;   // (past the region: the unit is decoded again anyway)
+          else x = f.ring[(uint64_t)rel & RM];
+          f.ring[(w + i) & RM] = x;
+        }
+        __builtin_amdgcn_wave_barrier();
         w += len;
+        if (w - wf >= 64) flush(w & ~63ull);
       }
-      if (status != GZ_OK) break;
+      if (bad) break;
     } else { status = GZ_ERR_TYPE; break; }
     if (last) { status = GZ_FINAL; break; }
-    if (b.bitpos() >= U.stop_bit) break;
+    if (b.bitpos() >= stop_bit) break;
   }
-  U.end_bit = b.bitpos();
-  if (!WRITE) U.n_sym = w;
-  else if (status <= GZ_FINAL && w != room) status = GZ_ERR_ROOM;
-  U.status = status;
+  flush(w);
+  if (lane == 0) { U.end_bit = b.bitpos(); U.n_sym = w; U.status = status; U.pad = (uint32_t)(__builtin_readcyclecounter() - cyc0); }
 }
 
 // ---- 3: windows in chain order --------------------------------------------------------------------------------------------
-// win_in[u] = the 32 KiB in front of unit u (bytes); the member starts with an empty (zero) window that nothing refers to
+// win_in[u] = the 32 KiB in front of unit u (bytes); the member starts with an empty (zero) window that nothing refers to.
+// One block per member; a step reads the unit's last 32 Ki symbols (32 per thread, loaded before any is used), resolves them
+// against the window in LDS and writes the next window.
 __global__ void __launch_bounds__(1024) gz_window_kernel(const GzUnit* __restrict__ units, uint32_t n_units, const uint16_t* __restrict__ sym,
                                                         uint8_t* __restrict__ win_in) {
   __shared__ uint8_t w0[32768];
   __shared__ uint8_t w1[32768];
   uint8_t* cur = w0; uint8_t* nxt = w1;
-  for (int i = threadIdx.x; i < 32768; i += 1024) cur[i] = 0;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 32768; i += 1024) cur[i] = 0;
+  // the unit's symbols are loaded ONE UNIT AHEAD (its descriptor two ahead): a step then waits for no global load
+  uint16_t x[32];
+  unsigned long long m = n_units ? units[0].n_sym : 0, so = n_units ? units[0].sym_off : 0;
+  unsigned long long m1 = n_units > 1 ? units[1].n_sym : 0, so1 = n_units > 1 ? units[1].sym_off : 0;
+  auto fetch = [&](unsigned long long mm, unsigned long long off) {
+    const uint16_t* s = sym + off;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const unsigned long long q = (unsigned long long)(tid + 1024 * j) + mm;   // byte (t + m) of (old window ++ resolved unit) = byte t of the new one
+      x[j] = q >= 32768 ? s[q - 32768] : (uint16_t)0xFFFF;
+    }
+  };
+  if (n_units) fetch(m, so);
   __syncthreads();
   for (uint32_t u = 0; u < n_units; ++u) {
     uint8_t* keep = win_in + (size_t)u * 32768;
-    for (int i = threadIdx.x * 4; i < 32768; i += 4096) *(uint32_t*)(keep + i) = *(const uint32_t*)(cur + i);
-    const uint64_t m = units[u].n_sym;
-    const uint16_t* s = sym + units[u].out_off;
-    for (int t = threadIdx.x; t < 32768; t += 1024) {
-      // byte t of the new window = byte (t + m) of (old window ++ resolved unit)
-      const uint64_t q = (uint64_t)t + m;
-      uint8_t v;
-      if (q < 32768) v = cur[q];
-      else { const uint16_t x = s[q - 32768]; v = x < 0x8000u ? (uint8_t)x : cur[x & 0x7FFFu]; }
-      nxt[t] = v;
+    for (int i = tid * 8; i < 32768; i += 8192) *(uint2*)(keep + i) = *(const uint2*)(cur + i);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int t = tid + 1024 * j;
+      const unsigned long long q = (unsigned long long)t + m;
+      nxt[t] = q < 32768 ? cur[q] : (x[j] < 0x8000u ? (uint8_t)x[j] : cur[x[j] & 0x7FFFu]);
     }
+    m = m1; so = so1;
+    if (u + 1 < n_units) fetch(m, so);
+    if (u + 2 < n_units) { m1 = units[u + 2].n_sym; so1 = units[u + 2].sym_off; }
     __syncthreads();
     uint8_t* t_ = cur; cur = nxt; nxt = t_;
   }
@@ -362,7 +655,7 @@ __global__ void __launch_bounds__(256) gz_resolve_kernel(const GzUnit* __restric
   const uint32_t u = blockIdx.x / blocks_per_unit, part = blockIdx.x % blocks_per_unit;
   if (u >= n_units) return;
   const uint64_t m = units[u].n_sym, off = units[u].out_off;
-  const uint16_t* s = sym + off;
+  const uint16_t* s = sym + units[u].sym_off;
   const uint8_t* w = win_in + (size_t)u * 32768;
   for (uint64_t i = (uint64_t)part * 256 + threadIdx.x; i < m; i += (uint64_t)blocks_per_unit * 256) {
     const uint16_t x = s[i];
@@ -405,7 +698,10 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   const uint32_t n_chunks = (uint32_t)((n + GZ_CHUNK - 1) / GZ_CHUNK);
   std::vector<unsigned long long> h_start(n_chunks);
   std::vector<GzUnit> units, chain;
+  std::vector<uint32_t> chain_idx;
   uint64_t total = 0;
+  unsigned long long sym_total = 0;
+  GzUnit* d_chain = nullptr;
   hipStream_t s = nullptr;
   {
     hipStream_t up, down;
@@ -437,51 +733,90 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
     u.start_bit = h_start[c];
     units.push_back(u);
   }
-  for (size_t i = 0; i < units.size(); ++i) units[i].stop_bit = i + 1 < units.size() ? units[i + 1].start_bit : ~0ull;
+  {
+    // every unit gets a region of the symbol buffer sized by its compressed span (8 x + 16 Ki symbols: FASTQ inflates 3-6 x);
+    // a unit that needs more is counted exactly by the same pass and decoded again into a region of its own
+    unsigned long long so = 0;
+    for (size_t i = 0; i < units.size(); ++i) {
+      units[i].stop_bit = i + 1 < units.size() ? units[i + 1].start_bit : ~0ull;
+      const unsigned long long span = ((i + 1 < units.size() ? units[i + 1].start_bit : (unsigned long long)n * 8) - units[i].start_bit) / 8 + 1;
+      units[i].sym_off = so; units[i].sym_cap = span * 8 + 16384;
+      so += units[i].sym_cap;
+    }
+    sym_total = so;
+  }
   GZTRY(hipMalloc(&d_units, units.size() * sizeof(GzUnit)));
+  GZTRY(hipMalloc(&d_sym, (sym_total + 8) * 2));
   GZTRY(hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
-  gz_decode_kernel<false><<<(unsigned)units.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), nullptr, 1);
+  lap("symbol buffer allocated");
+  gz_decode_kernel<true><<<(unsigned)units.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, nullptr);
   GZTRY(hipGetLastError());
   GZTRY(hipMemcpyAsync(units.data(), d_units, units.size() * sizeof(GzUnit), hipMemcpyDeviceToHost, s));
   GZTRY(hipStreamSynchronize(s));
-  lap("decode (counting)");
+  lap("decode");
+  if (timing) {
+    unsigned long long mx = 0, sum = 0, mxspan = 0;
+    unsigned long long mxc = 0, sumc = 0;
+    for (const GzUnit& u : units) { if (u.n_sym > mx) mx = u.n_sym; sum += u.n_sym; if (u.end_bit - u.start_bit > mxspan) mxspan = u.end_bit - u.start_bit; if (u.pad > mxc) mxc = u.pad; sumc += u.pad; }
+    fprintf(stderr, "[gz] cycles per unit: mean %llu, max %llu; cycles per output symbol %.1f\n", sumc / units.size(), mxc, (double)sumc / (double)(sum ? sum : 1));
+    fprintf(stderr, "[gz] units: %zu, symbols per unit: mean %llu, max %llu; longest span %llu bytes\n", units.size(), sum / units.size(), mx, mxspan / 8);
+  }
   // the chain: a unit is taken iff the chain so far ends exactly on its start; one that starts inside the chain was a false find
   {
     unsigned long long pos = units[0].start_bit;
     bool final = false;
+    std::vector<uint32_t> redo;
+    unsigned long long extra = 0;
     for (size_t i = 0; i < units.size() && !final; ++i) {
-      const GzUnit& u = units[i];
+      GzUnit& u = units[i];
       if (u.start_bit < pos) continue;
       if (u.start_bit > pos || u.status > GZ_FINAL) { rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: the units do not stitch (unit %zu, status %u)", i, u.status); goto done; }
-      GzUnit v = u;
-      v.out_off = total; total += u.n_sym;
-      chain.push_back(v);
+      if (u.n_sym > u.sym_cap) { redo.push_back((uint32_t)i); u.sym_off = sym_total + 8 + extra; u.sym_cap = u.n_sym; extra += u.n_sym; }
+      chain_idx.push_back((uint32_t)i);
       pos = u.end_bit;
       final = u.status == GZ_FINAL;
     }
     // behind the last block: the trailer, right there (bits up to the next byte are padding)
     if (!final || (pos + 7) / 8 != n) { rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: more than one member, or data behind the last block"); goto done; }
+    for (uint32_t i : chain_idx) { units[i].out_off = total; total += units[i].n_sym; }
     if ((uint32_t)total != isize) { rc = mic_set_error(MIC_E_INVALID, "Failed to uncompress input objects."); goto done; }
+    if (!redo.empty()) {
+      // (a second symbol buffer behind the first would need the first one's copy: the units that overflowed get a buffer of their own,
+      // addressed through the same base pointer - offsets are relative to d_sym, so the extra buffer is allocated as ONE with it)
+      uint16_t* bigger = nullptr;
+      GZTRY(hipMalloc(&bigger, (sym_total + 8 + extra + 8) * 2));
+      GZTRY(hipMemcpyAsync(bigger, d_sym, (sym_total + 8) * 2, hipMemcpyDeviceToDevice, s));
+      GZTRY(hipStreamSynchronize(s));
+      hipFree(d_sym); d_sym = bigger;
+      uint32_t* d_which = nullptr;
+      GZTRY(hipMalloc(&d_which, redo.size() * 4));
+      hipError_t e1 = hipMemcpyAsync(d_which, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, s);
+      if (e1 == hipSuccess) e1 = hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s);
+      if (e1 == hipSuccess) { gz_decode_kernel<true><<<(unsigned)redo.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, d_which); e1 = hipGetLastError(); }
+      std::vector<GzUnit> back(units.size());
+      if (e1 == hipSuccess) e1 = hipMemcpyAsync(back.data(), d_units, units.size() * sizeof(GzUnit), hipMemcpyDeviceToHost, s);
+      if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
+      hipFree(d_which);
+      GZTRY(e1);
+      for (uint32_t i : redo)
+        if (back[i].status != units[i].status || back[i].end_bit != units[i].end_bit || back[i].n_sym != units[i].n_sym) {
+          rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: the second decode of unit %u differs", i); goto done;
+        }
+      lap("decode again (units that overflowed their region)");
+    }
   }
-  GZTRY(hipMemcpyAsync(d_units, chain.data(), chain.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
-  GZTRY(hipMalloc(&d_sym, (total + 8) * 2));
+  for (uint32_t i : chain_idx) chain.push_back(units[i]);
+  GZTRY(hipMalloc(&d_chain, chain.size() * sizeof(GzUnit)));
+  GZTRY(hipMemcpyAsync(d_chain, chain.data(), chain.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
   GZTRY(hipMalloc(&d_win, chain.size() * (size_t)32768));
   GZTRY(hipMalloc(&d_out, total + 64));
-  gz_decode_kernel<true><<<(unsigned)chain.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)chain.size(), d_sym, 1);
-  GZTRY(hipGetLastError());
-  lap("decode (writing)");
-  gz_window_kernel<<<1, 1024, 0, s>>>(d_units, (uint32_t)chain.size(), d_sym, d_win);
+  lap("window and text buffers allocated");
+  gz_window_kernel<<<1, 1024, 0, s>>>(d_chain, (uint32_t)chain.size(), d_sym, d_win);
   GZTRY(hipGetLastError());
   lap("windows");
-  gz_resolve_kernel<<<(unsigned)chain.size() * 8u, 256, 0, s>>>(d_units, (uint32_t)chain.size(), d_sym, d_win, d_out, 8);
+  gz_resolve_kernel<<<(unsigned)chain.size() * 8u, 256, 0, s>>>(d_chain, (uint32_t)chain.size(), d_sym, d_win, d_out, 8);
   GZTRY(hipGetLastError());
-  {
-    std::vector<GzUnit> back(chain.size());
-    GZTRY(hipMemcpyAsync(back.data(), d_units, chain.size() * sizeof(GzUnit), hipMemcpyDeviceToHost, s));
-    GZTRY(hipStreamSynchronize(s));
-    for (size_t i = 0; i < back.size(); ++i)
-      if (back[i].status > GZ_FINAL || back[i].end_bit != chain[i].end_bit) { rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: the writing pass differs (unit %zu)", i); goto done; }
-  }
+  GZTRY(hipStreamSynchronize(s));
   lap("resolve");
   if (timing) fprintf(stderr, "[gz] %zu bytes -> %llu bytes, %u chunks, %zu units found, %zu in the chain\n", gz_bytes, (unsigned long long)total, n_chunks, units.size(), chain.size());
   *d_text = d_out; d_out = nullptr; *n_text = total;
@@ -489,6 +824,7 @@ done:
   if (d_in) hipFree(d_in);
   if (d_start) hipFree(d_start);
   if (d_units) hipFree(d_units);
+  if (d_chain) hipFree(d_chain);
   if (d_sym) hipFree(d_sym);
   if (d_win) hipFree(d_win);
   if (d_out) hipFree(d_out);
