@@ -95,6 +95,14 @@ SYMBOLS = [
     ("mic_gz_inflate_device", C.c_int, [_VP, _VP, _SZ, C.POINTER(_VP), C.POINTER(_SZ), C.POINTER(C.c_uint32)]),
     ("mic_gz_copy_text", C.c_int, [_VP, _VP, _SZ, _SZ, _VP]),
     ("mic_gz_free_text", C.c_int, [_VP, _VP]),
+    ("mic_gz_reserve", C.c_int, [_VP, _SZ, C.c_uint32]),
+    ("mic_gz_reserve_bytes", C.c_uint64, [_SZ, C.c_uint32]),
+    ("mic_gz_release", C.c_int, [_VP]),
+    ("mic_pairs_index_device", C.c_int, [_VP, _VP, _SZ, _VP, _SZ, C.POINTER(_VP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    ("mic_pairs_offsets", C.c_int, [_VP, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(_SZ), C.POINTER(C.c_uint32)]),
+    ("mic_pairs_merge_to_slot", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _SZ, C.POINTER(_SZ)]),
+    ("mic_pairs_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
+    ("mic_pairs_free", C.c_int, [_VP, _VP]),
     ("mic_format_ratio_g", C.c_int, [C.c_uint32, C.c_uint32, C.c_char_p]),
     ("mic_key_bytes_rule", C.c_int, [C.c_uint64, C.c_int]),
     ("mic_index_reads", C.c_long, [_VP, _SZ, _SZ, _U64P, _U64P, _U64P, _U64P, _U64P]),

@@ -169,8 +169,26 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
     size_t slot_bytes = 0, workers = 0;
     ingest_geometry(bytes, slot_bytes, workers);
     const size_t per_engine = (workers + engines_.size() - 1) / engines_.size();
-    for (mic_engine* e : engines_) mic_db_reserve_hbm(e, (uint64_t)per_engine * slot_bytes * 7);   // ~6.1 x the slot size per slot (mic_ingest.hip)
-    slots = std::thread([this, bytes] { try { ensure_ingest(bytes); } catch (const std::exception&) { release_ingest(); } });
+    // two compressed mates on one engine are inflated on the device (run_paired): the buffers of that are set up here as well
+    struct GzFile { size_t bytes; uint32_t isize; };
+    std::vector<GzFile> gz;
+    if (engines_.size() == 1 && !opt_.objects2.empty() && is_gzip(opt_.objects) && is_gzip(opt_.objects2) && !getenv("MIC_SERIAL_PAIRS") &&
+        !getenv("MIC_GZ_HOST")) {
+      for (const std::string* f : {&opt_.objects, &opt_.objects2}) {
+        const int fd = open(f->c_str(), O_RDONLY);
+        uint8_t t[4];
+        if (fd != -1 && fstat(fd, &st) == 0 && st.st_size > 18 && pread(fd, t, 4, st.st_size - 4) == 4)
+          gz.push_back({(size_t)st.st_size, (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24)});
+        if (fd != -1) close(fd);
+      }
+    }
+    uint64_t gz_hbm = 0;
+    for (const GzFile& g : gz) gz_hbm += mic_gz_reserve_bytes(g.bytes, g.isize);
+    for (mic_engine* e : engines_) mic_db_reserve_hbm(e, (uint64_t)per_engine * slot_bytes * 7 + gz_hbm);   // ~6.1 x the slot size per slot (mic_ingest.hip)
+    slots = std::thread([this, bytes, gz] {
+      try { ensure_ingest(bytes); } catch (const std::exception&) { release_ingest(); }
+      for (const GzFile& g : gz) if (mic_gz_reserve(engines_[0], g.bytes, g.isize) != MIC_OK) break;     // (without it the call allocates for itself)
+    });
   }
   std::string load_err;
   for (size_t d = 0; d < use && load_err.empty(); ++d) {
@@ -974,6 +992,107 @@ class PairedFileFeeder : public Classifier::Feeder {
   std::vector<uint8_t> scan_;
 };
 
+// Both mates gzip-compressed, one engine: the files are inflated ON the device (mic_gz_inflate_device, both at once), indexed and
+// checked there (mic_pairs_index_device), and every batch is merged straight into its ingest slot's device buffer
+// (mic_pairs_merge_to_slot: the reference's merge, file.cc:205-268) - the compressed bytes are all that crosses the link.
+// Whatever the device path does not take (several gzip members, block gzip, mates whose lines or ids do not pair up, texts of
+// 4 GiB or more) leaves ok() false and the caller inflates on the host as before.  Ranges count RECORDS: off = first, len = number.
+class DevicePairFeeder : public Classifier::Feeder {
+ public:
+  DevicePairFeeder(mic_engine* e, const std::string& f1, const std::string& f2) : e_(e) {
+    const bool timing = getenv("MIC_CLI_TIMING") != nullptr;
+    struct timeval t0, t1, t2;
+    gettimeofday(&t0, nullptr);
+    const std::string* names[2] = {&f1, &f2};
+    int rc[2] = {MIC_E_UNSUPPORTED, MIC_E_UNSUPPORTED};
+    auto inflate = [&](int i) {
+      const int fd = open(names[i]->c_str(), O_RDONLY);
+      struct stat st;
+      if (fd == -1) return;
+      if (fstat(fd, &st) == 0 && st.st_size > 18) {
+        void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+          uint32_t crc = 0;
+          rc[i] = mic_gz_inflate_device(e_, m, (size_t)st.st_size, &text_[i], &n_[i], &crc);
+          munmap(m, (size_t)st.st_size);
+        }
+      }
+      close(fd);
+    };
+    std::thread other([&] { inflate(1); });
+    inflate(0);
+    other.join();
+    gettimeofday(&t1, nullptr);
+    if (rc[0] != MIC_OK || rc[1] != MIC_OK) { why_ = "the device inflater does not take these files"; return; }
+    uint32_t status = 0;
+    if (mic_pairs_index_device(e_, text_[0], n_[0], text_[1], n_[1], &pairs_, &n_rec_, &status) != MIC_OK || status || !pairs_) {
+      why_ = "the mates do not pair up line by line";
+      return;
+    }
+    const uint64_t* s = nullptr; size_t ns = 0;
+    if (mic_pairs_offsets(pairs_, &s, &ns, &stride_) != MIC_OK || ns < 2) return;
+    off_.assign(s, s + ns);
+    gettimeofday(&t2, nullptr);
+    if (timing)
+      std::cerr << "[timing] device inflate: " << (n_[0] + n_[1]) / 1e6 << " MB of text in "
+                << ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_usec - t0.tv_usec) / 1e3) << " ms, " << n_rec_ << " pairs indexed and checked in "
+                << ((t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_usec - t1.tv_usec) / 1e3) << " ms" << std::endl;
+    ok_ = true;
+  }
+  ~DevicePairFeeder() override {
+    if (pairs_) mic_pairs_free(e_, pairs_);
+    for (void* t : text_) if (t) mic_gz_free_text(e_, t);
+  }
+  bool ok() const { return ok_; }
+  const char* why() const { return why_; }
+  uint64_t merged_bytes() const { return off_.empty() ? 0 : off_.back(); }
+  bool fastq() const override { return false; }          // what the slots get is the merged FASTA text
+  bool resident() const override { return true; }
+  uint64_t remaining() const override { return off_.back() - off_[cur_]; }
+
+  bool assign(size_t want, size_t cap, Classifier::Range& r) override {
+    if (rec_of(cur_) >= n_rec_) return false;
+    const uint64_t limit = std::min<uint64_t>(want, cap - cap / 16);
+    // the last boundary whose merged text still fits (at least one stride: a stride that does not fit is handed to the host path)
+    size_t hi = (size_t)(std::upper_bound(off_.begin() + (ptrdiff_t)cur_, off_.end(), off_[cur_] + limit) - off_.begin()) - 1;
+    if (hi <= cur_) hi = cur_ + 1;
+    while (hi + 1 < off_.size() && rec_of(hi) == rec_of(cur_)) ++hi;
+    r.off = rec_of(cur_); r.len = (size_t)(rec_of(hi) - rec_of(cur_)); r.off2 = 0; r.len2 = 0; r.mem = nullptr; r.keep.reset();
+    cur_ = hi;
+    return r.len != 0;
+  }
+  void read(const Classifier::Range&, size_t, uint8_t*, size_t) override { die("device-resident ranges are filled on the device"); }
+  size_t fill_resident(const Classifier::Range& r, mic_engine* e, size_t slot) override {
+    size_t n = 0;
+    if (e != e_ || mic_pairs_merge_to_slot(e_, pairs_, r.off, r.off + r.len, slot, &n) != MIC_OK) return (size_t)-1;
+    return n;
+  }
+  size_t fill(const Classifier::Range& r, uint8_t* dst, size_t cap) override {
+    size_t n = 0;
+    return mic_pairs_text(e_, pairs_, r.off, r.off + r.len, dst, cap, &n) == MIC_OK ? n : (size_t)-1;
+  }
+  void text(const Classifier::Range& r, std::string& out) override {
+    const uint64_t a = r.off / stride_, b = r.off + r.len >= n_rec_ ? off_.size() - 1 : (r.off + r.len) / stride_;
+    out.resize((size_t)(off_[b] - off_[a]));
+    size_t n = 0;
+    if (!out.empty()) check(mic_pairs_text(e_, pairs_, r.off, r.off + r.len, &out[0], out.size(), &n), "merged text of a batch");
+    out.resize(n);
+  }
+
+ private:
+  uint64_t rec_of(size_t i) const { return std::min<uint64_t>((uint64_t)i * stride_, n_rec_); }
+  mic_engine* e_;
+  void* text_[2] = {nullptr, nullptr};
+  size_t n_[2] = {0, 0};
+  mic_pairs* pairs_ = nullptr;
+  uint64_t n_rec_ = 0;
+  uint32_t stride_ = 64;
+  std::vector<uint64_t> off_;
+  size_t cur_ = 0;
+  bool ok_ = false;
+  const char* why_ = "";
+};
+
 }  // namespace
 
 std::string merge_paired(const std::string& file1, const std::string& file2) {
@@ -1072,6 +1191,20 @@ void Classifier::run_paired(const std::string& f1, const std::string& f2, const 
     if (list_mode) std::cout << "> Processing file: '" << merged_name << "' in " << opt_.batches << " batches." << std::endl;
     else std::cout << "Processing file: '" << merged_name << "' in " << opt_.batches << " batches using " << opt_.threads
                    << " CPU thread(s)." << std::endl;
+    if (device_ingest() && is_gzip(a) && is_gzip(b) && engines_.size() == 1 && !getenv("MIC_SERIAL_PAIRS") && !getenv("MIC_GZ_HOST")) {
+      // both mates compressed: inflated, paired up and merged on the device (MIC_GZ_HOST=1: on the host, below)
+      struct timeval ta, tb;
+      gettimeofday(&ta, nullptr);
+      DevicePairFeeder feed(engines_[0], a, b);
+      if (feed.ok()) {
+        gettimeofday(&tb, nullptr);
+        prelude_s_ = (tb.tv_sec - ta.tv_sec) + (tb.tv_usec - ta.tv_usec) / 1e6;
+        const bool done = run_stream(feed, res, true, (size_t)feed.merged_bytes());
+        prelude_s_ = 0;
+        mic_gz_release(engines_[0]);
+        if (done) return;
+      } else if (getenv("MIC_CLI_TIMING")) std::cerr << "[timing] device inflate: not used (" << feed.why() << ")" << std::endl;
+    }
     if (device_ingest() && (is_gzip(a) || is_gzip(b)) && !getenv("MIC_SERIAL_PAIRS")) {
       // compressed mates: both inflated up front and at the same time, then merged by the loaders like plain files
       struct timeval ta, tb;
@@ -1514,12 +1647,15 @@ bool Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
           if (!fits || phase != 0) it.host = true;
           it.n = w;
         } else {
-          const size_t got = feed.fill(it.r, dst, cap);
+          size_t got;
+          if (feed.resident()) { got = feed.fill_resident(it.r, engines_[slots[it.slot].eng], slots[it.slot].slot); it.flags |= MIC_INGEST_RESIDENT; }
+          else got = feed.fill(it.r, dst, cap);
           if (got == (size_t)-1) it.host = true; else it.n = got;
         }
         if (timing) {
           const uint64_t tn = now_us();
-          us_load += tn - ta; bytes_in += it.r.len + it.r.len2; if (!it.host) bytes_h2d += it.n;
+          us_load += tn - ta; const bool res = (it.flags & MIC_INGEST_RESIDENT) != 0;
+          bytes_in += res ? it.n : it.r.len + it.r.len2; if (!it.host && !res) bytes_h2d += it.n;
           uint64_t z = 0; ts_first_loaded.compare_exchange_strong(z, tn); ts_last_loaded = tn;
         }
       } catch (const std::exception& ex) { fail(ex.what()); it.host = true; it.n = 0; }

@@ -69,6 +69,10 @@ class Classifier {
     // into a string; for most feeders that is the bytes of the range, for a pair of files it is the merged text
     virtual size_t fill(const Range& r, uint8_t* dst, size_t cap) { if (r.len > cap) return (size_t)-1; read(r, 0, dst, r.len); return r.len; }
     virtual void text(const Range& r, std::string& out) { out.resize(r.len); if (r.len) read(r, 0, (uint8_t*)&out[0], r.len); }
+    // a feeder whose text is on the device already writes a range into an ingest slot's DEVICE buffer (returns its size, (size_t)-1
+    // when the range has to go through the host path); the batch is then classified with MIC_INGEST_RESIDENT
+    virtual bool resident() const { return false; }
+    virtual size_t fill_resident(const Range&, mic_engine*, size_t /*slot*/) { return (size_t)-1; }
     virtual bool gave_up() const { return false; }           // the input is not what the feeder can cut: run the serial reader instead
   };
   bool run_stream(Feeder& f, const std::string& results_base, bool paired, size_t total_bytes);   // false: feeder gave up, nothing written

@@ -488,6 +488,7 @@ int mic_destroy(mic_engine* e) {
   hipSetDevice(e->device);
   hipDeviceSynchronize();
   mic_ingest_free(e);
+  mic_gz_release(e);
   free_batches(e);
   if (e->slots) hipFree(e->slots);
   if (e->side) hipFree(e->side);

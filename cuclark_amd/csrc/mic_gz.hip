@@ -35,6 +35,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <mutex>
 #include <vector>
 
 // engine services (mic_engine.hip)
@@ -207,7 +208,7 @@ __device__ bool candidate(const uint8_t* d, uint64_t n, uint64_t bit) {      // 
   const int sh = (int)(bit & 7);
   uint64_t a = (lo >> sh) | (sh ? hi << (64 - sh) : 0);                        // bits 0..63 from `bit`
   const uint64_t b2 = hi >> sh;                                                 // bits 64.. from `bit`
-  if ((a & 7u) != 4u) return false;                                             // BFINAL = 0, BTYPE = 2
+  if ((a & 6u) != 4u) return false;                                             // BTYPE = 2 (BFINAL either way: the member's last block is a unit like any other)
   const uint32_t hlit = (uint32_t)(a >> 3) & 31u, hdist = (uint32_t)(a >> 8) & 31u, hclen = ((uint32_t)(a >> 13) & 15u) + 4u;
   if (hlit > 29u || hdist > 29u) return false;
   uint32_t sum = 0;
@@ -675,6 +676,21 @@ size_t gzip_header(const uint8_t* p, size_t n) {      // offset of the deflate d
   return q + 8 < n ? q : 0;
 }
 
+// Buffers set up ahead of a call (mic_gz_reserve): one scratch block for everything the call needs on the way and the text buffer.
+// A fresh gigabyte of device memory takes the driver tens of milliseconds (longer right behind a table build, whose freed pages it
+// still wipes) - as long as the decode; the command line reserves while its database loads, as it does for its ingest slots.
+struct GzReserve {
+  mic_engine* eng = nullptr; size_t gz_bytes = 0;
+  char* scratch = nullptr; size_t scratch_bytes = 0;
+  uint8_t* text = nullptr; size_t text_bytes = 0;
+  bool taken = false;
+};
+std::mutex g_res_mu;
+std::vector<GzReserve> g_res;
+
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+unsigned long long sym_bound_of(size_t n, uint32_t n_chunks) { return 8ull * (n + n_chunks) + 16384ull * n_chunks; }
+
 #define GZTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = mic_set_error(e_ == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "gzip on the device: %s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
 
 }  // namespace
@@ -700,33 +716,57 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   std::vector<GzUnit> units, chain;
   std::vector<uint32_t> chain_idx;
   uint64_t total = 0;
-  unsigned long long sym_total = 0;
+  unsigned long long sym_total = 0, sym_bound = 0;
   GzUnit* d_chain = nullptr;
-  hipStream_t s = nullptr;
+  hipStream_t s = nullptr;         // a stream of this call's own: the two mates of a pair are inflated by two host threads at once
+  // device memory: out of the reservation made for a file of this size, if there is one (mic_gz_reserve), else allocated here
+  char* arena = nullptr; size_t arena_left = 0;
+  std::vector<void*> owned;
   {
-    hipStream_t up, down;
-    mic_engine_copy_streams(e, &up, &down);
-    s = up;
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    for (GzReserve& r : g_res)
+      if (r.eng == e && r.gz_bytes == gz_bytes && !r.taken) {
+        r.taken = true; arena = r.scratch; arena_left = r.scratch_bytes;
+        if (r.text && (size_t)isize + 64 <= r.text_bytes) { d_out = r.text; r.text = nullptr; }      // (the text is this call's from here on)
+        break;
+      }
   }
+  auto dev_alloc = [&](void** ptr, size_t bytes) -> hipError_t {
+    const size_t b = up256(bytes);
+    if (b <= arena_left) { *ptr = arena; arena += b; arena_left -= b; return hipSuccess; }
+    const hipError_t he = hipMalloc(ptr, bytes);
+    if (he == hipSuccess) owned.push_back(*ptr);
+    return he;
+  };
+  auto dev_free = [&](void* ptr) {               // (memory of the reservation stays where it is)
+    for (size_t i = 0; i < owned.size(); ++i) if (owned[i] == ptr) { hipFree(ptr); owned.erase(owned.begin() + (ptrdiff_t)i); return; }
+  };
   const bool timing = getenv("MIC_GZ_TIMING") != nullptr;
   struct timespec tq0; clock_gettime(CLOCK_MONOTONIC, &tq0);
   auto lap = [&](const char* what) {
     if (!timing) return;
-    hipStreamSynchronize(s);
+    if (s) hipStreamSynchronize(s);
     struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
     fprintf(stderr, "[gz] %s: %.3f ms\n", what, (t1.tv_sec - tq0.tv_sec) * 1e3 + (t1.tv_nsec - tq0.tv_nsec) / 1e6);
     tq0 = t1;
   };
-  GZTRY(hipMalloc(&d_in, n + 16));
+  GZTRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  GZTRY(dev_alloc((void**)&d_in, n + 16));
   GZTRY(hipMemsetAsync(d_in + n, 0, 16, s));
   GZTRY(hipMemcpyAsync(d_in, p, n, hipMemcpyHostToDevice, s));
   lap("upload");
-  GZTRY(hipMalloc(&d_start, (size_t)n_chunks * 8));
+  GZTRY(dev_alloc((void**)&d_start, (size_t)n_chunks * 8));
   gz_find_kernel<<<n_chunks, 64, 0, s>>>(d_in, n, (uint64_t)hdr * 8, n_chunks, d_start);
   GZTRY(hipGetLastError());
   GZTRY(hipMemcpyAsync(h_start.data(), d_start, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s));
+  // The big buffers are allocated while the upload and the finder run (a fresh gigabyte takes the driver 30-40 ms: as much as the
+  // decode): the symbol buffer by its bound - every unit gets 8 x its compressed span + 16 Ki symbols, there are at most n_chunks
+  // units - and the text by the member's ISIZE, which the decode has to arrive at anyway
+  sym_bound = sym_bound_of(n, n_chunks);
+  GZTRY(dev_alloc((void**)&d_sym, (sym_bound + 8) * 2));
+  if (!d_out && (unsigned long long)isize <= 1100ull * n) GZTRY(hipMalloc(&d_out, (size_t)isize + 64));
   GZTRY(hipStreamSynchronize(s));
-  lap("find blocks");
+  lap("find blocks (+ symbol and text buffers allocated)");
   for (uint32_t c = 0; c < n_chunks; ++c) {
     if (h_start[c] == ~0ull) continue;
     GzUnit u; memset(&u, 0, sizeof(u));
@@ -745,13 +785,14 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
     }
     sym_total = so;
   }
-  GZTRY(hipMalloc(&d_units, units.size() * sizeof(GzUnit)));
-  GZTRY(hipMalloc(&d_sym, (sym_total + 8) * 2));
+  if (sym_total > sym_bound) { rc = mic_set_error(MIC_E_HIP, "gzip on the device: symbol regions beyond their bound"); goto done; }
+  GZTRY(dev_alloc((void**)&d_units, units.size() * sizeof(GzUnit)));
   GZTRY(hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
-  lap("symbol buffer allocated");
   gz_decode_kernel<true><<<(unsigned)units.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, nullptr);
   GZTRY(hipGetLastError());
   GZTRY(hipMemcpyAsync(units.data(), d_units, units.size() * sizeof(GzUnit), hipMemcpyDeviceToHost, s));
+  GZTRY(dev_alloc((void**)&d_chain, units.size() * sizeof(GzUnit)));           // (while the decode runs)
+  GZTRY(dev_alloc((void**)&d_win, units.size() * (size_t)32768));
   GZTRY(hipStreamSynchronize(s));
   lap("decode");
   if (timing) {
@@ -784,19 +825,19 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
       // (a second symbol buffer behind the first would need the first one's copy: the units that overflowed get a buffer of their own,
       // addressed through the same base pointer - offsets are relative to d_sym, so the extra buffer is allocated as ONE with it)
       uint16_t* bigger = nullptr;
-      GZTRY(hipMalloc(&bigger, (sym_total + 8 + extra + 8) * 2));
+      GZTRY(dev_alloc((void**)&bigger, (sym_total + 8 + extra + 8) * 2));
       GZTRY(hipMemcpyAsync(bigger, d_sym, (sym_total + 8) * 2, hipMemcpyDeviceToDevice, s));
       GZTRY(hipStreamSynchronize(s));
-      hipFree(d_sym); d_sym = bigger;
+      dev_free(d_sym); d_sym = bigger;
       uint32_t* d_which = nullptr;
-      GZTRY(hipMalloc(&d_which, redo.size() * 4));
+      GZTRY(dev_alloc((void**)&d_which, redo.size() * 4));
       hipError_t e1 = hipMemcpyAsync(d_which, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, s);
       if (e1 == hipSuccess) e1 = hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s);
       if (e1 == hipSuccess) { gz_decode_kernel<true><<<(unsigned)redo.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, d_which); e1 = hipGetLastError(); }
       std::vector<GzUnit> back(units.size());
       if (e1 == hipSuccess) e1 = hipMemcpyAsync(back.data(), d_units, units.size() * sizeof(GzUnit), hipMemcpyDeviceToHost, s);
       if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
-      hipFree(d_which);
+      dev_free(d_which);
       GZTRY(e1);
       for (uint32_t i : redo)
         if (back[i].status != units[i].status || back[i].end_bit != units[i].end_bit || back[i].n_sym != units[i].n_sym) {
@@ -806,11 +847,8 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
     }
   }
   for (uint32_t i : chain_idx) chain.push_back(units[i]);
-  GZTRY(hipMalloc(&d_chain, chain.size() * sizeof(GzUnit)));
   GZTRY(hipMemcpyAsync(d_chain, chain.data(), chain.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
-  GZTRY(hipMalloc(&d_win, chain.size() * (size_t)32768));
-  GZTRY(hipMalloc(&d_out, total + 64));
-  lap("window and text buffers allocated");
+  if (!d_out) GZTRY(hipMalloc(&d_out, total + 64));
   gz_window_kernel<<<1, 1024, 0, s>>>(d_chain, (uint32_t)chain.size(), d_sym, d_win);
   GZTRY(hipGetLastError());
   lap("windows");
@@ -821,14 +859,59 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   if (timing) fprintf(stderr, "[gz] %zu bytes -> %llu bytes, %u chunks, %zu units found, %zu in the chain\n", gz_bytes, (unsigned long long)total, n_chunks, units.size(), chain.size());
   *d_text = d_out; d_out = nullptr; *n_text = total;
 done:
-  if (d_in) hipFree(d_in);
-  if (d_start) hipFree(d_start);
-  if (d_units) hipFree(d_units);
-  if (d_chain) hipFree(d_chain);
-  if (d_sym) hipFree(d_sym);
-  if (d_win) hipFree(d_win);
+  if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); s = nullptr; }
+  for (void* q : owned) hipFree(q);
   if (d_out) hipFree(d_out);
+  lap("buffers freed");
   return rc;
+}
+
+extern "C" int mic_gz_reserve(mic_engine* e, size_t gz_bytes, uint32_t isize) {
+  if (!e || gz_bytes < 18) return mic_set_error(MIC_E_INVALID, "bad argument");
+  MicTable t_; int sc_, ncu_, dev_, k_; uint32_t nt_;
+  int rc = mic_engine_table(e, &t_, &sc_, &ncu_, &dev_, &k_, &nt_);
+  if (rc) return rc;
+  if (hipSetDevice(dev_) != hipSuccess) return mic_set_error(MIC_E_HIP, "hipSetDevice failed");
+  const size_t n = gz_bytes - 8;
+  const uint32_t n_chunks = (uint32_t)((n + GZ_CHUNK - 1) / GZ_CHUNK);
+  GzReserve r;
+  r.eng = e; r.gz_bytes = gz_bytes;
+  // input, block starts, units and chain, symbols by their bound, windows for a third of the chunks (a block of gzip's is three
+  // chunks and more; a file of smaller blocks gets the rest of its windows from hipMalloc)
+  r.scratch_bytes = up256(n + 16) + up256((size_t)n_chunks * 8) + 2 * up256((size_t)n_chunks * sizeof(GzUnit)) +
+                    up256((sym_bound_of(n, n_chunks) + 8) * 2) + up256(((size_t)n_chunks / 3 + 64) * 32768) + 4096;
+  hipError_t he = hipMalloc(&r.scratch, r.scratch_bytes);
+  if (he == hipSuccess && (unsigned long long)isize <= 1100ull * n) {
+    r.text_bytes = (size_t)isize + 64;
+    he = hipMalloc(&r.text, r.text_bytes);
+  }
+  if (he != hipSuccess) {
+    if (r.scratch) hipFree(r.scratch);
+    (void)hipGetLastError();
+    return mic_set_error(he == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "gzip on the device: reservation: %s", hipGetErrorString(he));
+  }
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  g_res.push_back(r);
+  return MIC_OK;
+}
+
+extern "C" uint64_t mic_gz_reserve_bytes(size_t gz_bytes, uint32_t isize) {
+  if (gz_bytes < 18) return 0;
+  const size_t n = gz_bytes - 8;
+  const uint32_t n_chunks = (uint32_t)((n + GZ_CHUNK - 1) / GZ_CHUNK);
+  return (uint64_t)(n + 16 + (size_t)n_chunks * (8 + 2 * sizeof(GzUnit)) + (sym_bound_of(n, n_chunks) + 8) * 2 + ((size_t)n_chunks / 3 + 64) * 32768 + 8192) +
+         (uint64_t)isize + 64;
+}
+
+extern "C" int mic_gz_release(mic_engine* e) {
+  std::vector<GzReserve> mine;
+  {
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    for (size_t i = 0; i < g_res.size();)
+      if (g_res[i].eng == e) { mine.push_back(g_res[i]); g_res.erase(g_res.begin() + (ptrdiff_t)i); } else ++i;
+  }
+  for (GzReserve& r : mine) { if (r.scratch) hipFree(r.scratch); if (r.text) hipFree(r.text); }
+  return MIC_OK;
 }
 
 extern "C" int mic_gz_copy_text(mic_engine* e, const void* d_text, size_t offset, size_t n, void* host_dst) {

@@ -342,6 +342,83 @@ __global__ void csv_finish_kernel(const uint32_t* __restrict__ line_off, uint32_
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
+// ---- a pair of FASTQ texts resident on the device (the inflated mates of -P a.fq.gz b.fq.gz): line index, checks, merge --------------
+// The reference merges a pair line by line into ">id\nseq1Nseq2\n" (file.cc:205-268); the command line's loaders do that on the
+// host for plain files.  Text that was inflated ON the device (mic_gz.hip) is merged here instead, record ranges straight into an
+// ingest slot's device buffer, so that the text never crosses the link.  Whatever the line arithmetic does not cover (line
+// counts that differ or are no multiple of four, a header without '@', ids that differ or are empty) is reported, and the
+// caller goes back to the host reader, which treats such files the way the reference does, messages included.
+enum { PS_LINES = MIC_PAIRS_LINES, PS_HEADER = MIC_PAIRS_HEADER, PS_ID = MIC_PAIRS_ID, PS_BIG = MIC_PAIRS_BIG };
+
+__device__ __forceinline__ bool pair_sep(uint8_t c) { return c == ' ' || c == '/' || c == '\t' || c == '@'; }     // file.cc:224
+// the id inside a header line [p, p + n): behind leading separators, up to the next one
+__device__ __forceinline__ void pair_id(const uint8_t* __restrict__ p, uint32_t n, uint32_t& a, uint32_t& len) {
+  a = 0;
+  while (a < n && pair_sep(p[a])) ++a;
+  uint32_t b = a;
+  while (b < n && !pair_sep(p[b])) ++b;
+  len = b - a;
+}
+
+struct PairText { const uint8_t* t; const uint32_t* ls; uint32_t nb; };
+// line L of a text without its '\n' (an unterminated last line has its virtual line end at nb: line_start = nb + 1)
+__device__ __forceinline__ void pair_line(const PairText& x, uint64_t L, const uint8_t*& p, uint32_t& n) {
+  const uint32_t a = x.ls[L], b = x.ls[L + 1];
+  p = x.t + a; n = b - 1u - a;
+}
+
+// one thread per record: checks, and the length of the merged record
+__global__ void __launch_bounds__(256) pair_len_kernel(PairText A, PairText B, uint64_t n_rec, unsigned long long* __restrict__ mlen,
+                                                       uint32_t* __restrict__ status) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r > n_rec) return;
+  if (r == n_rec) { mlen[r] = 0; return; }
+  const uint8_t *p, *q; uint32_t n, m;
+  pair_line(A, 4 * r, p, n); pair_line(B, 4 * r, q, m);
+  uint32_t bad = 0, ia = 0, la = 0, ib = 0, lb = 0;
+  if (n == 0 || m == 0 || p[0] != '@' || q[0] != '@') bad |= PS_HEADER;
+  else {
+    pair_id(p, n, ia, la); pair_id(q, m, ib, lb);
+    if (la == 0 || la != lb) bad |= PS_ID;
+    else for (uint32_t i = 0; i < la; ++i) if (p[ia + i] != q[ib + i]) { bad |= PS_ID; break; }
+  }
+  const uint32_t s1 = A.ls[4 * r + 2] - 1u - A.ls[4 * r + 1], s2 = B.ls[4 * r + 2] - 1u - B.ls[4 * r + 1];
+  mlen[r] = (unsigned long long)la + 2u + s1 + 1u + s2 + 1u;
+  if (bad) atomicOr(status, bad);
+}
+
+__global__ void __launch_bounds__(256) pair_sample_kernel(const unsigned long long* __restrict__ off, uint64_t n_rec, uint32_t stride,
+                                                          uint64_t n_samples, unsigned long long* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_samples) return;
+  const uint64_t r = i * stride;
+  out[i] = off[r < n_rec ? r : n_rec];
+}
+
+// one wavefront per record: ">id\n" seq1 "N" seq2 "\n" at off[r] - off[r0]
+__global__ void __launch_bounds__(256) pair_merge_kernel(PairText A, PairText B, uint64_t r0, uint64_t r1, const unsigned long long* __restrict__ off,
+                                                         uint8_t* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t r = r0 + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= r1) return;
+  uint8_t* o = dst + (off[r] - off[r0]);
+  const uint8_t *p, *q; uint32_t n, m;
+  pair_line(A, 4 * r, p, n);
+  uint32_t ia, la;
+  pair_id(p, n, ia, la);
+  if (lane == 0) o[0] = '>';
+  for (uint32_t i = lane; i < la; i += 64) o[1 + i] = p[ia + i];
+  if (lane == 0) o[1 + la] = '\n';
+  o += la + 2;
+  pair_line(A, 4 * r + 1, p, n);
+  for (uint32_t i = lane; i < n; i += 64) o[i] = p[i];
+  if (lane == 0) o[n] = 'N';
+  o += n + 1;
+  pair_line(B, 4 * r + 1, q, m);
+  for (uint32_t i = lane; i < m; i += 64) o[i] = q[i];
+  if (lane == 0) o[m] = '\n';
+}
+
 struct Slot {
   // pinned host
   uint8_t* h_raw = nullptr; char* h_csv = nullptr; uint32_t* h_hdr = nullptr; uint32_t* h_results = nullptr;
@@ -484,6 +561,17 @@ double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t
 
 }  // namespace
 
+struct mic_pairs {
+  PairText t[2];
+  void* d_scratch = nullptr; void* d_block = nullptr;     // the two device allocations everything below is carved from
+  uint32_t* d_ls[2] = {nullptr, nullptr};
+  unsigned long long* d_off = nullptr;          // off[r] = bytes of merged text in front of record r (n_rec + 1 entries)
+  uint64_t n_rec = 0;
+  uint32_t stride = 64;
+  std::vector<unsigned long long> samples;      // off[i * stride] for the host's batch arithmetic, then off[n_rec]
+  int device = 0;
+};
+
 // the engine keeps one Ingest* (opaque to it): mic_engine.hip
 void** mic_engine_ingest_slot(mic_engine* e);
 
@@ -566,7 +654,8 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int flags
   ITRY(hipSetDevice(dev));
   Slot& s = g->slots[slot_id];
   memset(out, 0, sizeof(*out));
-  const uint8_t first = s.h_raw[0];
+  const bool resident = (flags & MIC_INGEST_RESIDENT) != 0;      // the text is in the slot's device buffer already (mic_pairs_merge_to_slot: merged pairs)
+  const uint8_t first = resident ? (uint8_t)'>' : s.h_raw[0];
   if (first != '>' && first != '@') { out->status = MIC_INGEST_FALLBACK | MIC_INGEST_ODD_RECORD; return MIC_OK; }
   const int fasta = first == '>';
   static const bool timing = getenv("MIC_INGEST_TIMING") != nullptr;
@@ -578,9 +667,11 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int flags
   // back on its download stream (mic_engine.hip: one stream per direction keeps both directions of the link busy)
   hipStream_t up, down;
   mic_engine_copy_streams(e, &up, &down);
-  ITRY(hipMemcpyAsync(s.d_raw, s.h_raw, n_bytes, hipMemcpyHostToDevice, up));
-  ITRY(hipEventRecord(s.ev_up, up));
-  ITRY(hipStreamWaitEvent(st, s.ev_up, 0));
+  if (!resident) {
+    ITRY(hipMemcpyAsync(s.d_raw, s.h_raw, n_bytes, hipMemcpyHostToDevice, up));
+    ITRY(hipEventRecord(s.ev_up, up));
+    ITRY(hipStreamWaitEvent(st, s.ev_up, 0));
+  }
   ITRY(hipMemsetAsync(s.d_hdr, 0, H_WORDS * 4, st));
   line_count_kernel<<<n_tiles, 256, 0, st>>>(s.d_raw, nb, s.d_tile);
   ITRY(hipMemsetAsync(s.d_tile + n_tiles, 0, 4, st));
@@ -653,6 +744,156 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int flags
     fprintf(stderr, "[ingest] slot %zu: %u bytes, %u reads: lines %.0f us, pack+query+lengths %.0f us, csv %.0f us\n", slot_id, nb, n_reads,
             (t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6);
   }
+  return MIC_OK;
+}
+
+// ---- paired-end texts on the device -------------------------------------------------------------------------------------
+#define PTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    rc = mic_set_error(e_ == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+
+int mic_pairs_free(mic_engine* e, mic_pairs* p) {
+  (void)e;
+  if (!p) return MIC_OK;
+  hipSetDevice(p->device);
+  if (p->d_scratch) hipFree(p->d_scratch);
+  if (p->d_block) hipFree(p->d_block);
+  delete p;
+  return MIC_OK;
+}
+
+// Two device allocations and no hipFree on the way (each costs about a millisecond and a device-wide wait): a scratch block for the
+// line counts of both texts, then - once the numbers of lines are known - one block for everything that depends on them.
+int mic_pairs_index_device(mic_engine* e, const void* d_text1, size_t n1, const void* d_text2, size_t n2, mic_pairs** out,
+                           uint64_t* n_records, uint32_t* status) {
+  if (!e || !d_text1 || !d_text2 || !out || !n_records || !status) return mic_set_error(MIC_E_INVALID, "null argument");
+  *out = nullptr; *n_records = 0; *status = 0;
+  if (n1 == 0 || n2 == 0 || n1 >= 0xFFFFFF00ull || n2 >= 0xFFFFFF00ull) { *status = PS_BIG; return MIC_OK; }   // 32-bit line starts
+  MicTable t; int sc, ncu, dev, k; uint32_t nt;
+  int rc = mic_engine_table(e, &t, &sc, &ncu, &dev, &k, &nt);
+  if (rc) return rc;
+  if (hipSetDevice(dev) != hipSuccess) return mic_set_error(MIC_E_HIP, "hipSetDevice failed");
+  mic_pairs* p = new mic_pairs;
+  p->device = dev;
+  const uint8_t* raw[2] = {(const uint8_t*)d_text1, (const uint8_t*)d_text2};
+  const uint32_t nb[2] = {(uint32_t)n1, (uint32_t)n2};
+  const uint32_t n_tiles[2] = {(nb[0] + ING_TILE - 1) / ING_TILE, (nb[1] + ING_TILE - 1) / ING_TILE};
+  uint64_t n_lines[2] = {0, 0};
+  uint32_t nl[2] = {0, 0}; uint8_t last[2] = {0, 0};
+  hipStream_t st = nullptr;
+  uint32_t* d_tile[2]; uint32_t* d_tile_off[2]; void* d_tmp = nullptr;
+  size_t tmp_bytes = 0, tmp2 = 0;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  PTRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  {
+    size_t t0 = 0, t1 = 0;
+    PTRY(hipcub::DeviceScan::ExclusiveSum(nullptr, t0, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n_tiles[0] + 1), st));
+    PTRY(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n_tiles[1] + 1), st));
+    tmp_bytes = std::max(t0, t1);
+    const size_t a0 = up(((size_t)n_tiles[0] + 1) * 4), a1 = up(((size_t)n_tiles[1] + 1) * 4);
+    PTRY(hipMalloc(&p->d_scratch, 2 * a0 + 2 * a1 + up(tmp_bytes + 16)));
+    char* q = (char*)p->d_scratch;
+    d_tile[0] = (uint32_t*)q; q += a0; d_tile_off[0] = (uint32_t*)q; q += a0;
+    d_tile[1] = (uint32_t*)q; q += a1; d_tile_off[1] = (uint32_t*)q; q += a1;
+    d_tmp = q;
+  }
+  for (int i = 0; i < 2; ++i) {
+    line_count_kernel<<<n_tiles[i], 256, 0, st>>>(raw[i], nb[i], d_tile[i]);
+    PTRY(hipMemsetAsync(d_tile[i] + n_tiles[i], 0, 4, st));
+    size_t tb = tmp_bytes;
+    PTRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_tile[i], d_tile_off[i], (int)(n_tiles[i] + 1), st));
+    PTRY(hipMemcpyAsync(&nl[i], d_tile_off[i] + n_tiles[i], 4, hipMemcpyDeviceToHost, st));
+    PTRY(hipMemcpyAsync(&last[i], raw[i] + nb[i] - 1, 1, hipMemcpyDeviceToHost, st));
+  }
+  PTRY(hipStreamSynchronize(st));
+  for (int i = 0; i < 2; ++i) n_lines[i] = (uint64_t)nl[i] + (last[i] != '\n' ? 1 : 0);
+  if (n_lines[0] != n_lines[1] || n_lines[0] % 4 != 0 || n_lines[0] == 0) { *status = PS_LINES; goto done; }
+  {
+    const uint64_t n_rec = n_lines[0] / 4;
+    p->n_rec = n_rec;
+    const uint64_t n_samples = n_rec / p->stride + 2;
+    PTRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)(n_rec + 1), st));
+    const size_t b_ls = up((n_lines[0] + 2) * 4), b_off = up((n_rec + 1) * 8), b_smp = up(n_samples * 8);
+    PTRY(hipMalloc(&p->d_block, 2 * b_ls + 2 * b_off + b_smp + 256 + up(tmp2 + 16)));
+    char* q = (char*)p->d_block;
+    p->d_ls[0] = (uint32_t*)q; q += b_ls; p->d_ls[1] = (uint32_t*)q; q += b_ls;
+    p->d_off = (unsigned long long*)q; q += b_off;
+    unsigned long long* d_mlen = (unsigned long long*)q; q += b_off;
+    unsigned long long* d_samples = (unsigned long long*)q; q += b_smp;
+    uint32_t* d_status = (uint32_t*)q; q += 256;
+    void* d_tmp2 = q;
+    for (int i = 0; i < 2; ++i) {
+      line_start_kernel<<<n_tiles[i], 256, 0, st>>>(raw[i], nb[i], d_tile_off[i], p->d_ls[i], (uint32_t)std::min<uint64_t>(n_lines[i] + 2, 0xFFFFFFFFull));
+      PTRY(hipGetLastError());
+      if (last[i] != '\n') {                   // the virtual line end of an unterminated last line (lines_finish_kernel's convention)
+        nl[i] = nb[i] + 1;                     // (nl[] is done with; the source of an asynchronous copy has to outlive it)
+        PTRY(hipMemcpyAsync(p->d_ls[i] + n_lines[i], &nl[i], 4, hipMemcpyHostToDevice, st));
+      }
+      p->t[i].t = raw[i]; p->t[i].ls = p->d_ls[i]; p->t[i].nb = nb[i];
+    }
+    PTRY(hipMemsetAsync(d_status, 0, 4, st));
+    pair_len_kernel<<<(unsigned)((n_rec + 1 + 255) / 256), 256, 0, st>>>(p->t[0], p->t[1], n_rec, d_mlen, d_status);
+    PTRY(hipGetLastError());
+    PTRY(hipcub::DeviceScan::ExclusiveSum(d_tmp2, tmp2, d_mlen, p->d_off, (int)(n_rec + 1), st));
+    p->samples.resize(n_samples);
+    pair_sample_kernel<<<(unsigned)((n_samples + 255) / 256), 256, 0, st>>>(p->d_off, n_rec, p->stride, n_samples, d_samples);
+    PTRY(hipGetLastError());
+    PTRY(hipMemcpyAsync(p->samples.data(), d_samples, n_samples * 8, hipMemcpyDeviceToHost, st));
+    PTRY(hipMemcpyAsync(status, d_status, 4, hipMemcpyDeviceToHost, st));
+    PTRY(hipStreamSynchronize(st));
+  }
+done:
+  if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  if (rc != MIC_OK || *status) { mic_pairs_free(e, p); return rc; }
+  *out = p; *n_records = p->n_rec;
+  return MIC_OK;
+}
+
+// bytes of merged text in front of record r, for r a multiple of the stride or r == n_records
+static bool pairs_offset(const mic_pairs* p, uint64_t r, unsigned long long& off) {
+  if (r == p->n_rec) { off = p->samples.back() ; return true; }
+  if (r > p->n_rec || r % p->stride) return false;
+  off = p->samples[r / p->stride];
+  return true;
+}
+
+int mic_pairs_offsets(const mic_pairs* p, const uint64_t** samples, size_t* n_samples, uint32_t* stride) {
+  if (!p || !samples || !n_samples || !stride) return mic_set_error(MIC_E_INVALID, "null argument");
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
+  *samples = (const uint64_t*)p->samples.data(); *n_samples = p->samples.size(); *stride = p->stride;
+  return MIC_OK;
+}
+
+int mic_pairs_merge_to_slot(mic_engine* e, mic_pairs* p, uint64_t r0, uint64_t r1, size_t slot_id, size_t* n_bytes) {
+  if (!e || !p || !n_bytes) return mic_set_error(MIC_E_INVALID, "null argument");
+  Ingest* g = (Ingest*)*mic_engine_ingest_slot(e);
+  if (!g || slot_id >= g->slots.size()) return mic_set_error(MIC_E_STATE, "ingest slots are not allocated");
+  unsigned long long o0, o1;
+  if (r0 >= r1 || !pairs_offset(p, r0, o0) || !pairs_offset(p, r1, o1))
+    return mic_set_error(MIC_E_INVALID, "records [%llu, %llu): not a range of whole strides", (unsigned long long)r0, (unsigned long long)r1);
+  if (o1 - o0 > g->max_bytes) return mic_set_error(MIC_E_INVALID, "merged text of %llu bytes does not fit the slot (%zu)", o1 - o0, g->max_bytes);
+  ITRY(hipSetDevice(p->device));
+  Slot& s = g->slots[slot_id];
+  pair_merge_kernel<<<(unsigned)((r1 - r0 + 3) / 4), 256, 0, s.stream>>>(p->t[0], p->t[1], r0, r1, p->d_off, s.d_raw);
+  ITRY(hipGetLastError());
+  *n_bytes = (size_t)(o1 - o0);
+  return MIC_OK;
+}
+
+int mic_pairs_text(mic_engine* e, mic_pairs* p, uint64_t r0, uint64_t r1, void* host_dst, size_t cap, size_t* n_bytes) {
+  if (!e || !p || !host_dst || !n_bytes) return mic_set_error(MIC_E_INVALID, "null argument");
+  unsigned long long o0, o1;
+  if (r0 >= r1 || !pairs_offset(p, r0, o0) || !pairs_offset(p, r1, o1))
+    return mic_set_error(MIC_E_INVALID, "records [%llu, %llu): not a range of whole strides", (unsigned long long)r0, (unsigned long long)r1);
+  *n_bytes = (size_t)(o1 - o0);
+  if (*n_bytes > cap) return mic_set_error(MIC_E_INVALID, "merged text of %zu bytes does not fit the buffer (%zu)", *n_bytes, cap);
+  ITRY(hipSetDevice(p->device));
+  uint8_t* d = nullptr;
+  ITRY(hipMalloc(&d, *n_bytes + 16));
+  pair_merge_kernel<<<(unsigned)((r1 - r0 + 3) / 4), 256, 0, 0>>>(p->t[0], p->t[1], r0, r1, p->d_off, d);
+  hipError_t he = hipGetLastError();
+  if (he == hipSuccess) he = hipMemcpy(host_dst, d, *n_bytes, hipMemcpyDeviceToHost);
+  hipFree(d);
+  ITRY(he);
   return MIC_OK;
 }
 

@@ -178,6 +178,53 @@ class MiClarkDB:
             self.L.mic_gz_free_text(self.h, d_text)
         return out.tobytes(), int(crc.value)
 
+    def gunzip_device(self, gz_bytes):
+        """As gunzip, but the text stays on the device: (device pointer, size, crc32); free_text() releases it."""
+        buf = np.frombuffer(gz_bytes, np.uint8)
+        d_text, n, crc = C.c_void_p(), C.c_size_t(0), C.c_uint32(0)
+        rc = self.L.mic_gz_inflate_device(self.h, buf.ctypes.data, buf.size, C.byref(d_text), C.byref(n), C.byref(crc))
+        if rc == -7:
+            raise MiClarkUnsupported(self.L.mic_last_error().decode())
+        check(rc)
+        return d_text.value, int(n.value), int(crc.value)
+
+    def free_text(self, d_text):
+        self.L.mic_gz_free_text(self.h, d_text)
+
+    # -- paired-end FASTQ texts on the device: the reference's merge (file.cc:205-268) without the host (mic_pairs_*)
+    def pairs_index(self, d_text1, n1, d_text2, n2):
+        """Returns (handle, n_records, offsets, stride), or (None, status, None, None) when the texts need the host reader."""
+        h, n, st = C.c_void_p(), C.c_uint64(0), C.c_uint32(0)
+        check(self.L.mic_pairs_index_device(self.h, d_text1, n1, d_text2, n2, C.byref(h), C.byref(n), C.byref(st)))
+        if st.value:
+            return None, int(st.value), None, None
+        sp, ns, stride = C.POINTER(C.c_uint64)(), C.c_size_t(0), C.c_uint32(0)
+        check(self.L.mic_pairs_offsets(h, C.byref(sp), C.byref(ns), C.byref(stride)))
+        off = np.ctypeslib.as_array(sp, shape=(ns.value,)).copy()
+        return h, int(n.value), off, int(stride.value)
+
+    def pairs_text(self, handle, r0, r1, cap=1 << 30):
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t(0)
+        check(self.L.mic_pairs_text(self.h, handle, r0, r1, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].tobytes()
+
+    def pairs_classify(self, handle, slot, r0, r1):
+        """Records [r0, r1) merged into the slot on the device and classified there: as ingest_classify(paired=True)."""
+        n = C.c_size_t(0)
+        check(self.L.mic_pairs_merge_to_slot(self.h, handle, r0, r1, slot, C.byref(n)))
+        out = _lib.MicIngestResult()
+        check(self.L.mic_ingest_classify(self.h, slot, n.value, 1 | 4, C.byref(out)))
+        r = dict(status=int(out.status), n_reads=int(out.n_reads), n_lines=int(out.n_lines), csv=None, results=None, n_bytes=int(n.value))
+        if out.status == 0:
+            r["csv"] = C.string_at(out.csv, out.csv_bytes) if out.csv_bytes else b""
+            if out.results:
+                r["results"] = _as_np(out.results, (int(out.n_reads), MIC_RESULT_WORDS), np.uint32).copy()
+        return r
+
+    def pairs_free(self, handle):
+        self.L.mic_pairs_free(self.h, handle)
+
     # -- device-side ingest: raw FASTA/FASTQ bytes -> CSV text (mic_ingest_*)
     def ingest_alloc(self, n_slots, max_bytes, target_names, want_results=False):
         names = (C.c_char_p * len(target_names))(*[t.encode() for t in target_names])

@@ -238,6 +238,8 @@ int mic_last_query_ms(mic_engine* e, float* ms);
 #define MIC_INGEST_PAIRED 1        /* flags: objects are merged pairs: Length column minus the separator (CuCLARK_hh.hh:2119)        */
 #define MIC_INGEST_FASTQ_2LINE 2   /* flags: FASTQ records come as header + sequence line only (the caller dropped the '+' and
                                       quality lines, which nothing reads: halves the bytes that cross the host link)           */
+#define MIC_INGEST_RESIDENT 4       /* flags: the slot's DEVICE buffer already holds the n_bytes of merged paired-end text
+                                      (mic_pairs_merge_to_slot): nothing is uploaded                                            */
 #define MIC_INGEST_OK 0u
 #define MIC_INGEST_FALLBACK 1u     /* run the host path on this batch                                        */
 #define MIC_INGEST_ODD_RECORD 2u   /* empty read name, FASTA record without a sequence line, unknown format   */
@@ -271,6 +273,43 @@ int mic_ingest_free(mic_engine* e);
 int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_bytes, void** d_text, size_t* n_text, uint32_t* crc32_expected);
 int mic_gz_copy_text(mic_engine* e, const void* d_text, size_t offset, size_t n, void* host_dst);
 int mic_gz_free_text(mic_engine* e, void* d_text);
+/* mic_gz_reserve: the device buffers of one mic_gz_inflate_device call for a file of gz_bytes bytes whose trailer says isize
+ * (the last four bytes of the file), set up ahead of it - a fresh gigabyte of device memory takes the driver as long as the decode
+ * does; the command line reserves while its database loads, as it does with its ingest slots (CuClarkDB::malloc's place in the
+ * reference: CuCLARK_hh.hh:1600-1606).  The next call for a file of exactly this size uses them; mic_gz_release (also part of
+ * mic_destroy) frees what the engine's reservations still hold.  mic_gz_reserve_bytes: what a reservation takes, for
+ * mic_db_reserve_hbm. */
+int mic_gz_reserve(mic_engine* e, size_t gz_bytes, uint32_t isize);
+uint64_t mic_gz_reserve_bytes(size_t gz_bytes, uint32_t isize);
+int mic_gz_release(mic_engine* e);
+
+/* ---- paired-end FASTQ texts that are on the device already (inflated there): the reference's merge, on the device ----
+ * file.cc:205-268 (mergePairedFiles) writes ">id\nseq1Nseq2\n" per pair of records, id = the header's first field between
+ * the separators ' ', '/', '\t', '@' (file.cc:224), both ids equal.  The command line's loaders do that on the host for
+ * files (classifier.cpp: PairedFileFeeder); for two texts in device memory (mic_gz_inflate_device of both mates):
+ * mic_pairs_index_device  line index of both texts, every pair of records checked, the offsets of the merged records.
+ *                         *status != 0 (MIC_PAIRS_*): these files are not what the line arithmetic covers - line counts that
+ *                         differ or are no multiple of four, a header line without '@', ids that differ or are empty, a text
+ *                         of 4 GiB or more; nothing is returned and the caller runs its host reader, which treats such
+ *                         input the way the reference does.  The texts must stay allocated while the handle lives
+ *                         (16 readable bytes behind each: mic_gz_inflate_device's buffers have them).
+ * mic_pairs_offsets       host array: bytes of merged text in front of record i * stride (last entry: in front of record
+ *                         n_records = the whole text), from which the caller cuts batches that fit its slots.
+ * mic_pairs_merge_to_slot the merged text of records [r0, r1) written into an ingest slot's device buffer on the slot's
+ *                         stream (r0 and r1 multiples of the stride, or n_records); then mic_ingest_classify(slot, *n_bytes,
+ *                         MIC_INGEST_PAIRED | MIC_INGEST_RESIDENT).
+ * mic_pairs_text          the same text copied to the host (for a batch the device path hands back).                  */
+#define MIC_PAIRS_LINES 1u     /* line counts differ, are zero or no multiple of four */
+#define MIC_PAIRS_HEADER 2u    /* a record whose first line is empty or has no '@' in front */
+#define MIC_PAIRS_ID 4u        /* ids of a pair differ, or are empty */
+#define MIC_PAIRS_BIG 8u       /* a text of 4 GiB or more (32-bit line starts), or an empty one */
+typedef struct mic_pairs mic_pairs;
+int mic_pairs_index_device(mic_engine* e, const void* d_text1, size_t n1, const void* d_text2, size_t n2, mic_pairs** out,
+                           uint64_t* n_records, uint32_t* status);
+int mic_pairs_offsets(const mic_pairs* p, const uint64_t** samples, size_t* n_samples, uint32_t* stride);
+int mic_pairs_merge_to_slot(mic_engine* e, mic_pairs* p, uint64_t r0, uint64_t r1, size_t slot, size_t* n_bytes);
+int mic_pairs_text(mic_engine* e, mic_pairs* p, uint64_t r0, uint64_t r1, void* host_dst, size_t cap, size_t* n_bytes);
+int mic_pairs_free(mic_engine* e, mic_pairs* p);
 
 /* "%g" of (double)num / den for 0 < num <= den, by the integer-only formatter the device CSV kernel uses
  * (csrc/mic_fmt.h); writes at most 14 characters and a terminator, returns the length. */

@@ -443,3 +443,61 @@ def test_paired_files_merged_by_the_loaders_equal_the_serial_reader(tmp_path):
         for env in (dict(os.environ, MIC_SERIAL_PAIRS="1"), dict(os.environ, MIC_INGEST_KB="16")):
             r = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", os.path.join(tmp, "bad"), "-n", "3"], env=env)
             assert r.returncode != 0 and "read id does not match between files" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_compressed_mates_inflated_and_merged_on_the_device_equal_the_host_path(tmp_path):
+    """-P a.fq.gz b.fq.gz: both files are inflated on the device (mic_gz_inflate_device), paired up and merged there (mic_pairs_*),
+    the batches never cross the link as text; MIC_GZ_HOST=1 keeps the host inflater and the loaders' merge.  Same CSV over tiny and
+    large batches, CRLF and a last line without its end; files the device path does not take (two gzip members, mates with unequal
+    record counts or ids that differ) go through the host path and end as they did before."""
+    import gzip
+    import numpy as np
+    import test_ingest as ti
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "light_k27_u32", light=True)
+    t = _targets_file(tmp)
+    rng = np.random.default_rng(29)
+    genomes = ti._genomes()
+    cases = {"plain": _pair_files(rng, genomes, 6000), "crlf": _pair_files(rng, genomes, 700, crlf=True)}
+    a, b = _pair_files(rng, genomes, 500)
+    last = genomes[0][1000:1100]             # (a last record with an empty quality line would lose a whole line with its line end)
+    cases["no_last_eol"] = (a + b"@last/1\n" + last + b"\n+\n" + b"I" * 100, b + b"@last/2\n" + last[::-1] + b"\n+\n" + b"I" * 100)
+    a, b = _pair_files(rng, genomes, 600)
+    cases["unequal"] = (a, b"\n".join(b.split(b"\n")[:4 * 450]) + b"\n")
+    a, b = _pair_files(rng, genomes, 900)
+    cases["two_members"] = (a, b)
+    for name, (f1, f2) in cases.items():
+        p1, p2 = os.path.join(tmp, name + "_1.fq.gz"), os.path.join(tmp, name + "_2.fq.gz")
+        open(p1, "wb").write(gzip.compress(f1, 1))
+        open(p2, "wb").write(gzip.compress(f2, 6) if name != "two_members" else gzip.compress(f2[:len(f2) // 2]) + gzip.compress(f2[len(f2) // 2:]))
+        ref = os.path.join(tmp, "host_" + name)
+        r0 = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", ref, "-n", "4"], env=dict(os.environ, MIC_GZ_HOST="1", MIC_CLI_TIMING="1"))
+        assert r0.returncode == 0 and "device inflate" not in r0.stderr, r0.stderr
+        n_obj = re.search(r"\((\d+) objects\)", r0.stdout).group(1)
+        for kb, n in (("16", "4"), ("300", "6"), ("0", "3")):
+            out = os.path.join(tmp, f"dev{kb}_{name}")
+            env = dict(os.environ, MIC_CLI_TIMING="1")
+            if kb != "0":
+                env["MIC_INGEST_KB"] = kb
+            r = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", out, "-n", n], env=env)
+            assert r.returncode == 0, r.stderr
+            assert f"({n_obj} objects)" in r.stdout and r.stdout.count("Assignment time") == 1
+            assert open(out + ".csv", "rb").read() == open(ref + ".csv", "rb").read(), (name, kb)
+            if name in ("plain", "crlf", "no_last_eol"):
+                assert re.search(r"device inflate: [\d.]+ MB of text", r.stderr), r.stderr
+                assert re.search(r"over the link 0 MB", r.stderr), r.stderr            # no text went up
+                if kb == "16" and name == "plain":
+                    assert int(re.search(r"device ingest: (\d+) batches", r.stderr).group(1)) > 8, r.stderr
+            else:
+                assert "device inflate: not used" in r.stderr, r.stderr
+    # ids that differ: refused by the device's check, then the host readers stop with the reference's message
+    a, b = _pair_files(rng, genomes, 300)
+    b2 = b.replace(b"@p7/2", b"@p8/2").replace(b"@pair_7 ", b"@pair_8 ").replace(b"@q7\t", b"@q8\t").replace(b"@z7\n", b"@z8\n")
+    if b2 != b:
+        p1, p2 = os.path.join(tmp, "bad_1.fq.gz"), os.path.join(tmp, "bad_2.fq.gz")
+        open(p1, "wb").write(gzip.compress(a))
+        open(p2, "wb").write(gzip.compress(b2))
+        r = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", os.path.join(tmp, "bad"), "-n", "3"], env=dict(os.environ, MIC_CLI_TIMING="1"))
+        assert r.returncode != 0 and "read id does not match between files" in (r.stderr + r.stdout)
+        assert "device inflate: not used" in r.stderr

@@ -102,3 +102,27 @@ def test_what_the_path_does_not_take(engine):
     bad[-2] ^= 1                                                   # ISIZE wrong
     with pytest.raises((MiClarkUnsupported, MicError)):
         engine.gunzip(bytes(bad))
+
+
+def test_buffers_reserved_ahead_of_the_call(engine):
+    """mic_gz_reserve: the call for a file of the reserved size runs out of the reservation (text buffer included) and gives the same
+    bytes; a file of another size, a second call for the same size and a file whose blocks are smaller than the reservation assumed
+    (more windows than it holds) allocate for themselves."""
+    import struct
+    rng = np.random.default_rng(77)
+    data = _fastq(rng, 40000)
+    small_blocks = zlib.compressobj(1, zlib.DEFLATED, 31, 1)            # memLevel 1: a block every 127 symbols' worth of codes
+    gz_small = small_blocks.compress(data[:3_000_000]) + small_blocks.flush()
+    for gz, want in ((_gz(data, 1), data), (gz_small, data[:3_000_000])):
+        isize = struct.unpack("<I", gz[-4:])[0]
+        assert engine.L.mic_gz_reserve_bytes(len(gz), isize) > len(want)
+        assert engine.L.mic_gz_reserve(engine.h, len(gz), isize) == 0
+        for _ in range(2):
+            text, crc = engine.gunzip(gz)
+            assert text == want and crc == zlib.crc32(want)
+        other = _gz(data[:-316], 1)
+        text, _ = engine.gunzip(other)
+        assert text == data[:-316]
+        assert engine.L.mic_gz_release(engine.h) == 0
+        text, _ = engine.gunzip(gz)
+        assert text == want

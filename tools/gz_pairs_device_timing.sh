@@ -1,0 +1,16 @@
+#!/bin/bash
+# -P a.fq.gz b.fq.gz with the mates inflated and merged on the device against the host inflater (MIC_GZ_HOST=1):
+#   tools/gz_pairs_device_timing.sh [pairs]
+set -e
+N=${1:-1000000}
+D=/tmp/gzpd; rm -rf $D; mkdir -p $D
+python tools/make_synth_files.py $D --light --reads $N --kmers 60000000 --paired > $D/make.log 2>&1 || { tail -5 $D/make.log; exit 1; }
+for i in 1 2; do gzip -1 -k $D/reads_$i.fq; done
+ls -la $D/reads_1.fq $D/reads_1.fq.gz | awk '{print $5, $9}'
+echo "== host inflate"
+for rep in 1 2; do MIC_GZ_HOST=1 MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -P $D/reads_1.fq.gz $D/reads_2.fq.gz -R $D/host -n 12 2>&1 | grep -E "Assignment|inflate|device ingest" | sed 's/thread-seconds.*ms since start/.. ms since start/'; done
+echo "== device inflate"
+if [ -n "$GZ_TIMING" ]; then export MIC_GZ_TIMING=1; fi
+for rep in 1 2 3; do MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -P $D/reads_1.fq.gz $D/reads_2.fq.gz -R $D/dev -n 12 2>&1 | grep -E "Assignment|inflate|device ingest|^\[gz\]" | sed 's/thread-seconds.*ms since start/.. ms since start/'; done
+cmp $D/host.csv $D/dev.csv && echo "CSVs identical"
+rm -rf $D

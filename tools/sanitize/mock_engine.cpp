@@ -93,4 +93,15 @@ int mic_batch_wait(mic_engine*, size_t) { return MIC_E_NODEVICE; }
 int mic_batch_dense_counts(mic_engine*, size_t, size_t, uint32_t*) { return MIC_E_NODEVICE; }
 int mic_batch_merge_shards(mic_engine* const*, size_t, size_t) { return MIC_E_NODEVICE; }
 int mic_batches_free(mic_engine*) { return MIC_OK; }
+// compressed mates on the device: the mock has none, the command line inflates on the host
+int mic_gz_inflate_device(mic_engine*, const void*, size_t, void**, size_t*, uint32_t*) { return MIC_E_UNSUPPORTED; }
+int mic_gz_free_text(mic_engine*, void*) { return MIC_OK; }
+int mic_gz_reserve(mic_engine*, size_t, uint32_t) { return MIC_E_NODEVICE; }
+uint64_t mic_gz_reserve_bytes(size_t, uint32_t) { return 0; }
+int mic_gz_release(mic_engine*) { return MIC_OK; }
+int mic_pairs_index_device(mic_engine*, const void*, size_t, const void*, size_t, mic_pairs**, uint64_t*, uint32_t*) { return MIC_E_NODEVICE; }
+int mic_pairs_offsets(const mic_pairs*, const uint64_t**, size_t*, uint32_t*) { return MIC_E_NODEVICE; }
+int mic_pairs_merge_to_slot(mic_engine*, mic_pairs*, uint64_t, uint64_t, size_t, size_t*) { return MIC_E_NODEVICE; }
+int mic_pairs_text(mic_engine*, mic_pairs*, uint64_t, uint64_t, void*, size_t, size_t*) { return MIC_E_NODEVICE; }
+int mic_pairs_free(mic_engine*, mic_pairs*) { return MIC_OK; }
 }
