@@ -103,6 +103,11 @@ SYMBOLS = [
     ("mic_pairs_merge_to_slot", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _SZ, C.POINTER(_SZ)]),
     ("mic_pairs_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
     ("mic_pairs_free", C.c_int, [_VP, _VP]),
+    ("mic_text_index_device", C.c_int, [_VP, _VP, _SZ, C.POINTER(_VP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    ("mic_text_offsets", C.c_int, [_VP, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(_SZ), C.POINTER(C.c_uint32)]),
+    ("mic_text_to_slot", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _SZ, C.POINTER(_SZ)]),
+    ("mic_text_copy", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
+    ("mic_text_free", C.c_int, [_VP, _VP]),
     ("mic_format_ratio_g", C.c_int, [C.c_uint32, C.c_uint32, C.c_char_p]),
     ("mic_key_bytes_rule", C.c_int, [C.c_uint64, C.c_int]),
     ("mic_index_reads", C.c_long, [_VP, _SZ, _SZ, _U64P, _U64P, _U64P, _U64P, _U64P]),

@@ -172,9 +172,12 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
     // two compressed mates on one engine are inflated on the device (run_paired): the buffers of that are set up here as well
     struct GzFile { size_t bytes; uint32_t isize; };
     std::vector<GzFile> gz;
-    if (engines_.size() == 1 && !opt_.objects2.empty() && is_gzip(opt_.objects) && is_gzip(opt_.objects2) && !getenv("MIC_SERIAL_PAIRS") &&
-        !getenv("MIC_GZ_HOST")) {
-      for (const std::string* f : {&opt_.objects, &opt_.objects2}) {
+    const bool gz_pair = !opt_.objects2.empty() && is_gzip(opt_.objects) && is_gzip(opt_.objects2) && !getenv("MIC_SERIAL_PAIRS");
+    const bool gz_single = opt_.objects2.empty() && is_gzip(opt_.objects);
+    if (engines_.size() == 1 && (gz_pair || gz_single) && !getenv("MIC_GZ_HOST")) {
+      std::vector<const std::string*> files = {&opt_.objects};
+      if (gz_pair) files.push_back(&opt_.objects2);
+      for (const std::string* f : files) {
         const int fd = open(f->c_str(), O_RDONLY);
         uint8_t t[4];
         if (fd != -1 && fstat(fd, &st) == 0 && st.st_size > 18 && pread(fd, t, 4, st.st_size - 4) == 4)
@@ -992,19 +995,20 @@ class PairedFileFeeder : public Classifier::Feeder {
   std::vector<uint8_t> scan_;
 };
 
-// Both mates gzip-compressed, one engine: the files are inflated ON the device (mic_gz_inflate_device, both at once), indexed and
-// checked there (mic_pairs_index_device), and every batch is merged straight into its ingest slot's device buffer
-// (mic_pairs_merge_to_slot: the reference's merge, file.cc:205-268) - the compressed bytes are all that crosses the link.
-// Whatever the device path does not take (several gzip members, block gzip, mates whose lines or ids do not pair up, texts of
-// 4 GiB or more) leaves ok() false and the caller inflates on the host as before.  Ranges count RECORDS: off = first, len = number.
-class DevicePairFeeder : public Classifier::Feeder {
+// Gzip-compressed FASTQ on one engine: the file - or both mates of a pair at once - is inflated ON the device
+// (mic_gz_inflate_device), indexed and checked there, and every batch gets into its ingest slot's device buffer without leaving the
+// device: a pair merged the way the reference merges it (mic_pairs_merge_to_slot; file.cc:205-268), a single file's records copied
+// (mic_text_to_slot).  The compressed bytes are all that crosses the link.  Whatever the device path does not take (several gzip
+// members, block gzip, FASTA, mates whose lines or ids do not pair up, texts of 4 GiB or more) leaves ok() false and the caller
+// inflates on the host as before.  Ranges count RECORDS: off = first, len = number.
+class DeviceGzFeeder : public Classifier::Feeder {
  public:
-  DevicePairFeeder(mic_engine* e, const std::string& f1, const std::string& f2) : e_(e) {
+  DeviceGzFeeder(mic_engine* e, const std::string& f1, const std::string& f2) : e_(e), paired_(!f2.empty()) {
     const bool timing = getenv("MIC_CLI_TIMING") != nullptr;
     struct timeval t0, t1, t2;
     gettimeofday(&t0, nullptr);
     const std::string* names[2] = {&f1, &f2};
-    int rc[2] = {MIC_E_UNSUPPORTED, MIC_E_UNSUPPORTED};
+    int rc[2] = {MIC_E_UNSUPPORTED, paired_ ? MIC_E_UNSUPPORTED : MIC_OK};
     auto inflate = [&](int i) {
       const int fd = open(names[i]->c_str(), O_RDONLY);
       struct stat st;
@@ -1019,41 +1023,52 @@ class DevicePairFeeder : public Classifier::Feeder {
       }
       close(fd);
     };
-    std::thread other([&] { inflate(1); });
+    std::thread other;
+    if (paired_) other = std::thread([&] { inflate(1); });
     inflate(0);
-    other.join();
+    if (other.joinable()) other.join();
     gettimeofday(&t1, nullptr);
-    if (rc[0] != MIC_OK || rc[1] != MIC_OK) { why_ = "the device inflater does not take these files"; return; }
+    if (rc[0] != MIC_OK || rc[1] != MIC_OK) { why_ = "the device inflater does not take this file"; return; }
     uint32_t status = 0;
-    if (mic_pairs_index_device(e_, text_[0], n_[0], text_[1], n_[1], &pairs_, &n_rec_, &status) != MIC_OK || status || !pairs_) {
-      why_ = "the mates do not pair up line by line";
-      return;
-    }
     const uint64_t* s = nullptr; size_t ns = 0;
-    if (mic_pairs_offsets(pairs_, &s, &ns, &stride_) != MIC_OK || ns < 2) return;
+    if (paired_) {
+      if (mic_pairs_index_device(e_, text_[0], n_[0], text_[1], n_[1], &pairs_, &n_rec_, &status) != MIC_OK || status || !pairs_) {
+        why_ = "the mates do not pair up line by line";
+        return;
+      }
+      if (mic_pairs_offsets(pairs_, &s, &ns, &stride_) != MIC_OK || ns < 2) return;
+    } else {
+      if (mic_text_index_device(e_, text_[0], n_[0], &single_, &n_rec_, &status) != MIC_OK || status || !single_) {
+        why_ = "not FASTQ records of four lines";
+        return;
+      }
+      if (mic_text_offsets(single_, &s, &ns, &stride_) != MIC_OK || ns < 2) return;
+    }
     off_.assign(s, s + ns);
     gettimeofday(&t2, nullptr);
     if (timing)
       std::cerr << "[timing] device inflate: " << (n_[0] + n_[1]) / 1e6 << " MB of text in "
-                << ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_usec - t0.tv_usec) / 1e3) << " ms, " << n_rec_ << " pairs indexed and checked in "
-                << ((t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_usec - t1.tv_usec) / 1e3) << " ms" << std::endl;
+                << ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_usec - t0.tv_usec) / 1e3) << " ms, " << n_rec_ << (paired_ ? " pairs" : " records")
+                << " indexed and checked in " << ((t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_usec - t1.tv_usec) / 1e3) << " ms" << std::endl;
     ok_ = true;
   }
-  ~DevicePairFeeder() override {
+  ~DeviceGzFeeder() override {
     if (pairs_) mic_pairs_free(e_, pairs_);
+    if (single_) mic_text_free(e_, single_);
     for (void* t : text_) if (t) mic_gz_free_text(e_, t);
   }
   bool ok() const { return ok_; }
   const char* why() const { return why_; }
-  uint64_t merged_bytes() const { return off_.empty() ? 0 : off_.back(); }
-  bool fastq() const override { return false; }          // what the slots get is the merged FASTA text
+  uint64_t text_bytes() const { return off_.empty() ? 0 : off_.back(); }
+  bool fastq() const override { return false; }          // (nothing for the loaders to strip: the slots are filled on the device)
   bool resident() const override { return true; }
+  int resident_flags() const override { return paired_ ? MIC_INGEST_RESIDENT : MIC_INGEST_RESIDENT_FASTQ; }
   uint64_t remaining() const override { return off_.back() - off_[cur_]; }
 
   bool assign(size_t want, size_t cap, Classifier::Range& r) override {
     if (rec_of(cur_) >= n_rec_) return false;
     const uint64_t limit = std::min<uint64_t>(want, cap - cap / 16);
-    // the last boundary whose merged text still fits (at least one stride: a stride that does not fit is handed to the host path)
+    // the last boundary whose text still fits (at least one stride: a stride that does not fit is handed to the host path)
     size_t hi = (size_t)(std::upper_bound(off_.begin() + (ptrdiff_t)cur_, off_.end(), off_[cur_] + limit) - off_.begin()) - 1;
     if (hi <= cur_) hi = cur_ + 1;
     while (hi + 1 < off_.size() && rec_of(hi) == rec_of(cur_)) ++hi;
@@ -1064,27 +1079,33 @@ class DevicePairFeeder : public Classifier::Feeder {
   void read(const Classifier::Range&, size_t, uint8_t*, size_t) override { die("device-resident ranges are filled on the device"); }
   size_t fill_resident(const Classifier::Range& r, mic_engine* e, size_t slot) override {
     size_t n = 0;
-    if (e != e_ || mic_pairs_merge_to_slot(e_, pairs_, r.off, r.off + r.len, slot, &n) != MIC_OK) return (size_t)-1;
-    return n;
+    if (e != e_) return (size_t)-1;
+    const int rc = paired_ ? mic_pairs_merge_to_slot(e_, pairs_, r.off, r.off + r.len, slot, &n) : mic_text_to_slot(e_, single_, r.off, r.off + r.len, slot, &n);
+    return rc == MIC_OK ? n : (size_t)-1;
   }
   size_t fill(const Classifier::Range& r, uint8_t* dst, size_t cap) override {
     size_t n = 0;
-    return mic_pairs_text(e_, pairs_, r.off, r.off + r.len, dst, cap, &n) == MIC_OK ? n : (size_t)-1;
+    return to_host(r, dst, cap, n) == MIC_OK ? n : (size_t)-1;
   }
   void text(const Classifier::Range& r, std::string& out) override {
     const uint64_t a = r.off / stride_, b = r.off + r.len >= n_rec_ ? off_.size() - 1 : (r.off + r.len) / stride_;
     out.resize((size_t)(off_[b] - off_[a]));
     size_t n = 0;
-    if (!out.empty()) check(mic_pairs_text(e_, pairs_, r.off, r.off + r.len, &out[0], out.size(), &n), "merged text of a batch");
+    if (!out.empty()) check(to_host(r, &out[0], out.size(), n), "text of a batch");
     out.resize(n);
   }
 
  private:
+  int to_host(const Classifier::Range& r, void* dst, size_t cap, size_t& n) {
+    return paired_ ? mic_pairs_text(e_, pairs_, r.off, r.off + r.len, dst, cap, &n) : mic_text_copy(e_, single_, r.off, r.off + r.len, dst, cap, &n);
+  }
   uint64_t rec_of(size_t i) const { return std::min<uint64_t>((uint64_t)i * stride_, n_rec_); }
   mic_engine* e_;
+  bool paired_;
   void* text_[2] = {nullptr, nullptr};
   size_t n_[2] = {0, 0};
   mic_pairs* pairs_ = nullptr;
+  mic_text* single_ = nullptr;
   uint64_t n_rec_ = 0;
   uint32_t stride_ = 64;
   std::vector<uint64_t> off_;
@@ -1125,6 +1146,20 @@ void Classifier::run(const std::string& objects, const std::string& results) {
       // inflate up front (all threads), then the plain-file path on the inflated text
       struct timeval ta, tb;
       gettimeofday(&ta, nullptr);
+      if (engines_.size() == 1 && !getenv("MIC_GZ_HOST")) {
+        // inflated on the device, its FASTQ records handed to the ingest slots there (MIC_GZ_HOST=1: on the host, below)
+        DeviceGzFeeder feed(engines_[0], obj, "");
+        if (feed.ok()) {
+          gettimeofday(&tb, nullptr);
+          prelude_s_ = (tb.tv_sec - ta.tv_sec) + (tb.tv_usec - ta.tv_usec) / 1e6;
+          run_stream(feed, res, false, (size_t)feed.text_bytes());
+          prelude_s_ = 0;
+          mic_gz_release(engines_[0]);
+          return;
+        }
+        if (getenv("MIC_CLI_TIMING")) std::cerr << "[timing] device inflate: not used (" << feed.why() << ")" << std::endl;
+        mic_gz_release(engines_[0]);
+      }
       InflatedFile inf;
       const int rc = inf.inflate(obj, inflate_threads(opt_.threads, 1));
       if (rc < 0) die("Failed to uncompress input objects.");
@@ -1195,15 +1230,18 @@ void Classifier::run_paired(const std::string& f1, const std::string& f2, const 
       // both mates compressed: inflated, paired up and merged on the device (MIC_GZ_HOST=1: on the host, below)
       struct timeval ta, tb;
       gettimeofday(&ta, nullptr);
-      DevicePairFeeder feed(engines_[0], a, b);
+      DeviceGzFeeder feed(engines_[0], a, b);
       if (feed.ok()) {
         gettimeofday(&tb, nullptr);
         prelude_s_ = (tb.tv_sec - ta.tv_sec) + (tb.tv_usec - ta.tv_usec) / 1e6;
-        const bool done = run_stream(feed, res, true, (size_t)feed.merged_bytes());
+        const bool done = run_stream(feed, res, true, (size_t)feed.text_bytes());
         prelude_s_ = 0;
         mic_gz_release(engines_[0]);
         if (done) return;
-      } else if (getenv("MIC_CLI_TIMING")) std::cerr << "[timing] device inflate: not used (" << feed.why() << ")" << std::endl;
+      } else {
+        if (getenv("MIC_CLI_TIMING")) std::cerr << "[timing] device inflate: not used (" << feed.why() << ")" << std::endl;
+        mic_gz_release(engines_[0]);
+      }
     }
     if (device_ingest() && (is_gzip(a) || is_gzip(b)) && !getenv("MIC_SERIAL_PAIRS")) {
       // compressed mates: both inflated up front and at the same time, then merged by the loaders like plain files
@@ -1648,7 +1686,7 @@ bool Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
           it.n = w;
         } else {
           size_t got;
-          if (feed.resident()) { got = feed.fill_resident(it.r, engines_[slots[it.slot].eng], slots[it.slot].slot); it.flags |= MIC_INGEST_RESIDENT; }
+          if (feed.resident()) { got = feed.fill_resident(it.r, engines_[slots[it.slot].eng], slots[it.slot].slot); it.flags |= feed.resident_flags(); }
           else got = feed.fill(it.r, dst, cap);
           if (got == (size_t)-1) it.host = true; else it.n = got;
         }

@@ -72,6 +72,7 @@ class Classifier {
     // a feeder whose text is on the device already writes a range into an ingest slot's DEVICE buffer (returns its size, (size_t)-1
     // when the range has to go through the host path); the batch is then classified with MIC_INGEST_RESIDENT
     virtual bool resident() const { return false; }
+    virtual int resident_flags() const { return MIC_INGEST_RESIDENT; }
     virtual size_t fill_resident(const Range&, mic_engine*, size_t /*slot*/) { return (size_t)-1; }
     virtual bool gave_up() const { return false; }           // the input is not what the feeder can cut: run the serial reader instead
   };

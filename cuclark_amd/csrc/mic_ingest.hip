@@ -395,6 +395,16 @@ __global__ void __launch_bounds__(256) pair_sample_kernel(const unsigned long lo
   out[i] = off[r < n_rec ? r : n_rec];
 }
 
+// a single FASTQ text: out[i] = byte offset of record min(i * stride, n_rec) (line 4 r; behind the last record: the end of the text)
+__global__ void __launch_bounds__(256) text_sample_kernel(const uint32_t* __restrict__ ls, uint32_t nb, uint64_t n_rec, uint32_t stride,
+                                                          uint64_t n_samples, unsigned long long* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_samples) return;
+  const uint64_t r = i * stride < n_rec ? i * stride : n_rec;
+  const uint32_t o = ls[4 * r];
+  out[i] = o < nb ? o : nb;
+}
+
 // one wavefront per record: ">id\n" seq1 "N" seq2 "\n" at off[r] - off[r0]
 __global__ void __launch_bounds__(256) pair_merge_kernel(PairText A, PairText B, uint64_t r0, uint64_t r1, const unsigned long long* __restrict__ off,
                                                          uint8_t* __restrict__ dst) {
@@ -561,6 +571,16 @@ double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t
 
 }  // namespace
 
+struct mic_text {
+  const uint8_t* t = nullptr; uint32_t nb = 0;
+  void* d_scratch = nullptr; void* d_block = nullptr;
+  uint32_t* d_ls = nullptr;
+  uint64_t n_rec = 0;
+  uint32_t stride = 64;
+  std::vector<unsigned long long> samples;      // byte offset of record i * stride, then the size of the text
+  int device = 0;
+};
+
 struct mic_pairs {
   PairText t[2];
   void* d_scratch = nullptr; void* d_block = nullptr;     // the two device allocations everything below is carved from
@@ -655,7 +675,7 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int flags
   Slot& s = g->slots[slot_id];
   memset(out, 0, sizeof(*out));
   const bool resident = (flags & MIC_INGEST_RESIDENT) != 0;      // the text is in the slot's device buffer already (mic_pairs_merge_to_slot: merged pairs)
-  const uint8_t first = resident ? (uint8_t)'>' : s.h_raw[0];
+  const uint8_t first = resident ? (uint8_t)((flags & MIC_INGEST_RESIDENT_FASTQ) == MIC_INGEST_RESIDENT_FASTQ ? '@' : '>') : s.h_raw[0];
   if (first != '>' && first != '@') { out->status = MIC_INGEST_FALLBACK | MIC_INGEST_ODD_RECORD; return MIC_OK; }
   const int fasta = first == '>';
   static const bool timing = getenv("MIC_INGEST_TIMING") != nullptr;
@@ -894,6 +914,120 @@ int mic_pairs_text(mic_engine* e, mic_pairs* p, uint64_t r0, uint64_t r1, void* 
   if (he == hipSuccess) he = hipMemcpy(host_dst, d, *n_bytes, hipMemcpyDeviceToHost);
   hipFree(d);
   ITRY(he);
+  return MIC_OK;
+}
+
+// ---- one FASTQ text on the device (the inflated file of -O reads.fq.gz): where its records start ---------------------------
+int mic_text_free(mic_engine* e, mic_text* p) {
+  (void)e;
+  if (!p) return MIC_OK;
+  hipSetDevice(p->device);
+  if (p->d_scratch) hipFree(p->d_scratch);
+  if (p->d_block) hipFree(p->d_block);
+  delete p;
+  return MIC_OK;
+}
+
+int mic_text_index_device(mic_engine* e, const void* d_text, size_t n, mic_text** out, uint64_t* n_records, uint32_t* status) {
+  if (!e || !d_text || !out || !n_records || !status) return mic_set_error(MIC_E_INVALID, "null argument");
+  *out = nullptr; *n_records = 0; *status = 0;
+  if (n == 0 || n >= 0xFFFFFF00ull) { *status = PS_BIG; return MIC_OK; }
+  MicTable t; int sc, ncu, dev, k; uint32_t nt;
+  int rc = mic_engine_table(e, &t, &sc, &ncu, &dev, &k, &nt);
+  if (rc) return rc;
+  if (hipSetDevice(dev) != hipSuccess) return mic_set_error(MIC_E_HIP, "hipSetDevice failed");
+  mic_text* p = new mic_text;
+  p->device = dev; p->t = (const uint8_t*)d_text; p->nb = (uint32_t)n;
+  const uint8_t* raw = p->t;
+  const uint32_t nb = p->nb, n_tiles = (nb + ING_TILE - 1) / ING_TILE;
+  uint32_t nl = 0; uint8_t first = 0, last = 0;
+  uint64_t n_lines = 0;
+  hipStream_t st = nullptr;
+  uint32_t* d_tile = nullptr; uint32_t* d_tile_off = nullptr; void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  PTRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  PTRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n_tiles + 1), st));
+  {
+    const size_t a0 = up(((size_t)n_tiles + 1) * 4);
+    PTRY(hipMalloc(&p->d_scratch, 2 * a0 + up(tmp_bytes + 16)));
+    char* q = (char*)p->d_scratch;
+    d_tile = (uint32_t*)q; q += a0; d_tile_off = (uint32_t*)q; q += a0; d_tmp = q;
+  }
+  line_count_kernel<<<n_tiles, 256, 0, st>>>(raw, nb, d_tile);
+  PTRY(hipMemsetAsync(d_tile + n_tiles, 0, 4, st));
+  {
+    size_t tb = tmp_bytes;
+    PTRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_tile, d_tile_off, (int)(n_tiles + 1), st));
+  }
+  PTRY(hipMemcpyAsync(&nl, d_tile_off + n_tiles, 4, hipMemcpyDeviceToHost, st));
+  PTRY(hipMemcpyAsync(&last, raw + nb - 1, 1, hipMemcpyDeviceToHost, st));
+  PTRY(hipMemcpyAsync(&first, raw, 1, hipMemcpyDeviceToHost, st));
+  PTRY(hipStreamSynchronize(st));
+  n_lines = (uint64_t)nl + (last != '\n' ? 1 : 0);
+  if (first != '@') { *status = PS_HEADER; goto done; }                       // (FASTA and anything else: the host path)
+  if (n_lines % 4 != 0 || n_lines == 0) { *status = PS_LINES; goto done; }
+  {
+    const uint64_t n_rec = n_lines / 4;
+    p->n_rec = n_rec;
+    const uint64_t n_samples = n_rec / p->stride + 2;
+    const size_t b_ls = up((n_lines + 2) * 4), b_smp = up(n_samples * 8);
+    PTRY(hipMalloc(&p->d_block, b_ls + b_smp));
+    p->d_ls = (uint32_t*)p->d_block;
+    unsigned long long* d_samples = (unsigned long long*)((char*)p->d_block + b_ls);
+    line_start_kernel<<<n_tiles, 256, 0, st>>>(raw, nb, d_tile_off, p->d_ls, (uint32_t)std::min<uint64_t>(n_lines + 2, 0xFFFFFFFFull));
+    PTRY(hipGetLastError());
+    if (last != '\n') { nl = nb + 1; PTRY(hipMemcpyAsync(p->d_ls + n_lines, &nl, 4, hipMemcpyHostToDevice, st)); }
+    p->samples.resize(n_samples);
+    text_sample_kernel<<<(unsigned)((n_samples + 255) / 256), 256, 0, st>>>(p->d_ls, nb, n_rec, p->stride, n_samples, d_samples);
+    PTRY(hipGetLastError());
+    PTRY(hipMemcpyAsync(p->samples.data(), d_samples, n_samples * 8, hipMemcpyDeviceToHost, st));
+    PTRY(hipStreamSynchronize(st));
+  }
+done:
+  if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  if (rc != MIC_OK || *status) { mic_text_free(e, p); return rc; }
+  *out = p; *n_records = p->n_rec;
+  return MIC_OK;
+}
+
+static bool text_offset(const mic_text* p, uint64_t r, unsigned long long& off) {
+  if (r == p->n_rec) { off = p->samples.back(); return true; }
+  if (r > p->n_rec || r % p->stride) return false;
+  off = p->samples[r / p->stride];
+  return true;
+}
+
+int mic_text_offsets(const mic_text* p, const uint64_t** samples, size_t* n_samples, uint32_t* stride) {
+  if (!p || !samples || !n_samples || !stride) return mic_set_error(MIC_E_INVALID, "null argument");
+  *samples = (const uint64_t*)p->samples.data(); *n_samples = p->samples.size(); *stride = p->stride;
+  return MIC_OK;
+}
+
+int mic_text_to_slot(mic_engine* e, mic_text* p, uint64_t r0, uint64_t r1, size_t slot_id, size_t* n_bytes) {
+  if (!e || !p || !n_bytes) return mic_set_error(MIC_E_INVALID, "null argument");
+  Ingest* g = (Ingest*)*mic_engine_ingest_slot(e);
+  if (!g || slot_id >= g->slots.size()) return mic_set_error(MIC_E_STATE, "ingest slots are not allocated");
+  unsigned long long o0, o1;
+  if (r0 >= r1 || !text_offset(p, r0, o0) || !text_offset(p, r1, o1))
+    return mic_set_error(MIC_E_INVALID, "records [%llu, %llu): not a range of whole strides", (unsigned long long)r0, (unsigned long long)r1);
+  if (o1 - o0 > g->max_bytes) return mic_set_error(MIC_E_INVALID, "text of %llu bytes does not fit the slot (%zu)", o1 - o0, g->max_bytes);
+  ITRY(hipSetDevice(p->device));
+  Slot& s = g->slots[slot_id];
+  ITRY(hipMemcpyAsync(s.d_raw, p->t + o0, (size_t)(o1 - o0), hipMemcpyDeviceToDevice, s.stream));
+  *n_bytes = (size_t)(o1 - o0);
+  return MIC_OK;
+}
+
+int mic_text_copy(mic_engine* e, mic_text* p, uint64_t r0, uint64_t r1, void* host_dst, size_t cap, size_t* n_bytes) {
+  if (!e || !p || !host_dst || !n_bytes) return mic_set_error(MIC_E_INVALID, "null argument");
+  unsigned long long o0, o1;
+  if (r0 >= r1 || !text_offset(p, r0, o0) || !text_offset(p, r1, o1))
+    return mic_set_error(MIC_E_INVALID, "records [%llu, %llu): not a range of whole strides", (unsigned long long)r0, (unsigned long long)r1);
+  *n_bytes = (size_t)(o1 - o0);
+  if (*n_bytes > cap) return mic_set_error(MIC_E_INVALID, "text of %zu bytes does not fit the buffer (%zu)", *n_bytes, cap);
+  ITRY(hipSetDevice(p->device));
+  ITRY(hipMemcpy(host_dst, p->t + o0, *n_bytes, hipMemcpyDeviceToHost));
   return MIC_OK;
 }
 

@@ -225,6 +225,39 @@ class MiClarkDB:
     def pairs_free(self, handle):
         self.L.mic_pairs_free(self.h, handle)
 
+    # -- one FASTQ text on the device (mic_text_*)
+    def text_index(self, d_text, n):
+        """Returns (handle, n_records, offsets, stride), or (None, status, None, None) when the text needs the host reader."""
+        h, nr, st = C.c_void_p(), C.c_uint64(0), C.c_uint32(0)
+        check(self.L.mic_text_index_device(self.h, d_text, n, C.byref(h), C.byref(nr), C.byref(st)))
+        if st.value:
+            return None, int(st.value), None, None
+        sp, ns, stride = C.POINTER(C.c_uint64)(), C.c_size_t(0), C.c_uint32(0)
+        check(self.L.mic_text_offsets(h, C.byref(sp), C.byref(ns), C.byref(stride)))
+        off = np.ctypeslib.as_array(sp, shape=(ns.value,)).copy()
+        return h, int(nr.value), off, int(stride.value)
+
+    def text_copy(self, handle, r0, r1, cap=1 << 30):
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t(0)
+        check(self.L.mic_text_copy(self.h, handle, r0, r1, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].tobytes()
+
+    def text_classify(self, handle, slot, r0, r1):
+        n = C.c_size_t(0)
+        check(self.L.mic_text_to_slot(self.h, handle, r0, r1, slot, C.byref(n)))
+        out = _lib.MicIngestResult()
+        check(self.L.mic_ingest_classify(self.h, slot, n.value, 12, C.byref(out)))
+        r = dict(status=int(out.status), n_reads=int(out.n_reads), n_lines=int(out.n_lines), csv=None, results=None, n_bytes=int(n.value))
+        if out.status == 0:
+            r["csv"] = C.string_at(out.csv, out.csv_bytes) if out.csv_bytes else b""
+            if out.results:
+                r["results"] = _as_np(out.results, (int(out.n_reads), MIC_RESULT_WORDS), np.uint32).copy()
+        return r
+
+    def text_free(self, handle):
+        self.L.mic_text_free(self.h, handle)
+
     # -- device-side ingest: raw FASTA/FASTQ bytes -> CSV text (mic_ingest_*)
     def ingest_alloc(self, n_slots, max_bytes, target_names, want_results=False):
         names = (C.c_char_p * len(target_names))(*[t.encode() for t in target_names])

@@ -194,3 +194,44 @@ def test_texts_that_do_not_pair_up_are_refused():
         assert h is not None and n_rec == 500
         e.pairs_free(h)
         tx.free()
+
+
+@pytest.mark.parametrize("variant", ["plain", "unterminated", "crlf"])
+def test_single_fastq_text_on_the_device(variant):
+    """mic_text_*: the records of one FASTQ text cut at strides, copied into a slot on the device and classified there, against
+    the same bytes handed over from the host; FASTA, a line count that is no multiple of four: refused."""
+    import test_ingest as ti
+    rng = np.random.default_rng({"plain": 11, "unterminated": 12, "crlf": 13}[variant])
+    n = 2500
+    data = ti._random_reads(rng, _genomes(), n, fasta=False, crlf=variant == "crlf")
+    if variant == "unterminated":
+        data = data + b"@last\nACGTACGTACGTTTGACCA\n+\nIIIIIIIIIIIIIIIIIII"
+        n += 1
+    e, names = _engine()
+    with e:
+        d, nb, _ = e.gunzip_device(_gz(data))
+        assert nb == len(data)
+        h, n_rec, off, stride = e.text_index(d, nb)
+        assert h is not None and n_rec == n and off[0] == 0 and off[-1] == len(data)
+        lines = data.split(b"\n")
+        starts = np.cumsum([0] + [len(l) + 1 for l in lines])
+        for i in range(off.size):
+            assert off[i] == min(starts[4 * min(i * stride, n)], len(data))
+        e.ingest_alloc(2, 2 << 20, names, want_results=True)
+        cuts = sorted({0, n} | {int(c) * stride for c in rng.integers(0, n // stride + 1, 5)})
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            text = e.text_copy(h, r0, r1)
+            assert text == data[off[r0 // stride]:(off[-1] if r1 == n else off[r1 // stride])]
+            dv = e.text_classify(h, 1, r0, r1)
+            v = e.ingest_classify(0, text)
+            assert dv["status"] == v["status"], (r0, r1, dv["status"], v["status"])
+            if dv["status"] == 0:
+                assert dv["csv"] == v["csv"] and (dv["results"] == v["results"]).all()
+        e.text_free(h)
+        e.free_text(d)
+        for bad, status in ((b">r1\nACGT\n>r2\nACGT\n", 2), (data + b"@x\nAC\n+\n", 1), (b"@r\nACGT\n+\n", 1)):
+            d, nb, _ = e.gunzip_device(_gz(bad))
+            h, st, _, _ = e.text_index(d, nb)
+            assert h is None and st & status, (bad[:10], st)
+            e.free_text(d)
+        e.ingest_free()

@@ -104,4 +104,9 @@ int mic_pairs_offsets(const mic_pairs*, const uint64_t**, size_t*, uint32_t*) { 
 int mic_pairs_merge_to_slot(mic_engine*, mic_pairs*, uint64_t, uint64_t, size_t, size_t*) { return MIC_E_NODEVICE; }
 int mic_pairs_text(mic_engine*, mic_pairs*, uint64_t, uint64_t, void*, size_t, size_t*) { return MIC_E_NODEVICE; }
 int mic_pairs_free(mic_engine*, mic_pairs*) { return MIC_OK; }
+int mic_text_index_device(mic_engine*, const void*, size_t, mic_text**, uint64_t*, uint32_t*) { return MIC_E_NODEVICE; }
+int mic_text_offsets(const mic_text*, const uint64_t**, size_t*, uint32_t*) { return MIC_E_NODEVICE; }
+int mic_text_to_slot(mic_engine*, mic_text*, uint64_t, uint64_t, size_t, size_t*) { return MIC_E_NODEVICE; }
+int mic_text_copy(mic_engine*, mic_text*, uint64_t, uint64_t, void*, size_t, size_t*) { return MIC_E_NODEVICE; }
+int mic_text_free(mic_engine*, mic_text*) { return MIC_OK; }
 }
