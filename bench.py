@@ -195,7 +195,8 @@ def gzip_sub_leg(cmd, fqs, rec, n, res_base, tmp):
         t_assign = float(m.group(1))
         out[kind] = {"Mpairs_s": round(int(m.group(3)) / t_assign / 1e6, 2), "assignment_s": round(t_assign, 3),
                      "compressed_MB": round(sum(os.path.getsize(x) for x in names) / 1e6, 1), "made_in_s": round(t_make, 1),
-                     "csv_equals_plain_run": open(res + ".csv", "rb").read() == expect}
+                     "csv_equals_plain_run": open(res + ".csv", "rb").read() == expect,
+                     "inflated_on": "device" if re.search(r"device inflate: [0-9.]+ MB of text", r.stderr) else "host"}
     return out
 
 

@@ -180,7 +180,9 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
       for (const std::string* f : files) {
         const int fd = open(f->c_str(), O_RDONLY);
         uint8_t t[4];
-        if (fd != -1 && fstat(fd, &st) == 0 && st.st_size > 18 && pread(fd, t, 4, st.st_size - 4) == 4)
+        uint8_t h[18] = {0};
+        const bool bgzf = fd != -1 && pread(fd, h, 18, 0) == 18 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C';     // (block gzip: the host's path)
+        if (!bgzf && fd != -1 && fstat(fd, &st) == 0 && st.st_size > 18 && pread(fd, t, 4, st.st_size - 4) == 4)
           gz.push_back({(size_t)st.st_size, (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24)});
         if (fd != -1) close(fd);
       }

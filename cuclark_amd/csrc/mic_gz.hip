@@ -669,7 +669,16 @@ size_t gzip_header(const uint8_t* p, size_t n) {      // offset of the deflate d
   const int flg = p[3];
   if (flg & 0xE0) return 0;
   size_t q = 10;
-  if (flg & 4) { if (q + 2 > n) return 0; const size_t xlen = p[q] | (p[q + 1] << 8); q += 2 + xlen; }
+  if (flg & 4) {
+    if (q + 2 > n) return 0;
+    const size_t xlen = p[q] | (p[q + 1] << 8);
+    // block gzip (BGZF: a 'BC' subfield with the member's size) is thousands of members: the host inflates those block-parallel
+    for (size_t x = q + 2; x + 4 <= q + 2 + xlen && x + 4 <= n;) {
+      if (p[x] == 'B' && p[x + 1] == 'C') return 0;
+      x += 4 + (p[x + 2] | ((size_t)p[x + 3] << 8));
+    }
+    q += 2 + xlen;
+  }
   if (flg & 8) { while (q < n && p[q]) ++q; ++q; }
   if (flg & 16) { while (q < n && p[q]) ++q; ++q; }
   if (flg & 2) q += 2;

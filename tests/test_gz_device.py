@@ -91,6 +91,16 @@ def test_what_the_path_does_not_take(engine):
         engine.gunzip(gz + gz)
     with pytest.raises(MiClarkUnsupported):                       # not gzip at all
         engine.gunzip(data[:100000])
+    import struct
+    blk = data[:0xFF00]                                            # block gzip (one BGZF member): left to the host's block-parallel path
+    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+    body = c.compress(blk) + c.flush()
+    bgzf = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(blk), len(blk))
+    assert zlib.decompress(bgzf, 31) == blk
+    with pytest.raises(MiClarkUnsupported):
+        engine.gunzip(bgzf)
+    other_extra = bgzf[:12] + b"XY" + bgzf[14:]                    # (another subfield in the same place is skipped like any header field)
+    assert engine.gunzip(other_extra)[0] == blk
     bad = bytearray(gz)
     bad[len(bad) // 2] ^= 0x55                                     # a damaged block: unsupported or an error, never wrong text passing as right
     try:

@@ -13,4 +13,8 @@ echo "== device inflate"
 if [ -n "$GZ_TIMING" ]; then export MIC_GZ_TIMING=1; fi
 for rep in 1 2 3; do MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -P $D/reads_1.fq.gz $D/reads_2.fq.gz -R $D/dev -n 12 2>&1 | grep -E "Assignment|inflate|device ingest|^\[gz\]" | sed 's/thread-seconds.*ms since start/.. ms since start/'; done
 cmp $D/host.csv $D/dev.csv && echo "CSVs identical"
+echo "== one file: host inflate, device inflate"
+MIC_GZ_HOST=1 MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -O $D/reads_1.fq.gz -R $D/host1 -n 12 2>&1 | grep -E "Assignment|inflate" | sed 's/thread-seconds.*ms since start/.. ms since start/'
+for rep in 1 2; do MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -O $D/reads_1.fq.gz -R $D/dev1 -n 12 2>&1 | grep -E "Assignment|inflate" | sed 's/thread-seconds.*ms since start/.. ms since start/'; done
+cmp $D/host1.csv $D/dev1.csv && echo "CSVs identical"
 rm -rf $D
