@@ -685,6 +685,65 @@ size_t gzip_header(const uint8_t* p, size_t n) {      // offset of the deflate d
   return q + 8 < n ? q : 0;
 }
 
+// ---- CRC-32 of the text (the member's trailer holds it; gunzip checks it, and so does this path) ------------------------------------
+// Every thread the CRC of its own 4-KiB piece (table in LDS, a byte a step); the host strings the pieces together: the CRC of A || B
+// is the CRC of A carried over len(B) zero bytes - a 32 x 32 matrix over GF(2), the same for every whole piece - xor the CRC of B.
+constexpr uint32_t GZ_CRC_PIECE = 4096;
+
+__global__ void __launch_bounds__(256) gz_crc_kernel(const uint8_t* __restrict__ d, uint64_t n, uint32_t* __restrict__ out) {
+  __shared__ uint32_t tab[256];
+  uint32_t c = threadIdx.x;
+  for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+  tab[threadIdx.x] = c;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x, o = i * GZ_CRC_PIECE;
+  if (o >= n) return;
+  const uint32_t len = (uint32_t)(n - o < GZ_CRC_PIECE ? n - o : GZ_CRC_PIECE);
+  uint32_t crc = 0xFFFFFFFFu;
+  const uint8_t* p = d + o;                   // (the text buffer is 256-byte aligned: whole 16-byte words while they last)
+  uint32_t j = 0;
+  for (; j + 16 <= len; j += 16) {
+    const uint4 v = *(const uint4*)(p + j);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t x = w[q];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { crc = tab[(crc ^ x) & 0xFFu] ^ (crc >> 8); x >>= 8; }
+    }
+  }
+  for (; j < len; ++j) crc = tab[(crc ^ p[j]) & 0xFFu] ^ (crc >> 8);
+  out[i] = crc ^ 0xFFFFFFFFu;
+}
+
+struct Gf2 { uint32_t row[32]; };           // row[i] = image of bit i
+uint32_t gf2_times(const Gf2& m, uint32_t v) { uint32_t s = 0; for (int i = 0; v; v >>= 1, ++i) if (v & 1u) s ^= m.row[i]; return s; }
+Gf2 gf2_mul(const Gf2& a, const Gf2& b) { Gf2 c; for (int i = 0; i < 32; ++i) c.row[i] = gf2_times(a, b.row[i]); return c; }   // a after b
+Gf2 crc_zero_bytes(uint64_t n_bytes) {      // the operator "n_bytes zero bytes follow" on a (reflected) CRC-32 register
+  Gf2 one;                                   // one zero bit
+  one.row[0] = 0xEDB88320u;
+  for (int i = 1; i < 32; ++i) one.row[i] = 1u << (i - 1);
+  Gf2 p = gf2_mul(one, one); p = gf2_mul(p, p); p = gf2_mul(p, p);      // eight bits
+  Gf2 r;
+  for (int i = 0; i < 32; ++i) r.row[i] = 1u << i;                      // identity
+  for (; n_bytes; n_bytes >>= 1) { if (n_bytes & 1) r = gf2_mul(p, r); p = gf2_mul(p, p); }
+  return r;
+}
+uint32_t crc_of_pieces(const std::vector<uint32_t>& piece, uint64_t n) {
+  if (piece.empty()) return 0;
+  const Gf2 whole = crc_zero_bytes(GZ_CRC_PIECE);
+  static uint32_t tab[4][256];                 // the whole-piece operator byte by byte (77 k pieces in a 316-MB text: 32 conditional xors each took 10 ms)
+  static std::once_flag once;
+  std::call_once(once, [&] { for (int b = 0; b < 4; ++b) for (uint32_t v = 0; v < 256; ++v) tab[b][v] = gf2_times(whole, v << (8 * b)); });
+  uint32_t crc = piece[0];
+  for (size_t i = 1; i < piece.size(); ++i) {
+    const uint64_t len = i + 1 < piece.size() ? GZ_CRC_PIECE : n - (uint64_t)i * GZ_CRC_PIECE;
+    crc = (len == GZ_CRC_PIECE ? tab[0][crc & 255u] ^ tab[1][(crc >> 8) & 255u] ^ tab[2][(crc >> 16) & 255u] ^ tab[3][crc >> 24]
+                               : gf2_times(crc_zero_bytes(len), crc)) ^ piece[i];
+  }
+  return crc;
+}
+
 // Buffers set up ahead of a call (mic_gz_reserve): one scratch block for everything the call needs on the way and the text buffer.
 // A fresh gigabyte of device memory takes the driver tens of milliseconds (longer right behind a table build, whose freed pages it
 // still wipes) - as long as the decode; the command line reserves while its database loads, as it does for its ingest slots.
@@ -863,8 +922,20 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   lap("windows");
   gz_resolve_kernel<<<(unsigned)chain.size() * 8u, 256, 0, s>>>(d_chain, (uint32_t)chain.size(), d_sym, d_win, d_out, 8);
   GZTRY(hipGetLastError());
-  GZTRY(hipStreamSynchronize(s));
-  lap("resolve");
+  {
+    const size_t n_pieces = (size_t)((total + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE);
+    std::vector<uint32_t> piece(n_pieces);
+    if (n_pieces) {
+      uint32_t* d_crc = nullptr;
+      GZTRY(dev_alloc((void**)&d_crc, n_pieces * 4));
+      gz_crc_kernel<<<(unsigned)((n_pieces + 255) / 256), 256, 0, s>>>(d_out, total, d_crc);
+      GZTRY(hipGetLastError());
+      GZTRY(hipMemcpyAsync(piece.data(), d_crc, n_pieces * 4, hipMemcpyDeviceToHost, s));
+    }
+    GZTRY(hipStreamSynchronize(s));
+    lap("resolve + CRC-32 of the pieces");
+    if (crc_of_pieces(piece, total) != crc) { rc = mic_set_error(MIC_E_INVALID, "Failed to uncompress input objects."); goto done; }   // (gunzip: "crc error")
+  }
   if (timing) fprintf(stderr, "[gz] %zu bytes -> %llu bytes, %u chunks, %zu units found, %zu in the chain\n", gz_bytes, (unsigned long long)total, n_chunks, units.size(), chain.size());
   *d_text = d_out; d_out = nullptr; *n_text = total;
 done:
@@ -888,7 +959,7 @@ extern "C" int mic_gz_reserve(mic_engine* e, size_t gz_bytes, uint32_t isize) {
   // input, block starts, units and chain, symbols by their bound, windows for a third of the chunks (a block of gzip's is three
   // chunks and more; a file of smaller blocks gets the rest of its windows from hipMalloc)
   r.scratch_bytes = up256(n + 16) + up256((size_t)n_chunks * 8) + 2 * up256((size_t)n_chunks * sizeof(GzUnit)) +
-                    up256((sym_bound_of(n, n_chunks) + 8) * 2) + up256(((size_t)n_chunks / 3 + 64) * 32768) + 4096;
+                    up256((sym_bound_of(n, n_chunks) + 8) * 2) + up256(((size_t)n_chunks / 3 + 64) * 32768) + up256(((size_t)isize / GZ_CRC_PIECE + 2) * 4) + 4096;
   hipError_t he = hipMalloc(&r.scratch, r.scratch_bytes);
   if (he == hipSuccess && (unsigned long long)isize <= 1100ull * n) {
     r.text_bytes = (size_t)isize + 64;
@@ -908,7 +979,7 @@ extern "C" uint64_t mic_gz_reserve_bytes(size_t gz_bytes, uint32_t isize) {
   if (gz_bytes < 18) return 0;
   const size_t n = gz_bytes - 8;
   const uint32_t n_chunks = (uint32_t)((n + GZ_CHUNK - 1) / GZ_CHUNK);
-  return (uint64_t)(n + 16 + (size_t)n_chunks * (8 + 2 * sizeof(GzUnit)) + (sym_bound_of(n, n_chunks) + 8) * 2 + ((size_t)n_chunks / 3 + 64) * 32768 + 8192) +
+  return (uint64_t)(n + 16 + (size_t)n_chunks * (8 + 2 * sizeof(GzUnit)) + (sym_bound_of(n, n_chunks) + 8) * 2 + ((size_t)n_chunks / 3 + 64) * 32768 + ((size_t)isize / GZ_CRC_PIECE + 2) * 4 + 8192) +
          (uint64_t)isize + 64;
 }
 

@@ -109,6 +109,16 @@ def test_what_the_path_does_not_take(engine):
     except (MiClarkUnsupported, MicError):
         pass
     bad = bytearray(gz)
+    bad[-6] ^= 1                                                   # CRC-32 wrong: what gunzip calls a crc error
+    with pytest.raises(MicError):
+        engine.gunzip(bytes(bad))
+    stored = zlib.compressobj(0, zlib.DEFLATED, 31)                # a byte changed inside a stored block: everything stitches, the CRC does not
+    raw = bytearray(stored.compress(data[:200000]) + stored.flush())
+    assert engine.gunzip(bytes(raw))[0] == data[:200000]
+    raw[100000] ^= 0x20
+    with pytest.raises(MicError):
+        engine.gunzip(bytes(raw))
+    bad = bytearray(gz)
     bad[-2] ^= 1                                                   # ISIZE wrong
     with pytest.raises((MiClarkUnsupported, MicError)):
         engine.gunzip(bytes(bad))
