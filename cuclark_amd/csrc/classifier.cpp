@@ -181,8 +181,19 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
         const int fd = open(f->c_str(), O_RDONLY);
         uint8_t t[4];
         uint8_t h[18] = {0};
-        const bool bgzf = fd != -1 && pread(fd, h, 18, 0) == 18 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C';     // (block gzip: the host's path)
-        if (!bgzf && fd != -1 && fstat(fd, &st) == 0 && st.st_size > 18 && pread(fd, t, 4, st.st_size - 4) == 4)
+        const bool bgzf = fd != -1 && pread(fd, h, 18, 0) == 18 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C';
+        if (bgzf && fstat(fd, &st) == 0) {
+          // block gzip: the text is the sum over the members' trailers (a header and a trailer read per member, while the database loads)
+          uint64_t total = 0; off_t o = 0; bool good = true;
+          while (good && o < st.st_size) {
+            uint8_t b[18], z[4];
+            good = pread(fd, b, 18, o) == 18 && b[0] == 0x1f && b[1] == 0x8b && (b[3] & 4) && b[12] == 'B' && b[13] == 'C';
+            const off_t bsize = good ? (off_t)(b[16] | (b[17] << 8)) + 1 : 0;
+            good = good && bsize >= 28 && o + bsize <= st.st_size && pread(fd, z, 4, o + bsize - 4) == 4;
+            if (good) { total += (uint32_t)z[0] | ((uint32_t)z[1] << 8) | ((uint32_t)z[2] << 16) | ((uint32_t)z[3] << 24); o += bsize; }
+          }
+          if (good && total < 0xFFFFFF00ull) gz.push_back({(size_t)st.st_size, (uint32_t)total});
+        } else if (fd != -1 && fstat(fd, &st) == 0 && st.st_size > 18 && pread(fd, t, 4, st.st_size - 4) == 4)
           gz.push_back({(size_t)st.st_size, (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24)});
         if (fd != -1) close(fd);
       }

@@ -1,10 +1,9 @@
-// mic_gz.hip - one gzip member inflated ON THE DEVICE: the two-stage scheme of csrc/pgz.hpp (pugz / rapidgzip)
-// with one decode unit per deflate block - thousands of wavefronts - instead of sixteen threads.  BASELINE config 5 names gzip
-// FASTQ; the reference's scripts gunzip to a temporary file first (classify_metagenome.sh:116-142).  A LIBRARY ENTRY with its own
-// tests and timing tool (tests/test_gz_device.py, tools/gz_device_timing.py): 316 MB of FASTQ text out of 59 MB of gzip in 53 ms
-// (6 GB/s; pgz.hpp on the 16 allowed CPUs: 3 GB/s).  The command line does not call it yet: its loaders want the text in host
-// memory, and what the copy back and a second file in flight cost leaves 1.5 x - it pays once the ingest kernels read the
-// text where it is.
+// mic_gz.hip - gzip inflated ON THE DEVICE: the two-stage scheme of csrc/pgz.hpp (pugz / rapidgzip) with one decode
+// unit per deflate block - thousands of wavefronts - instead of sixteen threads.  BASELINE config 5 names gzip FASTQ; the
+// reference's scripts gunzip to a temporary file first (classify_metagenome.sh:116-142).  The command line's path for compressed
+// FASTQ on one engine: the text stays on the device, where the pair merge and the ingest kernels read it (mic_ingest.hip:
+// mic_pairs_*, mic_text_*).  316 MB of FASTQ out of 59 MB of gzip in 53-56 ms (pgz.hpp on the 16 allowed CPUs: 3 GB/s); a
+// block-gzip file (BGZF) of the same text, a wavefront per member, in 35-45 ms.  tests/test_gz_device.py, tools/gz_device_timing.py.
 //
 //   1  gz_find_kernel     one wavefront per 8 KiB of compressed data: the first bit offset at which a block with dynamic codes
 //                         starts - 64 offsets per step through the cheap tests (BFINAL / BTYPE bits, HLIT / HDIST in range, the
@@ -23,7 +22,8 @@
 //   3  gz_window_kernel   in chain order the last 32 KiB of every unit are resolved against the window handed on (one block,
 //                         the window in LDS, symbols loaded one unit ahead) and every unit's incoming window is kept;
 //   4  gz_resolve_kernel  all units at once: markers replaced, symbols narrowed to bytes at the unit's offset of the text.
-// The member's length is checked here (ISIZE); its CRC-32 is returned for the caller, who checks it on the copy it takes.
+//   5  gz_crc_kernel      the CRC-32 of the text in 4-KiB pieces, combined on the host: length (ISIZE) and CRC-32 are checked against
+//                         the member's trailer, as gunzip checks them.
 // Stored and fixed-code blocks are decoded; several members, a preset dictionary or anything that does not stitch:
 // MIC_E_UNSUPPORTED, and the caller inflates on the CPU as before - a wrong speculation cannot pass.
 #include "mi_clark.h"
@@ -472,14 +472,13 @@ __device__ void fixed_codes_w(Fast& f, int lane) {
 
 // WRITE = false: the counting form (units that did not fit their region are counted exactly and decoded again)
 template <bool WRITE>
-__global__ void __launch_bounds__(64) gz_decode_kernel(const uint8_t* __restrict__ d, uint64_t n, GzUnit* __restrict__ units, uint32_t n_units,
-                                                      uint16_t* __restrict__ sym, const uint32_t* __restrict__ which) {
-  __shared__ Fast f;
+__device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restrict__ d, uint64_t n, GzUnit* __restrict__ units, uint32_t n_units,
+                                               uint16_t* __restrict__ sym, const uint32_t* __restrict__ which, int all_known) {
   const uint32_t u = which ? which[blockIdx.x] : blockIdx.x;
   const int lane = threadIdx.x;
   if (u >= n_units) return;
   GzUnit& U = units[u];
-  const bool known = u == 0;                              // the member's first unit has nothing in front of it: no markers possible
+  const bool known = u == 0 || all_known;                 // a member's first unit has nothing in front of it: no markers possible
   const uint64_t cyc0 = __builtin_readcyclecounter();
   uint16_t* out = sym + UNI64(U.sym_off);
   const uint64_t room = WRITE ? UNI64(U.sym_cap) : 0;
@@ -606,6 +605,22 @@ __global__ void __launch_bounds__(64) gz_decode_kernel(const uint8_t* __restrict
   }
   flush(w);
   if (lane == 0) { U.end_bit = b.bitpos(); U.n_sym = w; U.status = status; U.pad = (uint32_t)(__builtin_readcyclecounter() - cyc0); }
+}
+
+// One member: a wavefront per deflate block, all resident, and the largest block is the kernel's time - wavefronts that share a SIMD
+// slow each other down, so the registers the compiler likes to take (158: three wavefronts per SIMD) are left to it.
+template <bool WRITE>
+__global__ void __launch_bounds__(64) gz_decode_kernel(const uint8_t* __restrict__ d, uint64_t n, GzUnit* __restrict__ units, uint32_t n_units,
+                                                      uint16_t* __restrict__ sym, const uint32_t* __restrict__ which, int all_known) {
+  __shared__ Fast f;
+  gz_decode_body<WRITE>(f, d, n, units, n_units, sym, which, all_known);
+}
+// Block gzip: thousands of small members, more wavefronts than the chip holds - 128 registers, four wavefronts per SIMD (measured on
+// 2 x 4 842 members: 22-27 ms against 28-32)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+gz_decode_members_kernel(const uint8_t* __restrict__ d, uint64_t n, GzUnit* __restrict__ units, uint32_t n_units, uint16_t* __restrict__ sym) {
+  __shared__ Fast f;
+  gz_decode_body<true>(f, d, n, units, n_units, sym, nullptr, 1);
 }
 
 // ---- 3: windows in chain order --------------------------------------------------------------------------------------------
@@ -744,6 +759,60 @@ uint32_t crc_of_pieces(const std::vector<uint32_t>& piece, uint64_t n) {
   return crc;
 }
 
+// ---- block gzip (BGZF: what bgzip / samtools write): thousands of small members, each with its compressed size in a 'BC' subfield of
+// its header and its CRC-32 and length in its trailer.  The members are independent - a wavefront each, no back-reference can leave
+// a member, no speculation, no windows - and their places in the text are known before anything is decoded.
+struct BgzfMember { uint64_t data_off, data_end; uint32_t isize, crc; uint64_t text_off; };
+
+bool bgzf_members(const uint8_t* p, size_t n, std::vector<BgzfMember>& out, uint64_t& total) {
+  size_t o = 0;
+  total = 0;
+  while (o < n) {
+    if (o + 18 > n || p[o] != 0x1f || p[o + 1] != 0x8b || p[o + 2] != 8 || !(p[o + 3] & 4) || (p[o + 3] & 0xFA)) return false;
+    const size_t xlen = p[o + 10] | ((size_t)p[o + 11] << 8);
+    if (o + 12 + xlen > n) return false;
+    size_t bsize = 0;
+    for (size_t x = o + 12; x + 4 <= o + 12 + xlen;) {
+      const size_t sl = p[x + 2] | ((size_t)p[x + 3] << 8);
+      if (p[x] == 'B' && p[x + 1] == 'C' && sl == 2 && x + 6 <= o + 12 + xlen) bsize = (p[x + 4] | ((size_t)p[x + 5] << 8)) + 1;
+      x += 4 + sl;
+    }
+    if (bsize < 12 + xlen + 8 + 2 || o + bsize > n) return false;
+    BgzfMember m;
+    m.data_off = o + 12 + xlen; m.data_end = o + bsize - 8;
+    const uint8_t* t = p + o + bsize - 8;
+    m.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    m.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+    if (m.isize > 65536u) return false;
+    m.text_off = total; total += m.isize;
+    out.push_back(m);
+    o += bsize;
+  }
+  return !out.empty();
+}
+
+// CRC-32 of every member's text: a wavefront per member, lane j its 4-KiB piece j (a member holds 64 KiB of text at most)
+__global__ void __launch_bounds__(64) gz_crc_members_kernel(const uint8_t* __restrict__ text, const unsigned long long* __restrict__ off,
+                                                            const uint32_t* __restrict__ size, uint32_t n_members, uint32_t* __restrict__ out) {
+  __shared__ uint32_t tab[256];
+  for (uint32_t v = threadIdx.x; v < 256; v += 64) {
+    uint32_t c = v;
+    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+    tab[v] = c;
+  }
+  __syncthreads();
+  const uint32_t m = blockIdx.x, j = threadIdx.x;
+  if (m >= n_members || j >= 16) return;
+  const uint32_t sz = size[m], from = j * GZ_CRC_PIECE;
+  if (from >= sz) return;
+  const uint32_t len = sz - from < GZ_CRC_PIECE ? sz - from : GZ_CRC_PIECE;
+  const uint8_t* p = text + off[m] + from;
+  uint32_t crc = 0xFFFFFFFFu;
+#pragma unroll 8
+  for (uint32_t i = 0; i < len; ++i) crc = tab[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+  out[m * 16 + j] = crc ^ 0xFFFFFFFFu;
+}
+
 // Buffers set up ahead of a call (mic_gz_reserve): one scratch block for everything the call needs on the way and the text buffer.
 // A fresh gigabyte of device memory takes the driver tens of milliseconds (longer right behind a table build, whose freed pages it
 // still wipes) - as long as the decode; the command line reserves while its database loads, as it does for its ingest slots.
@@ -763,6 +832,117 @@ unsigned long long sym_bound_of(size_t n, uint32_t n_chunks) { return 8ull * (n 
 
 }  // namespace
 
+namespace {
+int inflate_bgzf(mic_engine* e, const uint8_t* p, size_t gz_bytes, void** d_text, size_t* n_text) {
+  std::vector<BgzfMember> mem;
+  uint64_t total = 0;
+  if (!bgzf_members(p, gz_bytes, mem, total)) return mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: not a whole block-gzip file");
+  int rc = MIC_OK;
+  hipStream_t s = nullptr;
+  uint8_t* d_in = nullptr; GzUnit* d_units = nullptr; uint16_t* d_sym = nullptr; uint8_t* d_out = nullptr;
+  unsigned long long* d_off = nullptr; uint32_t* d_size = nullptr; uint32_t* d_crc = nullptr;
+  std::vector<GzUnit> units;
+  std::vector<uint32_t> unit_member;
+  std::vector<unsigned long long> h_off;
+  std::vector<uint32_t> h_size, h_crc;
+  char* arena = nullptr; size_t arena_left = 0;
+  std::vector<void*> owned;
+  {
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    for (GzReserve& r : g_res)
+      if (r.eng == e && r.gz_bytes == gz_bytes && !r.taken) {
+        r.taken = true; arena = r.scratch; arena_left = r.scratch_bytes;
+        if (r.text && (size_t)total + 64 <= r.text_bytes) { d_out = r.text; r.text = nullptr; }
+        break;
+      }
+  }
+  auto dev_alloc = [&](void** ptr, size_t bytes) -> hipError_t {
+    const size_t b = up256(bytes);
+    if (b <= arena_left) { *ptr = arena; arena += b; arena_left -= b; return hipSuccess; }
+    const hipError_t he = hipMalloc(ptr, bytes);
+    if (he == hipSuccess) owned.push_back(*ptr);
+    return he;
+  };
+  const bool timing = getenv("MIC_GZ_TIMING") != nullptr;
+  struct timespec tq0; clock_gettime(CLOCK_MONOTONIC, &tq0);
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    if (s) hipStreamSynchronize(s);
+    struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+    fprintf(stderr, "[gz] %s: %.3f ms\n", what, (t1.tv_sec - tq0.tv_sec) * 1e3 + (t1.tv_nsec - tq0.tv_nsec) / 1e6);
+    tq0 = t1;
+  };
+  for (size_t i = 0; i < mem.size(); ++i) {
+    if (mem[i].isize == 0) { if (mem[i].crc != 0) { rc = mic_set_error(MIC_E_INVALID, "Failed to uncompress input objects."); goto done; } continue; }   // (the end-of-file marker)
+    GzUnit u; memset(&u, 0, sizeof(u));
+    u.start_bit = mem[i].data_off * 8; u.stop_bit = ~0ull;
+    u.sym_off = mem[i].text_off; u.sym_cap = mem[i].isize; u.out_off = mem[i].text_off;
+    units.push_back(u); unit_member.push_back((uint32_t)i);
+    h_off.push_back(mem[i].text_off); h_size.push_back(mem[i].isize);
+  }
+  GZTRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  GZTRY(dev_alloc((void**)&d_in, gz_bytes + 16));
+  GZTRY(hipMemsetAsync(d_in + gz_bytes, 0, 16, s));
+  GZTRY(hipMemcpyAsync(d_in, p, gz_bytes, hipMemcpyHostToDevice, s));
+  if (!d_out) GZTRY(hipMalloc(&d_out, (size_t)total + 64));
+  if (!units.empty()) {
+    const uint32_t nu = (uint32_t)units.size();
+    GZTRY(dev_alloc((void**)&d_units, (size_t)nu * sizeof(GzUnit)));
+    GZTRY(dev_alloc((void**)&d_sym, ((size_t)total + 8) * 2));
+    GZTRY(dev_alloc((void**)&d_off, (size_t)nu * 8));
+    GZTRY(dev_alloc((void**)&d_size, (size_t)nu * 4));
+    GZTRY(dev_alloc((void**)&d_crc, (size_t)nu * 16 * 4));
+    GZTRY(hipMemcpyAsync(d_units, units.data(), (size_t)nu * sizeof(GzUnit), hipMemcpyHostToDevice, s));
+    GZTRY(hipMemcpyAsync(d_off, h_off.data(), (size_t)nu * 8, hipMemcpyHostToDevice, s));
+    GZTRY(hipMemcpyAsync(d_size, h_size.data(), (size_t)nu * 4, hipMemcpyHostToDevice, s));
+    lap("upload (block gzip)");
+    gz_decode_members_kernel<<<nu, 64, 0, s>>>(d_in, gz_bytes, d_units, nu, d_sym);
+    GZTRY(hipGetLastError());
+    GZTRY(hipMemcpyAsync(units.data(), d_units, (size_t)nu * sizeof(GzUnit), hipMemcpyDeviceToHost, s));
+    lap("decode (a wavefront per member)");
+    // no member can hold a marker (nothing in front of it is known to be nothing): the resolve pass only narrows symbols to bytes
+    gz_resolve_kernel<<<nu * 2u, 256, 0, s>>>(d_units, nu, d_sym, (const uint8_t*)d_sym, d_out, 2);
+    GZTRY(hipGetLastError());
+    gz_crc_members_kernel<<<nu, 64, 0, s>>>(d_out, d_off, d_size, nu, d_crc);
+    GZTRY(hipGetLastError());
+    h_crc.resize((size_t)nu * 16);
+    GZTRY(hipMemcpyAsync(h_crc.data(), d_crc, (size_t)nu * 16 * 4, hipMemcpyDeviceToHost, s));
+    GZTRY(hipStreamSynchronize(s));
+    lap("bytes + CRC-32 of the members");
+    {
+      const Gf2 whole = crc_zero_bytes(GZ_CRC_PIECE);
+      uint32_t wt[4][256];                                      // (the whole-piece operator byte by byte, as in crc_of_pieces)
+      for (int b = 0; b < 4; ++b) for (uint32_t v = 0; v < 256; ++v) wt[b][v] = gf2_times(whole, v << (8 * b));
+      uint32_t tail_len = 0; Gf2 tail = whole;                 // (the members of a file are of one size, but for the last)
+      for (uint32_t i = 0; i < nu; ++i) {
+        const GzUnit& u = units[i];
+        const BgzfMember& m = mem[unit_member[i]];
+        if (u.status != GZ_FINAL || u.n_sym != m.isize || (u.end_bit + 7) / 8 != m.data_end) {
+          rc = mic_set_error(MIC_E_INVALID, "Failed to uncompress input objects."); goto done;
+        }
+        const uint32_t np = (m.isize + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE;
+        uint32_t crc = h_crc[(size_t)i * 16];
+        for (uint32_t j = 1; j < np; ++j) {
+          const uint32_t len = j + 1 < np ? GZ_CRC_PIECE : m.isize - j * GZ_CRC_PIECE;
+          if (len == GZ_CRC_PIECE) crc = wt[0][crc & 255u] ^ wt[1][(crc >> 8) & 255u] ^ wt[2][(crc >> 16) & 255u] ^ wt[3][crc >> 24];
+          else { if (len != tail_len) { tail = crc_zero_bytes(len); tail_len = len; } crc = gf2_times(tail, crc); }
+          crc ^= h_crc[(size_t)i * 16 + j];
+        }
+        if (crc != m.crc) { rc = mic_set_error(MIC_E_INVALID, "Failed to uncompress input objects."); goto done; }     // (gunzip: "crc error")
+      }
+    }
+    lap("members checked");
+  } else GZTRY(hipStreamSynchronize(s));
+  if (timing) fprintf(stderr, "[gz] block gzip: %zu bytes -> %llu bytes, %zu members\n", gz_bytes, (unsigned long long)total, mem.size());
+  *d_text = d_out; d_out = nullptr; *n_text = (size_t)total;
+done:
+  if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); s = nullptr; }
+  for (void* q : owned) hipFree(q);
+  if (d_out) hipFree(d_out);
+  return rc;
+}
+}  // namespace
+
 extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_bytes, void** d_text, size_t* n_text, uint32_t* crc32_expected) {
   if (!e || !gz || !d_text || !n_text) return mic_set_error(MIC_E_INVALID, "null argument");
   *d_text = nullptr; *n_text = 0;
@@ -771,6 +951,10 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   if (rc) return rc;
   if (hipSetDevice(dev_) != hipSuccess) return mic_set_error(MIC_E_HIP, "hipSetDevice failed");
   const uint8_t* p = (const uint8_t*)gz;
+  if (gz_bytes >= 18 && p[0] == 0x1f && p[1] == 0x8b && (p[3] & 4) && p[12] == 'B' && p[13] == 'C') {      // block gzip
+    if (crc32_expected) *crc32_expected = 0;                                                               // (checked per member, inside)
+    return inflate_bgzf(e, p, gz_bytes, d_text, n_text);
+  }
   const size_t hdr = gzip_header(p, gz_bytes);
   if (!hdr) return mic_set_error(MIC_E_UNSUPPORTED, "not a plain gzip member");
   const size_t n = gz_bytes - 8;                                   // deflate data + nothing else expected in front of the trailer
@@ -856,7 +1040,7 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   if (sym_total > sym_bound) { rc = mic_set_error(MIC_E_HIP, "gzip on the device: symbol regions beyond their bound"); goto done; }
   GZTRY(dev_alloc((void**)&d_units, units.size() * sizeof(GzUnit)));
   GZTRY(hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
-  gz_decode_kernel<true><<<(unsigned)units.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, nullptr);
+  gz_decode_kernel<true><<<(unsigned)units.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, nullptr, 0);
   GZTRY(hipGetLastError());
   GZTRY(hipMemcpyAsync(units.data(), d_units, units.size() * sizeof(GzUnit), hipMemcpyDeviceToHost, s));
   GZTRY(dev_alloc((void**)&d_chain, units.size() * sizeof(GzUnit)));           // (while the decode runs)
@@ -901,7 +1085,7 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
       GZTRY(dev_alloc((void**)&d_which, redo.size() * 4));
       hipError_t e1 = hipMemcpyAsync(d_which, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, s);
       if (e1 == hipSuccess) e1 = hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s);
-      if (e1 == hipSuccess) { gz_decode_kernel<true><<<(unsigned)redo.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, d_which); e1 = hipGetLastError(); }
+      if (e1 == hipSuccess) { gz_decode_kernel<true><<<(unsigned)redo.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, d_which, 0); e1 = hipGetLastError(); }
       std::vector<GzUnit> back(units.size());
       if (e1 == hipSuccess) e1 = hipMemcpyAsync(back.data(), d_units, units.size() * sizeof(GzUnit), hipMemcpyDeviceToHost, s);
       if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);

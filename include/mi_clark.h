@@ -266,10 +266,12 @@ int mic_ingest_fetch_packed(mic_engine* e, size_t slot, uint32_t* reads_pointer,
 int mic_ingest_free(mic_engine* e);
 /* ---- compressed input: one gzip member inflated on the device ------------------------------------------------
  * Replaces the `gunzip` the reference's scripts run in front of the classifier (classify_metagenome.sh:116-142) for the
- * common case: ONE member, no preset dictionary.  `gz` = the whole .gz file in host memory.  On MIC_OK *d_text is a
- * device buffer of *n_text bytes of text (mic_gz_free_text releases it, mic_gz_copy_text copies a piece to the host),
- * the member's ISIZE has been checked and *crc32_expected is its CRC-32 for the caller to check on the copy it takes.
- * MIC_E_UNSUPPORTED: several members, data behind the last block, or blocks that could not be found speculatively - the
+ * common cases: ONE member without a preset dictionary (what `gzip` writes), or a whole block-gzip file (BGZF: members with a
+ * 'BC' size subfield, what bgzip / samtools write).  `gz` = the whole .gz file in host memory.  On MIC_OK *d_text is a
+ * device buffer of *n_text bytes of text (mic_gz_free_text releases it, mic_gz_copy_text copies a piece to the host);
+ * length (ISIZE) and CRC-32 of the member - of every member of a block-gzip file - have been checked against the trailer, as
+ * gunzip checks them; *crc32_expected is the one member's CRC-32 (0 for block gzip).
+ * MIC_E_UNSUPPORTED: several ordinary members, data behind the last block, or blocks that could not be found speculatively - the
  * caller inflates on the CPU (csrc/pgz.hpp / zlib) as before; MIC_E_INVALID: the data is damaged (zlib would fail too). */
 int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_bytes, void** d_text, size_t* n_text, uint32_t* crc32_expected);
 int mic_gz_copy_text(mic_engine* e, const void* d_text, size_t offset, size_t n, void* host_dst);

@@ -93,7 +93,7 @@ def test_bench_paired_config5_shape():
     assert gz["pairs"] == 1_000_000
     for kind in ("gzip", "bgzf"):
         assert gz[kind]["csv_equals_plain_run"] is True and gz[kind]["Mpairs_s"] > 0, gz
-    assert gz["gzip"]["inflated_on"] == "device" and gz["bgzf"]["inflated_on"] == "host", gz       # (block gzip: block-parallel on the host)
+    assert gz["gzip"]["inflated_on"] == "device" and gz["bgzf"]["inflated_on"] == "device", gz
 
 
 @pytest.mark.gpu

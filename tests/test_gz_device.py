@@ -92,13 +92,11 @@ def test_what_the_path_does_not_take(engine):
     with pytest.raises(MiClarkUnsupported):                       # not gzip at all
         engine.gunzip(data[:100000])
     import struct
-    blk = data[:0xFF00]                                            # block gzip (one BGZF member): left to the host's block-parallel path
+    blk = data[:0xFF00]                                            # one member with a 'BC' subfield, and the same bytes with another subfield
     c = zlib.compressobj(1, zlib.DEFLATED, -15)
     body = c.compress(blk) + c.flush()
     bgzf = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(blk), len(blk))
     assert zlib.decompress(bgzf, 31) == blk
-    with pytest.raises(MiClarkUnsupported):
-        engine.gunzip(bgzf)
     other_extra = bgzf[:12] + b"XY" + bgzf[14:]                    # (another subfield in the same place is skipped like any header field)
     assert engine.gunzip(other_extra)[0] == blk
     bad = bytearray(gz)
@@ -146,3 +144,53 @@ def test_buffers_reserved_ahead_of_the_call(engine):
         assert engine.L.mic_gz_release(engine.h) == 0
         text, _ = engine.gunzip(gz)
         assert text == want
+
+
+def _bgzf(data, block=0xFF00, level=1, eof=True):
+    import struct
+    out = []
+    for o in range(0, len(data), block):
+        blk = data[o:o + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(blk) + c.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(blk), len(blk)))
+    if eof:
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")
+    return b"".join(out)
+
+
+def test_block_gzip_members_side_by_side(engine):
+    """BGZF (bgzip / samtools): every member is a unit of its own - sizes from its header, place in the text from the trailers in front
+    of it, CRC-32 and length checked per member.  Against zlib; damage inside a member, in a trailer, a cut file: an error or
+    "unsupported", never wrong text."""
+    from cuclark_amd.db import MiClarkUnsupported
+    from cuclark_amd import MicError
+    rng = np.random.default_rng(21)
+    data = _fastq(rng, 30000)                                       # ~10 MB: 150 members
+    for block, level, eof in ((0xFF00, 1, True), (0xFF00, 6, False), (65536, 9, True), (1000, 1, True), (4096, 0, True)):
+        piece = data if block > 5000 else data[:300000]
+        gz = _bgzf(piece, block, level, eof)
+        assert zlib.decompressobj(31).decompress(gz)[:100] == piece[:100]
+        text, _ = engine.gunzip(gz)
+        assert text == piece, (block, level, eof)
+    assert engine.gunzip(_bgzf(b""))[0] == b""
+    whole = rng.integers(0, 256, 200000, dtype=np.uint8).tobytes() + data[:500000] + bytes(300000)      # stored, dynamic and run members
+    assert engine.gunzip(_bgzf(whole, 0xFF00, 6))[0] == whole
+    gz = bytearray(_bgzf(data[:1_000_000]))
+    bad = bytearray(gz); bad[len(bad) // 2] ^= 0x10                 # somewhere inside a member's deflate data
+    try:
+        text, _ = engine.gunzip(bytes(bad))
+        assert text == data[:1_000_000]                             # (a flipped bit that changes nothing is not possible, but say so)
+    except (MiClarkUnsupported, MicError):
+        pass
+    first = 18 + (gz[16] | (gz[17] << 8)) + 1 - 18                  # size of the first member
+    bad = bytearray(gz); bad[first - 8] ^= 1                        # its CRC-32
+    with pytest.raises(MicError):
+        engine.gunzip(bytes(bad))
+    bad = bytearray(gz); bad[first - 4] ^= 1                        # its ISIZE
+    with pytest.raises((MiClarkUnsupported, MicError)):
+        engine.gunzip(bytes(bad))
+    with pytest.raises((MiClarkUnsupported, MicError)):             # cut inside a member
+        engine.gunzip(bytes(gz[:len(gz) // 2]))
+    with pytest.raises((MiClarkUnsupported, MicError)):             # an ordinary member behind block-gzip ones
+        engine.gunzip(bytes(gz) + _gz(data[:1000]))
