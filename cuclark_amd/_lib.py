@@ -108,6 +108,7 @@ SYMBOLS = [
     ("mic_text_to_slot", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _SZ, C.POINTER(_SZ)]),
     ("mic_text_copy", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
     ("mic_text_free", C.c_int, [_VP, _VP]),
+    ("mic_text_format", C.c_int, [_VP]),
     ("mic_format_ratio_g", C.c_int, [C.c_uint32, C.c_uint32, C.c_char_p]),
     ("mic_key_bytes_rule", C.c_int, [C.c_uint64, C.c_int]),
     ("mic_index_reads", C.c_long, [_VP, _SZ, _SZ, _U64P, _U64P, _U64P, _U64P, _U64P]),

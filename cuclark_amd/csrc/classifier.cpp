@@ -1052,9 +1052,10 @@ class DeviceGzFeeder : public Classifier::Feeder {
       if (mic_pairs_offsets(pairs_, &s, &ns, &stride_) != MIC_OK || ns < 2) return;
     } else {
       if (mic_text_index_device(e_, text_[0], n_[0], &single_, &n_rec_, &status) != MIC_OK || status || !single_) {
-        why_ = "not FASTQ records of four lines";
+        why_ = "neither FASTA nor FASTQ records of four lines";
         return;
       }
+      fasta_ = mic_text_format(single_) == '>';
       if (mic_text_offsets(single_, &s, &ns, &stride_) != MIC_OK || ns < 2) return;
     }
     off_.assign(s, s + ns);
@@ -1075,7 +1076,7 @@ class DeviceGzFeeder : public Classifier::Feeder {
   uint64_t text_bytes() const { return off_.empty() ? 0 : off_.back(); }
   bool fastq() const override { return false; }          // (nothing for the loaders to strip: the slots are filled on the device)
   bool resident() const override { return true; }
-  int resident_flags() const override { return paired_ ? MIC_INGEST_RESIDENT : MIC_INGEST_RESIDENT_FASTQ; }
+  int resident_flags() const override { return paired_ || fasta_ ? MIC_INGEST_RESIDENT : MIC_INGEST_RESIDENT_FASTQ; }
   uint64_t remaining() const override { return off_.back() - off_[cur_]; }
 
   bool assign(size_t want, size_t cap, Classifier::Range& r) override {
@@ -1114,7 +1115,7 @@ class DeviceGzFeeder : public Classifier::Feeder {
   }
   uint64_t rec_of(size_t i) const { return std::min<uint64_t>((uint64_t)i * stride_, n_rec_); }
   mic_engine* e_;
-  bool paired_;
+  bool paired_, fasta_ = false;
   void* text_[2] = {nullptr, nullptr};
   size_t n_[2] = {0, 0};
   mic_pairs* pairs_ = nullptr;

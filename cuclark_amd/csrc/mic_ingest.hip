@@ -405,6 +405,25 @@ __global__ void __launch_bounds__(256) text_sample_kernel(const uint32_t* __rest
   out[i] = o < nb ? o : nb;
 }
 
+// FASTA: flag[L] = line L starts a record ('>' in its first column, CuCLARK_hh.hh:1369-1389); flag[n_lines] = 0 for the scan's total
+__global__ void __launch_bounds__(256) text_fasta_flag_kernel(const uint8_t* __restrict__ raw, uint32_t nb, const uint32_t* __restrict__ ls,
+                                                              uint64_t n_lines, uint32_t* __restrict__ flag) {
+  const uint64_t L = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (L > n_lines) return;
+  uint32_t f = 0;
+  if (L < n_lines) { const uint32_t p = ls[L]; f = p < nb && raw[p] == '>'; }
+  flag[L] = f;
+}
+// out[r / stride] = byte offset of record r for every stride-th record; the entries behind the last one: the end of the text
+__global__ void __launch_bounds__(256) text_fasta_sample_kernel(const uint32_t* __restrict__ ls, const uint32_t* __restrict__ flag,
+                                                                const uint32_t* __restrict__ rec_of_line, uint64_t n_lines, uint32_t stride,
+                                                                unsigned long long* __restrict__ out) {
+  const uint64_t L = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (L >= n_lines || !flag[L]) return;
+  const uint32_t r = rec_of_line[L];
+  if (r % stride == 0) out[r / stride] = ls[L];
+}
+
 // one wavefront per record: ">id\n" seq1 "N" seq2 "\n" at off[r] - off[r0]
 __global__ void __launch_bounds__(256) pair_merge_kernel(PairText A, PairText B, uint64_t r0, uint64_t r1, const unsigned long long* __restrict__ off,
                                                          uint8_t* __restrict__ dst) {
@@ -579,6 +598,7 @@ struct mic_text {
   uint32_t stride = 64;
   std::vector<unsigned long long> samples;      // byte offset of record i * stride, then the size of the text
   int device = 0;
+  bool fasta = false;
 };
 
 struct mic_pairs {
@@ -965,7 +985,41 @@ int mic_text_index_device(mic_engine* e, const void* d_text, size_t n, mic_text*
   PTRY(hipMemcpyAsync(&first, raw, 1, hipMemcpyDeviceToHost, st));
   PTRY(hipStreamSynchronize(st));
   n_lines = (uint64_t)nl + (last != '\n' ? 1 : 0);
-  if (first != '@') { *status = PS_HEADER; goto done; }                       // (FASTA and anything else: the host path)
+  if (first == '>') {
+    // FASTA: a record is a '>' line and what follows it up to the next one (sequences over several lines)
+    p->fasta = true;
+    const size_t b_ls = up((n_lines + 2) * 4), b_fl = up((n_lines + 1) * 4);
+    size_t tmp2 = 0;
+    PTRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n_lines + 1), st));
+    if (n_lines >= 0x7FFFFFF0ull) { *status = PS_BIG; goto done; }
+    // (the samples are sized by the lines - there are no more records than lines - and cut down once the count is known)
+    const size_t b_smp = up((n_lines / p->stride + 2) * 8);
+    PTRY(hipMalloc(&p->d_block, b_ls + 2 * b_fl + b_smp + up(tmp2 + 16)));
+    p->d_ls = (uint32_t*)p->d_block;
+    uint32_t* d_flag = (uint32_t*)((char*)p->d_block + b_ls);
+    uint32_t* d_rec = (uint32_t*)((char*)p->d_block + b_ls + b_fl);
+    unsigned long long* d_samples = (unsigned long long*)((char*)p->d_block + b_ls + 2 * b_fl);
+    void* d_tmp2 = (char*)p->d_block + b_ls + 2 * b_fl + b_smp;
+    line_start_kernel<<<n_tiles, 256, 0, st>>>(raw, nb, d_tile_off, p->d_ls, (uint32_t)(n_lines + 2));
+    PTRY(hipGetLastError());
+    if (last != '\n') { nl = nb + 1; PTRY(hipMemcpyAsync(p->d_ls + n_lines, &nl, 4, hipMemcpyHostToDevice, st)); }
+    const unsigned gl = (unsigned)((n_lines + 1 + 255) / 256);
+    text_fasta_flag_kernel<<<gl, 256, 0, st>>>(raw, nb, p->d_ls, n_lines, d_flag);
+    PTRY(hipcub::DeviceScan::ExclusiveSum(d_tmp2, tmp2, d_flag, d_rec, (int)(n_lines + 1), st));
+    uint32_t n_rec32 = 0;
+    PTRY(hipMemcpyAsync(&n_rec32, d_rec + n_lines, 4, hipMemcpyDeviceToHost, st));
+    text_fasta_sample_kernel<<<gl, 256, 0, st>>>(p->d_ls, d_flag, d_rec, n_lines, p->stride, d_samples);
+    PTRY(hipGetLastError());
+    PTRY(hipStreamSynchronize(st));
+    p->n_rec = n_rec32;
+    if (n_rec32 == 0) { *status = PS_HEADER; goto done; }
+    const uint64_t n_samples = p->n_rec / p->stride + 2;
+    p->samples.assign(n_samples, (unsigned long long)nb);
+    const uint64_t have = (p->n_rec + p->stride - 1) / p->stride;          // samples the kernel wrote: records 0, stride, ...
+    PTRY(hipMemcpy(p->samples.data(), d_samples, have * 8, hipMemcpyDeviceToHost));
+    goto done;
+  }
+  if (first != '@') { *status = PS_HEADER; goto done; }                       // (anything else: the host path)
   if (n_lines % 4 != 0 || n_lines == 0) { *status = PS_LINES; goto done; }
   {
     const uint64_t n_rec = n_lines / 4;
@@ -997,6 +1051,8 @@ static bool text_offset(const mic_text* p, uint64_t r, unsigned long long& off) 
   off = p->samples[r / p->stride];
   return true;
 }
+
+int mic_text_format(const mic_text* p) { return p ? (p->fasta ? '>' : '@') : 0; }
 
 int mic_text_offsets(const mic_text* p, const uint64_t** samples, size_t* n_samples, uint32_t* stride) {
   if (!p || !samples || !n_samples || !stride) return mic_set_error(MIC_E_INVALID, "null argument");

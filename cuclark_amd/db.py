@@ -243,11 +243,14 @@ class MiClarkDB:
         check(self.L.mic_text_copy(self.h, handle, r0, r1, out.ctypes.data, cap, C.byref(n)))
         return out[: n.value].tobytes()
 
+    def text_format(self, handle):
+        return chr(self.L.mic_text_format(handle))
+
     def text_classify(self, handle, slot, r0, r1):
         n = C.c_size_t(0)
         check(self.L.mic_text_to_slot(self.h, handle, r0, r1, slot, C.byref(n)))
         out = _lib.MicIngestResult()
-        check(self.L.mic_ingest_classify(self.h, slot, n.value, 12, C.byref(out)))
+        check(self.L.mic_ingest_classify(self.h, slot, n.value, 12 if self.text_format(handle) == "@" else 4, C.byref(out)))
         r = dict(status=int(out.status), n_reads=int(out.n_reads), n_lines=int(out.n_lines), csv=None, results=None, n_bytes=int(n.value))
         if out.status == 0:
             r["csv"] = C.string_at(out.csv, out.csv_bytes) if out.csv_bytes else b""

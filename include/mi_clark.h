@@ -238,8 +238,9 @@ int mic_last_query_ms(mic_engine* e, float* ms);
 #define MIC_INGEST_PAIRED 1        /* flags: objects are merged pairs: Length column minus the separator (CuCLARK_hh.hh:2119)        */
 #define MIC_INGEST_FASTQ_2LINE 2   /* flags: FASTQ records come as header + sequence line only (the caller dropped the '+' and
                                       quality lines, which nothing reads: halves the bytes that cross the host link)           */
-#define MIC_INGEST_RESIDENT 4       /* flags: the slot's DEVICE buffer already holds the n_bytes of merged paired-end text
-                                      (mic_pairs_merge_to_slot): nothing is uploaded                                            */
+#define MIC_INGEST_RESIDENT 4       /* flags: the slot's DEVICE buffer already holds the n_bytes of FASTA text - merged pairs
+                                      (mic_pairs_merge_to_slot, with MIC_INGEST_PAIRED) or records of a FASTA text
+                                      (mic_text_to_slot): nothing is uploaded                                                    */
 #define MIC_INGEST_RESIDENT_FASTQ 12 /* flags: as MIC_INGEST_RESIDENT, and the text is four-line FASTQ (mic_text_to_slot), not merged pairs */
 #define MIC_INGEST_OK 0u
 #define MIC_INGEST_FALLBACK 1u     /* run the host path on this batch                                        */
@@ -315,14 +316,17 @@ int mic_pairs_text(mic_engine* e, mic_pairs* p, uint64_t r0, uint64_t r1, void* 
 int mic_pairs_free(mic_engine* e, mic_pairs* p);
 
 /* ---- one FASTQ text that is on the device already (the inflated file of -O reads.fq.gz) ------------------------------------
- * mic_text_index_device  where the records start: the text must begin with '@' and have a multiple of four lines, else *status
- *                        (MIC_PAIRS_HEADER: FASTA or something else, MIC_PAIRS_LINES, MIC_PAIRS_BIG) and the caller's host reader.
+ * mic_text_index_device  where the records start: FASTQ (the text begins with '@' and has a multiple of four lines) or FASTA (it
+ *                        begins with '>'; a record is a '>' line and the lines up to the next one); else *status
+ *                        (MIC_PAIRS_HEADER: something else, MIC_PAIRS_LINES, MIC_PAIRS_BIG) and the caller's host reader.
+ * mic_text_format        '@' or '>': what the index found.
  * mic_text_offsets       host array: byte offset of record i * stride (last entry: the size of the text).
  * mic_text_to_slot       records [r0, r1) copied device to device into an ingest slot's buffer on the slot's stream; then
- *                        mic_ingest_classify(slot, *n_bytes, MIC_INGEST_RESIDENT_FASTQ): records the device path does not
+ *                        mic_ingest_classify(slot, *n_bytes, MIC_INGEST_RESIDENT_FASTQ, or MIC_INGEST_RESIDENT for FASTA): records the device path does not
  *                        reproduce come back as MIC_INGEST_FALLBACK as always, and mic_text_copy gives their bytes to the host. */
 typedef struct mic_text mic_text;
 int mic_text_index_device(mic_engine* e, const void* d_text, size_t n, mic_text** out, uint64_t* n_records, uint32_t* status);
+int mic_text_format(const mic_text* p);
 int mic_text_offsets(const mic_text* p, const uint64_t** samples, size_t* n_samples, uint32_t* stride);
 int mic_text_to_slot(mic_engine* e, mic_text* p, uint64_t r0, uint64_t r1, size_t slot, size_t* n_bytes);
 int mic_text_copy(mic_engine* e, mic_text* p, uint64_t r0, uint64_t r1, void* host_dst, size_t cap, size_t* n_bytes);

@@ -196,14 +196,15 @@ def test_texts_that_do_not_pair_up_are_refused():
         tx.free()
 
 
-@pytest.mark.parametrize("variant", ["plain", "unterminated", "crlf"])
+@pytest.mark.parametrize("variant", ["plain", "unterminated", "crlf", "fasta", "fasta_crlf"])
 def test_single_fastq_text_on_the_device(variant):
     """mic_text_*: the records of one FASTQ text cut at strides, copied into a slot on the device and classified there, against
     the same bytes handed over from the host; FASTA, a line count that is no multiple of four: refused."""
     import test_ingest as ti
-    rng = np.random.default_rng({"plain": 11, "unterminated": 12, "crlf": 13}[variant])
+    rng = np.random.default_rng({"plain": 11, "unterminated": 12, "crlf": 13, "fasta": 14, "fasta_crlf": 15}[variant])
     n = 2500
-    data = ti._random_reads(rng, _genomes(), n, fasta=False, crlf=variant == "crlf")
+    fasta = variant.startswith("fasta")
+    data = ti._random_reads(rng, _genomes(), n, fasta=fasta, crlf=variant.endswith("crlf"))
     if variant == "unterminated":
         data = data + b"@last\nACGTACGTACGTTTGACCA\n+\nIIIIIIIIIIIIIIIIIII"
         n += 1
@@ -212,11 +213,16 @@ def test_single_fastq_text_on_the_device(variant):
         d, nb, _ = e.gunzip_device(_gz(data))
         assert nb == len(data)
         h, n_rec, off, stride = e.text_index(d, nb)
-        assert h is not None and n_rec == n and off[0] == 0 and off[-1] == len(data)
+        assert h is not None and n_rec == n and off[0] == 0 and off[-1] == len(data) and e.text_format(h) == (">" if fasta else "@")
         lines = data.split(b"\n")
         starts = np.cumsum([0] + [len(l) + 1 for l in lines])
+        if fasta:
+            rec_start = [int(starts[i]) for i, l in enumerate(lines) if l[:1] == b">"] + [len(data)]     # (multi-line sequences: a record is a '>' line to the next)
+        else:
+            rec_start = [int(min(starts[4 * r], len(data))) for r in range(n + 1)]
+        assert len(rec_start) == n + 1
         for i in range(off.size):
-            assert off[i] == min(starts[4 * min(i * stride, n)], len(data))
+            assert off[i] == rec_start[min(i * stride, n)]
         e.ingest_alloc(2, 2 << 20, names, want_results=True)
         cuts = sorted({0, n} | {int(c) * stride for c in rng.integers(0, n // stride + 1, 5)})
         for r0, r1 in zip(cuts[:-1], cuts[1:]):
@@ -229,7 +235,7 @@ def test_single_fastq_text_on_the_device(variant):
                 assert dv["csv"] == v["csv"] and (dv["results"] == v["results"]).all()
         e.text_free(h)
         e.free_text(d)
-        for bad, status in ((b">r1\nACGT\n>r2\nACGT\n", 2), (data + b"@x\nAC\n+\n", 1), (b"@r\nACGT\n+\n", 1)):
+        for bad, status in ((b"r1\nACGT\n>r2\nACGT\n", 2), (b"@x\nAC\n+\n" + (data if not fasta else b""), 1), (b"@r\nACGT\n+\n", 1), (b"\n>r\nAC\n", 2)):
             d, nb, _ = e.gunzip_device(_gz(bad))
             h, st, _, _ = e.text_index(d, nb)
             assert h is None and st & status, (bad[:10], st)

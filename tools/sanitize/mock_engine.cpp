@@ -109,4 +109,5 @@ int mic_text_offsets(const mic_text*, const uint64_t**, size_t*, uint32_t*) { re
 int mic_text_to_slot(mic_engine*, mic_text*, uint64_t, uint64_t, size_t, size_t*) { return MIC_E_NODEVICE; }
 int mic_text_copy(mic_engine*, mic_text*, uint64_t, uint64_t, void*, size_t, size_t*) { return MIC_E_NODEVICE; }
 int mic_text_free(mic_engine*, mic_text*) { return MIC_OK; }
+int mic_text_format(const mic_text*) { return 0; }
 }
