@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One FASTQ file of the bench's shape, gzip -1, inflated on the device (mic_gz_inflate_device) with its stage times
-(MIC_GZ_TIMING=1) next to zlib on one host thread.    python tools/gz_device_timing.py [reads]"""
+(MIC_GZ_TIMING=1) next to zlib on one host thread.    python tools/gz_device_timing.py [reads [binned]]"""
 import os
 import sys
 import time
@@ -15,6 +15,10 @@ rng = np.random.default_rng(3)
 nt = np.frombuffer(b"ACGT", np.uint8)
 seqs = nt[rng.integers(0, 4, (n, 150))]
 qual = np.full((n, 150), ord("I"), np.uint8)        # the bench's files (mic_synth_reads_text_device): one quality value
+if len(sys.argv) > 2 and sys.argv[2] == "binned":    # binned qualities as sequencers of the last decade write them: four values in runs
+    runs = rng.integers(0, 4, (n, 150 // 5))
+    qual = np.frombuffer(b"F:,#", np.uint8)[np.repeat(runs, 5, axis=1)]
+    qual[rng.random((n, 150)) < 0.85] = ord("F")
 recs = np.empty((n, 316), np.uint8)
 for i, h in enumerate(np.char.mod("@r%09d\n", np.arange(n)).astype("S12")):
     pass
