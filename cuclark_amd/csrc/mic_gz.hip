@@ -525,11 +525,19 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
       else if (!read_dynamic_w(b, f, lane)) { status = GZ_ERR_CODE; break; }
       const uint32_t t6 = first_level(f, lane);
       bool bad = false;
+      uint32_t go = 1u;              // the symbol loop has ONE exit, and it is uniform by construction: with an exit the compiler cannot prove
+                                     // uniform the whole loop runs under an exec mask and every value it carries lives in vector registers
+                                     // (eleven v_readfirstlane and seven moves back per symbol)
+      // (said before the loop as well: a value that enters the loop from the header's code, which the compiler cannot prove uniform,
+      // makes the loop's own copy of it a vector register whatever the loop does with it)
+      b.buf = UNI64(b.buf); b.pos = UNI64(b.pos); b.cnt = (int)UNI((uint32_t)b.cnt); b.base = UNI64(b.base);
+      w = UNI64(w); wf = UNI64(wf); b.over = UNI((uint32_t)b.over) != 0u;
       for (;;) {
+        if (!UNI(go)) break;
         // (the loop-carried state, said uniform once per symbol: the compiler keeps it in scalar registers from here to the back edge)
         b.buf = UNI64(b.buf); b.pos = UNI64(b.pos); b.cnt = (int)UNI((uint32_t)b.cnt); b.base = UNI64(b.base);
-        w = UNI64(w); wf = UNI64(wf);
-        if (b.over) { status = GZ_ERR_OVER; bad = true; break; }
+        w = UNI64(w); wf = UNI64(wf); b.over = UNI((uint32_t)b.over) != 0u;
+        if (b.over) { status = GZ_ERR_OVER; bad = true; go = 0u; continue; }
         const uint32_t v = b.peek(15);
         {
           const uint32_t q = __builtin_amdgcn_readlane(t6, (int)(v & 63u));
@@ -539,7 +547,7 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
             if (lane == 0) { f.ring[w & RM] = (uint16_t)(q & 0xFFu); if (cnt2 == 2) f.ring[(w + 1) & RM] = (uint16_t)((q >> 8) & 0xFFu); }
             w += cnt2;
             if ((w & 63u) < cnt2) {
-              if (w > (1ull << 28)) { status = GZ_ERR_ROOM; bad = true; break; }
+              if (w > (1ull << 28)) { status = GZ_ERR_ROOM; bad = true; go = 0u; continue; }
               if (w - wf >= 64) flush(w & ~63ull);
             }
             continue;
@@ -548,19 +556,19 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
         const uint32_t e = UNI(f.lit_fast[v & ((1u << GZ_FAST_LIT) - 1)]);
         int s;
         if (e) { b.drop((int)(e >> 12)); s = (int)(e & 0xFFF); }
-        else { s = slow_decode(f.sc.lit, b, 288); if (s < 0) { status = GZ_ERR_CODE; bad = true; break; } }
+        else { s = slow_decode(f.sc.lit, b, 288); if (s < 0) { status = GZ_ERR_CODE; bad = true; go = 0u; continue; } }
         if (s < 256) {
           if (lane == 0) f.ring[w & RM] = (uint16_t)s;
           ++w;
           if ((w & 63u) == 0) {
-            if (w > (1ull << 28)) { status = GZ_ERR_ROOM; bad = true; break; }       // (one wavefront would work for seconds: the CPU path)
+            if (w > (1ull << 28)) { status = GZ_ERR_ROOM; bad = true; go = 0u; continue; }       // (one wavefront would work for seconds: the CPU path)
             if (w - wf >= 64) flush(w);
           }
           continue;
         }
-        if (s == 256) break;
+        if (s == 256) { go = 0u; continue; }
         s -= 257;
-        if (s >= 29) { status = GZ_ERR_CODE; bad = true; break; }
+        if (s >= 29) { status = GZ_ERR_CODE; bad = true; go = 0u; continue; }
         const uint32_t lt = UNI(f.len_tab[s]);
         const uint32_t len = (lt & 0xFFFFu) + b.get((int)(lt >> 16));
         const uint32_t v2 = b.peek(15);
@@ -568,10 +576,10 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
         int ds;
         if (e2) { b.drop((int)(e2 >> 12)); ds = (int)(e2 & 0xFFF); }
         else { ds = slow_decode(f.sc.dist, b, 30); }
-        if (ds < 0 || ds >= 30) { status = GZ_ERR_CODE; bad = true; break; }
+        if (ds < 0 || ds >= 30) { status = GZ_ERR_CODE; bad = true; go = 0u; continue; }
         const uint32_t dt = UNI(f.dist_tab[ds]);
         const uint32_t dist = (dt & 0xFFFFu) + b.get((int)(dt >> 16));
-        if (dist > w && (known || dist - w > 32768u)) { status = GZ_ERR_DIST; bad = true; break; }
+        if (dist > w && (known || dist - w > 32768u)) { status = GZ_ERR_DIST; bad = true; go = 0u; continue; }
         // The match, one element per lane: element i comes from w - dist + i, or - where that is inside the match itself - from
         // w - dist + (i mod dist).  In front of the unit: position 32768 - (dist - (w + i)) of the unknown window, as a marker; inside
         // the ring (the last GZ_RING symbols, minus what this match overwrites): an LDS copy; further back: the symbol buffer, once
