@@ -481,16 +481,19 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
   const bool known = u == 0 || all_known;                 // a member's first unit has nothing in front of it: no markers possible
   const uint64_t cyc0 = __builtin_readcyclecounter();
   uint16_t* out = sym + UNI64(U.sym_off);
-  const uint64_t room = WRITE ? UNI64(U.sym_cap) : 0;
+  const uint64_t room64 = WRITE ? UNI64(U.sym_cap) : 0;
+  const uint32_t room = room64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room64;
   const uint64_t stop_bit = UNI64(U.stop_bit);
-  uint64_t w = 0, wf = 0;                                 // symbols produced / symbols that have left the ring for the symbol buffer
+  uint32_t w = 0, wf = 0;                                 // symbols produced / symbols that have left the ring for the symbol buffer
+                                                          // (32 bits - a unit of more than 2^28 symbols is given back, below: the scalar unit
+                                                          // compares 32-bit numbers, 64-bit ones go through vector compares)
   uint32_t status = GZ_OK;
   constexpr uint32_t RM = GZ_RING - 1;
   // symbols [wf, upto) out of the ring, 64 per store (only what fits the unit's region: the rest is counted, and decoded again)
-  auto flush = [&](uint64_t upto) {
+  auto flush = [&](uint32_t upto) {
     __builtin_amdgcn_wave_barrier();
-    for (uint64_t g = wf; g < upto; g += 64) {
-      const uint64_t at = g + (uint64_t)lane;
+    for (uint32_t g = wf; g < upto; g += 64) {
+      const uint32_t at = g + (uint32_t)lane;
       if (at < upto && at < room) out[at] = f.ring[at & RM];
     }
     wf = upto;
@@ -517,6 +520,7 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
         if (len - i <= GZ_RING) f.ring[(w + i) & RM] = c;
       }
       w += len; wf = w;
+      if (w > (1u << 28)) { status = GZ_ERR_ROOM; break; }
       __threadfence();                                     // (rare; the far path above counts on whole groups otherwise)
       __builtin_amdgcn_wave_barrier();
       b.pos = from + len; b.buf = 0; b.cnt = 0;
@@ -531,12 +535,12 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
       // (said before the loop as well: a value that enters the loop from the header's code, which the compiler cannot prove uniform,
       // makes the loop's own copy of it a vector register whatever the loop does with it)
       b.buf = UNI64(b.buf); b.pos = UNI64(b.pos); b.cnt = (int)UNI((uint32_t)b.cnt); b.base = UNI64(b.base);
-      w = UNI64(w); wf = UNI64(wf); b.over = UNI((uint32_t)b.over) != 0u;
+      w = UNI(w); wf = UNI(wf); b.over = UNI((uint32_t)b.over) != 0u;
       for (;;) {
         if (!UNI(go)) break;
         // (the loop-carried state, said uniform once per symbol: the compiler keeps it in scalar registers from here to the back edge)
         b.buf = UNI64(b.buf); b.pos = UNI64(b.pos); b.cnt = (int)UNI((uint32_t)b.cnt); b.base = UNI64(b.base);
-        w = UNI64(w); wf = UNI64(wf); b.over = UNI((uint32_t)b.over) != 0u;
+        w = UNI(w); wf = UNI(wf); b.over = UNI((uint32_t)b.over) != 0u;
         if (b.over) { status = GZ_ERR_OVER; bad = true; go = 0u; continue; }
         const uint32_t v = b.peek(15);
         {
@@ -547,8 +551,8 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
             if (lane == 0) { f.ring[w & RM] = (uint16_t)(q & 0xFFu); if (cnt2 == 2) f.ring[(w + 1) & RM] = (uint16_t)((q >> 8) & 0xFFu); }
             w += cnt2;
             if ((w & 63u) < cnt2) {
-              if (w > (1ull << 28)) { status = GZ_ERR_ROOM; bad = true; go = 0u; continue; }
-              if (w - wf >= 64) flush(w & ~63ull);
+              if (w > (1u << 28)) { status = GZ_ERR_ROOM; bad = true; go = 0u; continue; }
+              if (w - wf >= 64) flush(w & ~63u);
             }
             continue;
           }
@@ -561,7 +565,7 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
           if (lane == 0) f.ring[w & RM] = (uint16_t)s;
           ++w;
           if ((w & 63u) == 0) {
-            if (w > (1ull << 28)) { status = GZ_ERR_ROOM; bad = true; go = 0u; continue; }       // (one wavefront would work for seconds: the CPU path)
+            if (w > (1u << 28)) { status = GZ_ERR_ROOM; bad = true; go = 0u; continue; }       // (one wavefront would work for seconds: the CPU path)
             if (w - wf >= 64) flush(w);
           }
           continue;
@@ -595,16 +599,16 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
         for (uint32_t i = lane; i < len; i += 64) {
           uint32_t j = i;
           if (j >= dist) j = dist == 1 ? 0u : j % dist;      // (len > dist: a run; dist 1 is the common one)
-          const int64_t rel = (int64_t)w - (int64_t)dist + (int64_t)j;
+          const int32_t rel = (int32_t)(w - dist + j);          // (w <= 2^28, dist <= 32 Ki)
           uint16_t x;
           if (rel < 0) x = (uint16_t)(0x8000u | (uint32_t)(32768 + rel));
-          else if (far && (uint64_t)rel < wf) x = (uint64_t)rel < room ? __atomic_load_n(&out[rel], __ATOMIC_RELAXED) : (uint16_t)0;   // (past the region: the unit is decoded again anyway)
-          else x = f.ring[(uint64_t)rel & RM];
+          else if (far && (uint32_t)rel < wf) x = (uint32_t)rel < room ? __atomic_load_n(&out[rel], __ATOMIC_RELAXED) : (uint16_t)0;   // (past the region: the unit is decoded again anyway)
+          else x = f.ring[(uint32_t)rel & RM];
           f.ring[(w + i) & RM] = x;
         }
         __builtin_amdgcn_wave_barrier();
         w += len;
-        if (w - wf >= 64) flush(w & ~63ull);
+        if (w - wf >= 64) flush(w & ~63u);
       }
       if (bad) break;
     } else { status = GZ_ERR_TYPE; break; }
