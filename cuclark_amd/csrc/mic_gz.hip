@@ -35,6 +35,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -803,6 +804,10 @@ bool bgzf_members(const uint8_t* p, size_t n, std::vector<BgzfMember>& out, uint
   return !out.empty();
 }
 
+// The device code of this file is loaded when its first kernel is launched (the runtime defers it, file by file): 4 ms that belong
+// in front of the first call, with the reservation
+__global__ void gz_warm_kernel(uint32_t* p) { if (p && threadIdx.x == 1000) *p = 0; }
+
 // CRC-32 of every member's text: a wavefront per member, lane j its 4-KiB piece j (a member holds 64 KiB of text at most)
 __global__ void __launch_bounds__(64) gz_crc_members_kernel(const uint8_t* __restrict__ text, const unsigned long long* __restrict__ off,
                                                             const uint32_t* __restrict__ size, uint32_t n_members, uint32_t* __restrict__ out) {
@@ -836,6 +841,38 @@ struct GzReserve {
 };
 std::mutex g_res_mu;
 std::vector<GzReserve> g_res;
+
+// A call runs on one of the engine's two copy streams, taken in turn: the two mates of a pair are inflated by two host threads at
+// once and want a stream each, and creating one costs two milliseconds (a hardware queue) - more than the upload of a file.  (Two
+// calls that meet on one stream take turns on it; nothing else depends on which one a call gets.)
+std::atomic<unsigned> g_call_no{0};
+hipStream_t call_stream(mic_engine* e) {
+  hipStream_t up, down;
+  mic_engine_copy_streams(e, &up, &down);
+  return (g_call_no.fetch_add(1) & 1u) ? down : up;
+}
+
+// Host buffers that large copies from the device land in are kept for the next call instead of freed: the runtime pins the pages of
+// such a destination for the copy, an allocation of this size is a mapping of its own, and unmapping pages that were pinned a
+// moment ago makes the driver take the process's queues off the device and put them back - the next kernel, whoever launches it,
+// starts 4 ms late (measured: the first kernel behind a call).
+std::mutex g_hostbuf_mu;
+std::vector<std::vector<uint32_t>> g_hostbufs;
+std::vector<uint32_t> take_hostbuf(size_t n) {
+  std::vector<uint32_t> v;
+  {
+    std::lock_guard<std::mutex> lk(g_hostbuf_mu);
+    for (size_t i = 0; i < g_hostbufs.size(); ++i)
+      if (g_hostbufs[i].capacity() >= n) { v.swap(g_hostbufs[i]); g_hostbufs.erase(g_hostbufs.begin() + (ptrdiff_t)i); break; }
+  }
+  v.resize(n);
+  return v;
+}
+void keep_hostbuf(std::vector<uint32_t>& v) {
+  if (v.capacity() == 0) return;
+  std::lock_guard<std::mutex> lk(g_hostbuf_mu);
+  if (g_hostbufs.size() < 8) { g_hostbufs.emplace_back(); g_hostbufs.back().swap(v); }
+}
 
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 unsigned long long sym_bound_of(size_t n, uint32_t n_chunks) { return 8ull * (n + n_chunks) + 16384ull * n_chunks; }
@@ -892,7 +929,7 @@ int inflate_bgzf(mic_engine* e, const uint8_t* p, size_t gz_bytes, void** d_text
     units.push_back(u); unit_member.push_back((uint32_t)i);
     h_off.push_back(mem[i].text_off); h_size.push_back(mem[i].isize);
   }
-  GZTRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  s = call_stream(e);
   GZTRY(dev_alloc((void**)&d_in, gz_bytes + 16));
   GZTRY(hipMemsetAsync(d_in + gz_bytes, 0, 16, s));
   GZTRY(hipMemcpyAsync(d_in, p, gz_bytes, hipMemcpyHostToDevice, s));
@@ -917,7 +954,7 @@ int inflate_bgzf(mic_engine* e, const uint8_t* p, size_t gz_bytes, void** d_text
     GZTRY(hipGetLastError());
     gz_crc_members_kernel<<<nu, 64, 0, s>>>(d_out, d_off, d_size, nu, d_crc);
     GZTRY(hipGetLastError());
-    h_crc.resize((size_t)nu * 16);
+    h_crc = take_hostbuf((size_t)nu * 16);
     GZTRY(hipMemcpyAsync(h_crc.data(), d_crc, (size_t)nu * 16 * 4, hipMemcpyDeviceToHost, s));
     GZTRY(hipStreamSynchronize(s));
     lap("bytes + CRC-32 of the members");
@@ -948,9 +985,10 @@ int inflate_bgzf(mic_engine* e, const uint8_t* p, size_t gz_bytes, void** d_text
   if (timing) fprintf(stderr, "[gz] block gzip: %zu bytes -> %llu bytes, %zu members\n", gz_bytes, (unsigned long long)total, mem.size());
   *d_text = d_out; d_out = nullptr; *n_text = (size_t)total;
 done:
-  if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); s = nullptr; }
+  if (s) { hipStreamSynchronize(s); s = nullptr; }
   for (void* q : owned) hipFree(q);
   if (d_out) hipFree(d_out);
+  keep_hostbuf(h_crc);
   return rc;
 }
 }  // namespace
@@ -982,7 +1020,7 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   uint64_t total = 0;
   unsigned long long sym_total = 0, sym_bound = 0;
   GzUnit* d_chain = nullptr;
-  hipStream_t s = nullptr;         // a stream of this call's own: the two mates of a pair are inflated by two host threads at once
+  hipStream_t s = nullptr;         // (call_stream: one of the engine's copy streams)
   // device memory: out of the reservation made for a file of this size, if there is one (mic_gz_reserve), else allocated here
   char* arena = nullptr; size_t arena_left = 0;
   std::vector<void*> owned;
@@ -1014,7 +1052,7 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
     fprintf(stderr, "[gz] %s: %.3f ms\n", what, (t1.tv_sec - tq0.tv_sec) * 1e3 + (t1.tv_nsec - tq0.tv_nsec) / 1e6);
     tq0 = t1;
   };
-  GZTRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  s = call_stream(e);
   GZTRY(dev_alloc((void**)&d_in, n + 16));
   GZTRY(hipMemsetAsync(d_in + n, 0, 16, s));
   GZTRY(hipMemcpyAsync(d_in, p, n, hipMemcpyHostToDevice, s));
@@ -1120,7 +1158,8 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   GZTRY(hipGetLastError());
   {
     const size_t n_pieces = (size_t)((total + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE);
-    std::vector<uint32_t> piece(n_pieces);
+    std::vector<uint32_t> piece = take_hostbuf(n_pieces);
+    struct Keep { std::vector<uint32_t>& v; ~Keep() { keep_hostbuf(v); } } keep{piece};
     if (n_pieces) {
       uint32_t* d_crc = nullptr;
       GZTRY(dev_alloc((void**)&d_crc, n_pieces * 4));
@@ -1135,7 +1174,7 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   if (timing) fprintf(stderr, "[gz] %zu bytes -> %llu bytes, %u chunks, %zu units found, %zu in the chain\n", gz_bytes, (unsigned long long)total, n_chunks, units.size(), chain.size());
   *d_text = d_out; d_out = nullptr; *n_text = total;
 done:
-  if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); s = nullptr; }
+  if (s) { hipStreamSynchronize(s); s = nullptr; }
   for (void* q : owned) hipFree(q);
   if (d_out) hipFree(d_out);
   lap("buffers freed");
@@ -1166,6 +1205,8 @@ extern "C" int mic_gz_reserve(mic_engine* e, size_t gz_bytes, uint32_t isize) {
     (void)hipGetLastError();
     return mic_set_error(he == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "gzip on the device: reservation: %s", hipGetErrorString(he));
   }
+  gz_warm_kernel<<<1, 64>>>((uint32_t*)r.scratch);
+  (void)hipDeviceSynchronize();
   std::lock_guard<std::mutex> lk(g_res_mu);
   g_res.push_back(r);
   return MIC_OK;

@@ -11,7 +11,7 @@ echo "== host inflate"
 for rep in 1 2; do MIC_GZ_HOST=1 MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -P $D/reads_1.fq.gz $D/reads_2.fq.gz -R $D/host -n 12 2>&1 | grep -E "Assignment|inflate|device ingest" | sed 's/thread-seconds.*ms since start/.. ms since start/'; done
 echo "== device inflate"
 if [ -n "$GZ_TIMING" ]; then export MIC_GZ_TIMING=1; fi
-for rep in 1 2 3; do MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -P $D/reads_1.fq.gz $D/reads_2.fq.gz -R $D/dev -n 12 2>&1 | grep -E "Assignment|inflate|device ingest|^\[gz\]" | sed 's/thread-seconds.*ms since start/.. ms since start/'; done
+for rep in 1 2 3; do MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -P $D/reads_1.fq.gz $D/reads_2.fq.gz -R $D/dev -n 12 2>&1 | grep -E "Assignment|inflate|device ingest|^\[gz\]|^\[pairs\]" | sed 's/thread-seconds.*ms since start/.. ms since start/'; done
 cmp $D/host.csv $D/dev.csv && echo "CSVs identical"
 echo "== one file: host inflate, device inflate"
 MIC_GZ_HOST=1 MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -O $D/reads_1.fq.gz -R $D/host1 -n 12 2>&1 | grep -E "Assignment|inflate" | sed 's/thread-seconds.*ms since start/.. ms since start/'
@@ -33,6 +33,6 @@ for i in (1, 2):
         f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")
 PY
 MIC_GZ_HOST=1 MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -P $D/reads_1.fq.bgz.gz $D/reads_2.fq.bgz.gz -R $D/hostb -n 12 2>&1 | grep -E "Assignment|inflate" | sed 's/thread-seconds.*ms since start/.. ms since start/'
-for rep in 1 2 3; do MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -P $D/reads_1.fq.bgz.gz $D/reads_2.fq.bgz.gz -R $D/devb -n 12 2>&1 | grep -E "Assignment|inflate|^\[gz\]" | sed 's/thread-seconds.*ms since start/.. ms since start/'; done
+for rep in 1 2 3; do MIC_CLI_TIMING=1 ./exe/cuCLARK-l -T $D/targets.txt -D $D/DB/ -P $D/reads_1.fq.bgz.gz $D/reads_2.fq.bgz.gz -R $D/devb -n 12 2>&1 | grep -E "Assignment|inflate|^\[gz\]|^\[pairs\]" | sed 's/thread-seconds.*ms since start/.. ms since start/'; done
 cmp $D/hostb.csv $D/devb.csv && cmp $D/hostb.csv $D/host.csv && echo "CSVs identical"
 rm -rf $D
