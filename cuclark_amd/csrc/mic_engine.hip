@@ -132,6 +132,7 @@ void fill_table(mic_engine* e, const MicBuildOut& b, uint64_t htsize, uint64_t s
   i.max_chain = layout != MIC_LAYOUT_DIRECT ? b.max_chain : 0; i.reserved = (layout == MIC_LAYOUT_SUPER || layout == MIC_LAYOUT_SUPER2) ? b.walk_ppm : 0;
   i.n_entries = b.n_entries ? b.n_entries : b.n_elems;
   e->db_loaded = true;
+  (void)mic_kernels_warm(e->stream);          // (the query kernels' code on the device before the first batch asks for it)
 }
 
 int check_shard(uint64_t htsize, uint64_t& s0, uint64_t& s1) {

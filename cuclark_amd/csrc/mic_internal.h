@@ -125,6 +125,7 @@ extern thread_local uint64_t mic_build_reserved_hbm;
 
 // launchers (mic_kernels.hip)
 hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hipStream_t s);
+hipError_t mic_kernels_warm(hipStream_t s);      // loads the query kernels' device code (a no-op kernel of their file)
 hipError_t mic_launch_merge_rows(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t row_words, size_t n,
                                  uint32_t* flags_results, hipStream_t s);
 hipError_t mic_launch_result_from_rows(const uint32_t* rows, uint32_t row_words, uint32_t* results, size_t n,
