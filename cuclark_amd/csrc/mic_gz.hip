@@ -597,6 +597,11 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
           asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
         __builtin_amdgcn_wave_barrier();
+        if (len <= 64u && dist >= len && dist <= w && !far) {
+          // the common match in one step: at most 64 symbols, its source whole inside the ring and in front of the match (three
+          // scalar compares instead of the general loop's per-lane cases: self-overlap, markers, sources that left the ring)
+          if ((uint32_t)lane < len) f.ring[(w + (uint32_t)lane) & RM] = f.ring[(w - dist + (uint32_t)lane) & RM];
+        } else
         for (uint32_t i = lane; i < len; i += 64) {
           uint32_t j = i;
           if (j >= dist) j = dist == 1 ? 0u : j % dist;      // (len > dist: a run; dist 1 is the common one)
