@@ -58,9 +58,20 @@ def rig(tmp_path_factory):
             body = c.compress(blk) + c.flush()
             f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(blk), len(blk)))
         f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")
-    for i, (a, b) in enumerate(((fq1, "p_1.fq.gz"), (fq2, "p_2.fq.gz"))):
+    for i, (a, b) in enumerate(((fq1, "p_1.fq.gz"), (fq2, "p_2.fq.gz"), (fq, "r1.fq.gz"), (fa, "r.fa.gz"))):
         with gzip.open(os.path.join(tmp, b), "wb", compresslevel=1) as f:
             f.write(a)
+
+    def bgzf(path, data):
+        with open(path, "wb") as f:
+            for o in range(0, len(data), 0xFF00):
+                blk = data[o:o + 0xFF00]
+                c = zlib.compressobj(1, zlib.DEFLATED, -15)
+                body = c.compress(blk) + c.flush()
+                f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(blk), len(blk)))
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")
+    bgzf(os.path.join(tmp, "p_1.bgzf.fq.gz"), fq1)
+    bgzf(os.path.join(tmp, "p_2.bgzf.fq.gz"), fq2)
     # a database that only has to exist (the mock engine loads nothing)
     db = os.path.join(tmp, "DB")
     os.makedirs(db)
@@ -100,6 +111,17 @@ CASES = [
     ("pairs_parallel_merge", ["-P", "p_1.fq", "p_2.fq"], "pairs", {"MIC_INGEST_MB": "2"}),
     ("pairs_serial_reader", ["-P", "p_1.fq", "p_2.fq"], "pairs", {"MIC_SERIAL_PAIRS": "1", "MIC_INGEST_MB": "2"}),
     ("pairs_gzip", ["-P", "p_1.fq.gz", "p_2.fq.gz"], "pairs", {"MIC_INGEST_MB": "2"}),
+    # compressed input "on the device" (the mock's CPU stand-ins for mic_gz_* / mic_pairs_* / mic_text_*: the command line's
+    # DeviceGzFeeder - batches cut at the sampled offsets, slots filled in place - is what runs under the sanitizer) and the same
+    # files through the host inflater
+    ("pairs_gzip_small_slots", ["-P", "p_1.fq.gz", "p_2.fq.gz"], "pairs", {"MIC_INGEST_KB": "96"}),
+    ("pairs_gzip_host", ["-P", "p_1.fq.gz", "p_2.fq.gz"], "pairs", {"MIC_INGEST_MB": "2", "MIC_GZ_HOST": "1"}),
+    ("pairs_bgzf", ["-P", "p_1.bgzf.fq.gz", "p_2.bgzf.fq.gz"], "pairs", {"MIC_INGEST_MB": "2"}),
+    ("pairs_bgzf_host", ["-P", "p_1.bgzf.fq.gz", "p_2.bgzf.fq.gz"], "pairs", {"MIC_INGEST_MB": "2", "MIC_GZ_HOST": "1"}),
+    ("gzip_one_member", ["-O", "r1.fq.gz"], "single", {"MIC_INGEST_KB": "96"}),
+    ("gzip_one_member_host", ["-O", "r1.fq.gz"], "single", {"MIC_INGEST_MB": "2", "MIC_GZ_HOST": "1"}),
+    ("fasta_gzip", ["-O", "r.fa.gz"], "single", {"MIC_INGEST_MB": "2"}),
+    ("bgzf_host", ["-O", "r.bgzf.fq.gz"], "single", {"MIC_INGEST_MB": "2", "MIC_GZ_HOST": "1"}),
 ]
 
 

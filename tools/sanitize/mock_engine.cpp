@@ -1,6 +1,6 @@
 // mock_engine.cpp - a stand-in for libmi_clark.so's DEVICE entry points, for sanitizer builds of the host code only
 // (tests/test_sanitizers.py: AddressSanitizer + UBSan, ThreadSanitizer; there is no GPU sanitizer on this pool).
-// exe-side code under test, unchanged: classifier.cpp (FileFeeder, SegmentFeeder, PairedFileFeeder, PairedSource, GzSource,
+// exe-side code under test, unchanged: classifier.cpp (FileFeeder, SegmentFeeder, PairedFileFeeder, DeviceGzFeeder, PairedSource, GzSource,
 // InflateStream, strip_fastq, run_stream's loader / device / writer threads), cli_main.cpp, and mic_host.cpp (indexer, packer,
 // CSV).  What is mocked: the engine.  mic_ingest_classify here "classifies" a slot on the CPU: it walks the records of the
 // slot's bytes and writes one CSV line "<name>,<length>" per record - a pure function of the input, so the test can check
@@ -11,6 +11,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <zlib.h>
+
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -93,21 +96,159 @@ int mic_batch_wait(mic_engine*, size_t) { return MIC_E_NODEVICE; }
 int mic_batch_dense_counts(mic_engine*, size_t, size_t, uint32_t*) { return MIC_E_NODEVICE; }
 int mic_batch_merge_shards(mic_engine* const*, size_t, size_t) { return MIC_E_NODEVICE; }
 int mic_batches_free(mic_engine*) { return MIC_OK; }
-// compressed mates on the device: the mock has none, the command line inflates on the host
-int mic_gz_inflate_device(mic_engine*, const void*, size_t, void**, size_t*, uint32_t*) { return MIC_E_UNSUPPORTED; }
-int mic_gz_free_text(mic_engine*, void*) { return MIC_OK; }
-int mic_gz_reserve(mic_engine*, size_t, uint32_t) { return MIC_E_NODEVICE; }
+// ---- compressed input "on the device": the same entry points on the CPU, so that the command line's DeviceGzFeeder (batch
+// arithmetic over the sampled offsets, slots filled in place, the hand-back path) runs under the sanitizers too.  "Device" memory
+// is malloc memory of the exact size; a slot's device buffer is its raw buffer.  One gzip member or a block-gzip file, as the real
+// entry point takes them; anything else: MIC_E_UNSUPPORTED.
+int mic_gz_inflate_device(mic_engine*, const void* gz, size_t gz_bytes, void** d_text, size_t* n_text, uint32_t* crc32_expected) {
+  const uint8_t* p = (const uint8_t*)gz;
+  *d_text = nullptr; *n_text = 0;
+  if (gz_bytes < 18 || p[0] != 0x1f || p[1] != 0x8b) return MIC_E_UNSUPPORTED;
+  const bool bgzf = (p[3] & 4) && p[12] == 'B' && p[13] == 'C';
+  std::string out;
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (inflateInit2(&z, 31) != Z_OK) return MIC_E_HIP;
+  z.next_in = (Bytef*)p; z.avail_in = (uInt)gz_bytes;
+  std::vector<uint8_t> buf(1 << 16);
+  int members = 0;
+  for (;;) {
+    z.next_out = buf.data(); z.avail_out = (uInt)buf.size();
+    const int r = inflate(&z, Z_NO_FLUSH);
+    out.append((const char*)buf.data(), buf.size() - z.avail_out);
+    if (r == Z_STREAM_END) {
+      ++members;
+      if (z.avail_in == 0) break;
+      if (!bgzf) { inflateEnd(&z); return MIC_E_UNSUPPORTED; }       // several ordinary members: the host's affair
+      if (inflateReset(&z) != Z_OK) { inflateEnd(&z); return MIC_E_INVALID; }
+    } else if (r != Z_OK) { inflateEnd(&z); return MIC_E_INVALID; }
+  }
+  inflateEnd(&z);
+  if (crc32_expected) *crc32_expected = 0;
+  uint8_t* t = (uint8_t*)malloc(out.size() ? out.size() : 1);
+  memcpy(t, out.data(), out.size());
+  *d_text = t; *n_text = out.size();
+  return MIC_OK;
+}
+int mic_gz_free_text(mic_engine*, void* t) { free(t); return MIC_OK; }
+int mic_gz_copy_text(mic_engine*, const void* t, size_t off, size_t n, void* dst) { memcpy(dst, (const uint8_t*)t + off, n); return MIC_OK; }
+int mic_gz_reserve(mic_engine*, size_t, uint32_t) { return MIC_OK; }
 uint64_t mic_gz_reserve_bytes(size_t, uint32_t) { return 0; }
 int mic_gz_release(mic_engine*) { return MIC_OK; }
-int mic_pairs_index_device(mic_engine*, const void*, size_t, const void*, size_t, mic_pairs**, uint64_t*, uint32_t*) { return MIC_E_NODEVICE; }
-int mic_pairs_offsets(const mic_pairs*, const uint64_t**, size_t*, uint32_t*) { return MIC_E_NODEVICE; }
-int mic_pairs_merge_to_slot(mic_engine*, mic_pairs*, uint64_t, uint64_t, size_t, size_t*) { return MIC_E_NODEVICE; }
-int mic_pairs_text(mic_engine*, mic_pairs*, uint64_t, uint64_t, void*, size_t, size_t*) { return MIC_E_NODEVICE; }
-int mic_pairs_free(mic_engine*, mic_pairs*) { return MIC_OK; }
-int mic_text_index_device(mic_engine*, const void*, size_t, mic_text**, uint64_t*, uint32_t*) { return MIC_E_NODEVICE; }
-int mic_text_offsets(const mic_text*, const uint64_t**, size_t*, uint32_t*) { return MIC_E_NODEVICE; }
-int mic_text_to_slot(mic_engine*, mic_text*, uint64_t, uint64_t, size_t, size_t*) { return MIC_E_NODEVICE; }
-int mic_text_copy(mic_engine*, mic_text*, uint64_t, uint64_t, void*, size_t, size_t*) { return MIC_E_NODEVICE; }
-int mic_text_free(mic_engine*, mic_text*) { return MIC_OK; }
-int mic_text_format(const mic_text*) { return 0; }
+}  // extern "C"
+
+namespace {
+// line starts of a text; ls[n_lines] = one behind the last line's end (+ 1 for a last line without its line end: as on the device)
+std::vector<size_t> line_starts(const uint8_t* t, size_t n) {
+  std::vector<size_t> ls(1, 0);
+  for (size_t i = 0; i < n; ++i) if (t[i] == '\n') ls.push_back(i + 1);
+  if (n && t[n - 1] != '\n') ls.push_back(n + 1);
+  return ls;
+}
+bool sep(uint8_t c) { return c == ' ' || c == '/' || c == '\t' || c == '@'; }
+void id_of(const uint8_t* p, size_t n, size_t& a, size_t& len) { a = 0; while (a < n && sep(p[a])) ++a; size_t b = a; while (b < n && !sep(p[b])) ++b; len = b - a; }
+}  // namespace
+
+struct mic_pairs {
+  const uint8_t* t[2]; std::vector<size_t> ls[2];
+  std::vector<uint64_t> off, samples;
+  uint64_t n_rec = 0; uint32_t stride = 64;
+  std::string merged(uint64_t r0, uint64_t r1) const {
+    std::string o;
+    for (uint64_t r = r0; r < r1; ++r) {
+      const uint8_t* h = t[0] + ls[0][4 * r]; const size_t hn = ls[0][4 * r + 1] - 1 - ls[0][4 * r];
+      size_t a, len; id_of(h, hn, a, len);
+      o += '>'; o.append((const char*)h + a, len); o += '\n';
+      o.append((const char*)t[0] + ls[0][4 * r + 1], ls[0][4 * r + 2] - 1 - ls[0][4 * r + 1]); o += 'N';
+      o.append((const char*)t[1] + ls[1][4 * r + 1], ls[1][4 * r + 2] - 1 - ls[1][4 * r + 1]); o += '\n';
+    }
+    return o;
+  }
+};
+struct mic_text {
+  const uint8_t* t; size_t n; bool fasta = false;
+  std::vector<uint64_t> rec, samples;       // rec[r] = offset of record r, rec[n_rec] = n
+  uint64_t n_rec = 0; uint32_t stride = 64;
+};
+
+extern "C" {
+int mic_pairs_index_device(mic_engine*, const void* t1, size_t n1, const void* t2, size_t n2, mic_pairs** out, uint64_t* n_records, uint32_t* status) {
+  *out = nullptr; *n_records = 0; *status = 0;
+  if (!n1 || !n2) { *status = MIC_PAIRS_BIG; return MIC_OK; }
+  mic_pairs* p = new mic_pairs;
+  p->t[0] = (const uint8_t*)t1; p->t[1] = (const uint8_t*)t2;
+  p->ls[0] = line_starts(p->t[0], n1); p->ls[1] = line_starts(p->t[1], n2);
+  const size_t l0 = p->ls[0].size() - 1, l1 = p->ls[1].size() - 1;
+  if (l0 != l1 || l0 % 4 || !l0) { *status = MIC_PAIRS_LINES; delete p; return MIC_OK; }
+  p->n_rec = l0 / 4;
+  p->off.assign(p->n_rec + 1, 0);
+  for (uint64_t r = 0; r < p->n_rec; ++r) {
+    const uint8_t* h[2]; size_t hn[2], a[2], len[2];
+    for (int i = 0; i < 2; ++i) { h[i] = p->t[i] + p->ls[i][4 * r]; hn[i] = p->ls[i][4 * r + 1] - 1 - p->ls[i][4 * r]; }
+    if (!hn[0] || !hn[1] || h[0][0] != '@' || h[1][0] != '@') { *status |= MIC_PAIRS_HEADER; continue; }
+    id_of(h[0], hn[0], a[0], len[0]); id_of(h[1], hn[1], a[1], len[1]);
+    if (!len[0] || len[0] != len[1] || memcmp(h[0] + a[0], h[1] + a[1], len[0])) *status |= MIC_PAIRS_ID;
+    p->off[r + 1] = p->off[r] + len[0] + 2 + (p->ls[0][4 * r + 2] - 1 - p->ls[0][4 * r + 1]) + 1 + (p->ls[1][4 * r + 2] - 1 - p->ls[1][4 * r + 1]) + 1;
+  }
+  if (*status) { delete p; return MIC_OK; }
+  for (uint64_t i = 0; i < p->n_rec / p->stride + 2; ++i) p->samples.push_back(p->off[std::min<uint64_t>(i * p->stride, p->n_rec)]);
+  *out = p; *n_records = p->n_rec;
+  return MIC_OK;
+}
+int mic_pairs_offsets(const mic_pairs* p, const uint64_t** s, size_t* n, uint32_t* stride) { *s = p->samples.data(); *n = p->samples.size(); *stride = p->stride; return MIC_OK; }
+static bool whole_strides(uint64_t n_rec, uint32_t stride, uint64_t r0, uint64_t r1) { return r0 < r1 && r1 <= n_rec && r0 % stride == 0 && (r1 % stride == 0 || r1 == n_rec); }
+int mic_pairs_merge_to_slot(mic_engine* e, mic_pairs* p, uint64_t r0, uint64_t r1, size_t slot, size_t* n_bytes) {
+  if (!whole_strides(p->n_rec, p->stride, r0, r1) || slot >= e->raw.size()) return MIC_E_INVALID;
+  const std::string m = p->merged(r0, r1);
+  if (m.size() > e->max_bytes) return MIC_E_INVALID;
+  memcpy(e->raw[slot].data(), m.data(), m.size());
+  *n_bytes = m.size();
+  return MIC_OK;
+}
+int mic_pairs_text(mic_engine*, mic_pairs* p, uint64_t r0, uint64_t r1, void* dst, size_t cap, size_t* n_bytes) {
+  if (!whole_strides(p->n_rec, p->stride, r0, r1)) return MIC_E_INVALID;
+  const std::string m = p->merged(r0, r1);
+  if (m.size() > cap) return MIC_E_INVALID;
+  memcpy(dst, m.data(), m.size()); *n_bytes = m.size();
+  return MIC_OK;
+}
+int mic_pairs_free(mic_engine*, mic_pairs* p) { delete p; return MIC_OK; }
+
+int mic_text_index_device(mic_engine*, const void* t, size_t n, mic_text** out, uint64_t* n_records, uint32_t* status) {
+  *out = nullptr; *n_records = 0; *status = 0;
+  if (!n) { *status = MIC_PAIRS_BIG; return MIC_OK; }
+  mic_text* p = new mic_text;
+  p->t = (const uint8_t*)t; p->n = n;
+  const std::vector<size_t> ls = line_starts(p->t, n);
+  const size_t nl = ls.size() - 1;
+  if (p->t[0] == '>') {
+    p->fasta = true;
+    for (size_t L = 0; L < nl; ++L) if (ls[L] < n && p->t[ls[L]] == '>') p->rec.push_back(ls[L]);
+  } else if (p->t[0] == '@') {
+    if (nl % 4 || !nl) { *status = MIC_PAIRS_LINES; delete p; return MIC_OK; }
+    for (size_t r = 0; r < nl / 4; ++r) p->rec.push_back(ls[4 * r]);
+  } else { *status = MIC_PAIRS_HEADER; delete p; return MIC_OK; }
+  p->n_rec = p->rec.size();
+  p->rec.push_back(n);
+  for (uint64_t i = 0; i < p->n_rec / p->stride + 2; ++i) p->samples.push_back(p->rec[std::min<uint64_t>(i * p->stride, p->n_rec)]);
+  *out = p; *n_records = p->n_rec;
+  return MIC_OK;
+}
+int mic_text_format(const mic_text* p) { return p ? (p->fasta ? '>' : '@') : 0; }
+int mic_text_offsets(const mic_text* p, const uint64_t** s, size_t* n, uint32_t* stride) { *s = p->samples.data(); *n = p->samples.size(); *stride = p->stride; return MIC_OK; }
+int mic_text_to_slot(mic_engine* e, mic_text* p, uint64_t r0, uint64_t r1, size_t slot, size_t* n_bytes) {
+  if (!whole_strides(p->n_rec, p->stride, r0, r1) || slot >= e->raw.size()) return MIC_E_INVALID;
+  const size_t m = (size_t)(p->rec[r1] - p->rec[r0]);
+  if (m > e->max_bytes) return MIC_E_INVALID;
+  memcpy(e->raw[slot].data(), p->t + p->rec[r0], m);
+  *n_bytes = m;
+  return MIC_OK;
+}
+int mic_text_copy(mic_engine*, mic_text* p, uint64_t r0, uint64_t r1, void* dst, size_t cap, size_t* n_bytes) {
+  if (!whole_strides(p->n_rec, p->stride, r0, r1)) return MIC_E_INVALID;
+  const size_t m = (size_t)(p->rec[r1] - p->rec[r0]);
+  if (m > cap) return MIC_E_INVALID;
+  memcpy(dst, p->t + p->rec[r0], m); *n_bytes = m;
+  return MIC_OK;
+}
+int mic_text_free(mic_engine*, mic_text* p) { delete p; return MIC_OK; }
 }
