@@ -839,7 +839,6 @@ int mic_pairs_index_device(mic_engine* e, const void* d_text1, size_t n1, const 
   double tl = timing ? now_s() : 0;
   auto lap = [&](const char* what) { if (!timing) return; const double t = now_s(); fprintf(stderr, "[pairs] %s: %.3f ms\n", what, (t - tl) * 1e3); tl = t; };
   { hipStream_t up_, down_; mic_engine_copy_streams(e, &up_, &down_); st = up_; }      // (a stream of its own would cost 2 ms to create)
-  lap("stream");
   {
     size_t t0 = 0, t1 = 0;
     PTRY(hipcub::DeviceScan::ExclusiveSum(nullptr, t0, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n_tiles[0] + 1), st));
