@@ -16,7 +16,8 @@ Workloads, all synthetic, generated in HBM by libmi_clark.so's 
   light  config 2, k=31 side variant: same reads vs. HTSIZE 57777779, k=31 (u64 keys), ~54 M k-mers (not reachable through the
          reference's binaries; kept because the metric says k=31).
   tiny   plumbing-size case for quick checks.
-Multi-GPU (one process per GPU, launched with torch.distributed.run):
+Multi-GPU (one process per GPU over RCCL: `python bench.py --gpus N` starts its N ranks itself under torch.distributed.run as a
+child process before anything touches the GPU; launched BY torch.distributed.run it is one of the ranks):
   read   reads sharded, table replicated, no collective (config 5 shape)      -> "scaling": "weak"   [default]
   db     table sharded (mic_db_set_part: super-k-mer layouts by resident slot range, so a run of a read belongs to one rank;
          other layouts by on-disk bucket range), every rank sees all reads, per-read sparse target-score rows exchanged
@@ -309,6 +310,46 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
     return out
 
 
+def cpu_quota_cpus():
+    """CPUs' worth of CPU time the process's cgroup allows (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us), or None
+    when there is no quota - what csrc/pgz.hpp: usable_cpus() reads for the command line's thread pools."""
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(period), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return round(q / period, 2) if q > 0 and period > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def launch_ranks(args, n_dev):
+    """Start `args.gpus` ranks of this script under torch.distributed.run (one process per GPU over RCCL, rendezvous on
+    127.0.0.1) as a child process, pass its stdout (rank 0's one JSON line) and stderr through, return its exit code.
+    Called before anything in this process has initialised the GPU."""
+    import socket
+    import subprocess
+    if args.backend == "nccl" and n_dev < args.gpus:
+        log(f"bench.py: --gpus {args.gpus} over RCCL needs {args.gpus} visible devices, this box has {n_dev}. "
+            "RCCL needs one device per rank; --backend gloo lets ranks share a GPU (validation only)")
+        return 2
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: starting", args.gpus, "ranks:", " ".join(cmd[1:8]), "...")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,12 +389,23 @@ def main():
 
     if os.environ.get("MIC_LIB_PATH") and not args.allow_variant_lib:
         sys.exit("bench.py: MIC_LIB_PATH is set (a measuring build of the library); unset it or pass --allow-variant-lib")
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    n_dev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: this process has not touched the GPU yet - it starts the N ranks as a
+        # fresh child (one process per GPU under torch.distributed.run), relays their output and exits with their code
+        sys.exit(launch_ranks(args, n_dev))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; pass --gpus {world} "
+                 f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it starts its ranks itself)")
+    if args.backend == "nccl" and world > 1 and local_rank >= n_dev:
+        sys.exit(f"bench.py: rank {rank} (local rank {local_rank}) has no GPU of its own: {n_dev} device(s) visible for {world} ranks. "
+                 "RCCL needs one device per rank; --backend gloo lets ranks share a GPU (validation only)")
+    local_rank = local_rank % max(n_dev, 1)    # (gloo validation runs: ranks may share a GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # --mode db at N = 1 still goes through the collectives (a degenerate all_to_all, merge loop of length 0, the overflow
@@ -377,6 +429,10 @@ def main():
         lib_id = {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "sha256_16": hashlib.sha256(f.read()).hexdigest()[:16],
                   "variant": bool(os.environ.get("MIC_LIB_PATH"))}
     w = dict(WORKLOADS[args.workload])
+    if args.workload == "paired" and world > 1 and args.mode == "read":
+        # BASELINE config 5 names 100 M pairs on the 8-GPU node: 12.5 M pairs per GPU (weak scaling keeps that per-GPU share)
+        w["n_reads"] = 12_500_000
+        w["name"] = w["name"].replace("10M pairs", "12.5M pairs per GPU")
     if args.reads:
         w["n_reads"] = args.reads
     if args.read_len:
@@ -631,7 +687,10 @@ def main():
         h_sizes = d_sizes.cpu().numpy()
         h_keys = d_keys[:n_el].cpu().numpy().view(np.uint32 if key_b == 4 else np.uint64)
         h_labels = d_labels[:n_el].cpu().numpy().view(np.uint16)
-        cores = len(os.sched_getaffinity(0))
+        cores_visible = len(os.sched_getaffinity(0))
+        cpu_quota = cpu_quota_cpus()               # CPUs of CPU time the cgroup allows (None: no quota)
+        # threads follow what the process may USE: more threads than the quota run slower under CFS throttling
+        cores = max(1, min(cores_visible, int(np.ceil(cpu_quota)) if cpu_quota else cores_visible))
         # the table is copied once more: one replica per NUMA node, written (first touch) and probed by threads pinned to that
         # node, huge pages requested - the round-1 baseline had every page on the node of the one thread that received the
         # download and was DRAM-bound on that socket
@@ -653,6 +712,7 @@ def main():
         equal = equal and bool((ref0 == res[:ns0, :5]).all())
         kmers_sample = st["kmers"] * ns / n_reads
         cpu = {"value": round(ns / t_cpu / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
+               "cores_visible": cores_visible, "cpu_quota": cpu_quota, "threads_used": cores,
                "sample": f"first {ns} of the {n_reads} reads of the same workload, same table in host RAM, one replica per NUMA node "
                          f"({t_copy:.0f} s download + copy + prefix sums, not timed); {t_cpu:.2f} s wall",
                "objects_per_min": int(ns / t_cpu * 60), "probes_per_s_per_core_M": round(kmers_sample / t_cpu / cores / 1e6, 3),

@@ -66,6 +66,10 @@ SYMBOLS = [
     ("mic_db_load_device", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_int, _VP, C.c_uint32, C.c_uint64, C.c_uint64]),
     ("mic_db_set_part", C.c_int, [_VP, C.c_uint32, C.c_uint32]),
     ("mic_db_reserve_hbm", C.c_int, [_VP, C.c_uint64]),
+    ("mic_peer_matrix", C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    ("mic_device_memory", C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("mic_db_load_files_multi", C.c_int, [C.POINTER(C.c_void_p), _SZ, C.c_char_p, C.c_int, C.c_uint32]),
+    ("mic_db_kernel_name", C.c_int, [_VP, C.c_char_p, _SZ]),
     ("mic_db_get_info", C.c_int, [_VP, C.POINTER(MicDbInfo)]),
     ("mic_db_unload", C.c_int, [_VP]),
     ("mic_db_last_build_report", C.c_char_p, []),
@@ -90,6 +94,7 @@ SYMBOLS = [
     ("mic_last_query_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
     ("mic_ingest_alloc", C.c_int, [_VP, _SZ, _SZ, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.POINTER(_VP)]),
     ("mic_ingest_classify", C.c_int, [_VP, _SZ, _SZ, C.c_int, C.POINTER(MicIngestResult)]),
+    ("mic_ingest_classify_group", C.c_int, [C.POINTER(C.c_void_p), _SZ, _SZ, _SZ, _SZ, C.c_int, C.POINTER(MicIngestResult)]),
     ("mic_ingest_fetch_packed", C.c_int, [_VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("mic_ingest_free", C.c_int, [_VP]),
     ("mic_gz_inflate_device", C.c_int, [_VP, _VP, _SZ, C.POINTER(_VP), C.POINTER(_SZ), C.POINTER(C.c_uint32)]),

@@ -133,21 +133,39 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
   check(mic_device_count(&n_dev), "device discovery");
   if (n_dev == 0) die("No HIP device found.");
   size_t use = opt_.devices == 0 ? (size_t)n_dev : std::min(opt_.devices, (size_t)n_dev);
-  // --db-sharded: the reference's multi-device mode (every device holds a bucket range, CuClarkDB.cu:566-574).
-  // MIC_SHARD_ENGINES=<n> forces n engines (round-robin over the devices) - used to test the mode on one GPU.
+  // MIC_SHARD_ENGINES=<n> forces n engines (round-robin over the devices) in either multi-device mode: both modes can then be
+  // tested on one GPU
+  bool forced = false;
+  if (const char* env = getenv("MIC_SHARD_ENGINES")) { long v = atol(env); if (v >= 1 && v <= 64) { use = (size_t)v; forced = true; } }
+  if (!opt_.db_sharded && !forced && opt_.batches < use) use = std::max<size_t>(1, opt_.batches);
+  // Multi-device layout: `use` engines = groups_ read groups x parts_ table parts.
+  //   default (-d N):   the table replicated, N groups of one engine, batches dealt to the groups (reads are independent)
+  //   --db-sharded:     the reference's mode (every device holds a share of the table, CuClarkDB.cu:566-574): parts_ engines hold one
+  //                     part of the table each (mic_db_set_part) and answer every batch of their group together; --parts P picks P,
+  //                     the default is the smallest P that divides the engines and whose part fits a device - a part's kernel
+  //                     costs nearly as much as the whole table's, so engines beyond that divide the READS
+  parts_ = 1;
   if (opt_.db_sharded) {
-    if (const char* env = getenv("MIC_SHARD_ENGINES")) { long v = atol(env); if (v >= 1 && v <= 64) use = (size_t)v; }
-  } else if (opt_.batches < use) {
-    use = std::max<size_t>(1, opt_.batches);
+    if (opt_.parts) {
+      if (use % opt_.parts != 0) die("--parts " + std::to_string(opt_.parts) + " does not divide the " + std::to_string(use) + " device(s) in use.");
+      parts_ = opt_.parts;
+    } else {
+      struct stat sz, ky;
+      uint64_t dev_free = 0, dev_total = 0;
+      if (stat((db + ".sz").c_str(), &sz) != 0 || stat((db + ".ky").c_str(), &ky) != 0) die("Failed to open " + db + ".sz");
+      check(mic_device_memory(0, &dev_free, &dev_total), "device memory");
+      const int kb = mic_key_bytes_rule((uint64_t)sz.st_size, (int)opt_.k);
+      const uint64_t n_el = (uint64_t)ky.st_size / (uint64_t)(kb > 0 ? kb : 4);
+      const uint64_t images = (uint64_t)sz.st_size + n_el * (uint64_t)(kb + 2);          // every part is built from the whole images
+      const uint64_t table = opt_.k >= 24 ? n_el * 12 : (uint64_t)sz.st_size * 64;       // resident bytes: super-k-mer slots / direct slots
+      parts_ = use;
+      for (size_t p = 1; p <= use; ++p)
+        if (use % p == 0 && images + 2 * (table / p) + ((uint64_t)2 << 30) <= dev_total) { parts_ = p; break; }
+    }
   }
+  groups_ = use / parts_;
   std::cerr << "Loading database [" << db << ".*] (s=" << opt_.sampling << ")..." << std::endl;
-  const size_t per_engine_batches = opt_.db_sharded ? std::max<size_t>(1, opt_.batches) : (opt_.batches + use - 1) / use;
-  uint64_t htsize = 0;
-  if (opt_.db_sharded) {
-    struct stat st;
-    if (stat((db + ".sz").c_str(), &st) != 0) die("Failed to open " + db + ".sz");
-    htsize = (uint64_t)st.st_size;
-  }
+  const size_t per_engine_batches = std::max<size_t>(1, (opt_.batches + groups_ - 1) / groups_);
   for (size_t d = 0; d < use; ++d) {
     mic_config cfg;
     memset(&cfg, 0, sizeof(cfg));
@@ -157,6 +175,24 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
     mic_engine* e = nullptr;
     check(mic_create(&cfg, &e), "engine creation");
     engines_.push_back(e);
+    if (parts_ > 1) check(mic_db_set_part(e, (uint32_t)(d % parts_), (uint32_t)parts_), "table part");
+  }
+  gz_on_device_ = true;
+  if (use > 1) {
+    // peer access between the devices in use (the reference: CuClarkDB.cu:184-208): the row exchange of the table-sharded mode and
+    // the slots filled from a text inflated on another device go over it
+    const int nd = (int)std::min<size_t>(use, (size_t)n_dev);
+    std::vector<int> pm((size_t)nd * nd, 0);
+    check(mic_peer_matrix(pm.data(), nd), "peer access");
+    std::cerr << "Devices: " << use << " engine(s) on " << nd << " device(s)";
+    if (opt_.db_sharded) std::cerr << ", table-sharded: " << parts_ << " part(s) x " << groups_ << " read group(s)";
+    else std::cerr << ", read-sharded (table replicated)";
+    std::cerr << "; peer access:";
+    for (int i = 0; i < nd; ++i) {
+      std::cerr << (i ? " | " : " ");
+      for (int j = 0; j < nd; ++j) { std::cerr << pm[(size_t)i * nd + j]; if (i != j && !pm[(size_t)i * nd + j]) gz_on_device_ = false; }
+    }
+    std::cerr << std::endl;
   }
   // the ingest slots (pinned and device buffers of the streaming path) are set up while the database loads
   // The slots' device memory is announced to the engines first (mic_db_reserve_hbm): the table build sizes its staging area
@@ -169,12 +205,14 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
     size_t slot_bytes = 0, workers = 0;
     ingest_geometry(bytes, slot_bytes, workers);
     const size_t per_engine = (workers + engines_.size() - 1) / engines_.size();
+    // table-sharded: every engine also holds the partial rows, gathered rows and packed reads of every slot of its group (~6.5 x the slot)
+    const size_t group_extra = parts_ > 1 ? ((workers + groups_ - 1) / groups_) * 13 / 2 : 0;
     // two compressed mates on one engine are inflated on the device (run_paired): the buffers of that are set up here as well
     struct GzFile { size_t bytes; uint32_t isize; };
     std::vector<GzFile> gz;
     const bool gz_pair = !opt_.objects2.empty() && is_gzip(opt_.objects) && is_gzip(opt_.objects2) && !getenv("MIC_SERIAL_PAIRS");
     const bool gz_single = opt_.objects2.empty() && is_gzip(opt_.objects);
-    if (engines_.size() == 1 && (gz_pair || gz_single) && !getenv("MIC_GZ_HOST")) {
+    if (gz_on_device_ && (gz_pair || gz_single) && !getenv("MIC_GZ_HOST")) {
       std::vector<const std::string*> files = {&opt_.objects};
       if (gz_pair) files.push_back(&opt_.objects2);
       for (const std::string* f : files) {
@@ -200,16 +238,18 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
     }
     uint64_t gz_hbm = 0;
     for (const GzFile& g : gz) gz_hbm += mic_gz_reserve_bytes(g.bytes, g.isize);
-    for (mic_engine* e : engines_) mic_db_reserve_hbm(e, (uint64_t)per_engine * slot_bytes * 7 + gz_hbm);   // ~6.1 x the slot size per slot (mic_ingest.hip)
+    for (mic_engine* e : engines_)      // ~6.1 x the slot size per slot (mic_ingest.hip); the inflated text lives on the first engine's device
+      mic_db_reserve_hbm(e, (uint64_t)(per_engine * 7 + group_extra) * slot_bytes + (e == engines_[0] ? gz_hbm : 0));
     slots = std::thread([this, bytes, gz] {
       try { ensure_ingest(bytes); } catch (const std::exception&) { release_ingest(); }
       for (const GzFile& g : gz) if (mic_gz_reserve(engines_[0], g.bytes, g.isize) != MIC_OK) break;     // (without it the call allocates for itself)
     });
   }
   std::string load_err;
-  for (size_t d = 0; d < use && load_err.empty(); ++d) {
-    const uint64_t s0 = opt_.db_sharded ? htsize * d / use : 0, s1 = opt_.db_sharded ? htsize * (d + 1) / use : 0;
-    int rc = mic_db_load_files(engines_[d], db.c_str(), 0, opt_.sampling, s0, s1);
+  {
+    // one read of .sz/.ky/.lb for all engines; one thread per device builds its tables (a single engine: the same call)
+    const int rc = engines_.size() == 1 ? mic_db_load_files(engines_[0], db.c_str(), 0, opt_.sampling, 0, 0)
+                                        : mic_db_load_files_multi(engines_.data(), engines_.size(), db.c_str(), 0, opt_.sampling);
     if (rc != MIC_OK) load_err = std::string("Failed to load the database: ") + mic_last_error();
   }
   if (slots.joinable()) slots.join();
@@ -226,7 +266,11 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
   static const char* const layout_name[] = {"?", "direct", "minimizer-keyed", "super-k-mer", "super-k-mer, both strands"};
   std::cerr << "Total DB size in HBM:\t" << info.hbm_bytes / 1000000 / 1000.0 << " GB (" << info.n_elems << " k-mers, "
             << info.n_overflow << " overflow slots, " << layout_name[info.layout >= 1 && info.layout <= 4 ? info.layout : 0]
-            << " table) on " << use << " device(s)\n";
+            << " table" << (parts_ > 1 ? ", part 0 of " + std::to_string(parts_) : std::string()) << ") on " << use << " device(s)\n";
+  if (getenv("MIC_CLI_TIMING")) {
+    char kn[128] = "";
+    if (mic_db_kernel_name(engines_[0], kn, sizeof(kn)) > 0) std::cerr << "[timing] query kernel: " << kn << std::endl;
+  }
 }
 
 Classifier::~Classifier() {
@@ -1008,7 +1052,7 @@ class PairedFileFeeder : public Classifier::Feeder {
   std::vector<uint8_t> scan_;
 };
 
-// Gzip-compressed FASTQ on one engine: the file - or both mates of a pair at once - is inflated ON the device
+// Gzip-compressed FASTQ: the file - or both mates of a pair at once - is inflated ON the first engine's device
 // (mic_gz_inflate_device), indexed and checked there, and every batch gets into its ingest slot's device buffer without leaving the
 // device: a pair merged the way the reference merges it (mic_pairs_merge_to_slot; file.cc:205-268), a single file's records copied
 // (mic_text_to_slot).  The compressed bytes are all that crosses the link.  Whatever the device path does not take (several gzip
@@ -1096,8 +1140,8 @@ class DeviceGzFeeder : public Classifier::Feeder {
   void read(const Classifier::Range&, size_t, uint8_t*, size_t) override { die("device-resident ranges are filled on the device"); }
   size_t fill_resident(const Classifier::Range& r, mic_engine* e, size_t slot) override {
     size_t n = 0;
-    if (e != e_) return (size_t)-1;
-    const int rc = paired_ ? mic_pairs_merge_to_slot(e_, pairs_, r.off, r.off + r.len, slot, &n) : mic_text_to_slot(e_, single_, r.off, r.off + r.len, slot, &n);
+    // (e: the engine the slot belongs to - on another device than the text it reads / copies over peer access)
+    const int rc = paired_ ? mic_pairs_merge_to_slot(e, pairs_, r.off, r.off + r.len, slot, &n) : mic_text_to_slot(e, single_, r.off, r.off + r.len, slot, &n);
     return rc == MIC_OK ? n : (size_t)-1;
   }
   size_t fill(const Classifier::Range& r, uint8_t* dst, size_t cap) override {
@@ -1165,7 +1209,9 @@ void Classifier::run(const std::string& objects, const std::string& results) {
       // inflate up front (all threads), then the plain-file path on the inflated text
       struct timeval ta, tb;
       gettimeofday(&ta, nullptr);
-      if (engines_.size() == 1 && !getenv("MIC_GZ_HOST")) {
+      if (engines_.size() > 1 && !gz_on_device_ && !getenv("MIC_GZ_HOST"))
+        std::cerr << "Note: the compressed input is inflated on the host (no peer access between the devices in use)." << std::endl;
+      if (gz_on_device_ && !getenv("MIC_GZ_HOST")) {
         // inflated on the device, its FASTQ records handed to the ingest slots there (MIC_GZ_HOST=1: on the host, below)
         DeviceGzFeeder feed(engines_[0], obj, "");
         if (feed.ok()) {
@@ -1245,7 +1291,9 @@ void Classifier::run_paired(const std::string& f1, const std::string& f2, const 
     if (list_mode) std::cout << "> Processing file: '" << merged_name << "' in " << opt_.batches << " batches." << std::endl;
     else std::cout << "Processing file: '" << merged_name << "' in " << opt_.batches << " batches using " << opt_.threads
                    << " CPU thread(s)." << std::endl;
-    if (device_ingest() && is_gzip(a) && is_gzip(b) && engines_.size() == 1 && !getenv("MIC_SERIAL_PAIRS") && !getenv("MIC_GZ_HOST")) {
+    if (device_ingest() && is_gzip(a) && is_gzip(b) && engines_.size() > 1 && !gz_on_device_ && !getenv("MIC_GZ_HOST"))
+      std::cerr << "Note: the compressed input is inflated on the host (no peer access between the devices in use)." << std::endl;
+    if (device_ingest() && is_gzip(a) && is_gzip(b) && gz_on_device_ && !getenv("MIC_SERIAL_PAIRS") && !getenv("MIC_GZ_HOST")) {
       // both mates compressed: inflated, paired up and merged on the device (MIC_GZ_HOST=1: on the host, below)
       struct timeval ta, tb;
       gettimeofday(&ta, nullptr);
@@ -1328,7 +1376,7 @@ void Classifier::ensure_batches(size_t max_reads, size_t max_cont) {
   if (!lent_.empty() && max_reads <= slot_reads_ && max_cont <= slot_cont_) return;
   release_batches();
   const size_t n_eng = engines_.size();
-  slots_per_engine_ = opt_.db_sharded ? std::max<size_t>(1, opt_.batches) : (opt_.batches + n_eng - 1) / n_eng;
+  slots_per_engine_ = std::max<size_t>(1, (opt_.batches + groups_ - 1) / groups_);
   slot_reads_ = max_reads + max_reads / 8 + 64;
   slot_cont_ = max_cont + max_cont / 8 + 64;
   row_words_ = opt_.extended ? (uint32_t)std::min<size_t>(names_.size() + 1, 65) : 16;
@@ -1339,7 +1387,7 @@ void Classifier::ensure_batches(size_t max_reads, size_t max_cont) {
     Lent& L = lent_[d];
     L.rp.resize(slots_per_engine_); L.ct.resize(slots_per_engine_);
     check(mic_batches_alloc(engines_[d], slots_per_engine_ * slot_reads_, slot_reads_, slot_cont_, index.data(),
-                            (opt_.extended || opt_.db_sharded) ? 1 : 0,
+                            (opt_.extended || parts_ > 1) ? 1 : 0,
                             &L.results, &L.rows, L.rp.data(), L.ct.data()), "batch allocation");
   }
 }
@@ -1390,7 +1438,7 @@ void Classifier::run_segments(SegmentSource& src, const std::string& results_bas
 
 // ---- device-ingest streaming ----------------------------------------------------------------------------------------
 bool Classifier::device_ingest() const {
-  return !opt_.extended && !opt_.db_sharded && getenv("MIC_HOST_INGEST") == nullptr;
+  return !opt_.extended && getenv("MIC_HOST_INGEST") == nullptr;
 }
 
 void Classifier::release_ingest() {
@@ -1739,7 +1787,11 @@ bool Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
       try {
         if (!failed && !it.host) {
           mic_ingest_result res;
-          check(mic_ingest_classify(engines_[slots[it.slot].eng], slots[it.slot].slot, it.n, it.flags, &res), "device ingest");
+          // the slot's engine alone, or - table-sharded - its group of parts_ engines, each probing the batch against its part
+          const size_t eng = slots[it.slot].eng;
+          if (parts_ == 1) check(mic_ingest_classify(engines_[eng], slots[it.slot].slot, it.n, it.flags, &res), "device ingest");
+          else check(mic_ingest_classify_group(engines_.data() + eng / parts_ * parts_, parts_, eng % parts_, slots[it.slot].slot, it.n, it.flags, &res),
+                     "device ingest (table-sharded)");
           if (res.status == MIC_INGEST_OK) { it.text = res.csv; it.text_n = (size_t)res.csv_bytes; it.reads = (size_t)res.n_reads; }
           else it.host = true;
         }
@@ -1859,7 +1911,6 @@ size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, F
   const size_t N = (size_t)n_reads;
   lap("index reads");
   const int k = (int)opt_.k;
-  const size_t n_eng = engines_.size();
   const size_t nb_total = std::max<size_t>(1, std::min(opt_.batches, std::max<size_t>(N, 1)));
   const size_t per = (N + nb_total - 1) / nb_total;
   std::vector<size_t> cut(nb_total + 1);
@@ -1900,8 +1951,10 @@ size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, F
   for (long bi = 0; bi < (long)nb_total; ++bi) {
     double ts = timing ? now_s() : 0;
     auto tick = [&](double& acc) { if (timing) { const double n = now_s(); acc += n - ts; ts = n; } };
-    const bool sharded = opt_.db_sharded;
-    const size_t b = (size_t)bi, d = sharded ? 0 : b % n_eng, lb = sharded ? b : b / n_eng;
+    // batch b belongs to read group b % groups_: one engine (table replicated), or the parts_ engines that hold the table's parts
+    const bool sharded = parts_ > 1;
+    const size_t b = (size_t)bi, grp = b % groups_, d = grp * parts_, lb = b / groups_;
+    mic_engine* const* group = engines_.data() + d;
     Lent& L = lent_[d];
     const size_t r0 = cut[b], cnt = cut[b + 1] - cut[b];
     try {
@@ -1913,16 +1966,17 @@ size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, F
         check(mic_batch_query(engines_[d], lb, opt_.extended ? 1 : 0, 0), "queryBatch");
         check(mic_batch_wait(engines_[d], lb), "waitForBatch");
       } else {
-        // every engine probes the same reads against its bucket range; rows are summed into engine 0
-        for (size_t g = 0; g < n_eng; ++g) {
+        // every engine of the group probes the same reads against its part of the table; the rows are summed read-range owned
+        // and land in the first engine's host arrays (mic_batch_merge_shards)
+        for (size_t g = 0; g < parts_; ++g) {
           if (g) {
-            memcpy(lent_[g].rp[lb], L.rp[lb], (cnt + 1) * sizeof(uint32_t));
-            memcpy(lent_[g].ct[lb], L.ct[lb], m * sizeof(uint16_t));
+            memcpy(lent_[d + g].rp[lb], L.rp[lb], (cnt + 1) * sizeof(uint32_t));
+            memcpy(lent_[d + g].ct[lb], L.ct[lb], m * sizeof(uint16_t));
           }
-          check(mic_batch_ready(engines_[g], lb, cnt, m), "readyBatch");
-          check(mic_batch_query(engines_[g], lb, 1, 0), "queryBatch");
+          check(mic_batch_ready(group[g], lb, cnt, m), "readyBatch");
+          check(mic_batch_query(group[g], lb, 1, 0), "queryBatch");
         }
-        check(mic_batch_merge_shards(engines_.data(), n_eng, lb), "merge of the table shards");
+        check(mic_batch_merge_shards(group, parts_, lb), "merge of the table shards");
       }
       tick(t_query);
       std::string& s = out[b];
@@ -1946,8 +2000,8 @@ size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, F
             // reference's order (count descending, target ascending)
             std::vector<uint32_t> part(T);
             std::fill(dense.begin(), dense.end(), 0u);
-            for (size_t g = 0; g < n_eng; ++g) {
-              check(mic_batch_dense_counts(engines_[g], lb, i, part.data()), "dense counts");
+            for (size_t g = 0; g < parts_; ++g) {
+              check(mic_batch_dense_counts(group[g], lb, i, part.data()), "dense counts");
               for (uint32_t t2 = 0; t2 < T; ++t2) dense[t2] += part[t2];
             }
             uint32_t sum = 0, best = 0, ib = 0, sb = 0, is = 0, hit = 0;

@@ -27,7 +27,8 @@ struct Options {
   bool tsk = false;           // --tsk
   bool extended = false;      // --extended
   bool light = false;         // cuCLARK-l
-  bool db_sharded = false;    // --db-sharded: every device holds a bucket range of the table (the reference's -d mode)
+  bool db_sharded = false;    // --db-sharded: the devices hold parts of the table (the reference's -d mode), see Classifier's ctor
+  size_t parts = 0;           // --parts P: parts the table is cut into under --db-sharded (0 = the smallest number whose part fits a device)
   uint64_t htsize = 1610612741ull;  // parameters.hh:39 / parameters_light_hh:40; --htsize overrides
   std::string targets, folder, objects, objects2, results;
 };
@@ -102,7 +103,9 @@ class Classifier {
   Options opt_;
   std::vector<std::pair<std::string, std::string>> targets_id_;
   std::vector<std::string> labels_, labels_c_, names_;
-  std::vector<mic_engine*> engines_;
+  std::vector<mic_engine*> engines_;          // groups_ x parts_ engines: engine g * parts_ + p holds part p of the table for read group g
+  size_t parts_ = 1, groups_ = 1;
+  bool gz_on_device_ = true;                  // compressed input is inflated on the first engine's device (needs peer access from the others)
   std::atomic<size_t> n_objects_{0};
   double prelude_s_ = 0;                      // seconds spent inflating a compressed input before the streaming path started
 };

@@ -45,7 +45,11 @@ static void print_usage(const char* prog) {
   std::cout << "-d <numberofdevices> GPUs to use (default: all)\n";
   std::cout << "-g <iteration>,      gap for the light database name (>= 4)\n";
   std::cout << "-s <factor>,         sampling factor in [2," << SFACTORMAX << "]\n";
-  std::cout << "--tsk, --extended, --light, --htsize <n>, --db-sharded, --help, --version\n\n";
+  std::cout << "--db-sharded,        several GPUs: the table is cut into parts held by different GPUs (the mode of CuCLARK's -d); default: the table\n"
+               "                     is replicated on every GPU and the batches are dealt to the GPUs\n";
+  std::cout << "--parts <P>,         with --db-sharded: number of parts (divides -d; the GPUs form d/P groups that share the reads);\n"
+               "                     default: the smallest number of parts that fit a GPU's memory\n";
+  std::cout << "--tsk, --extended, --light, --htsize <n>, --help, --version\n\n";
 }
 
 int main(int argc, char** argv) {
@@ -131,6 +135,7 @@ int main(int argc, char** argv) {
   bool light = prog.size() >= 2 && prog.compare(prog.size() - 2, 2, "-l") == 0;
   uint64_t htsize_override = 0;
   bool db_sharded = false;
+  size_t parts = 0;
   int i_targets = -1, i_objects = -1, i_objects2 = -1, i_folder = -1, i_results = -1;
 
   for (int i = 1; i < argc; i++) {
@@ -159,6 +164,13 @@ int main(int argc, char** argv) {
     if (val == "--tsk") { tsk = true; continue; }
     if (val == "--extended") { ext = true; continue; }
     if (val == "--db-sharded") { db_sharded = true; continue; }
+    if (val == "--parts") {
+      need("Please specify the number of parts of the table!");
+      int p = atoi(argv[i]);
+      if (p < 1 || p > 64) { std::cerr << "The number of parts should be in [1,64]." << std::endl; exit(1); }
+      parts = (size_t)p; db_sharded = true;
+      continue;
+    }
     if (val == "--light") { light = true; continue; }
     if (val == "--htsize") {
       need("Please specify the table size!");
@@ -237,7 +249,7 @@ int main(int argc, char** argv) {
     exit(1);
   }
   o.k = k; o.min_count_t = minT; o.threads = cpu; o.batches = batches; o.devices = devices; o.sampling = sfactor; o.gap = gap;
-  o.tsk = tsk; o.extended = ext; o.light = light; o.db_sharded = db_sharded;
+  o.tsk = tsk; o.extended = ext; o.light = light; o.db_sharded = db_sharded; o.parts = parts;
   if (tsk) std::cerr << "Note: --tsk is accepted for compatibility; the per-target .ht text files (k-mer, count) are not written." << std::endl;
   o.htsize = htsize_override ? htsize_override : (light ? HTSIZE_LIGHT : HTSIZE_FULL);
   o.targets = argv[i_targets];

@@ -21,6 +21,8 @@
 #include <vector>
 
 int mic_bind_thread_near_device(int device, int on);   // below: host memory near the device
+bool mic_peer_enable(int from, int to);                 // below: several devices in one process
+void mic_peer_enable_engines(mic_engine* const* engines, size_t n);
 
 namespace {
 
@@ -144,26 +146,35 @@ int check_shard(uint64_t htsize, uint64_t& s0, uint64_t& s1) {
 }
 
 // stream a byte range of a file into device memory through two pinned staging buffers; every chunk is read by several
-// threads (pread on disjoint slices): one fread stream moves ~6 GB/s out of the page cache, the link takes ~50
-int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStream_t s, const char* what) {
+// threads (pread on disjoint slices): one fread stream moves ~6 GB/s out of the page cache, the link takes ~50.
+// Several destinations (mic_db_load_files_multi: one per device): every chunk is read ONCE and uploaded to each of them.
+struct UploadDst { int device; void* dst; hipStream_t stream; };
+int upload_file_range_multi(FILE* f, uint64_t off, uint64_t bytes, const std::vector<UploadDst>& dsts, const char* what) {
   const size_t CH = 256u << 20;
   const int fd = fileno(f);
   static const int n_readers = [] { const char* e = getenv("MIC_LOAD_THREADS"); int v = e ? atoi(e) : 0; return v > 0 ? (v > 64 ? 64 : v) : 8; }();
   void* stage[2] = {nullptr, nullptr};
-  hipEvent_t ev[2] = {nullptr, nullptr};
+  const size_t nd = dsts.size();
+  std::vector<hipEvent_t> ev(2 * nd, nullptr);
   int rc = MIC_OK;
-  if (bytes == 0) return MIC_OK;
+  if (bytes == 0 || nd == 0) return MIC_OK;
   int dev_now = 0;
   hipGetDevice(&dev_now);
-  mic_bind_thread_near_device(dev_now, 1);
-  for (int i = 0; i < 2 && rc == MIC_OK; ++i) {
+  mic_bind_thread_near_device(dsts[0].device, 1);
+  for (int i = 0; i < 2 && rc == MIC_OK; ++i)
+    // (HIP has one context per process: pinned host memory is reachable from every device, whatever device was current)
     if (hipHostMalloc(&stage[i], CH, hipHostMallocDefault) != hipSuccess) rc = fail(MIC_E_NOMEM, "pinned staging alloc failed");
-    else if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(MIC_E_HIP, "event create failed");
+  for (size_t i = 0; i < 2 * nd && rc == MIC_OK; ++i) {
+    if (hipSetDevice(dsts[i % nd].device) != hipSuccess || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
+      rc = fail(MIC_E_HIP, "event create failed");
   }
   uint64_t done = 0; int cur = 0; bool used[2] = {false, false};
   while (rc == MIC_OK && done < bytes) {
     size_t n = (size_t)((bytes - done) < CH ? (bytes - done) : CH);
-    if (used[cur] && hipEventSynchronize(ev[cur]) != hipSuccess) { rc = fail(MIC_E_HIP, "event sync failed"); break; }
+    if (used[cur])
+      for (size_t d = 0; d < nd; ++d)
+        if (hipEventSynchronize(ev[(size_t)cur * nd + d]) != hipSuccess) { rc = fail(MIC_E_HIP, "event sync failed"); break; }
+    if (rc != MIC_OK) break;
     {
       std::atomic<bool> short_read(false);
       const size_t per = ((n + (size_t)n_readers - 1) / (size_t)n_readers + 4095) & ~(size_t)4095;
@@ -184,14 +195,25 @@ int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStrea
       for (auto& t : th) t.join();
       if (short_read) { rc = fail(MIC_E_IO, "%s is shorter than the bucket sizes imply", what); break; }
     }
-    if (hipMemcpyAsync((char*)dst + done, stage[cur], n, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipEventRecord(ev[cur], s) != hipSuccess) { rc = fail(MIC_E_HIP, "H2D copy failed"); break; }
+    for (size_t d = 0; d < nd && rc == MIC_OK; ++d) {
+      if (hipSetDevice(dsts[d].device) != hipSuccess ||
+          hipMemcpyAsync((char*)dsts[d].dst + done, stage[cur], n, hipMemcpyHostToDevice, dsts[d].stream) != hipSuccess ||
+          hipEventRecord(ev[(size_t)cur * nd + d], dsts[d].stream) != hipSuccess) rc = fail(MIC_E_HIP, "H2D copy failed");
+    }
     used[cur] = true; cur ^= 1; done += n;
   }
-  hipStreamSynchronize(s);
-  for (int i = 0; i < 2; ++i) { if (stage[i]) hipHostFree(stage[i]); if (ev[i]) hipEventDestroy(ev[i]); }
-  mic_bind_thread_near_device(dev_now, 0);
+  for (size_t d = 0; d < nd; ++d) { hipSetDevice(dsts[d].device); hipStreamSynchronize(dsts[d].stream); }
+  for (int i = 0; i < 2; ++i) if (stage[i]) hipHostFree(stage[i]);
+  for (hipEvent_t e : ev) if (e) hipEventDestroy(e);
+  mic_bind_thread_near_device(dsts[0].device, 0);
+  hipSetDevice(dev_now);
   return rc;
+}
+
+int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStream_t s, const char* what) {
+  int dev_now = 0;
+  hipGetDevice(&dev_now);
+  return upload_file_range_multi(f, off, bytes, {UploadDst{dev_now, dst, s}}, what);
 }
 
 // layout: explicit request, else the environment (MIC_LAYOUT=direct|minimizer|super|super2), else by k
@@ -432,6 +454,35 @@ void mic_build_report_add(const char* what, double seconds) {
   snprintf(line, sizeof(line), "%s: %.4f\n", what, seconds);
   std::lock_guard<std::mutex> lk(g_report_mu);
   g_report += line;
+}
+
+// ---- several devices in one process -----------------------------------------------------------------------------------
+namespace {
+std::mutex g_peer_mu;
+signed char g_peer[64][64];          // [from][to]: 0 unknown, 1 direct access enabled, -1 none (copies are staged by the runtime)
+}
+// enables device `from`'s access to device `to`'s memory (once; "already enabled" is success); true when direct access is on
+bool mic_peer_enable(int from, int to) {
+  if (from == to) return true;
+  if (from < 0 || to < 0 || from >= 64 || to >= 64) return false;
+  std::lock_guard<std::mutex> lk(g_peer_mu);
+  if (g_peer[from][to]) return g_peer[from][to] > 0;
+  int can = 0, cur = 0;
+  hipGetDevice(&cur);
+  bool ok = false;
+  if (hipDeviceCanAccessPeer(&can, from, to) == hipSuccess && can && hipSetDevice(from) == hipSuccess) {
+    const hipError_t he = hipDeviceEnablePeerAccess(to, 0);
+    ok = he == hipSuccess || he == hipErrorPeerAccessAlreadyEnabled;
+    (void)hipGetLastError();
+  }
+  hipSetDevice(cur);
+  g_peer[from][to] = ok ? 1 : -1;
+  return ok;
+}
+void mic_peer_enable_engines(mic_engine* const* engines, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < n; ++j)
+      if (engines[i] && engines[j] && engines[i]->device != engines[j]->device) mic_peer_enable(engines[i]->device, engines[j]->device);
 }
 
 extern "C" {
@@ -801,8 +852,11 @@ int mic_batch_dense_counts(mic_engine* e, size_t batch, size_t read_in_batch, ui
   return MIC_OK;
 }
 
-// Table-sharded batches (the reference's multi-GPU mode, CuClarkDB.cu:934-1001: queryBatch on every device, the
-// partial rows copied to device 0 with cudaMemcpyPeer and summed there by mergeKernel, then resultKernel).
+// Table-sharded batches (the reference's multi-GPU mode, CuClarkDB.cu:934-1001: queryBatch on every device, the partial rows
+// copied to device 0 with cudaMemcpyPeer one device after another and summed there by mergeKernel, then resultKernel).
+// Here the sum is READ-RANGE OWNED: engine j fetches the rows of reads [n j / N, n (j + 1) / N) from the other N - 1 engines
+// (peer copies, all engines at once on their own streams), sums and finishes them, and writes results and rows of its range
+// straight into engines[0]'s host arrays.
 int mic_batch_merge_shards(mic_engine* const* engines, size_t n_engines, size_t batch) {
   if (!engines || n_engines == 0 || !engines[0]) return fail(MIC_E_INVALID, "bad argument");
   mic_engine* dst = engines[0];
@@ -819,31 +873,168 @@ int mic_batch_merge_shards(mic_engine* const* engines, size_t n_engines, size_t 
     int rc = mic_batch_wait(e, batch);          // kernels done, flagged reads resolved inside their shard
     if (rc) return rc;
   }
-  int rc = set_device(dst);
-  if (rc) return rc;
-  std::lock_guard<std::mutex> lock(dst->submit_mu);
-  const size_t bytes = D.n_reads * (size_t)rw * 4;
-  if (n_engines > 1 && !D.d_peer) {
-    HIPTRY(hipMalloc(&D.d_peer, (D.max_reads + 1) * (size_t)rw * 4));
-    HIPTRY(hipMalloc(&D.d_acc, (D.max_reads + 1) * (size_t)rw * 4));
+  mic_peer_enable_engines(engines, n_engines);
+  const size_t n = D.n_reads;
+  int rc = MIC_OK;
+  for (size_t j = 0; j < n_engines && rc == MIC_OK; ++j) {
+    mic_engine* e = engines[j];
+    Batch& J = e->batches[batch];
+    const size_t lo = n * j / n_engines, hi = n * (j + 1) / n_engines, len = hi - lo;
+    if (!len) continue;
+    if ((rc = set_device(e))) break;
+    std::lock_guard<std::mutex> lock(e->submit_mu);
+    if (n_engines > 1 && !J.d_peer) {
+      HIPTRY(hipMalloc(&J.d_peer, (J.max_reads + 1) * (size_t)rw * 4));
+      HIPTRY(hipMalloc(&J.d_acc, (J.max_reads + 1) * (size_t)rw * 4));
+    }
+    uint32_t* buf[2] = {J.d_rows + lo * rw, J.d_acc};   // the running sum ping-pongs between the range of the batch's own rows and a spare
+    int c = 0; size_t got = 0;
+    for (size_t p = 0; p < n_engines; ++p) {
+      if (p == j) continue;
+      const Batch& P = engines[p]->batches[batch];
+      uint32_t* in = J.d_peer + got * len * rw;
+      HIPTRY(hipMemcpyPeerAsync(in, e->device, P.d_rows + lo * rw, engines[p]->device, len * (size_t)rw * 4, J.stream));
+      HIPTRY(mic_launch_merge_rows(buf[c], in, buf[c ^ 1], rw, len, nullptr, J.stream));
+      c ^= 1; ++got;
+    }
+    uint32_t* cur = buf[c];
+    HIPTRY(mic_launch_result_from_rows(cur, rw, J.d_results + lo * MIC_RESULT_WORDS, len, J.stream));
+    HIPTRY(hipMemcpyAsync(dst->h_results + (D.first_read + lo) * MIC_RESULT_WORDS, J.d_results + lo * MIC_RESULT_WORDS,
+                          len * MIC_RESULT_WORDS * 4, hipMemcpyDeviceToHost, J.stream));
+    HIPTRY(hipMemcpyAsync(dst->h_rows + (D.first_read + lo) * (size_t)rw, cur, len * (size_t)rw * 4, hipMemcpyDeviceToHost, J.stream));
   }
-  uint32_t* buf[2] = {D.d_rows, D.d_acc};   // running sum ping-pongs between the batch's own rows and the spare buffer
-  int c = 0;
-  for (size_t i = 1; i < n_engines && bytes; ++i) {
-    const Batch& B = engines[i]->batches[batch];
-    HIPTRY(hipMemcpyPeerAsync(D.d_peer, dst->device, B.d_rows, engines[i]->device, bytes, D.stream));
-    HIPTRY(mic_launch_merge_rows(buf[c], D.d_peer, buf[c ^ 1], rw, D.n_reads, nullptr, D.stream));
-    c ^= 1;
+  for (size_t j = 0; j < n_engines; ++j) {
+    if (set_device(engines[j]) != MIC_OK) continue;
+    hipError_t he = hipStreamSynchronize(engines[j]->batches[batch].stream);
+    if (he != hipSuccess && rc == MIC_OK) rc = fail(MIC_E_HIP, "merge of the table shards: %s", hipGetErrorString(he));
   }
-  uint32_t* cur = buf[c];
-  if (bytes) {
-    HIPTRY(mic_launch_result_from_rows(cur, rw, D.d_results, D.n_reads, D.stream));
-    HIPTRY(hipMemcpyAsync(dst->h_results + D.first_read * MIC_RESULT_WORDS, D.d_results, D.n_reads * MIC_RESULT_WORDS * 4,
-                          hipMemcpyDeviceToHost, D.stream));
-    HIPTRY(hipMemcpyAsync(dst->h_rows + D.first_read * (size_t)rw, cur, bytes, hipMemcpyDeviceToHost, D.stream));
-    HIPTRY(hipStreamSynchronize(D.stream));
-  }
+  return rc;
+}
+
+int mic_peer_matrix(int* matrix, int n_devices) {
+  if (!matrix || n_devices < 1 || n_devices > 64) return fail(MIC_E_INVALID, "bad argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n_devices > n) return fail(MIC_E_INVALID, "%d devices asked for, %d present", n_devices, n);
+  for (int i = 0; i < n_devices; ++i)
+    for (int j = 0; j < n_devices; ++j) matrix[i * n_devices + j] = mic_peer_enable(i, j) ? 1 : 0;
   return MIC_OK;
+}
+
+int mic_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (!free_bytes || !total_bytes) return fail(MIC_E_INVALID, "null argument");
+  int cur = 0;
+  hipGetDevice(&cur);
+  size_t f = 0, t = 0;
+  hipError_t he = hipSetDevice(device);
+  if (he == hipSuccess) he = hipMemGetInfo(&f, &t);
+  hipSetDevice(cur);
+  if (he != hipSuccess) return fail(MIC_E_HIP, "hipMemGetInfo: %s", hipGetErrorString(he));
+  *free_bytes = f; *total_bytes = t;
+  return MIC_OK;
+}
+
+int mic_db_kernel_name(const mic_engine* e, char* buf, size_t cap) {
+  if (!e || !buf || cap < 2) return fail(MIC_E_INVALID, "bad argument");
+  if (!e->db_loaded) return fail(MIC_E_STATE, "no database loaded");
+  return mic_query_kernel_name(e->table, e->slot_class, buf, cap);
+}
+
+// The database into several engines from one read of the files: images uploaded to every device that hosts an engine, chunk by
+// chunk from the same pinned buffer; then one thread per device builds the tables of its engines (reference: one
+// read() loop over the files filling every device's parts, CuClarkDB.cu:604-808).
+int mic_db_load_files_multi(mic_engine* const* engines, size_t n_engines, const char* prefix, int key_bytes, uint32_t sampling) {
+  if (!engines || !n_engines || !prefix) return fail(MIC_E_INVALID, "null argument");
+  for (size_t i = 0; i < n_engines; ++i) {
+    if (!engines[i]) return fail(MIC_E_INVALID, "null engine");
+    if (engines[i]->cfg.k != engines[0]->cfg.k) return fail(MIC_E_INVALID, "the engines differ in k");
+  }
+  std::string p(prefix);
+  FILE* fs = fopen((p + ".sz").c_str(), "rb");
+  FILE* fk = fopen((p + ".ky").c_str(), "rb");
+  FILE* fl = fopen((p + ".lb").c_str(), "rb");
+  struct Dev { int device; std::vector<size_t> eng; uint8_t* d_sz = nullptr; void* d_ky = nullptr; uint16_t* d_lb = nullptr; hipStream_t stream = nullptr; };
+  std::vector<Dev> devs;
+  uint8_t* h_sz = nullptr;
+  int rc = MIC_OK;
+  const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
+  struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    fprintf(stderr, "[load x%zu] %s: %.3f s\n", n_engines, what, (t.tv_sec - t_prev.tv_sec) + (t.tv_nsec - t_prev.tv_nsec) / 1e9);
+    t_prev = t;
+  };
+  do {
+    if (!fs) { rc = fail(MIC_E_IO, "Failed to open %s.sz", prefix); break; }
+    if (!fk) { rc = fail(MIC_E_IO, "Failed to open %s.ky", prefix); break; }
+    if (!fl) { rc = fail(MIC_E_IO, "Failed to open %s.lb", prefix); break; }
+    fseeko(fs, 0, SEEK_END);
+    const uint64_t htsize = (uint64_t)ftello(fs);
+    fseeko(fs, 0, SEEK_SET);
+    uint64_t z0 = 0, z1 = 0;
+    if ((rc = check_shard(htsize, z0, z1))) break;
+    if (key_bytes == 0) key_bytes = mic_key_bytes_rule(htsize, engines[0]->cfg.k);
+    if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) { rc = fail(MIC_E_INVALID, "key_bytes must be 2, 4 or 8"); break; }
+    h_sz = (uint8_t*)malloc(htsize);
+    if (!h_sz) { rc = fail(MIC_E_NOMEM, "out of host memory for bucket sizes"); break; }
+    if (fread(h_sz, 1, htsize, fs) != htsize) { rc = fail(MIC_E_IO, "short read on %s.sz", prefix); break; }
+    uint64_t n_el = 0;
+    for (uint64_t i = 0; i < htsize; ++i) n_el += h_sz[i];
+    lap("read .sz, sum bucket sizes");
+    for (size_t i = 0; i < n_engines; ++i) {
+      size_t d = 0;
+      while (d < devs.size() && devs[d].device != engines[i]->device) ++d;
+      if (d == devs.size()) { devs.emplace_back(); devs[d].device = engines[i]->device; devs[d].stream = engines[i]->stream; }
+      devs[d].eng.push_back(i);
+    }
+    for (Dev& dv : devs) {
+      if (hipSetDevice(dv.device) != hipSuccess) { rc = fail(MIC_E_HIP, "hipSetDevice failed"); break; }
+      for (size_t i : dv.eng) if (engines[i]->db_loaded) mic_db_unload(engines[i]);
+      hipError_t he = hipMalloc(&dv.d_sz, htsize);
+      if (he == hipSuccess) he = hipMalloc(&dv.d_ky, n_el * key_bytes + 16);
+      if (he == hipSuccess) he = hipMalloc(&dv.d_lb, n_el * 2 + 16);
+      if (he != hipSuccess) { rc = fail(he == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "DB image allocation on device %d: %s", dv.device, hipGetErrorString(he)); break; }
+    }
+    if (rc) break;
+    std::vector<UploadDst> dz, dk, dl;
+    for (Dev& dv : devs) { dz.push_back({dv.device, dv.d_sz, dv.stream}); dk.push_back({dv.device, dv.d_ky, dv.stream}); dl.push_back({dv.device, dv.d_lb, dv.stream}); }
+    if ((rc = upload_file_range_multi(fs, 0, htsize, dz, "the .sz file"))) break;
+    if ((rc = upload_file_range_multi(fk, 0, n_el * key_bytes, dk, "the .ky file"))) break;
+    if ((rc = upload_file_range_multi(fl, 0, n_el * 2, dl, "the .lb file"))) break;
+    lap("images uploaded to every device");
+    // one thread per device; the engines of a device one after another (a build sizes its staging area from the free HBM)
+    std::vector<int> rcs(devs.size(), MIC_OK);
+    std::vector<std::string> msgs(devs.size());
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < devs.size(); ++d)
+      th.emplace_back([&, d] {
+        Dev& dv = devs[d];
+        for (size_t i : dv.eng) {
+          mic_engine* e = engines[i];
+          uint64_t s0 = 0, s1 = htsize, base_elems = 0, base_rank = 0;
+          int r = set_device(e);
+          if (!r) r = apply_part(e, htsize, s0, s1);
+          if (!r && s0 > 0 && mic_reduce_sizes(dv.d_sz, s0, &base_elems, &base_rank, e->stream) != 0) r = fail(MIC_E_HIP, "size reduction failed");
+          if (!r) r = build_from_device(e, dv.d_sz + s0, htsize, s0, s1, (const char*)dv.d_ky + base_elems * key_bytes, key_bytes,
+                                        dv.d_lb + base_elems, sampling, base_rank);
+          if (r) { rcs[d] = r; msgs[d] = g_err; return; }
+        }
+      });
+    for (auto& t : th) t.join();
+    for (size_t d = 0; d < devs.size(); ++d) if (rcs[d]) { rc = fail(rcs[d], "%s", msgs[d].c_str()); break; }
+    lap("tables built");
+  } while (0);
+  if (fs) fclose(fs);
+  if (fk) fclose(fk);
+  if (fl) fclose(fl);
+  free(h_sz);
+  for (Dev& dv : devs) {
+    hipSetDevice(dv.device);
+    if (dv.d_sz) hipFree(dv.d_sz);
+    if (dv.d_ky) hipFree(dv.d_ky);
+    if (dv.d_lb) hipFree(dv.d_lb);
+  }
+  return rc;
 }
 
 int mic_batch_check(mic_engine* e, size_t batch, int* done) {

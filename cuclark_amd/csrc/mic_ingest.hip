@@ -33,6 +33,8 @@ int mic_engine_table(mic_engine* e, MicTable* t, int* slot_class, int* n_cu, int
 int mic_set_error(int code, const char* fmt, ...);
 int mic_bind_thread_near_device(int device, int on);
 void mic_engine_copy_streams(mic_engine* e, hipStream_t* up, hipStream_t* down);
+void mic_peer_enable_engines(mic_engine* const* engines, size_t n);
+bool mic_peer_enable(int from, int to);
 
 namespace {
 
@@ -472,10 +474,24 @@ struct Slot {
   hipEvent_t ev = nullptr, ev_up = nullptr, ev_k = nullptr;
   uint32_t n_reads = 0, cont_used = 0;
   std::vector<void*> dev_allocs, host_allocs;
+  // table-sharded batches (mic_ingest_classify_group): what this slot keeps on every engine of its group, the owner included
+  struct Peer {
+    mic_engine* eng = nullptr; int device = 0;
+    void* block = nullptr;
+    uint32_t* d_rp = nullptr; uint16_t* d_cont = nullptr;   // the packed reads (helpers: a peer copy; owner: the slot's own arrays)
+    uint32_t* d_rows = nullptr;                             // this engine's partial rows of ALL reads of the batch
+    uint32_t* d_gather = nullptr; uint32_t* d_acc = nullptr;  // rows of this engine's read range from the others; the sum's other buffer
+    uint32_t* d_res = nullptr;                              // helpers: results of all reads from the query kernel, then of the range
+    uint32_t* d_flagged = nullptr;
+    hipStream_t stream = nullptr;                           // helpers: a stream on their device; owner: the slot's stream
+    hipEvent_t ev_q = nullptr, ev_done = nullptr;           // this engine's rows are written; its range is finished and delivered
+  };
+  std::vector<Peer> peers;
+  hipEvent_t ev_pack = nullptr;
 };
 
 struct Ingest {
-  mic_engine* eng = nullptr;
+  mic_engine* eng = nullptr; int device = 0;
   size_t max_bytes = 0, max_lines = 0, max_reads = 0, max_tiles = 0, cont_cap = 0, csv_cap = 0;
   char* d_tnames = nullptr; uint32_t* d_tname_off = nullptr; uint32_t n_targets = 0;
   int want_results = 0;
@@ -580,10 +596,14 @@ int alloc_slot(Ingest* g, Slot& s, size_t tmp, int device) {
   return MIC_OK;
 }
 
+void free_peers(Slot& s);
 void free_ingest(Ingest* g) {
   if (!g) return;
   for (Slot& s : g->slots) {
     if (s.stream) hipStreamSynchronize(s.stream);
+    free_peers(s);
+    if (s.ev_pack) hipEventDestroy(s.ev_pack);
+    hipSetDevice(g->device);
     for (void* p : s.dev_allocs) hipFree(p);
     for (void* p : s.host_allocs) hipHostFree(p);
     if (s.ev) hipEventDestroy(s.ev);
@@ -597,6 +617,133 @@ void free_ingest(Ingest* g) {
 }
 
 double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec / 1e9; }
+
+// ---- table-sharded batches: the slot's buffers on the engines of its group, and the exchange ------------------------------
+const uint32_t kGroupRowWords = 16;      // 15 (target, count) pairs per partial row = the reference's MAXHITS rows (parameters.hh:44)
+
+// reads whose summed row did not fit (result word 6: MIC_FLAG_ROW_OVERFLOW) are counted into the slot's flagged counter: the
+// batch is then handed back with MIC_INGEST_DENSE like a batch with a read of more than 64 targets
+__global__ void __launch_bounds__(256) group_overflow_kernel(const uint32_t* __restrict__ results, uint32_t n, uint32_t* __restrict__ flagged) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && (results[(size_t)i * 8 + 6] & MIC_FLAG_ROW_OVERFLOW_)) atomicAdd(&flagged[0], 1u);
+}
+
+void free_peers(Slot& s) {
+  for (Slot::Peer& p : s.peers) {
+    hipSetDevice(p.device);
+    if (p.stream && p.stream != s.stream) { hipStreamSynchronize(p.stream); hipStreamDestroy(p.stream); }
+    if (p.ev_q) hipEventDestroy(p.ev_q);
+    if (p.ev_done) hipEventDestroy(p.ev_done);
+    if (p.block) hipFree(p.block);
+  }
+  s.peers.clear();
+}
+
+int setup_peers(Ingest* g, Slot& s, mic_engine* const* group, size_t P, size_t owner) {
+  free_peers(s);
+  s.peers.resize(P);
+  const size_t len_max = g->max_reads / P + 2, rw = kGroupRowWords;
+  for (size_t p = 0; p < P; ++p) {
+    Slot::Peer& q = s.peers[p];
+    MicTable t; int sc, ncu, dev, k; uint32_t nt;
+    int rc = mic_engine_table(group[p], &t, &sc, &ncu, &dev, &k, &nt);
+    if (rc) return rc;
+    q.eng = group[p]; q.device = dev;
+    ITRY(hipSetDevice(dev));
+    const bool own = p == owner;
+    for (int pass = 0; pass < 2; ++pass) {          // pass 0 adds the sizes up, pass 1 hands the pieces out
+      Arena a;
+      a.base = pass ? (char*)q.block : nullptr;
+      a.take(&q.d_rows, (g->max_reads + 1) * rw);
+      a.take(&q.d_gather, (P - 1) * len_max * rw);
+      a.take(&q.d_acc, len_max * rw);
+      if (!own) {
+        a.take(&q.d_rp, g->max_reads + 2);
+        a.take(&q.d_cont, g->cont_cap + 192);
+        a.take(&q.d_res, (g->max_reads + 1) * 8);
+        a.take(&q.d_flagged, (size_t)kFlaggedCapI + 1);
+      }
+      if (!pass) {
+        hipError_t e = hipMalloc(&q.block, a.off + 256);
+        if (e != hipSuccess) return mic_set_error(MIC_E_NOMEM, "table-sharded ingest slot: %zu bytes on device %d: %s", a.off, dev, hipGetErrorString(e));
+      }
+    }
+    ITRY(hipEventCreateWithFlags(&q.ev_q, hipEventDisableTiming));
+    ITRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
+    if (own) { q.d_rp = s.d_rp; q.d_cont = s.d_cont; q.d_res = s.d_results; q.d_flagged = s.d_flagged; q.stream = s.stream; }
+    else {
+      ITRY(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+      ITRY(hipMemsetAsync(q.d_cont, 0, (g->cont_cap + 192) * 2, q.stream));     // (the query kernel's read-ahead looks past the last read)
+      ITRY(hipStreamSynchronize(q.stream));
+    }
+  }
+  ITRY(hipSetDevice(s.peers[owner].device));
+  if (!s.ev_pack) ITRY(hipEventCreateWithFlags(&s.ev_pack, hipEventDisableTiming));
+  mic_peer_enable_engines(group, P);
+  return MIC_OK;
+}
+
+// Every engine of the group probes the batch's packed reads (on the owner's device after pack_kernel) against its part; the rows
+// are summed read-range owned; the owner's d_results hold best / second-best of all reads when its stream has passed the waits
+// queued here.  Nothing blocks the host.
+int group_query(mic_engine* const* group, size_t P, size_t owner, Ingest* g, Slot& s, uint32_t n, uint32_t nb, int k) {
+  bool same = s.peers.size() == P;
+  for (size_t p = 0; same && p < P; ++p) same = s.peers[p].eng == group[p];
+  if (!same) { int rc = setup_peers(g, s, group, P, owner); if (rc) return rc; }
+  const size_t rw = kGroupRowWords;
+  Slot::Peer& O = s.peers[owner];
+  // containers the packer can have written for nb bytes in n reads (record_kernel's reservations) + what the kernel reads ahead
+  const size_t cont_n = std::min<size_t>(g->cont_cap + 192, (size_t)nb / 8 + 2 * ((size_t)nb / (size_t)(k + 1)) + 10 * (size_t)n + 128);
+  ITRY(hipSetDevice(O.device));
+  ITRY(hipEventRecord(s.ev_pack, s.stream));
+  for (size_t p = 0; p < P; ++p) {
+    Slot::Peer& q = s.peers[p];
+    MicTable t; int sc, ncu, dev, kk; uint32_t nt;
+    int rc = mic_engine_table(group[p], &t, &sc, &ncu, &dev, &kk, &nt);
+    if (rc) return rc;
+    if (!t.slots) return mic_set_error(MIC_E_STATE, "no database loaded on engine %zu of the group", p);
+    ITRY(hipSetDevice(dev));
+    if (p != owner) {
+      ITRY(hipStreamWaitEvent(q.stream, s.ev_pack, 0));
+      ITRY(hipMemcpyPeerAsync(q.d_rp, dev, O.d_rp, O.device, ((size_t)n + 2) * 4, q.stream));
+      ITRY(hipMemcpyPeerAsync(q.d_cont, dev, O.d_cont, O.device, cont_n * 2, q.stream));
+    }
+    ITRY(hipMemsetAsync(q.d_flagged, 0, 4, q.stream));
+    MicQueryArgs qa;
+    qa.t = t; qa.reads_ptr = q.d_rp; qa.cont = q.d_cont; qa.n_reads = n; qa.row_words = (uint32_t)rw; qa.results = q.d_res;
+    qa.rows = q.d_rows; qa.flagged = q.d_flagged; qa.flagged_cap = kFlaggedCapI;
+    ITRY(mic_launch_query(qa, sc, ncu, q.stream));
+    ITRY(hipEventRecord(q.ev_q, q.stream));
+  }
+  for (size_t j = 0; j < P; ++j) {
+    Slot::Peer& q = s.peers[j];
+    const size_t lo = (size_t)n * j / P, hi = (size_t)n * (j + 1) / P, len = hi - lo;
+    ITRY(hipSetDevice(q.device));
+    if (len) {
+      uint32_t* buf[2] = {q.d_rows + lo * rw, q.d_acc};
+      int c = 0; size_t got = 0;
+      for (size_t p = 0; p < P; ++p) {
+        if (p == j) continue;
+        uint32_t* in = q.d_gather + got * len * rw;
+        ITRY(hipStreamWaitEvent(q.stream, s.peers[p].ev_q, 0));
+        ITRY(hipMemcpyPeerAsync(in, q.device, s.peers[p].d_rows + lo * rw, s.peers[p].device, len * rw * 4, q.stream));
+        ITRY(mic_launch_merge_rows(buf[c], in, buf[c ^ 1], (uint32_t)rw, len, nullptr, q.stream));
+        c ^= 1; ++got;
+      }
+      if (j == owner) ITRY(mic_launch_result_from_rows(buf[c], (uint32_t)rw, O.d_res + lo * 8, len, q.stream));
+      else {
+        ITRY(mic_launch_result_from_rows(buf[c], (uint32_t)rw, q.d_res, len, q.stream));
+        ITRY(hipMemcpyPeerAsync(O.d_res + lo * 8, O.device, q.d_res, q.device, len * 32, q.stream));
+      }
+    }
+    ITRY(hipEventRecord(q.ev_done, q.stream));
+  }
+  ITRY(hipSetDevice(O.device));
+  for (size_t j = 0; j < P; ++j) if (j != owner) ITRY(hipStreamWaitEvent(s.stream, s.peers[j].ev_done, 0));
+  group_overflow_kernel<<<(n + 255) / 256, 256, 0, s.stream>>>(O.d_res, n, s.d_flagged);
+  ITRY(hipGetLastError());
+  return MIC_OK;
+}
 
 }  // namespace
 
@@ -638,7 +785,7 @@ int mic_ingest_alloc(mic_engine* e, size_t n_slots, size_t max_bytes, const char
   ITRY(hipSetDevice(dev));
   mic_ingest_free(e);
   Ingest* g = new Ingest();
-  g->eng = e;
+  g->eng = e; g->device = dev;
   g->max_bytes = (max_bytes + ING_TILE - 1) / ING_TILE * ING_TILE;
   g->max_tiles = g->max_bytes / ING_TILE;
   g->max_lines = g->max_bytes / 16 + 64;          // fewer than 16 bytes per line on average: host path
@@ -692,6 +839,14 @@ int mic_ingest_free(mic_engine* e) {
 }
 
 int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int flags, mic_ingest_result* out) {
+  return mic_ingest_classify_group(&e, 1, 0, slot_id, n_bytes, flags, out);
+}
+
+int mic_ingest_classify_group(mic_engine* const* group, size_t n_group, size_t owner, size_t slot_id, size_t n_bytes, int flags,
+                              mic_ingest_result* out) {
+  if (!group || n_group == 0 || owner >= n_group) return mic_set_error(MIC_E_INVALID, "bad group");
+  for (size_t p = 0; p < n_group; ++p) if (!group[p]) return mic_set_error(MIC_E_INVALID, "null engine in the group");
+  mic_engine* e = group[owner];
   const int paired = flags & MIC_INGEST_PAIRED;
   const uint32_t lpr = (flags & MIC_INGEST_FASTQ_2LINE) ? 2u : 4u;      // lines per FASTQ record
   if (!e || !out) return mic_set_error(MIC_E_INVALID, "null argument");
@@ -758,11 +913,17 @@ int mic_ingest_classify(mic_engine* e, size_t slot_id, size_t n_bytes, int flags
     if (blocks > cap) blocks = cap;
     pack_kernel<<<blocks, 256, 0, st>>>(s.d_raw, s.rec.seq_s, s.rec.seq_e, s.d_rp, s.d_cont, n_reads, k);
   }
-  ITRY(hipMemsetAsync(s.d_flagged, 0, 4, st));
-  MicQueryArgs qa;
-  qa.t = t; qa.reads_ptr = s.d_rp; qa.cont = s.d_cont; qa.n_reads = n_reads; qa.row_words = 0; qa.results = s.d_results;
-  qa.rows = nullptr; qa.flagged = s.d_flagged; qa.flagged_cap = kFlaggedCapI;
-  ITRY(mic_launch_query(qa, sc, ncu, st));
+  if (n_group == 1) {
+    ITRY(hipMemsetAsync(s.d_flagged, 0, 4, st));
+    MicQueryArgs qa;
+    qa.t = t; qa.reads_ptr = s.d_rp; qa.cont = s.d_cont; qa.n_reads = n_reads; qa.row_words = 0; qa.results = s.d_results;
+    qa.rows = nullptr; qa.flagged = s.d_flagged; qa.flagged_cap = kFlaggedCapI;
+    ITRY(mic_launch_query(qa, sc, ncu, st));
+  } else {
+    // table-sharded: all engines of the group probe the batch against their parts, the rows are summed read-range owned
+    if ((rc = group_query(group, n_group, owner, g, s, n_reads, nb, k))) return rc;
+    ITRY(hipSetDevice(dev));
+  }
   CsvArgs ca;
   ca.raw = s.d_raw; ca.name_s = s.rec.name_s; ca.name_len = s.rec.name_len; ca.length = s.rec.length; ca.results = s.d_results;
   ca.tnames = g->d_tnames; ca.tname_off = g->d_tname_off; ca.n_targets = g->n_targets; ca.n_reads = n_reads; ca.k = k; ca.paired = paired ? 1 : 0;
@@ -933,7 +1094,11 @@ int mic_pairs_merge_to_slot(mic_engine* e, mic_pairs* p, uint64_t r0, uint64_t r
   if (r0 >= r1 || !pairs_offset(p, r0, o0) || !pairs_offset(p, r1, o1))
     return mic_set_error(MIC_E_INVALID, "records [%llu, %llu): not a range of whole strides", (unsigned long long)r0, (unsigned long long)r1);
   if (o1 - o0 > g->max_bytes) return mic_set_error(MIC_E_INVALID, "merged text of %llu bytes does not fit the slot (%zu)", o1 - o0, g->max_bytes);
-  ITRY(hipSetDevice(p->device));
+  // the kernel runs on the SLOT's device and stream; when the texts live on another device (several engines, one inflated input)
+  // it reads them through peer access
+  if (g->device != p->device && !mic_peer_enable(g->device, p->device))
+    return mic_set_error(MIC_E_UNSUPPORTED, "device %d has no peer access to device %d, where the inflated text lives", g->device, p->device);
+  ITRY(hipSetDevice(g->device));
   Slot& s = g->slots[slot_id];
   pair_merge_kernel<<<(unsigned)((r1 - r0 + 3) / 4), 256, 0, s.stream>>>(p->t[0], p->t[1], r0, r1, p->d_off, s.d_raw);
   ITRY(hipGetLastError());
@@ -1092,9 +1257,12 @@ int mic_text_to_slot(mic_engine* e, mic_text* p, uint64_t r0, uint64_t r1, size_
   if (r0 >= r1 || !text_offset(p, r0, o0) || !text_offset(p, r1, o1))
     return mic_set_error(MIC_E_INVALID, "records [%llu, %llu): not a range of whole strides", (unsigned long long)r0, (unsigned long long)r1);
   if (o1 - o0 > g->max_bytes) return mic_set_error(MIC_E_INVALID, "text of %llu bytes does not fit the slot (%zu)", o1 - o0, g->max_bytes);
-  ITRY(hipSetDevice(p->device));
+  ITRY(hipSetDevice(g->device));
   Slot& s = g->slots[slot_id];
-  ITRY(hipMemcpyAsync(s.d_raw, p->t + o0, (size_t)(o1 - o0), hipMemcpyDeviceToDevice, s.stream));
+  if (g->device != p->device) {
+    mic_peer_enable(g->device, p->device);      // (without peer access the runtime stages the copy through host memory)
+    ITRY(hipMemcpyPeerAsync(s.d_raw, g->device, p->t + o0, p->device, (size_t)(o1 - o0), s.stream));
+  } else ITRY(hipMemcpyAsync(s.d_raw, p->t + o0, (size_t)(o1 - o0), hipMemcpyDeviceToDevice, s.stream));
   *n_bytes = (size_t)(o1 - o0);
   return MIC_OK;
 }

@@ -125,6 +125,8 @@ extern thread_local uint64_t mic_build_reserved_hbm;
 
 // launchers (mic_kernels.hip)
 hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hipStream_t s);
+// name of the instantiation mic_launch_query picks for this table, as a kernel trace shows it; returns the length
+int mic_query_kernel_name(const MicTable& t, int slot_class, char* buf, size_t cap);
 hipError_t mic_kernels_warm(hipStream_t s);      // loads the query kernels' device code (a no-op kernel of their file)
 hipError_t mic_launch_merge_rows(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t row_words, size_t n,
                                  uint32_t* flags_results, hipStream_t s);

@@ -2032,6 +2032,28 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   return hipGetLastError();
 }
 
+// The instantiation mic_launch_query launches for table t, spelled the way a kernel trace spells it (same decisions, same order).
+int mic_query_kernel_name(const MicTable& t, int slot_class, char* buf, size_t cap) {
+  if (t.layout == 2) {
+    static const bool generic = getenv("MIC_S_GENERIC") != nullptr;
+    const bool pt = t.parted != 0, fw = t.fwd != 0, per_kmer = per_kmer_env();
+    const bool run_ok = 2 * t.k - t.m > 32 && 2 * t.k - t.m <= 48;
+    const bool sh = t.sharded != 0 || (pt && (per_kmer || (!fw && !run_ok)));
+    const bool sd = t.side != nullptr;
+    const bool spec = !generic && t.m == 20 && (t.k == 31 || t.k == 27 || t.k == 32);
+    const int kk = spec ? t.k : 0, mm = spec ? t.m : 0;
+    const char* b[2] = {"false", "true"};
+    if (!sh && !per_kmer && (fw || run_ok))
+      return snprintf(buf, cap, "query_kernel_r<%d, %d, %s, %s, %s>", kk, mm, b[fw], b[pt], b[sd]);
+    return snprintf(buf, cap, "query_kernel_s<%d, %d, %s, %s>", kk, mm, b[sh], b[fw]);
+  }
+  if (t.layout) {
+    const bool spec = MIC_SPEC && t.m == 20 && (t.k == 31 || t.k == 27);
+    return snprintf(buf, cap, "query_kernel_m<%d, %d>", spec ? t.k : 0, spec ? t.m : 0);
+  }
+  return snprintf(buf, cap, "query_kernel<%s>", slot_class == 64 ? "true" : "false");
+}
+
 hipError_t mic_launch_merge_rows(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t row_words, size_t n,
                                  uint32_t* flags_results, hipStream_t s) {
   if (!n) return hipSuccess;

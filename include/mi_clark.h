@@ -129,6 +129,23 @@ int mic_db_set_part(mic_engine* e, uint32_t part, uint32_t n_parts);
  * slots, set up on a side thread): the table builders size their staging areas from the free HBM minus this, so the layout
  * and the number of build passes do not depend on which allocation comes first.  0 clears it. */
 int mic_db_reserve_hbm(mic_engine* e, uint64_t bytes);
+/* ---- several devices in one process (the command line's -d N; the reference: CuClarkDB ctor + read, CuClarkDB.cu:104-208, 461-808) ----
+ * mic_peer_matrix       the reference checks and enables peer access for every pair of its devices before it merges their
+ *                       partial rows with cudaMemcpyPeer (CuClarkDB.cu:184-208, 954-974).  Here: matrix[i * n + j] = 1 when device
+ *                       i reaches device j's memory directly (hipDeviceCanAccessPeer; enabled once per ordered pair, "already
+ *                       enabled" is fine), 0 when copies between the two are staged through host memory by the runtime; the
+ *                       diagonal is 1.  n_devices <= mic_device_count.  The table-sharded exchange calls it for its engines itself.
+ * mic_db_load_files_multi   the database of mic_db_load_files into n engines from ONE read of <prefix>.sz/.ky/.lb: every chunk
+ *                       of the files is read once into pinned memory and uploaded to every device that hosts an engine; the
+ *                       tables - each engine's part when mic_db_set_part was called, the whole table otherwise - are then built
+ *                       by one thread per device at the same time.  Engines that share a device share its copy of the images. */
+int mic_peer_matrix(int* matrix, int n_devices);
+/* Free and total memory of a device in bytes (hipMemGetInfo): how many parts a table needs is decided from it. */
+int mic_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
+int mic_db_load_files_multi(mic_engine* const* engines, size_t n_engines, const char* prefix, int key_bytes, uint32_t sampling);
+/* Name of the query-kernel instantiation mic_query_device / the batch API / the ingest path launch for this engine's table (what
+ * rocprofv3's kernel trace shows), e.g. "query_kernel_r<31, 20, false, true, false>"; returns the length, < 0 without a table. */
+int mic_db_kernel_name(const mic_engine* e, char* buf, size_t cap);
 int mic_db_get_info(const mic_engine* e, mic_db_info* info);
 int mic_db_unload(mic_engine* e);
 /* Stage times of the last table build of this process, one "<stage>: <seconds>" per line (what MIC_LOAD_TIMING=1 prints on
@@ -171,6 +188,13 @@ int mic_batch_check(mic_engine* e, size_t batch, int* done);
  * row does not fit (MIC_FLAG_ROW_OVERFLOW in its results word 6, row[0] == MIC_ROW_INVALID) is completed by the
  * caller: the sum over the engines of mic_batch_dense_counts.  Synchronous.  Engines may share a device. */
 int mic_batch_merge_shards(mic_engine* const* engines, size_t n_engines, size_t batch);
+/* (How the rows are summed: READ-RANGE OWNED, all engines at once - engine j fetches the rows of the j-th 1/n of the batch's
+ * reads from the other n - 1 engines (n - 1 peer copies of 1/n of the rows each, hipMemcpyPeerAsync over xGMI with peer access
+ * enabled), sums them, finishes best / second-best for its range and writes results and rows of the range straight into
+ * engines[0]'s host arrays.  The reference funnels whole row arrays into device 0 one after another, CuClarkDB.cu:954-974.
+ * Peer copies, not RCCL: one process drives all devices here, the copy engines move the rows while the compute units run the
+ * next batch's kernels, and there is nothing to rendez-vous; the one-process-per-GPU form of the same exchange is bench.py's
+ * all_to_all over RCCL, cuclark_amd/multi.py.) */
 int mic_sync(mic_engine* e);
 /* Host threads that fill the engine's pinned buffers should run on the socket the device hangs off: on != 0 binds the
  * calling thread to the CPUs of the device's NUMA node, on == 0 restores its previous mask (no-op when the node is
@@ -262,6 +286,17 @@ typedef struct mic_ingest_result {
 int mic_ingest_alloc(mic_engine* e, size_t n_slots, size_t max_bytes, const char* const* target_names, uint32_t n_targets,
                      int want_results, uint8_t** raw /*[n_slots]*/);
 int mic_ingest_classify(mic_engine* e, size_t slot, size_t n_bytes, int flags, mic_ingest_result* out);
+/* The same for a table-sharded run (cuCLARK --db-sharded): group[p] holds part p of n_group parts of the database
+ * (mic_db_set_part(p, n_group)); the slot belongs to group[owner] (mic_ingest_alloc on that engine), which indexes and packs the
+ * batch and formats its CSV.  In between, every engine of the group probes ALL reads of the batch against its part (the packed
+ * reads travel to the other engines by peer copy: 44 B per 150-bp read), and the per-read sparse rows are summed READ-RANGE
+ * OWNED: engine j fetches the rows of the j-th 1/n_group of the reads from the other engines, sums, finishes best / second-best
+ * and sends the 32-byte results of its range to the owner - all engines at once, nothing funnels through one device (the
+ * reference: queryBatch on every device, cudaMemcpyPeer of whole row arrays into device 0, CuClarkDB.cu:886-1001).  A batch with
+ * a read whose summed row does not fit (more than 15 targets) comes back as MIC_INGEST_FALLBACK | MIC_INGEST_DENSE like any other
+ * batch the device path hands back.  n_group == 1 is mic_ingest_classify.  Blocking; one host thread per slot. */
+int mic_ingest_classify_group(mic_engine* const* group, size_t n_group, size_t owner, size_t slot, size_t n_bytes, int flags,
+                              mic_ingest_result* out);
 int mic_ingest_fetch_packed(mic_engine* e, size_t slot, uint32_t* reads_pointer, size_t rp_cap, uint16_t* containers,
                             size_t cont_cap, uint64_t* n_reads, uint64_t* n_containers);
 int mic_ingest_free(mic_engine* e);

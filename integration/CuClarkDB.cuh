@@ -18,8 +18,8 @@
 #include "mi_clark.h"
 
 template <typename HKMERr> class CuClarkDB {
-  // numDevices engines, each holding one bucket range of the table (the reference's multi-device mode,
-  // CuClarkDB.cu:104-208, 566-574, 886-974): every engine gets the batch's reads, the sparse rows are summed into engine 0
+  // numDevices engines, each holding one part of the table (the reference's multi-device mode, CuClarkDB.cu:104-208, 566-574,
+  // 886-974): every engine gets the batch's reads, the sparse rows are summed read-range owned (mic_batch_merge_shards)
   std::vector<mic_engine*> e_; size_t nb_; uint8_t k_; bool ext_ = false; uint32_t rw_ = 16;   // rw_: u32 words per sparse row
   uint32_t *res32_ = nullptr, *rows32_ = nullptr; RESULTS *final_ = nullptr, *full_ = nullptr;
   std::vector<ITYPE> index_; std::vector<size_t> nreads_, ncont_; size_t rowSize_ = 0, finalRowSize_ = 5;
@@ -41,12 +41,15 @@ template <typename HKMERr> class CuClarkDB {
     fileSize = 0;
     uint64_t H = (uint64_t)HTSIZE;                                // the table size is the size of the .sz file (= HTSIZE in a CuCLARK build)
     if (FILE* f = fopen((std::string(prefix) + ".sz").c_str(), "rb")) { fseek(f, 0, SEEK_END); H = (uint64_t)ftell(f); fclose(f); }
-    for (size_t d = 0; d < e_.size(); ++d) {                                                // CuClarkDB.cu:461-808
-      const uint64_t s0 = e_.size() > 1 ? H * d / e_.size() : 0, s1 = e_.size() > 1 ? H * (d + 1) / e_.size() : 0;
-      int rc = mic_db_load_files(e_[d], prefix, sizeof(HKMERr), mod, s0, s1);               // bucket ranges: CuClarkDB.cu:566-574
-      if (rc == MIC_E_IO) { std::cerr << mic_last_error() << std::endl; return false; }     // "Failed to open ..."
-      ck(rc); mic_db_info i; mic_db_get_info(e_[d], &i); fileSize += i.hbm_bytes;
-    }
+    (void)H;
+    // every device answers for one part of the table (the reference's m_partPointer ranges, CuClarkDB.cu:566-574; here a slot range
+    // of the resident table, mic_db_set_part); the files are read once for all devices, the parts built at the same time (:461-808)
+    for (size_t d = 0; d < e_.size() && e_.size() > 1; ++d) ck(mic_db_set_part(e_[d], (uint32_t)d, (uint32_t)e_.size()));
+    int rc = e_.size() > 1 ? mic_db_load_files_multi(e_.data(), e_.size(), prefix, sizeof(HKMERr), mod)
+                           : mic_db_load_files(e_[0], prefix, sizeof(HKMERr), mod, 0, 0);
+    if (rc == MIC_E_IO) { std::cerr << mic_last_error() << std::endl; return false; }       // "Failed to open ..."
+    ck(rc);
+    for (size_t d = 0; d < e_.size(); ++d) { mic_db_info i; mic_db_get_info(e_[d], &i); fileSize += i.hbm_bytes; }
     dbParts = 1; return true;
   }
   bool swapDbParts() { return false; }            // whole table resident: no cycles        // CuClarkDB.cu:813-858
@@ -81,7 +84,7 @@ template <typename HKMERr> class CuClarkDB {
     return true;
   }
   bool waitForBatch(size_t b) {                                                             // CuClarkDB.cu:440-445
-    if (e_.size() > 1) ck(mic_batch_merge_shards(e_.data(), e_.size(), b));                 // copy + mergeKernel + resultKernel, :954-1024
+    if (e_.size() > 1) ck(mic_batch_merge_shards(e_.data(), e_.size(), b));                 // peer copies + mergeKernel + resultKernel, :954-1024
     else ck(mic_batch_wait(e_[0], b));
     for (size_t r = index_[b]; r < index_[b] + nreads_[b]; ++r) {      // u32 -> RESULTS, the layout CuCLARK_hh.hh reads
       for (int w = 0; w < 5; ++w) final_[r * finalRowSize_ + w] = (RESULTS)res32_[r * MIC_RESULT_WORDS + w];

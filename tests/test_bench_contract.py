@@ -31,6 +31,11 @@ def test_bench_tiny_json_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] == "port" and cb["parity_with_gpu_on_sample"] is True
+    # the CPU baseline states its real resources: CPUs in the affinity mask, the cgroup's CPU-time quota, threads it ran
+    for key in ("cores_visible", "cpu_quota", "threads_used"):
+        assert key in cb, key
+    assert 1 <= cb["threads_used"] <= cb["cores_visible"] and cb["cores"] == cb["threads_used"]
+    assert cb["cpu_quota"] is None or cb["threads_used"] <= cb["cpu_quota"] + 1
     assert d["value"] > 0 and abs(d["value"] - d["config"]["reads_per_gpu"] / d["ms_per_step"] / 1e3) / d["value"] < 0.02
     assert d["known_answer"]["label_and_count_ok"] == 1.0
     # the two extra legs (SURVEY.md 8d ii, iii): batch-API pipeline and files-in / CSV-out through exe/cuCLARK
@@ -175,3 +180,41 @@ def test_bench_four_ranks_two_dimensional_layout():
     td = ts["two_parts_2d"]
     assert td["parts"] == 2 and td["read_groups"] == 2 and td["reads_this_rank"] == d["config"]["reads_per_gpu"] // 2
     assert td["known_answer"]["label_and_count_ok"] == 1.0 and td["known_answer"]["random_reads_no_hit"] == 1.0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_its_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the script starts its ranks as a child process under
+    torch.distributed.run before it touches the GPU and relays rank 0's line (gloo: the two ranks share this box's one GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(gu.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny",
+                        "--backend", "gloo", "--no-db-leg"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["known_answer"]["label_and_count_ok"] == 1.0
+    assert abs(d["value"] - 2 * d["config"]["reads_per_gpu"] / d["ms_per_step"] / 1e3) / d["value"] < 0.02
+
+
+def _refusal(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(gu.ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_bench_refuses_more_rccl_ranks_than_devices():
+    """--gpus N over RCCL with fewer visible devices than ranks exits non-zero with the reason (no rank is stacked on another's GPU);
+    runs anywhere: the check comes before anything touches a GPU (here: no device at all, or one)."""
+    import torch
+    n = torch.cuda.device_count()
+    r = _refusal(["--gpus", str(n + 2), "--workload", "tiny", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "RCCL needs one device per rank" in r.stderr and f"has {n}" in r.stderr, r.stderr[-1000:]
+    # the same inside a rank a launcher started (WORLD_SIZE set): a local rank without a device of its own refuses
+    r = _refusal(["--gpus", str(n + 2), "--workload", "tiny"], {"WORLD_SIZE": str(n + 2), "RANK": str(n + 1), "LOCAL_RANK": str(n + 1)})
+    assert r.returncode != 0 and "has no GPU of its own" in r.stderr, r.stderr[-1000:]
+    # a launcher that started another number of ranks than --gpus says
+    r = _refusal(["--gpus", "4", "--workload", "tiny"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -258,32 +258,52 @@ def test_set_targets_then_classify_end_to_end(tmp_path):
 
 
 @pytest.mark.gpu
-def test_db_sharded_cli_matches_golden(tmp_path):
-    """--db-sharded: every engine holds a bucket range of the table (the reference's multi-device mode); three engines
-    share the one GPU here (MIC_SHARD_ENGINES).  CSVs identical to the whole-table ones, plain, extended, paired, with
-    sampling, and with 80 targets (rows that do not fit 15 entries: dense counts summed over the shards)."""
+@pytest.mark.parametrize("engines,parts", [(3, 3), (8, 8), (4, 2)])
+def test_db_sharded_cli_matches_golden(tmp_path, engines, parts):
+    """--db-sharded [--parts P]: the engines hold parts of the table (mic_db_set_part: the super-k-mer table cut by resident slot
+    range, the per-run kernel's PART instantiation) and answer every batch of their read group together, rows summed read-range
+    owned - the reference's multi-device mode (CuClarkDB.cu:886-1024).  `engines` engines share the one GPU here
+    (MIC_SHARD_ENGINES); 4 engines / 2 parts = the 2-D layout (2 read groups).  CSVs identical to the whole-table ones: the
+    streaming device path (plain, paired, FASTQ), the batch path (--extended), with sampling, and with 80 targets (rows that do
+    not fit 15 entries: the batch falls back, dense counts summed over the parts)."""
     tmp = str(tmp_path)
     d = _db_dir(tmp, "light_k27_u32", light=True)
     t = _targets_file(tmp)
-    env = dict(os.environ, MIC_SHARD_ENGINES="3")
+    env = dict(os.environ, MIC_SHARD_ENGINES=str(engines), MIC_CLI_TIMING="1")
+    sh = ["--db-sharded", "--parts", str(parts)]
     for flag, src, exp in (([], ["-O", os.path.join(gu.GOLDEN, "reads_k27.fa")], "expected_k27_fa.csv"),
+                           (["-n", "3"], ["-O", os.path.join(gu.GOLDEN, "reads_k27.fq")], "expected_k27_fq.csv"),
                            (["--extended", "-n", "2", "-b", "4"], ["-O", os.path.join(gu.GOLDEN, "reads_k27.fa")], "expected_k27_fa_ext.csv"),
                            (["-b", "3"], ["-P", os.path.join(gu.GOLDEN, "pairs_k27_1.fq"), os.path.join(gu.GOLDEN, "pairs_k27_2.fq")],
                             "expected_k27_pairs.csv")):
         out = os.path.join(tmp, "sh_" + exp)
-        r = _run([EXE_L, "-T", t, "-D", d, *src, "-R", out, "--db-sharded", *flag], env=env)
+        r = _run([EXE_L, "-T", t, "-D", d, *src, "-R", out, *sh, *flag], env=env)
         assert r.returncode == 0, r.stderr
-        assert "on 3 device(s)" in r.stderr
+        assert f"on {engines} device(s)" in r.stderr and f"table-sharded: {parts} part(s) x {engines // parts} read group(s)" in r.stderr, r.stderr
+        assert "peer access: 1" in r.stderr
+        # the per-run kernel's PART instantiation (k = 27, m = 20, one strand, slot-range part)
+        assert "[timing] query kernel: query_kernel_r<27, 20, false, true," in r.stderr, r.stderr
         assert open(out + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, exp), "rb").read(), exp
-    # sampling: whole table vs shards
+        if "--extended" not in flag:      # the streaming path, nothing handed back to the host
+            assert re.search(r"device ingest: \d+ batches .* 0 through the host path", r.stderr), r.stderr
+    if (engines, parts) != (3, 3):
+        return
+    # sampling: whole table vs parts
     outs = []
-    for extra, e in ((["-s", "3"], dict(os.environ)), (["-s", "3", "--db-sharded"], env)):
+    for extra, e in ((["-s", "3"], dict(os.environ)), (["-s", "3", *sh], env)):
         out = os.path.join(tmp, "samp%d" % len(outs))
         r = _run([EXE, "-k", "27", "--htsize", "57777779", "-T", t, "-D", _db_dir(os.path.join(tmp, "full"), "light_k27_u32", light=False),
                   "-O", os.path.join(gu.GOLDEN, "reads_k27.fa"), "-R", out, *extra], env=e)
         assert r.returncode == 0, r.stderr
         outs.append(open(out + ".csv", "rb").read())
     assert outs[0] == outs[1] and outs[0].count(b"\n") == 132
+    # the default number of parts: the smallest whose part fits a device - one for this table: the engines split the reads
+    out = os.path.join(tmp, "auto")
+    r = _run([EXE_L, "-T", t, "-D", d, "-O", os.path.join(gu.GOLDEN, "reads_k27.fa"), "-R", out, "--db-sharded"], env=env)
+    assert r.returncode == 0 and "table-sharded: 1 part(s) x 3 read group(s)" in r.stderr, r.stderr
+    assert open(out + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, "expected_k27_fa.csv"), "rb").read()
+    r = _run([EXE_L, "-T", t, "-D", d, "-O", os.path.join(gu.GOLDEN, "reads_k27.fa"), "-R", out, "--db-sharded", "--parts", "2"], env=env)
+    assert r.returncode != 0 and "--parts 2 does not divide the 3 device(s)" in r.stderr
     # many targets: one read made of k-mers of 80 different targets
     import numpy as np
     rng = np.random.default_rng(3)
@@ -313,14 +333,74 @@ def test_db_sharded_cli_matches_golden(tmp_path):
     with open(reads, "w") as f:
         f.write(">all\n" + "N".join(seqs) + "\n>few\n" + "N".join(seqs[:3]) + "\n")
     res = []
-    for extra, e in (([], dict(os.environ)), (["--db-sharded"], env)):
+    for extra, e in (([], dict(os.environ)), (sh, env)):
         for ext in ([], ["--extended"]):
             out = os.path.join(tmp, "t80_%d" % len(res))
             r = _run([EXE, "-k", str(k), "--htsize", str(htsize), "-T", tt, "-D", dd, "-O", reads, "-R", out, *extra, *ext], env=e)
             assert r.returncode == 0, r.stderr
             res.append(open(out + ".csv", "rb").read())
+            if extra and not ext:      # the summed row of "all" does not fit: the batch went through the host path, exactly
+                assert re.search(r"device ingest: 1 batches .* 1 through the host path", r.stderr), r.stderr
     assert res[0] == res[2] and res[1] == res[3]
     assert res[0].splitlines()[1].startswith(b"all,") and b",L00,5," in res[0].splitlines()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engines", [2, 3])
+def test_read_sharded_cli_with_several_engines_on_one_gpu(tmp_path, engines):
+    """-d N, the default multi-device mode: the table replicated on every engine, the ingest slots - and with them the batches -
+    dealt over the engines.  MIC_SHARD_ENGINES puts N engines on this box's one GPU.  Every input form gives the one-engine
+    run's CSV byte for byte (every record once, in order): plain FASTA / FASTQ over many small batches, --extended (batch API),
+    two plain mates, gzip and block gzip (inflated on the first engine's device, slots of the other engines filled from there),
+    compressed mates, list-of-files."""
+    import gzip
+    import numpy as np
+    import test_ingest as ti
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "light_k27_u32", light=True)
+    t = _targets_file(tmp)
+    rng = np.random.default_rng(41)
+    genomes = ti._genomes()
+    fq = os.path.join(tmp, "r.fq")
+    fa = os.path.join(tmp, "r.fa")
+    open(fq, "wb").write(ti._random_reads(rng, genomes, 5000, fasta=False))
+    open(fa, "wb").write(ti._random_reads(rng, genomes, 1500, fasta=True))
+    m1, m2 = _pair_files(rng, genomes, 3000)
+    p1, p2 = os.path.join(tmp, "m_1.fq"), os.path.join(tmp, "m_2.fq")
+    open(p1, "wb").write(m1)
+    open(p2, "wb").write(m2)
+    gz, bg = os.path.join(tmp, "r.fq.gz"), os.path.join(tmp, "r.fq.bgz")
+    open(gz, "wb").write(gzip.compress(open(fq, "rb").read(), 1))
+    _write_bgzf(fq, bg, block=60000)
+    g1, g2 = p1 + ".gz", p2 + ".gz"
+    open(g1, "wb").write(gzip.compress(m1, 1))
+    open(g2, "wb").write(gzip.compress(m2, 6))
+    lo, lr = os.path.join(tmp, "objs.txt"), os.path.join(tmp, "ress.txt")
+    open(lo, "w").write(fa + "\n" + fq + "\n")
+    cases = {"fq": ["-O", fq], "fa": ["-O", fa], "ext": ["-O", fa, "--extended", "-b", "7"], "pairs": ["-P", p1, p2], "gz": ["-O", gz],
+             "bgzf": ["-O", bg], "gzpairs": ["-P", g1, g2], "list": ["-O", lo]}
+    multi = dict(os.environ, MIC_SHARD_ENGINES=str(engines), MIC_CLI_TIMING="1", MIC_INGEST_KB="24")
+    for name, src in cases.items():
+        outs = []
+        for tag, env in (("one", dict(os.environ, MIC_CLI_TIMING="1", MIC_INGEST_KB="24")), ("multi", multi)):
+            out = os.path.join(tmp, f"{tag}_{name}")
+            res = ["-R", out]
+            if name == "list":
+                open(lr, "w").write(out + "_a\n" + out + "_b\n")
+                res = ["-R", lr]
+            r = _run([EXE_L, "-T", t, "-D", d, *src, *res, "-n", "5"], env=env)
+            assert r.returncode == 0, (name, r.stderr)
+            if tag == "multi":
+                assert f"{engines} engine(s) on 1 device(s), read-sharded (table replicated)" in r.stderr, r.stderr
+                assert f"on {engines} device(s)" in r.stderr
+                if name in ("gz", "bgzf", "gzpairs"):      # inflated on the device although the slots sit on several engines
+                    assert re.search(r"device inflate: [\d.]+ MB of text", r.stderr) and "over the link 0 MB" in r.stderr, r.stderr
+                if name != "ext":
+                    m = re.search(r"device ingest: (\d+) batches of <= 24 KB on (\d+) slot", r.stderr)
+                    assert m and int(m.group(1)) > 2 * engines and int(m.group(2)) >= engines, r.stderr
+            outs.append([open(out + sfx + ".csv", "rb").read() for sfx in (("_a", "_b") if name == "list" else ("",))])
+        assert outs[0] == outs[1], name
+        assert all(len(x) > 1000 for x in outs[0])
 
 
 @pytest.mark.gpu

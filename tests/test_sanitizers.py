@@ -87,7 +87,7 @@ def rig(tmp_path_factory):
     return dict(tmp=tmp, single=single, pairs=pairs)
 
 
-def _run(exe, rig, objects, env_extra=(), threads="4"):
+def _run(exe, rig, objects, env_extra=(), threads="4", extra_args=()):
     tmp = rig["tmp"]
     out = os.path.join(tmp, "out")
     if os.path.exists(out + ".csv"):
@@ -95,7 +95,7 @@ def _run(exe, rig, objects, env_extra=(), threads="4"):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1",
                **dict(env_extra))
     cmd = [exe, "-k", "31", "--htsize", "64", "-T", os.path.join(tmp, "targets.txt"), "-D", os.path.join(tmp, "DB"),
-           *objects, "-R", out, "-n", threads]
+           *objects, "-R", out, "-n", threads, *extra_args]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
     lines = open(out + ".csv").read().split("\n", 1)
@@ -122,16 +122,27 @@ CASES = [
     ("gzip_one_member_host", ["-O", "r1.fq.gz"], "single", {"MIC_INGEST_MB": "2", "MIC_GZ_HOST": "1"}),
     ("fasta_gzip", ["-O", "r.fa.gz"], "single", {"MIC_INGEST_MB": "2"}),
     ("bgzf_host", ["-O", "r.bgzf.fq.gz"], "single", {"MIC_INGEST_MB": "2", "MIC_GZ_HOST": "1"}),
+    # several engines (MIC_SHARD_ENGINES: two / three mock engines): the slots - and the batches - are dealt over the engines, the
+    # "device" text of a compressed input fills slots of every engine; read-sharded (default) and table-sharded (--db-sharded:
+    # groups of engines answer a slot together, mic_ingest_classify_group)
+    ("fastq_two_engines", ["-O", "r.fq"], "single", {"MIC_INGEST_KB": "96", "MIC_SHARD_ENGINES": "2"}),
+    ("fasta_three_engines", ["-O", "r.fa"], "single", {"MIC_INGEST_KB": "96", "MIC_SHARD_ENGINES": "3"}),
+    ("pairs_two_engines", ["-P", "p_1.fq", "p_2.fq"], "pairs", {"MIC_INGEST_KB": "96", "MIC_SHARD_ENGINES": "2"}),
+    ("pairs_gzip_two_engines", ["-P", "p_1.fq.gz", "p_2.fq.gz"], "pairs", {"MIC_INGEST_KB": "96", "MIC_SHARD_ENGINES": "2"}),
+    ("gzip_three_engines", ["-O", "r1.fq.gz"], "single", {"MIC_INGEST_KB": "96", "MIC_SHARD_ENGINES": "3"}),
+    ("bgzf_two_engines", ["-O", "r.bgzf.fq.gz"], "single", {"MIC_INGEST_KB": "96", "MIC_SHARD_ENGINES": "2"}),
+    ("fastq_table_sharded_2x2", ["-O", "r.fq"], "single", {"MIC_INGEST_KB": "96", "MIC_SHARD_ENGINES": "4"}, ["--db-sharded", "--parts", "2"]),
+    ("pairs_gzip_table_sharded_3", ["-P", "p_1.fq.gz", "p_2.fq.gz"], "pairs", {"MIC_INGEST_KB": "96", "MIC_SHARD_ENGINES": "3"}, ["--parts", "3"]),
 ]
 
 
 @pytest.mark.parametrize("flavour", ["asan", "tsan"])
 def test_host_pipeline_under_sanitizers(flavour, rig):
     exe = _build(rig["tmp"], flavour)
-    for name, objects, want, env in CASES:
+    for name, objects, want, env, *more in CASES:
         objects = [o if o.startswith("-") else os.path.join(rig["tmp"], o) for o in objects]
         for threads in (("1", "7") if flavour == "asan" else ("5",)):
-            got = _run(exe, rig, objects, env.items(), threads)
+            got = _run(exe, rig, objects, env.items(), threads, more[0] if more else ())
             assert got == rig[want], (flavour, name, threads, got[:200], rig[want][:200])
     # the merge verb (no engine at all), golden pair files
     f1, f2 = (os.path.join(gu.GOLDEN, f"pairs_k31_{i}.fq") for i in (1, 2))

@@ -36,6 +36,11 @@ int mic_device_count(int* count) { *count = 1; return MIC_OK; }
 int mic_create(const mic_config* cfg, mic_engine** out) { mic_engine* e = new mic_engine(); e->cfg = *cfg; *out = e; return MIC_OK; }
 int mic_destroy(mic_engine* e) { delete e; return MIC_OK; }
 int mic_db_load_files(mic_engine*, const char*, int, uint32_t, uint64_t, uint64_t) { return MIC_OK; }
+int mic_db_load_files_multi(mic_engine* const*, size_t, const char*, int, uint32_t) { return MIC_OK; }
+int mic_db_set_part(mic_engine*, uint32_t, uint32_t) { return MIC_OK; }
+int mic_peer_matrix(int* m, int n) { for (int i = 0; i < n * n; ++i) m[i] = 1; return MIC_OK; }
+int mic_device_memory(int, uint64_t* f, uint64_t* t) { *f = *t = (uint64_t)1 << 40; return MIC_OK; }
+int mic_db_kernel_name(const mic_engine*, char* buf, size_t cap) { return snprintf(buf, cap, "mock"); }
 int mic_db_reserve_hbm(mic_engine*, uint64_t) { return MIC_OK; }
 const char* mic_db_last_build_report(void) { return ""; }
 int mic_db_get_info(const mic_engine*, mic_db_info* info) { memset(info, 0, sizeof(*info)); info->layout = MIC_LAYOUT_SUPER; return MIC_OK; }
@@ -86,6 +91,12 @@ int mic_ingest_classify(mic_engine* e, size_t slot, size_t n_bytes, int flags, m
   }
   out->n_reads = n_reads; out->csv_bytes = csv.size(); out->csv = csv.data(); out->results = nullptr; out->status = MIC_INGEST_OK;
   return MIC_OK;
+}
+
+// table-sharded: the slot's owner "classifies"; the other engines of the group have nothing to add in the mock
+int mic_ingest_classify_group(mic_engine* const* group, size_t n_group, size_t owner, size_t slot, size_t n_bytes, int flags, mic_ingest_result* out) {
+  if (!group || owner >= n_group) return MIC_E_INVALID;
+  return mic_ingest_classify(group[owner], slot, n_bytes, flags, out);
 }
 
 // the batch API is only reached when a slot is handed back (MIC_INGEST_FALLBACK): the mock never does
