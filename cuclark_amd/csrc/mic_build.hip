@@ -278,6 +278,8 @@ int mic_build_table(const uint8_t* d_sizes, uint64_t n_buckets, const void* d_ke
   out->max_bucket = maxb;
   (void)tot_kept;
 done:
+  // (an error return: copies queued on s may still name this frame's host variables - they must have landed before it goes)
+  if (rc) hipStreamSynchronize(s);
   if (d_a) hipFree(d_a);
   if (d_b) hipFree(d_b);
   if (d_kept) hipFree(d_kept);
@@ -1023,6 +1025,8 @@ int mic_build_mtable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   out->n_main = n_mslots; out->n_overflow = tot_ovf; out->n_elems = h_kept; out->n_elems_file = tot_elems;
   out->max_bucket = 0; out->max_chain = h_max;
 done:
+  // (an error return: copies queued on s may still name this frame's host variables - they must have landed before it goes)
+  if (rc) hipStreamSynchronize(s);
   if (d_a) hipFree(d_a);
   if (d_cnt) hipFree(d_cnt);
   if (d_cur) hipFree(d_cur);
@@ -1382,6 +1386,8 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   out->n_main = n_slots; out->n_overflow = n_chain; out->n_elems = h_scal[0]; out->n_elems_file = tot_elems;
   out->max_bucket = 0; out->max_chain = h_max; out->n_entries = h_entries; out->alloc_slots = alloc_slots;
 done:
+  // (an error return: copies queued on s may still name this frame's host variables - they must have landed before it goes)
+  if (rc) hipStreamSynchronize(s);
   if (d_a) hipFree(d_a);
   if (d_cnt) hipFree(d_cnt);
   if (d_cur) hipFree(d_cur);

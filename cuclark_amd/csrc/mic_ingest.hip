@@ -480,7 +480,7 @@ struct Slot {
     void* block = nullptr;
     uint32_t* d_rp = nullptr; uint16_t* d_cont = nullptr;   // the packed reads (helpers: a peer copy; owner: the slot's own arrays)
     uint32_t* d_rows = nullptr;                             // this engine's partial rows of ALL reads of the batch
-    uint32_t* d_gather = nullptr; uint32_t* d_acc = nullptr;  // rows of this engine's read range from the others; the sum's other buffer
+    uint32_t* d_gather = nullptr; uint32_t* d_acc = nullptr; uint32_t* d_acc2 = nullptr;  // rows of this engine's read range from the others; the running sum's two buffers
     uint32_t* d_res = nullptr;                              // helpers: results of all reads from the query kernel, then of the range
     uint32_t* d_flagged = nullptr;
     hipStream_t stream = nullptr;                           // helpers: a stream on their device; owner: the slot's stream
@@ -657,6 +657,7 @@ int setup_peers(Ingest* g, Slot& s, mic_engine* const* group, size_t P, size_t o
       a.take(&q.d_rows, (g->max_reads + 1) * rw);
       a.take(&q.d_gather, (P - 1) * len_max * rw);
       a.take(&q.d_acc, len_max * rw);
+      a.take(&q.d_acc2, len_max * rw);
       if (!own) {
         a.take(&q.d_rp, g->max_reads + 2);
         a.take(&q.d_cont, g->cont_cap + 192);
@@ -720,19 +721,22 @@ int group_query(mic_engine* const* group, size_t P, size_t owner, Ingest* g, Slo
     const size_t lo = (size_t)n * j / P, hi = (size_t)n * (j + 1) / P, len = hi - lo;
     ITRY(hipSetDevice(q.device));
     if (len) {
-      uint32_t* buf[2] = {q.d_rows + lo * rw, q.d_acc};
+      // the running sum: this engine's own rows of the range, then the two spare buffers in turn (the partial rows stay as the
+      // kernel wrote them: mic_ingest_fetch_group_rows)
+      const uint32_t* cur = q.d_rows + lo * rw;
+      uint32_t* spare[2] = {q.d_acc, q.d_acc2};
       int c = 0; size_t got = 0;
       for (size_t p = 0; p < P; ++p) {
         if (p == j) continue;
         uint32_t* in = q.d_gather + got * len * rw;
         ITRY(hipStreamWaitEvent(q.stream, s.peers[p].ev_q, 0));
         ITRY(hipMemcpyPeerAsync(in, q.device, s.peers[p].d_rows + lo * rw, s.peers[p].device, len * rw * 4, q.stream));
-        ITRY(mic_launch_merge_rows(buf[c], in, buf[c ^ 1], (uint32_t)rw, len, nullptr, q.stream));
-        c ^= 1; ++got;
+        ITRY(mic_launch_merge_rows(cur, in, spare[c], (uint32_t)rw, len, nullptr, q.stream));
+        cur = spare[c]; c ^= 1; ++got;
       }
-      if (j == owner) ITRY(mic_launch_result_from_rows(buf[c], (uint32_t)rw, O.d_res + lo * 8, len, q.stream));
+      if (j == owner) ITRY(mic_launch_result_from_rows(cur, (uint32_t)rw, O.d_res + lo * 8, len, q.stream));
       else {
-        ITRY(mic_launch_result_from_rows(buf[c], (uint32_t)rw, q.d_res, len, q.stream));
+        ITRY(mic_launch_result_from_rows(cur, (uint32_t)rw, q.d_res, len, q.stream));
         ITRY(hipMemcpyPeerAsync(O.d_res + lo * 8, O.device, q.d_res, q.device, len * 32, q.stream));
       }
     }
@@ -1294,6 +1298,25 @@ int mic_ingest_fetch_packed(mic_engine* e, size_t slot_id, uint32_t* reads_point
   if (containers) {
     if (cont_cap < s.cont_used) return mic_set_error(MIC_E_INVALID, "containers capacity too small");
     ITRY(hipMemcpy(containers, s.d_cont, (size_t)s.cont_used * 2, hipMemcpyDeviceToHost));
+  }
+  return MIC_OK;
+}
+
+int mic_ingest_fetch_group_rows(mic_engine* owner, size_t slot_id, size_t part, uint32_t* rows, size_t cap_words, uint64_t* n_reads,
+                                uint32_t* row_words) {
+  if (!owner) return mic_set_error(MIC_E_INVALID, "null engine");
+  Ingest* g = (Ingest*)*mic_engine_ingest_slot(owner);
+  if (!g || slot_id >= g->slots.size()) return mic_set_error(MIC_E_STATE, "ingest slots are not allocated");
+  Slot& s = g->slots[slot_id];
+  if (part >= s.peers.size()) return mic_set_error(MIC_E_STATE, "the slot's last batch was not table-sharded over %zu parts", part + 1);
+  if (n_reads) *n_reads = s.n_reads;
+  if (row_words) *row_words = kGroupRowWords;
+  if (rows) {
+    const size_t words = (size_t)s.n_reads * kGroupRowWords;
+    if (cap_words < words) return mic_set_error(MIC_E_INVALID, "rows capacity too small");
+    ITRY(hipSetDevice(s.peers[part].device));
+    ITRY(hipMemcpy(rows, s.peers[part].d_rows, words * 4, hipMemcpyDeviceToHost));
+    ITRY(hipSetDevice(g->device));
   }
   return MIC_OK;
 }

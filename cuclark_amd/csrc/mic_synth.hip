@@ -317,6 +317,8 @@ int mic_synth_db_device(const mic_synth_spec* spec, uint8_t* d_sizes, void* d_ke
   }
   HIPCK(hipStreamSynchronize(s));
 done:
+  // (an error return: copies queued on s may still name this frame's host variables - they must have landed before it goes)
+  if (rc) hipStreamSynchronize(s);
   if (d_cnt) hipFree(d_cnt);
   if (d_tile) hipFree(d_tile);
   if (d_off) hipFree(d_off);

@@ -282,6 +282,30 @@ class MiClarkDB:
                 r["results"] = _as_np(out.results, (int(out.n_reads), MIC_RESULT_WORDS), np.uint32).copy()
         return r
 
+    @staticmethod
+    def ingest_classify_group(group, owner, slot, data, paired=False):
+        """Table-sharded ingest (mic_ingest_classify_group): group[p] holds part p of len(group) parts, the slot belongs to group[owner]."""
+        e = group[owner]
+        buf = np.frombuffer(data, np.uint8)
+        e._ingest["raw"][slot][: buf.size] = buf
+        out = _lib.MicIngestResult()
+        hs = (C.c_void_p * len(group))(*[g.h for g in group])
+        check(e.L.mic_ingest_classify_group(hs, len(group), owner, slot, buf.size, int(bool(paired)), C.byref(out)))
+        r = dict(status=int(out.status), n_reads=int(out.n_reads), n_lines=int(out.n_lines), csv=None, results=None)
+        if out.status == 0:
+            r["csv"] = C.string_at(out.csv, out.csv_bytes) if out.csv_bytes else b""
+            if out.results:
+                r["results"] = _as_np(out.results, (int(out.n_reads), MIC_RESULT_WORDS), np.uint32).copy()
+        return r
+
+    def ingest_fetch_group_rows(self, slot, part):
+        """test hook: the partial rows engine `part` of the group computed for the slot's last table-sharded batch"""
+        n, rw = C.c_uint64(0), C.c_uint32(0)
+        check(self.L.mic_ingest_fetch_group_rows(self.h, slot, part, None, 0, C.byref(n), C.byref(rw)))
+        rows = np.zeros((n.value, rw.value), np.uint32)
+        check(self.L.mic_ingest_fetch_group_rows(self.h, slot, part, rows.ctypes.data, rows.size, None, None))
+        return rows
+
     def ingest_fetch_packed(self, slot):
         n, m = C.c_uint64(0), C.c_uint64(0)
         check(self.L.mic_ingest_fetch_packed(self.h, slot, None, 0, None, 0, C.byref(n), C.byref(m)))

@@ -299,6 +299,10 @@ int mic_ingest_classify_group(mic_engine* const* group, size_t n_group, size_t o
                               mic_ingest_result* out);
 int mic_ingest_fetch_packed(mic_engine* e, size_t slot, uint32_t* reads_pointer, size_t rp_cap, uint16_t* containers,
                             size_t cont_cap, uint64_t* n_reads, uint64_t* n_containers);
+/* mic_ingest_fetch_group_rows  test hook: the partial sparse rows (row_words u32 per read) engine `part` of the slot's group
+ * computed for the slot's last table-sharded batch, as its kernel wrote them. */
+int mic_ingest_fetch_group_rows(mic_engine* owner, size_t slot, size_t part, uint32_t* rows, size_t cap_words, uint64_t* n_reads,
+                                uint32_t* row_words);
 int mic_ingest_free(mic_engine* e);
 /* ---- compressed input: one gzip member inflated on the device ------------------------------------------------
  * Replaces the `gunzip` the reference's scripts run in front of the classifier (classify_metagenome.sh:116-142) for the

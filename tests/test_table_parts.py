@@ -418,3 +418,59 @@ def test_parts_at_scale(super_layout):
     okk = (truth[g, 1] == 0) | ((r[g, 1] == truth[g, 0]) & (r[g, 2] >= truth[g, 1]))
     assert okk.mean() > 0.999
     print(f"\n[{super_layout}] whole table {ms_w:.3f} ms; parts of 8: {' '.join(f'{t:.3f}' for t in ms)} ms")
+
+
+@pytest.mark.parametrize("n_parts,owner", [(2, 1), (3, 0), (5, 3)])
+def test_streaming_ingest_of_a_group_of_parts_equals_the_oracle_part_by_part(n_parts, owner, super_layout):
+    """The command line's table-sharded path (mic_ingest_classify_group: what exe/cuCLARK --db-sharded runs per ingest slot): the
+    bytes of a FASTA batch go to the slot's owner, every engine of the group probes the packed reads against ITS part - its partial
+    rows must be exactly what oracle/part_rule.c says that part answers for -, the rows are summed read-range owned and the CSV
+    the owner formats is the whole table's, byte for byte."""
+    from cuclark_amd import MiClarkDB, host
+    rng = np.random.default_rng(900 + n_parts)
+    k, T, htsize = 31, 12, 1 << 18           # (12 targets: every summed row fits the 15 pairs of a partial row)
+    codes, sizes, keys, lab = _genome_db(rng, 250_000, k, htsize, T, stride=7000)
+    data = _reads_from(rng, codes, 2000, 150)
+    names = [f"T{i}" for i in range(T)]
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    n = rp.size - 1
+    odb = gu.oracle().db_from_arrays(sizes, keys, lab)
+    counts, expect = _oracle_results(odb, k, rp, cont, T)
+    with _engine(k, T) as whole:
+        whole.read_arrays(sizes, keys, lab)
+        whole.ingest_alloc(1, 1 << 20, names, want_results=True)
+        r_w = whole.ingest_classify(0, data)
+        whole.ingest_free()
+    assert r_w["status"] == 0 and (r_w["results"][:, :5] == expect).all()
+    group = [_engine(k, T) for _ in range(n_parts)]
+    try:
+        for p, e in enumerate(group):
+            e.set_part(p, n_parts)
+            e.read_arrays(sizes, keys, lab)
+        group[owner].ingest_alloc(2, 1 << 20, names, want_results=True)
+        for rep in range(2):          # the slot and its buffers on the other engines are reused
+            r = MiClarkDB.ingest_classify_group(group, owner, 1, data)
+            assert r["status"] == 0 and r["n_reads"] == n
+            assert r["csv"] == r_w["csv"] and (r["results"][:, :5] == expect).all()
+        total = np.zeros((n, T), np.int64)
+        for p, e in enumerate(group):
+            info = e.info()
+            want, bad = odb.query_batch_slot_part(k, info["minimizer_len"], info["layout"] == 4, info["n_slots_whole"], p, n_parts, rp, cont, T)
+            assert bad == 0
+            rows = group[owner].ingest_fetch_group_rows(1, p)
+            got = np.zeros((n, T), np.int64)
+            for i in range(n):
+                m = int(rows[i, 0])
+                assert m != 0xFFFFFFFF
+                ent = rows[i, 1:1 + m]
+                assert (np.diff((ent & 0xFFFF).astype(np.int64)) > 0).all()          # ascending targets (CuClarkDB.cu:1178-1243)
+                got[i, ent & 0xFFFF] = ent >> 16
+            assert (got == want).all(), p
+            total += got
+        assert (total == counts).all()
+        # a batch with a read that hits more targets than a partial row holds is handed back (the caller's host path completes it)
+        group[owner].ingest_free()
+    finally:
+        for e in group:
+            e.close()
