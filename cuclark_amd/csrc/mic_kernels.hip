@@ -16,14 +16,8 @@
 
 #include <stdlib.h>
 
-#ifndef MIC_S_ABLATE
-#define MIC_S_ABLATE 0   /* timing-only builds: 1 no tally, 2 no wait before the read-ahead take, 3 no finish_read */
-#endif
 #ifndef MIC_FUNNEL64
 #define MIC_FUNNEL64 1
-#endif
-#ifndef MIC_S_LINEAR
-#define MIC_S_LINEAR 0
 #endif
 
 namespace {
@@ -413,9 +407,6 @@ __device__ __forceinline__ uint32_t row_suffix_min(uint32_t t) {
 // P = prefix minimum, S = suffix minimum inside the row; a window of 16 that starts at x is S(x) and P(x + 15) (the next
 // row, or the same one when x starts a row), and a window of W is two windows of 16, at x and at x + W - 16.  Two rounds of
 // ds_bpermute instead of the five of the doubling form (sliding_min3), which serves W < 16.
-#ifndef MIC_SLIDE_Q
-#define MIC_SLIDE_Q 1
-#endif
 template <int BANKS>
 __device__ __forceinline__ uint32_t with_row_in_front(uint32_t P) {     // min(P, lane 15 of the row in front) in the lanes of BANKS, rows 1-3
   const uint32_t f = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)P, 0x142, 0xE, BANKS, false);      // row_bcast:15
@@ -423,7 +414,6 @@ __device__ __forceinline__ uint32_t with_row_in_front(uint32_t P) {     // min(P
 }
 __device__ __forceinline__ void sliding_min_rows(uint32_t& a0, uint32_t& a1, uint32_t a2, int W, int lane, int lane_inv) {
   const uint32_t P0 = row_prefix_min(a0), P1 = row_prefix_min(a1), P2 = row_prefix_min(a2);
-#if MIC_SLIDE_Q
   if (W > 16 && ((W - 16) & 3) == 0) {
     // One round of ds_bpermute: the window [x, x + W) is the rest of x's row, S(x), the prefix P(e) of the row of its last
     // position e = x + W - 1, and - when that row is the next but one, which is when e sits in lanes 0 .. W-18 of its row -
@@ -452,7 +442,6 @@ __device__ __forceinline__ void sliding_min_rows(uint32_t& a0, uint32_t& a1, uin
     a0 = v0 < S0 ? v0 : S0; a1 = v1 < S1 ? v1 : S1;
     return;
   }
-#endif
   const uint32_t S0 = row_suffix_min(a0), S1 = row_suffix_min(a1), S2 = row_suffix_min(a2);
   const int at = lane_inv << 2;                                   // ds_bpermute wraps the lane number by itself
   const uint32_t x0 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + 60, (int)P0), x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(at + 60, (int)P1),
@@ -520,46 +509,6 @@ __device__ __forceinline__ void sampled_positions(uint32_t wd, int ln, int lane_
   qa0 = (uint32_t)lane_inv + d0; qa1 = 64u + (uint32_t)lane_inv + d1;
 }
 
-// -DMIC_PHASE_TIMING: per-phase cycle sums of query_kernel_m (s_memtime around each phase, one atomicAdd per wave),
-// printed by the launcher.  A measuring build only: the counter reads themselves cost ~5 %.
-// -DMIC_PERTURB: sensitivity analysis.  MIC_PERTURB_VALU / _LDS / _SALU = number of 8-instruction groups of dummy
-// v_bfi_b32 / ds_bpermute_b32 / s_add_u32 added to every chunk; the slowdown per added instruction says which unit
-// the kernel is actually short of.
-#ifdef MIC_PERTURB
-#define PERTURB_PARAMS , int pert_v, int pert_l, int pert_s
-#define PERTURB_POINT                                                                                               \
-  {                                                                                                                 \
-    uint32_t pv_ = lane, ps_ = 0;                                                                                   \
-    for (int i_ = 0; i_ < pert_v; ++i_)                                                                       \
-      asm volatile("v_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0\n\t" \
-                   "v_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0\n\tv_bfi_b32 %0, %0, %0, %0" : "+v"(pv_)); \
-    for (int i_ = 0; i_ < pert_l; ++i_) {                                                                     \
-      asm volatile("ds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\t" \
-                   "ds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\tds_bpermute_b32 %0, %0, %0\n\t" \
-                   "s_waitcnt lgkmcnt(0)" : "+v"(pv_));                                                                \
-    }                                                                                                               \
-    for (int i_ = 0; i_ < pert_s; ++i_)                                                                       \
-      asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\t"          \
-                   "s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1" : "+s"(ps_) : : "scc"); \
-    if (pv_ == 0x7FFFFFF1u && ps_ == 0x7FFFFFF1u) total += 1;                                                       \
-  }
-#else
-#define PERTURB_POINT
-#define PERTURB_PARAMS
-#endif
-#ifdef MIC_PHASE_TIMING
-__device__ unsigned long long g_phase[8];
-#define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ph_t0 = ph_t;
-#define PH(i) { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[i] += n_ - ph_t; ph_t = n_; }
-#define PH_END { ph_acc[7] = __builtin_readcyclecounter() - ph_t0; if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase[i_], ph_acc[i_]); }
-#else
-#define PH_DECL
-#define PH(i)
-#define PH_END
-#endif
-#ifndef MIC_TAIL_KEYS
-#define MIC_TAIL_KEYS 1
-#endif
 #ifndef MIC_SPEC
 #define MIC_SPEC 1
 #endif
@@ -569,7 +518,7 @@ __device__ unsigned long long g_phase[8];
 // KK / MM: k and the minimizer length as compile-time constants (0 = take them from the table): the launcher picks the
 // instantiation for cuCLARK's k = 31 and cuCLARK-l's k = 27 with m = 20; shift counts, masks and the window loop fold.
 template <int KK, int MM>
-__global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m(const MicQueryArgs a PERTURB_PARAMS) {
+__global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m(const MicQueryArgs a) {
   __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE + (MIC_RMAX / 8 - 1) * MIC_M_SKEW];
   __shared__ uint32_t s_run[MIC_M_WPB][MIC_RMAX];
   __shared__ uint32_t s_ahead[MIC_M_WPB][2][64];
@@ -586,7 +535,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
   // number of set bits of a 64-bit lane mask below this lane (v_mbcnt_lo/hi: no mask register to keep alive)
   auto below = [](uint64_t mask) { return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
 
-  PH_DECL
   // Read-ahead through LDS (global_load_lds_dword): no VGPR lives across a read and no load result is touched near its
   // issue, so nothing waits for it.  One DMA instruction per read fetches {header + first window of read j+2 (lanes
   // 0..11, aligned dwords), reads_ptr of read j+3 (lanes 12, 13)}; it is taken one read later, before the result stores
@@ -630,7 +578,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
     ahead_sel = 1;
   }
   for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
-    PH(6)
     uint32_t pp = cur_pp;
     const uint32_t pe = cur_pe;
     RowAcc acc; acc.label1 = 0; acc.count = 0;
@@ -656,7 +603,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
         // reverse complement (no third assembly pass) and the minimum over positions 128 .. 64+lane+w-1 is a prefix
         // minimum inside the last DPP row.  A chunk of at most 129-w k-mers (every 100/125-bp read) needs neither.
         const bool past = nk - base > (uint32_t)(129 - w);
-        const bool tail_path = MIC_TAIL_KEYS && w <= 16;
+        const bool tail_path = w <= 16;
         uint32_t tail = 0xFFFFFFFFu;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -703,8 +650,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
         uint32_t sl0 = act[0] ? mslot_of_key(hk0, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         uint32_t sl1 = act[1] ? mslot_of_key(hk1, (uint32_t)t.n_main) : 0xFFFFFFFFu;
         uint32_t res0 = 0, res1 = 0, res2 = 0;   // label + 1 of the hit: passes 0, 1 and the compacted deeper levels
-        PERTURB_POINT
-        PH(0)
 
         // one level of the table on both passes: runs of equal slots, LDS-DMA of the distinct slots, lockstep search
         auto level = [&](uint32_t s0_, uint32_t s1_, uint64_t k0_, uint64_t k1_, uint32_t& o0_, uint32_t& o1_, uint32_t& y0_, uint32_t& y1_) {
@@ -779,7 +724,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
         if (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {
           uint32_t nx0, nx1;
           level(sl0, sl1, c[0], c[1], res0, res1, nx0, nx1);
-          PH(3)
           sl0 = nx0; sl1 = nx1;
           // ---- deeper levels of the bucket trees.  Nearly every chunk has k-mers in buckets of more than 12 entries (two
           // super-k-mers sharing a slot are enough), but only ~40 % of its k-mers: instead of a second full round over
@@ -846,7 +790,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
           }
         }
         tally3(res0, res1, res2, acc, n_ent, overflow, total, lane);
-        PH(4)
       }
     }
     // next read's header/window and the pointers of the one after it: take before the stores below, issue after
@@ -855,7 +798,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
     __builtin_amdgcn_wave_barrier();
     ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_w, t_pp, t_pe);
     __builtin_amdgcn_wave_barrier();
-    PH(4)
     {
       // The output pointers are needed once per read: they are re-read from the kernarg segment here (scalar loads
       // that hit the scalar cache) instead of living in SGPRs for the whole kernel - the kernel was spilling 35 SGPRs
@@ -870,9 +812,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
     ahead_issue(ahead_sel ? ahead0 : ahead1, t_pp, r + 3 * n_waves);
     ahead_sel ^= 1;
     cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; cur_w = t_w; n_pp = t_pp; n_pe = t_pe;
-    PH(5)
   }
-  PH_END
 }
 
 // =====================================================================================================================
@@ -885,9 +825,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_m
 // =====================================================================================================================
 // FWD: the table holds both strands of every k-mer under forward-strand minimizers (MIC_LAYOUT_SUPER2, mic_device.h:
 // s_candidates_fwd): a k-mer is looked up as it stands in the read - no reverse complement, no canonical m-mer, no strand.
-#ifndef MIC_R_HDR_LDS
-#define MIC_R_HDR_LDS 1
-#endif
 template <int KK, int MM, bool SHARDED, bool FWD>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s(const MicQueryArgs a) {
   __shared__ uint4 s_stage[MIC_M_WPB][MIC_RMAX * MIC_MSTRIDE + (MIC_RMAX / 8 - 1) * MIC_R_SKEW];
@@ -906,7 +843,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
   // number of set bits of a 64-bit lane mask below this lane (v_mbcnt_lo/hi: no mask register to keep alive)
   auto below = [](uint64_t mask) { return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
 
-  PH_DECL
   // Read-ahead through LDS (global_load_lds_dword): no VGPR lives across a read and no load result is touched near its
   // issue, so nothing waits for it.  One DMA instruction per read fetches {header + first window of read j+2 (lanes
   // 0..11, aligned dwords), reads_ptr of read j+3 (lanes 12, 13)}; it is taken one read later, before the result stores
@@ -956,7 +892,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
     ahead_sel = 1;
   }
   for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
-    PH(6)
     uint32_t pp = cur_pp;
     const uint32_t pe = cur_pe;
     RowAcc acc; acc.label1 = 0; acc.count = 0;
@@ -970,7 +905,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
       {
         const uint32_t rel = pp - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);    // u16 offset inside the entry
         if (first_part) plen = cur_hdr;
-        else if (MIC_R_HDR_LDS && rel < 24u) {
+        else if (rel < 24u) {
           const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
           plen = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu);
         } else plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
@@ -1046,7 +981,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
         }
         uint32_t sl0 = sl[0], sl1 = sl[1];
         uint32_t res0 = 0, res1 = 0;   // label + 1 of the hit
-        PH(0)
 
         // one level of the table on both passes: runs of equal slots, LDS-DMA of the distinct slots, lockstep search
         auto level = [&](uint32_t s0_, uint32_t s1_, uint32_t& o0_, uint32_t& o1_, uint32_t& y0_, uint32_t& y1_) {
@@ -1079,10 +1013,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
                                                  (__attribute__((address_space(3))) void*)(stage + (64 + MIC_R_SKEW) * i), 16, 0, 0);
             }
-            PH(1)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            PH(2)
             // Both k-mers of the lane look in their staged slot in lockstep: lower bound of the sort key among the six
             // (three reads), then the entry: key, super-k-mer, mask | label.  Lanes without a search read slot 0 and discard.
             {
@@ -1090,17 +1022,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
               const uint32_t* q0 = (const uint32_t*)(stage + (v0 ? staged_at(rid0 - rbase) : 0));
               const uint32_t* q1 = (const uint32_t*)(stage + (v1 ? staged_at(rid1 - rbase) : 0));
               const uint32_t t0 = tk32[0], t1 = tk32[1];
-#if MIC_S_LINEAR
-              // all six sort keys in one LDS round trip; rank = number of keys below t
-              const uint4 ka0 = *(const uint4*)q0, ka1 = *(const uint4*)q1;
-              const uint2 kb0 = *(const uint2*)(q0 + 4), kb1 = *(const uint2*)(q1 + 4);
-              uint32_t e0 = (ka0.x < t0) + (ka0.y < t0) + (ka0.z < t0) + (ka0.w < t0) + (kb0.x < t0) + (kb0.y < t0);
-              uint32_t e1 = (ka1.x < t1) + (ka1.y < t1) + (ka1.z < t1) + (ka1.w < t1) + (kb1.x < t1) + (kb1.y < t1);
-#else
               uint32_t e0 = q0[3] < t0 ? 4u : 0u, e1 = q1[3] < t1 ? 4u : 0u;
               e0 += q0[e0 + 1] < t0 ? 2u : 0u; e1 += q1[e1 + 1] < t1 ? 2u : 0u;                    // index <= 5
               e0 += q0[e0 < 5 ? e0 : 5] < t0 ? 1u : 0u; e1 += q1[e1 < 5 ? e1 : 5] < t1 ? 1u : 0u;
-#endif
               const uint32_t mz0 = q0[30], mz1 = q1[30];      // entries | NEXT
               bool more0 = v0 && e0 < 6, more1 = v1 && e1 < 6;
               uint32_t hit0 = 0, hit1 = 0;
@@ -1147,29 +1071,17 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
         while (__ballot(sl0 != 0xFFFFFFFFu) | __ballot(sl1 != 0xFFFFFFFFu)) {   // second and later rounds: continuation slots (rare)
           uint32_t nx0, nx1;
           level(sl0, sl1, res0, res1, nx0, nx1);
-          PH(3)
           sl0 = nx0; sl1 = nx1;
         }
-#if MIC_S_ABLATE != 1
         tally2(res0, res1, acc, n_ent, overflow, total, lane);
-#else
-        total += __popcll(__ballot(res0 != 0)) + __popcll(__ballot(res1 != 0));
-#endif
-        PH(4)
       }
     }
     // next read's header/window and the pointers of the one after it: take before the stores below, issue after
     uint32_t t_hdr, t_pp, t_pe;
-#if MIC_S_ABLATE != 2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     __builtin_amdgcn_wave_barrier();
-#ifdef MIC_PHASE_SPLIT_TAKE
-    PH(5)
-#endif
     ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_pp, t_pe);
     __builtin_amdgcn_wave_barrier();
-    PH(6)
     {
       // The output pointers are needed once per read: they are re-read from the kernarg segment here (scalar loads
       // that hit the scalar cache) instead of living in SGPRs for the whole kernel - the kernel was spilling 35 SGPRs
@@ -1179,18 +1091,12 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
       const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
       struct { uint32_t* results; uint32_t* rows; uint32_t* flagged; uint32_t row_words, flagged_cap; } fa;
       fa.results = kc->results; fa.rows = kc->rows; fa.flagged = kc->flagged; fa.row_words = kc->row_words; fa.flagged_cap = kc->flagged_cap;
-#if MIC_S_ABLATE != 3
       finish_read(acc, n_ent, total, overflow, r, fa, lane);
-#else
-      if (total == 0x7FFFFFFFu && lane == 0) fa.results[r * 8] = acc.count;
-#endif
     }
     ahead_issue(ahead_sel ? ahead0 : ahead1, t_pp, r + 3 * n_waves);
     ahead_sel ^= 1;
     cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; n_pp = t_pp; n_pe = t_pe;
-    PH(5)
   }
-  PH_END
 }
 
 
@@ -1224,47 +1130,16 @@ __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cb
     mm &= ~wballot(mine);
     const uint32_t c = mine ? cnt : 0u;
     uint32_t sum = 0;
-#if MIC_R_TALLY_DPP
-    // runs sit in lanes 0 .. MIC_RMAX - 1 = the first two rows of 16: an inclusive row scan by DPP (4 full-rate adds) leaves the
-    // rows' sums in lanes 15 and 31 - against one and-compare pair and three scalar operations per count bit
-    {
-      uint32_t v = c;
-      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
-      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
-      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
-      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
-      sum = __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31);
-    }
-#else
+    // one ballot per count bit (a run has at most w <= 16 k-mers: 4-5 bits).  (An inclusive DPP row scan of the counts - sums
+    // in lanes 15 and 31 - is 11 scalar instructions shorter and measured +-0: DESIGN.md 4.1f.)
 #pragma unroll
     for (int b = 0; b < 5; ++b)
       if (b < cbits) sum += (uint32_t)__popcll(wballot((c & (1u << b)) != 0)) << b;
-#endif
     total += sum;
     row_add(acc, n_ent, overflow, l1, sum, lane);
   }
 }
 
-#ifndef MIC_R_TALLY_DPP
-#define MIC_R_TALLY_DPP 1      // 0: a run's hits summed with one ballot per count bit (rounds 2-3)
-#endif
-static_assert(MIC_RMAX == 32, "tally_counts sums the first two rows of lanes");
-#ifndef MIC_R_LINEAR
-#define MIC_R_LINEAR 1      // 0: three-step binary search over the six keys (three dependent LDS reads): 1.2 % slower
-#endif
-#ifndef MIC_R_EAGER_ENTRY
-#define MIC_R_EAGER_ENTRY 1
-#endif
-#ifndef MIC_R_BPERM_WRAP
-#define MIC_R_BPERM_WRAP 1        // 0: the four window words of a run's region with explicitly wrapped lane numbers (round 2's form)
-#endif
-#ifndef MIC_R_AHEAD_MASK
-#define MIC_R_AHEAD_MASK 0        // 1: mask the read-ahead window to the part's containers (round 2's form)
-#endif
-#ifndef MIC_R_TALLY_PER_ROUND
-#define MIC_R_TALLY_PER_ROUND 0   // 1: a lane keeps (label, count) of its run and the wave tallies once per round instead of once per entry
-                                  // iteration: 2 VGPRs and a ballot more, ~0.3 tally calls per read fewer - measured 1.5 % SLOWER (6.10 vs 6.00 ms)
-#endif
 template <int KK, int MM, bool FWD, bool PART, bool SIDE>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r(const MicQueryArgs a) {
   // staged slots: 8 per LDS-DMA instruction, 128 bytes apart (the DMA's own layout: lane L lands at base + 16 L); each
@@ -1290,14 +1165,10 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
   // read-ahead through LDS: see query_kernel_s
   uint32_t* ahead0 = s_ahead[wv][0];
   uint32_t* ahead1 = s_ahead[wv][1];
-#ifndef MIC_R_AHEAD_SPLIT
-#define MIC_R_AHEAD_SPLIT 1
-#endif
   auto ahead_issue = [&](uint32_t* entry, uint32_t pp_w, uint32_t r_ptr) {
     const uint64_t abase = ((uint64_t)(cont + pp_w)) & ~3ULL;
     const uint32_t rr = r_ptr < a.n_reads ? r_ptr : a.n_reads - 1;
     const uint64_t pbase = (uint64_t)(a.reads_ptr + rr) - 48;
-#if MIC_R_AHEAD_SPLIT
     // two LDS-DMA instructions under their lanes' masks, scalar base + 4 * lane each (lane L lands at entry + 4 L whatever
     // the mask): 12 window dwords, 2 pointers - 14 loads instead of 64, and none of the selects of the one-instruction form
     // (the pointers are loaded by lanes 0, 1 into entry + 12: with one destination the compiler merges the two loads again)
@@ -1307,14 +1178,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     if (lane < 2)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const uint32_t*)(pbase + 48) + lane),
                                        (__attribute__((address_space(3))) void*)(entry + 12), 4, 0, 0);
-#else
-    uint32_t lv = (uint32_t)lane;
-    asm volatile("" : "+v"(lv));
-    const uint32_t li = lv < 14 ? lv : 0u;
-    const uint64_t addr = (li < 12 ? abase : pbase) + 4 * li;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
-                                     (__attribute__((address_space(3))) void*)entry, 4, 0, 0);
-#endif
   };
   auto ahead_take = [&](const uint32_t* entry, uint32_t pp_w, uint32_t& hdr, uint32_t& npp, uint32_t& npe) {
     const uint32_t raw = entry[lane];
@@ -1355,7 +1218,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
       {
         const uint32_t rel = pp - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);    // u16 offset inside the entry
         if (first_part) plen = cur_hdr;
-        else if (MIC_R_HDR_LDS && rel < 24u) {
+        else if (rel < 24u) {
           const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
           plen = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu);
         } else plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
@@ -1374,10 +1237,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         // the kernel they cost scalar register pairs the kernel does not have (34 -> 15 spill moves, +4 VALU, -6 SALU per read)
         int ln = lane;
         asm volatile("" : "+v"(ln));
-#if MIC_R_AHEAD_MASK
-        const uint32_t wd = window_word_w(cont, first, cend, base, ln, use_ahead,
-                                          use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp) : 0u);
-#else
         // The first window of a part comes out of the read-ahead entry AS IT IS: what lies behind the part's last nucleotide
         // (the next part's header, the next read, lanes 12+ of the entry) is never part of a k-mer that is counted - the active
         // k-mers end inside the part, the keys of m-mers behind them only reach lanes that are not active, and a run's region is
@@ -1385,7 +1244,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         // (8 VALU per read).  Later chunks are loaded container by container and stay bounded by the part's end.
         const uint32_t wd = use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp)
                                       : window_word_w(cont, first, cend, base, ln, false, 0u);
-#endif
         // position in the chunk of the sampled m-mer of the k-mers at positions lane and 64 + lane (mod-sampling, mic_device.h)
         const uint32_t n_act = nk - base < 128u ? nk - base : 128u;
         const bool past = n_act + (uint32_t)(k - s_tlen(k, m)) >= 129u;   // the last k-mers' windows reach t-mers past position 127
@@ -1393,10 +1251,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         sampled_positions<!FWD>(wd, ln, lane, k, m, past, qa0, qa1);
         // runs: k-mers next to each other whose sampled m-mer sits at the same position of the chunk (one-strand table: the
         // strand is that of the m-mer, so a run has one)
-#ifndef MIC_R_SENTINEL
-#define MIC_R_SENTINEL 1
-#endif
-#if MIC_R_SENTINEL
         // k-mers behind the last one of the chunk get a position no m-mer has: the first of them then "leads a run" whose record
         // is exactly the closing record (first k-mer = n_act) - no compound predicates for the ballots, no extra write
         qa0 = (uint32_t)lane < n_act ? qa0 : 0xFFu;
@@ -1416,22 +1270,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
           if (ln == 0) rec[R] = (uint16_t)(128u << 8);
         }
         __builtin_amdgcn_wave_barrier();
-#else
-        const uint32_t last0 = __builtin_amdgcn_readlane(qa0, 63);
-        uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)qa0, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 keeps -1
-        uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)last0, (int)qa1, 0x138, 0xF, 0xF, false);
-        const bool f0 = (uint32_t)lane < n_act && qa0 != p0, f1 = 64u + (uint32_t)lane < n_act && qa1 != p1;
-        // (the leaders' masks cut to the active k-mers in scalar registers instead of a ballot of the compound predicate:
-        // 4 VALU fewer, 16 SALU more per read, measured 1.5 % slower - the scalar unit is as busy as the vector units)
-        const uint64_t b0 = wballot(f0), b1 = wballot(f1);
-        const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1);
-        __builtin_amdgcn_wave_barrier();
-        // record: position of the sampled m-mer (8 bits) | first k-mer << 8; the closing record holds n_act
-        if (f0) rec[below(b0)] = (uint16_t)(qa0 | ((uint32_t)lane << 8));
-        if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
-        if (ln == 0) rec[R] = (uint16_t)(n_act << 8);
-        __builtin_amdgcn_wave_barrier();
-#endif
 
         for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
           const uint32_t nrun = R - rbase < MIC_RMAX ? R - rbase : MIC_RMAX;
@@ -1445,15 +1283,11 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
           const int s1 = qa - ctx - 1;
           const int D = s1 >> 4;                                  // -1 (the region starts in front of the chunk) .. 8
           const uint32_t tsh = 30u - 2u * (uint32_t)(s1 & 15);
-#if MIC_R_BPERM_WRAP
           // ds_bpermute takes its lane from bits 7..2 of the byte address: D = -1 (the region starts in front of the chunk) wraps
           // to lane 63 by itself, and D + 1 .. D + 3 are the same address plus 4, 8, 12 - no masking, one shift
           const int a0 = D << 2;
           const uint32_t W0 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0, (int)wd), W1 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 4, (int)wd),
                          W2 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 8, (int)wd), W3 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 12, (int)wd);
-#else
-          const uint32_t W0 = bperm((D) & 63, wd), W1 = bperm((D + 1) & 63, wd), W2 = bperm((D + 2) & 63, wd), W3 = bperm((D + 3) & 63, wd);
-#endif
           uint32_t G0 = __builtin_amdgcn_alignbit(W0, W1, tsh), G1 = __builtin_amdgcn_alignbit(W1, W2, tsh), G2 = __builtin_amdgcn_alignbit(W2, W3, tsh);
           // minimizer value x = nucleotides ctx .. ctx + m - 1 of the region: its low word is one funnel shift of (G0, G1), the
           // bits above it (m > 16) one bit-field extract of G0 - 64-bit shifts run at half rate
@@ -1505,9 +1339,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             cur = mine ? cur : 0xFFFFFFFFu;
           }
           int remaining = mine ? n : 0;
-#if MIC_R_TALLY_PER_ROUND
-          uint32_t run_lab = 0, run_cnt = 0;        // label + 1 and hits of this lane's run so far
-#endif
           bool crowded = false;                     // SIDE: the run's minimizer is a crowded one (marker entry): its k-mers are in the side table
           do {
             uint32_t sidx[MIC_RMAX / 8];
@@ -1529,16 +1360,10 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             __builtin_amdgcn_wave_barrier();
             const bool vl = cur != 0xFFFFFFFFu;
             const uint32_t* q = (const uint32_t*)(stage + (vl ? staged_at((uint32_t)lane) : 0));
-#if MIC_R_LINEAR
             // all six sort keys in one LDS round trip (the slot is 16-byte aligned); rank = number of keys below ours
             const uint4 ka = *(const uint4*)q;
             const uint2 kb = *(const uint2*)(q + 4);
             uint32_t e = (ka.x < key) + (ka.y < key) + (ka.z < key) + (ka.w < key) + (kb.x < key) + (kb.y < key);
-#else
-            uint32_t e = q[3] < key ? 4u : 0u;
-            e += q[e + 1] < key ? 2u : 0u;                                  // index <= 5
-            e += q[e < 5 ? e : 5] < key ? 1u : 0u;
-#endif
             const uint32_t mz = q[30];
             bool more = vl && e < 6;
             e = e < 5 ? e : 5;
@@ -1546,9 +1371,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
               uint32_t e3 = e + (e << 1);
               asm volatile("" : "+v"(e3));     // (the compiler would turn 3 e into a 64-bit multiply-add of the LDS address: quarter rate)
               uint32_t g = q[e], S0 = q[6 + e3], S1 = q[7 + e3], S2 = q[8 + e3], pl = q[24 + e];
-#if MIC_R_EAGER_ENTRY
               asm volatile("" : "+v"(S2));     // read with the others: the compiler would sink it into the branch below, one more LDS round trip
-#endif
               const bool same = more && g == key;
               const uint32_t d0 = G0 ^ S0, d1 = G1 ^ S1, d2 = G2 ^ S2;
               // the whole minimizer, not only its low 32 bits: its nucleotides are the low 32 - 2 ctx bits of word 0 and the top
@@ -1569,13 +1392,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
               // label (the same minimizer in two targets' genomes, both contexts matching parts of the run) is tallied on the
               // spot - a wave-uniform branch that is virtually never taken.
               const uint32_t lab_new = (pl & 0xFFFFu) + 1u;
-#if MIC_R_TALLY_PER_ROUND
-              const bool other = hits != 0 && run_lab != 0 && run_lab != lab_new;
-              if (wballot(other)) tally_counts(other ? lab_new : 0u, other ? hits : 0u, cbits, acc, n_ent, overflow, total, lane);
-              if (hits != 0 && !other) { run_lab = lab_new; run_cnt += hits; }
-#else
               tally_counts(hits ? lab_new : 0u, hits, cbits, acc, n_ent, overflow, total, lane);
-#endif
               remaining -= (int)hits;
               more = same && remaining > 0 && e < 5;                        // another entry of the same minimizer?
               e += more ? 1u : 0u;
@@ -1586,9 +1403,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             cur = 0xFFFFFFFFu;
             if (wballot(nx)) { if (nx && q[5] <= key) cur = q[31]; }
           } while (wballot(cur != 0xFFFFFFFFu));
-#if MIC_R_TALLY_PER_ROUND
-          tally_counts(run_lab, run_cnt, cbits, acc, n_ent, overflow, total, lane);
-#endif
           if (SIDE && wballot(crowded)) {
             // Rare path (a database with microsatellites, a read that overlaps one): the k-mers of the crowded runs are looked
             // up ONE BY ONE in the side table, keyed by the k-mer as the table stores it (as it reads; the one-strand table: in
@@ -1987,45 +1801,14 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     else LAUNCH_S(0, 0);
 #undef LAUNCH_S
 #undef LAUNCH_R
-#ifdef MIC_PHASE_TIMING
-    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hipStreamSynchronize(s);
-    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h));
-    hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
-    fprintf(stderr, "[phase cycles, %% of wave time] reads=%zu:", (size_t)a.n_reads);
-    const char* nm[8] = {"kmers+minimizers+slots", "runs+dma issue", "wait hbm", "slot search", "tally", "finish", "read setup + take of the read-ahead", "total"};
-    for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * h[i] / (double)h[7]);
-    fprintf(stderr, " | cycles/read/wave %.0f\n", (double)h[7] / (double)a.n_reads);
-#endif
   }
   else if (a.t.layout) {
-#ifdef MIC_PERTURB
-    {
-      int pv[4] = {0, 0, 0, 0};
-      const char* e;
-      if ((e = getenv("MIC_PERTURB_VALU"))) pv[0] = atoi(e);
-      if ((e = getenv("MIC_PERTURB_LDS"))) pv[1] = atoi(e);
-      if ((e = getenv("MIC_PERTURB_SALU"))) pv[2] = atoi(e);
-      query_kernel_m<0, 0><<<(blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, 64 * MIC_M_WPB, 0, s>>>(a, pv[0], pv[1], pv[2]);
-    }
-#else
     {
       const unsigned g = (blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, b = 64 * MIC_M_WPB;
       if (MIC_SPEC && a.t.k == 31 && a.t.m == 20) query_kernel_m<31, 20><<<g, b, 0, s>>>(a);        // cuCLARK
       else if (MIC_SPEC && a.t.k == 27 && a.t.m == 20) query_kernel_m<27, 20><<<g, b, 0, s>>>(a);   // cuCLARK-l
       else query_kernel_m<0, 0><<<g, b, 0, s>>>(a);
     }
-#endif
-#ifdef MIC_PHASE_TIMING
-    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hipStreamSynchronize(s);
-    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h));
-    hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
-    fprintf(stderr, "[phase cycles, %% of wave time] reads=%zu waves=%u:", (size_t)a.n_reads, blocks * 4);
-    const char* nm[8] = {"kmers+minimizers", "runs+dma issue", "wait hbm", "slot search", "tally", "finish", "read setup + take of the read-ahead", "total"};
-    for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * h[i] / (double)h[7]);
-    fprintf(stderr, " | cycles/read/wave %.0f\n", (double)h[7] / (double)a.n_reads);
-#endif
   }
   else if (slot_class == 64) query_kernel<true><<<blocks, 256, 0, s>>>(a);
   else query_kernel<false><<<blocks, 256, 0, s>>>(a);
