@@ -1473,8 +1473,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
   }
 }
 
-#include "mic_kernel_duo.inc"
-
 
 // ---- merge / result on sparse rows ----------------------------------------------------------------
 // mergeKernel (CuClarkDB.cu:1321-1415): one thread per read, two-pointer merge by ascending target.
@@ -1747,7 +1745,6 @@ hipError_t mic_launch_probe_stats(const MicTable& t, int slot_class, const uint3
   return hipGetLastError();
 }
 
-static bool duo_env() { static const bool v = getenv("MIC_NO_DUO") == nullptr; return v; }
 static bool per_kmer_env() { static const bool v = getenv("MIC_S_PER_KMER") != nullptr; return v; }
 
 // The runtime loads this file's device code (the query kernels: megabytes of instantiations) when its first kernel is launched;
@@ -1790,19 +1787,8 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     const bool run_ok = 2 * a.t.k - a.t.m > 32 && 2 * a.t.k - a.t.m <= 48;
     static const unsigned extra_lds = [] { const char* e = getenv("MIC_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();   // occupancy experiments
     const bool sd = a.t.side != nullptr;    // crowded minimizers in a side table: the instantiation with the rare per-k-mer path
-    // two reads per wavefront (query_kernel_d, mic_kernel_duo.inc) wherever the per-run kernel applies and the table has no side
-    // table: 4 wavefronts of 2 reads per SIMD; the grid counts PAIRS.  MIC_NO_DUO=1 keeps query_kernel_r for comparison.
-    const bool duo = !sd && duo_env();
-    const unsigned n_pairs = (a.n_reads + 1) / 2;
-    unsigned blocks_d = (n_pairs + 3) / 4;
-    { const unsigned cap_d = (unsigned)n_cu * (unsigned)(per_cu / 2), fill_d = (unsigned)n_cu * 4u, work_d = (n_pairs + 15) / 16;
-      const unsigned want_d = work_d > fill_d ? work_d : fill_d;
-      if (blocks_d > cap_d) blocks_d = cap_d;
-      if (blocks_d > want_d) blocks_d = want_d; }
-    const unsigned gd = (blocks_d * 4 + MIC_M_WPB - 1) / MIC_M_WPB;
 #define LAUNCH_R(KK_, MM_, FW_) do { \
-      if (duo) { if (pt) query_kernel_d<KK_, MM_, FW_, true><<<gd, b, 0, s>>>(a); else query_kernel_d<KK_, MM_, FW_, false><<<gd, b, 0, s>>>(a); } \
-      else if (pt) { if (sd) query_kernel_r<KK_, MM_, FW_, true, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, FW_, true, false><<<g, b, extra_lds, s>>>(a); } \
+      if (pt) { if (sd) query_kernel_r<KK_, MM_, FW_, true, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, FW_, true, false><<<g, b, extra_lds, s>>>(a); } \
       else { if (sd) query_kernel_r<KK_, MM_, FW_, false, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, FW_, false, false><<<g, b, extra_lds, s>>>(a); } } while (0)
 #define LAUNCH_S(KK_, MM_) do { \
       if (fw && !sh && !per_kmer) LAUNCH_R(KK_, MM_, true); \
@@ -1840,10 +1826,8 @@ int mic_query_kernel_name(const MicTable& t, int slot_class, char* buf, size_t c
     const bool spec = !generic && t.m == 20 && (t.k == 31 || t.k == 27 || t.k == 32);
     const int kk = spec ? t.k : 0, mm = spec ? t.m : 0;
     const char* b[2] = {"false", "true"};
-    if (!sh && !per_kmer && (fw || run_ok)) {
-      if (!sd && duo_env()) return snprintf(buf, cap, "query_kernel_d<%d, %d, %s, %s>", kk, mm, b[fw], b[pt]);
+    if (!sh && !per_kmer && (fw || run_ok))
       return snprintf(buf, cap, "query_kernel_r<%d, %d, %s, %s, %s>", kk, mm, b[fw], b[pt], b[sd]);
-    }
     return snprintf(buf, cap, "query_kernel_s<%d, %d, %s, %s>", kk, mm, b[sh], b[fw]);
   }
   if (t.layout) {
