@@ -652,8 +652,11 @@ __device__ inline bool s_less(unsigned long long Ka, uint32_t ma, unsigned long 
 struct SWriter {   // where the entries of one slot go: the main slot, then its contiguous continuation slots
   uint32_t* slots; uint64_t main, chain; uint32_t n_total, n_out;
   uint64_t cur, n_slots; uint32_t n_here, pool_cap; uint32_t* pool; bool full;     // one-pass form
+  uint32_t* main_q;      // where the MAIN slot's 32 words are put together: its row of the block's LDS staging (written out coalesced
+                         // by the whole block), or the slot itself
+  __device__ uint32_t* at(uint64_t slot) const { return slot == main ? main_q : slots + slot * 32; }
   __device__ uint32_t* slot_of(uint32_t idx) const {
-    return slots + (idx < MIC_S_CAP ? main : chain + (idx - MIC_S_CAP) / MIC_S_CAP) * 32;
+    return idx < MIC_S_CAP ? main_q : slots + (chain + (idx - MIC_S_CAP) / MIC_S_CAP) * 32;
   }
 };
 
@@ -673,7 +676,7 @@ __device__ inline void s_emit(const SOpen& o, uint64_t x, int L, SWriter& wr) {
       const uint32_t idx = atomicAdd(wr.pool, 1u);
       if (idx >= wr.pool_cap) { wr.full = true; atomicMax(wr.pool + 1, 1u); }
       else {
-        uint32_t* q = wr.slots + wr.cur * 32;
+        uint32_t* q = wr.at(wr.cur);
         const uint64_t nxt = wr.n_slots + idx;
         q[30] = MIC_S_CAP | MIC_S_NEXT; q[31] = (uint32_t)nxt;
         s_slot_init(wr.slots + nxt * 32);
@@ -681,7 +684,7 @@ __device__ inline void s_emit(const SOpen& o, uint64_t x, int L, SWriter& wr) {
       }
     }
     if (!wr.full) {
-      uint32_t* q = wr.slots + wr.cur * 32;
+      uint32_t* q = wr.at(wr.cur);
       const uint32_t e = wr.n_here++;
       const u128 v = o.S << (96 - 2 * L);
       q[e] = (uint32_t)x;
@@ -701,30 +704,51 @@ __device__ inline void s_emit(const SOpen& o, uint64_t x, int L, SWriter& wr) {
 }
 
 #define S_MAXOPEN 4
+// One thread per slot: sort the slot's staged candidates, merge them into entries, put the slot together.  The block works
+// out of LDS (round 4): the candidates of its S_TPB consecutive slots are one contiguous piece of the staging area - loaded
+// cooperatively (coalesced), sorted and merged by their threads at LDS latency instead of one dependent global access per
+// comparison - and the S_TPB main slots are put together in LDS rows and written out as ONE contiguous piece of the table
+// (coalesced; one thread writing its 128-byte row word by word before).  A block whose slots hold more candidates than the LDS
+// piece (crowded minimizers) works on the staging area directly, as before; continuation slots are written directly (rare).
+#define S_TPB 128
+#define S_LDS_CAND 2048
 template <int MODE>
-__global__ void __launch_bounds__(256) s_merge_kernel(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ cnt,
-                                                      uint64_t n_slots, unsigned long long* __restrict__ cand_k,
-                                                      uint32_t* __restrict__ cand_m, int k, int m,
-                                                      uint32_t* __restrict__ n_ent, const unsigned long long* __restrict__ chain_off,
-                                                      uint32_t* __restrict__ slots, uint32_t* __restrict__ max_ent,
-                                                      uint64_t slot_lo, uint64_t slot_hi, unsigned long long base, int sort_now,
-                                                      uint32_t* __restrict__ pool, uint32_t pool_cap) {
+__global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long* __restrict__ off, const uint32_t* __restrict__ cnt,
+                                                        uint64_t n_slots, unsigned long long* __restrict__ cand_k,
+                                                        uint32_t* __restrict__ cand_m, int k, int m,
+                                                        uint32_t* __restrict__ n_ent, const unsigned long long* __restrict__ chain_off,
+                                                        uint32_t* __restrict__ slots, uint32_t* __restrict__ max_ent,
+                                                        uint64_t slot_lo, uint64_t slot_hi, unsigned long long base, int sort_now,
+                                                        uint32_t* __restrict__ pool, uint32_t pool_cap) {
   constexpr bool WRITE = MODE == 1;
-  const uint64_t s = slot_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= slot_hi) return;
-  const uint32_t n = cnt[s];
-  unsigned long long* K = cand_k + (off[s] - base);
-  uint32_t* M = cand_m + (off[s] - base);
+  __shared__ unsigned long long s_k[S_LDS_CAND];
+  __shared__ uint32_t s_m[S_LDS_CAND];
+  __shared__ uint32_t s_row[MODE != 0 ? S_TPB : 1][33];
+  const uint64_t s_first = slot_lo + (uint64_t)blockIdx.x * S_TPB;
+  const uint64_t s_end = s_first + S_TPB < slot_hi ? s_first + S_TPB : slot_hi;     // (the grid covers [slot_lo, slot_hi): s_first < slot_hi)
+  const uint64_t s = s_first + threadIdx.x;
+  const bool live = s < slot_hi;
+  const unsigned long long c0 = off[s_first] - base, c1 = off[s_end - 1] + cnt[s_end - 1] - base;
+  const bool in_lds = c1 - c0 <= S_LDS_CAND;
+  if (in_lds) {
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(c1 - c0); i += S_TPB) { s_k[i] = cand_k[c0 + i]; s_m[i] = cand_m[c0 + i]; }
+    __syncthreads();
+  }
+  const uint32_t n = live ? cnt[s] : 0;
+  const unsigned long long my = live ? off[s] - base : c0;
+  unsigned long long* K = in_lds ? s_k + (my - c0) : cand_k + my;
+  uint32_t* M = in_lds ? s_m + (my - c0) : cand_m + my;
   const int w = k - m + 1, L = k + w - 1;
   SWriter wr; wr.slots = slots; wr.main = s; wr.chain = 0; wr.n_total = 0; wr.n_out = 0;
   wr.cur = s; wr.n_slots = n_slots; wr.n_here = 0; wr.pool_cap = pool_cap; wr.pool = pool; wr.full = false;
-  if (MODE == 2) s_slot_init(slots + s * 32);
-  if (WRITE) {
+  wr.main_q = MODE != 0 ? s_row[MODE != 0 ? threadIdx.x : 0] : nullptr;
+  if (MODE == 2 && live) s_slot_init(wr.main_q);
+  if (WRITE && live) {
     wr.n_total = n_ent[s];
     const uint32_t n_chain = wr.n_total > MIC_S_CAP ? (wr.n_total - 1) / MIC_S_CAP : 0;
     wr.chain = n_slots + chain_off[s];
     for (uint32_t c = 0; c <= n_chain; ++c) {               // headers and empty entries of every slot of this bucket
-      uint32_t* q = slots + (c == 0 ? s : wr.chain + c - 1) * 32;
+      uint32_t* q = c == 0 ? wr.main_q : slots + (wr.chain + c - 1) * 32;
       for (int e = 0; e < 6; ++e) q[e] = 0xFFFFFFFFu;
       for (int e = 6; e < 30; ++e) q[e] = 0;
       const uint32_t here = wr.n_total - c * MIC_S_CAP > MIC_S_CAP ? MIC_S_CAP : wr.n_total - c * MIC_S_CAP;
@@ -771,8 +795,18 @@ __global__ void __launch_bounds__(256) s_merge_kernel(const unsigned long long* 
     }
   }
   for (int o = 0; o < n_open; ++o) s_emit<MODE>(open[o], cur_x, L, wr);
-  if (MODE != 1) { n_ent[s] = wr.n_out; if (wr.n_out > MIC_S_CAP) atomicMax(max_ent, wr.n_out); }
-  if (MODE == 2 && !wr.full) { uint32_t* q = slots + wr.cur * 32; q[30] = wr.n_here; q[31] = 0; }
+  if (MODE != 1 && live) { n_ent[s] = wr.n_out; if (wr.n_out > MIC_S_CAP) atomicMax(max_ent, wr.n_out); }
+  if (MODE == 2 && live && !wr.full) { uint32_t* q = wr.at(wr.cur); q[30] = wr.n_here; q[31] = 0; }
+  __syncthreads();
+  // the counting pass of the two-pass form leaves the candidates sorted for the writing pass (one range: it does not sort again)
+  if (MODE == 0 && sort_now && in_lds)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(c1 - c0); i += S_TPB) { cand_k[c0 + i] = s_k[i]; cand_m[c0 + i] = s_m[i]; }
+  // the block's main slots: one contiguous piece of the table
+  if (MODE != 0) {
+    const uint32_t words = (uint32_t)(s_end - s_first) * 32u;
+    uint32_t* out = slots + s_first * 32;
+    for (uint32_t i = threadIdx.x; i < words; i += S_TPB) out[i] = s_row[MODE != 0 ? i >> 5 : 0][i & 31u];
+  }
 }
 
 __global__ void s_chain_demand_kernel(const uint32_t* __restrict__ n_ent, uint64_t n, uint32_t* __restrict__ demand) {
@@ -1231,7 +1265,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       for (size_t r = 0; r < n_ranges && e_ == hipSuccess; ++r) {
         const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
         BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
-        s_merge_kernel<2><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, nullptr, slots - part_lo * 32,
+        s_merge_kernel<2><<<(unsigned)((hi - lo + S_TPB - 1) / S_TPB), S_TPB, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, nullptr, slots - part_lo * 32,
                                                                            d_max, lo, hi, range_base[r], 1, d_pool, (uint32_t)pool_cap);
         e_ = hipGetLastError();
       }
@@ -1254,7 +1288,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
     BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
     HIPCK(hipGetLastError());
-    s_merge_kernel<0><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, nullptr,
+    s_merge_kernel<0><<<(unsigned)((hi - lo + S_TPB - 1) / S_TPB), S_TPB, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, nullptr,
                                                                        nullptr, d_max, lo, hi, range_base[r], 1, nullptr, 0);
     HIPCK(hipGetLastError());
   }
@@ -1332,7 +1366,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
       HIPCK(hipGetLastError());
     }
-    s_merge_kernel<1><<<(unsigned)((hi - lo + 255) / 256), 256, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, d_coff,
+    s_merge_kernel<1><<<(unsigned)((hi - lo + S_TPB - 1) / S_TPB), S_TPB, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, d_coff,
                                                                        slots - part_lo * 32, d_max, lo, hi, range_base[r], n_ranges > 1 ? 1 : 0, nullptr, 0);
     HIPCK(hipGetLastError());
   }
