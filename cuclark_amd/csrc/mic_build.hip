@@ -758,7 +758,8 @@ __global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long
   }
   if (sort_now) {
     // shell sort of the staged candidates (in place; a second run over the same staging area finds them sorted)
-    const uint32_t gaps[] = {701, 301, 132, 57, 23, 10, 4, 1};
+    constexpr uint32_t gaps[8] = {701, 301, 132, 57, 23, 10, 4, 1};
+#pragma unroll
     for (int g = 0; g < 8; ++g) {
       const uint32_t gap = gaps[g];
       if (gap >= n) continue;
@@ -770,31 +771,45 @@ __global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long
       }
     }
   }
+  // the open contexts live in registers: every index below is a constant after unrolling (a dynamically indexed array goes to
+  // scratch memory - 208 bytes per thread and a memory round trip per access before round 4)
   SOpen open[S_MAXOPEN]; int n_open = 0; uint64_t cur_x = 0;
+#pragma unroll
+  for (int o = 0; o < S_MAXOPEN; ++o) { open[o].S = 0; open[o].known = 0; open[o].pmask = 0; open[o].label = 0; }
   const u128 kmask = (((u128)1) << (2 * k)) - 1;
   for (uint32_t i = 0; i < n; ++i) {
     const unsigned long long kv = K[i]; const uint32_t mv = M[i];
     const uint32_t j = mv & 0xFF, lb = mv >> 8;
     const uint64_t x = s_x_of(kv, j, k, m);
-    if (n_open && x != cur_x) { for (int o = 0; o < n_open; ++o) s_emit<MODE>(open[o], cur_x, L, wr); n_open = 0; }
+    if (n_open && x != cur_x) {
+#pragma unroll
+      for (int o = 0; o < S_MAXOPEN; ++o) if (o < n_open) s_emit<MODE>(open[o], cur_x, L, wr);
+      n_open = 0;
+    }
     cur_x = x;
     const u128 SK = (u128)kv << (2 * j), MK = kmask << (2 * j);
     bool done = false;
-    for (int o = 0; o < n_open && !done; ++o) {
-      if (open[o].label == lb && !((open[o].pmask >> j) & 1) && ((open[o].S ^ SK) & open[o].known & MK) == 0) {
+#pragma unroll
+    for (int o = 0; o < S_MAXOPEN; ++o) {
+      if (o < n_open && !done && open[o].label == lb && !((open[o].pmask >> j) & 1) && ((open[o].S ^ SK) & open[o].known & MK) == 0) {
         open[o].S |= SK; open[o].known |= MK; open[o].pmask |= 1u << j; done = true;
       }
     }
     if (!done) {
       if (n_open == S_MAXOPEN) {                              // keep the most recent contexts open
         s_emit<MODE>(open[0], cur_x, L, wr);
+#pragma unroll
         for (int o = 1; o < S_MAXOPEN; ++o) open[o - 1] = open[o];
         --n_open;
       }
-      open[n_open].S = SK; open[n_open].known = MK; open[n_open].pmask = 1u << j; open[n_open].label = lb; ++n_open;
+#pragma unroll
+      for (int o = 0; o < S_MAXOPEN; ++o)
+        if (o == n_open) { open[o].S = SK; open[o].known = MK; open[o].pmask = 1u << j; open[o].label = lb; }
+      ++n_open;
     }
   }
-  for (int o = 0; o < n_open; ++o) s_emit<MODE>(open[o], cur_x, L, wr);
+#pragma unroll
+  for (int o = 0; o < S_MAXOPEN; ++o) if (o < n_open) s_emit<MODE>(open[o], cur_x, L, wr);
   if (MODE != 1 && live) { n_ent[s] = wr.n_out; if (wr.n_out > MIC_S_CAP) atomicMax(max_ent, wr.n_out); }
   if (MODE == 2 && live && !wr.full) { uint32_t* q = wr.at(wr.cur); q[30] = wr.n_here; q[31] = 0; }
   __syncthreads();
