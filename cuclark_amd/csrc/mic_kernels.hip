@@ -1121,7 +1121,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
 // =====================================================================================================================
 __device__ __forceinline__ uint64_t wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-__device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cbits, RowAcc& acc, uint32_t& n_ent, uint32_t& overflow,
+static_assert(MIC_RMAX <= 32, "tally_counts sums the first two rows of lanes");
+__device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, RowAcc& acc, uint32_t& n_ent, uint32_t& overflow,
                                              uint32_t& total, int lane) {
   uint64_t mm = wballot(lab1 != 0);
   while (mm) {
@@ -1130,11 +1131,17 @@ __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, int cb
     mm &= ~wballot(mine);
     const uint32_t c = mine ? cnt : 0u;
     uint32_t sum = 0;
-    // one ballot per count bit (a run has at most w <= 16 k-mers: 4-5 bits).  (An inclusive DPP row scan of the counts - sums
-    // in lanes 15 and 31 - is 11 scalar instructions shorter and measured +-0: DESIGN.md 4.1f.)
-#pragma unroll
-    for (int b = 0; b < 5; ++b)
-      if (b < cbits) sum += (uint32_t)__popcll(wballot((c & (1u << b)) != 0)) << b;
+    // the runs sit in lanes 0 .. 31 = the first two rows of 16 lanes: an inclusive row scan by DPP (four full-rate adds) leaves the
+    // rows' sums in lanes 15 and 31.  (One ballot per count bit - 4-5 and-compare pairs and three scalar operations each - was
+    // what the product ran until round 4: 1.0-1.5 % slower, 4.99 against 5.04-5.08 ms.)
+    {
+      uint32_t v = c;
+      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+      sum = __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31);
+    }
     total += sum;
     row_add(acc, n_ent, overflow, l1, sum, lane);
   }
@@ -1203,7 +1210,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     ahead_issue(ahead1, n_pp, wave0 + 2 * n_waves);
     ahead_sel = 1;
   }
-  const int cbits = w > 15 ? 5 : 4;                        // a run has at most w k-mers
   for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
     uint32_t pp = cur_pp;
     const uint32_t pe = cur_pe;
@@ -1392,7 +1398,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
               // label (the same minimizer in two targets' genomes, both contexts matching parts of the run) is tallied on the
               // spot - a wave-uniform branch that is virtually never taken.
               const uint32_t lab_new = (pl & 0xFFFFu) + 1u;
-              tally_counts(hits ? lab_new : 0u, hits, cbits, acc, n_ent, overflow, total, lane);
+              tally_counts(hits ? lab_new : 0u, hits, acc, n_ent, overflow, total, lane);
               remaining -= (int)hits;
               more = same && remaining > 0 && e < 5;                        // another entry of the same minimizer?
               e += more ? 1u : 0u;
@@ -1760,8 +1766,9 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   unsigned blocks = (a.n_reads + 3) / 4;
   // Resident blocks per CU are 8; the grid is much larger so that each wave strides over only ~20 reads: reads differ in
   // cost (rounds, parts) and the hardware's block scheduler then evens the waves out.  Measured on the headline
-  // workload: 8 blocks/CU 697 Mreads/s, 32: 760, 128: 811, 512: 835, 1024: 821 (direct layout: flat).
-  static int per_cu = [] { const char* e = getenv("MIC_BLOCKS_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  // workload: 8 blocks/CU 697 Mreads/s, 32: 760, 128: 811, 512: 835, 1024: 821 (direct layout: flat); round 4, per-run kernel:
+  // 96: 5.08 ms, 128: 5.07, 192: 5.04, 256: 5.02, 320: 5.05, 512: 5.07, 1024: 5.18, 2048: 5.24.
+  static int per_cu = [] { const char* e = getenv("MIC_BLOCKS_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
   unsigned cap = (unsigned)n_cu * (unsigned)per_cu;
   if (blocks > cap) blocks = cap;
   {
