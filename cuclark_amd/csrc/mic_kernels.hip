@@ -1164,7 +1164,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
   const uint32_t n_waves = gridDim.x * MIC_M_WPB;
   const MicTable& t = a.t;
   if (PART) { if (lane == 0) { s_part[wv][0] = t.slot_lo; s_part[wv][1] = t.slot_cnt; } __builtin_amdgcn_wave_barrier(); }
-  const int k = KK ? KK : t.k, m = MM ? MM : t.m, w = k - m + 1, ctx = k - m;
+  const int k = KK ? KK : t.k, m = MM ? MM : t.m, ctx = k - m;
   const uint4* __restrict__ slots = t.slots;
   const uint16_t* __restrict__ cont = a.cont;
   auto below = [](uint64_t mask) { return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
