@@ -345,18 +345,13 @@ def test_db_sharded_cli_matches_golden(tmp_path, engines, parts):
     assert res[0].splitlines()[1].startswith(b"all,") and b",L00,5," in res[0].splitlines()[1]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("engines", [2, 3])
-def test_read_sharded_cli_with_several_engines_on_one_gpu(tmp_path, engines):
-    """-d N, the default multi-device mode: the table replicated on every engine, the ingest slots - and with them the batches -
-    dealt over the engines.  MIC_SHARD_ENGINES puts N engines on this box's one GPU.  Every input form gives the one-engine
-    run's CSV byte for byte (every record once, in order): plain FASTA / FASTQ over many small batches, --extended (batch API),
-    two plain mates, gzip and block gzip (inflated on the first engine's device, slots of the other engines filled from there),
-    compressed mates, list-of-files."""
+@pytest.fixture(scope="module")
+def multi_engine_rig(tmp_path_factory):
+    """Inputs of every form the command line takes, and the ONE-engine run's CSV of each (the reference of the multi-engine runs)."""
     import gzip
     import numpy as np
     import test_ingest as ti
-    tmp = str(tmp_path)
+    tmp = str(tmp_path_factory.mktemp("multi_engine"))
     d = _db_dir(tmp, "light_k27_u32", light=True)
     t = _targets_file(tmp)
     rng = np.random.default_rng(41)
@@ -375,32 +370,48 @@ def test_read_sharded_cli_with_several_engines_on_one_gpu(tmp_path, engines):
     g1, g2 = p1 + ".gz", p2 + ".gz"
     open(g1, "wb").write(gzip.compress(m1, 1))
     open(g2, "wb").write(gzip.compress(m2, 6))
-    lo, lr = os.path.join(tmp, "objs.txt"), os.path.join(tmp, "ress.txt")
+    lo = os.path.join(tmp, "objs.txt")
     open(lo, "w").write(fa + "\n" + fq + "\n")
     cases = {"fq": ["-O", fq], "fa": ["-O", fa], "ext": ["-O", fa, "--extended", "-b", "7"], "pairs": ["-P", p1, p2], "gz": ["-O", gz],
              "bgzf": ["-O", bg], "gzpairs": ["-P", g1, g2], "list": ["-O", lo]}
+    rig = dict(tmp=tmp, d=d, t=t, cases=cases, lr=os.path.join(tmp, "ress.txt"))
+
+    def run(name, tag, env):
+        out = os.path.join(tmp, f"{tag}_{name}")
+        res = ["-R", out]
+        if name == "list":
+            open(rig["lr"], "w").write(out + "_a\n" + out + "_b\n")
+            res = ["-R", rig["lr"]]
+        r = _run([EXE_L, "-T", t, "-D", d, *cases[name], *res, "-n", "5"], env=env)
+        assert r.returncode == 0, (name, r.stderr)
+        return r, [open(out + sfx + ".csv", "rb").read() for sfx in (("_a", "_b") if name == "list" else ("",))]
+    rig["run"] = run
+    one = dict(os.environ, MIC_CLI_TIMING="1", MIC_INGEST_KB="24")
+    rig["one"] = {name: run(name, "one", one)[1] for name in cases}
+    return rig
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engines", [2, 3])
+def test_read_sharded_cli_with_several_engines_on_one_gpu(multi_engine_rig, engines):
+    """-d N, the default multi-device mode: the table replicated on every engine, the ingest slots - and with them the batches -
+    dealt over the engines.  MIC_SHARD_ENGINES puts N engines on this box's one GPU.  Every input form gives the one-engine
+    run's CSV byte for byte (every record once, in order): plain FASTA / FASTQ over many small batches, --extended (batch API),
+    two plain mates, gzip and block gzip (inflated on the first engine's device, slots of the other engines filled from there),
+    compressed mates, list-of-files."""
+    rig = multi_engine_rig
     multi = dict(os.environ, MIC_SHARD_ENGINES=str(engines), MIC_CLI_TIMING="1", MIC_INGEST_KB="24")
-    for name, src in cases.items():
-        outs = []
-        for tag, env in (("one", dict(os.environ, MIC_CLI_TIMING="1", MIC_INGEST_KB="24")), ("multi", multi)):
-            out = os.path.join(tmp, f"{tag}_{name}")
-            res = ["-R", out]
-            if name == "list":
-                open(lr, "w").write(out + "_a\n" + out + "_b\n")
-                res = ["-R", lr]
-            r = _run([EXE_L, "-T", t, "-D", d, *src, *res, "-n", "5"], env=env)
-            assert r.returncode == 0, (name, r.stderr)
-            if tag == "multi":
-                assert f"{engines} engine(s) on 1 device(s), read-sharded (table replicated)" in r.stderr, r.stderr
-                assert f"on {engines} device(s)" in r.stderr
-                if name in ("gz", "bgzf", "gzpairs"):      # inflated on the device although the slots sit on several engines
-                    assert re.search(r"device inflate: [\d.]+ MB of text", r.stderr) and "over the link 0 MB" in r.stderr, r.stderr
-                if name != "ext":
-                    m = re.search(r"device ingest: (\d+) batches of <= 24 KB on (\d+) slot", r.stderr)
-                    assert m and int(m.group(1)) > 2 * engines and int(m.group(2)) >= engines, r.stderr
-            outs.append([open(out + sfx + ".csv", "rb").read() for sfx in (("_a", "_b") if name == "list" else ("",))])
-        assert outs[0] == outs[1], name
-        assert all(len(x) > 1000 for x in outs[0])
+    for name in rig["cases"]:
+        r, got = rig["run"](name, f"multi{engines}", multi)
+        assert f"{engines} engine(s) on 1 device(s), read-sharded (table replicated)" in r.stderr, r.stderr
+        assert f"on {engines} device(s)" in r.stderr
+        if name in ("gz", "bgzf", "gzpairs"):      # inflated on the device although the slots sit on several engines
+            assert re.search(r"device inflate: [\d.]+ MB of text", r.stderr) and "over the link 0 MB" in r.stderr, r.stderr
+        if name != "ext":
+            m = re.search(r"device ingest: (\d+) batches of <= 24 KB on (\d+) slot", r.stderr)
+            assert m and int(m.group(1)) > 2 * engines and int(m.group(2)) >= engines, r.stderr
+        assert got == rig["one"][name], name
+        assert all(len(x) > 1000 for x in got)
 
 
 @pytest.mark.gpu
