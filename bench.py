@@ -383,6 +383,8 @@ def main():
     ap.add_argument("--allow-variant-lib", action="store_true",
                     help="accept MIC_LIB_PATH (a measuring build of the library, tools/*_sweep.sh); refused otherwise: the line must "
                          "describe the product library")
+    ap.add_argument("--pitch-layout", action="store_true",
+                    help="leave the reads as the generator writes them (fixed pitch, a 0 behind every read) instead of the packer's format")
     ap.add_argument("--no-db-leg", action="store_true",
                     help="N > 1, read mode: skip the extra table-sharded measurement reported as \"table_sharded\"")
     args = ap.parse_args()
@@ -488,10 +490,44 @@ def main():
     d_cont = torch.zeros(n_reads * pitch + 64, dtype=torch.int16, device=dev)
     d_truth = torch.empty(n_reads * 2, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    rc = L.mic_synth_reads_device2(C.byref(spec), read_seed, n_reads, read_len, int(paired), 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
-                                   d_cont.numel(), d_truth.data_ptr(), None)
-    assert rc == 0, f"mic_synth_reads_device failed ({rc})"
-    torch.cuda.synchronize()
+    def generate_reads(seed):
+        """n_reads packed reads of this workload in HBM, IN THE PACKER'S FORMAT: reads back to back, readsPointer[r + 1] = the end of
+        read r, no terminator (CuCLARK_hh.hh:1616-1716, the arrays queryBatch receives).  The generator writes every read at a
+        fixed pitch with a 0 behind its last part (it works on all reads at once); the compaction below (device, not timed) removes
+        pitch and terminators - a terminator costs the kernel a second pass of its part loop per read (2.3 %,
+        tools/compact_reads_probe.py) that the reference's format does not have."""
+        nonlocal d_rp, d_cont
+        rc_ = L.mic_synth_reads_device2(C.byref(spec), seed, n_reads, read_len, int(paired), 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
+                                        d_cont.numel(), d_truth.data_ptr(), None)
+        assert rc_ == 0, f"mic_synth_reads_device failed ({rc_})"
+        torch.cuda.synchronize()
+        if args.pitch_layout:
+            return
+        rp64 = d_rp.to(torch.int64) & 0xFFFFFFFF
+        cu16 = d_cont.view(torch.int16).to(torch.int32) & 0xFFFF
+        pos, end = rp64[:-1].clone(), rp64[1:]
+        live = torch.ones(n_reads, dtype=torch.bool, device=dev)
+        for _ in range(4096):                         # parts of a read: a length slot, then ceil(len / 8) containers
+            live &= pos < end
+            plen = torch.where(live, cu16[torch.clamp(pos, max=cu16.numel() - 1)].to(torch.int64), torch.zeros_like(pos))
+            live &= plen > 0
+            if not bool(live.any()):
+                break
+            pos = torch.where(live, pos + 1 + (plen + 7) // 8, pos)
+        used = pos - rp64[:-1]
+        rp_c = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(used, 0, out=rp_c[1:])
+        total = int(rp_c[-1].item())
+        src = torch.repeat_interleave(rp64[:-1] - rp_c[:-1], used, output_size=total) + torch.arange(total, dtype=torch.int64, device=dev)
+        compact = torch.zeros(total + 64, dtype=torch.int16, device=dev)          # (the kernel's read-ahead looks past the last read)
+        compact[:total] = d_cont[src]
+        del src, cu16
+        d_cont = compact
+        d_rp = rp_c.to(torch.int32)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    generate_reads(read_seed)
     d_res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
     n_flagged = [0]
     stream = torch.cuda.current_stream(dev)
@@ -845,10 +881,9 @@ def main():
             eng.close()
             del d_res
             torch.cuda.empty_cache()
-            rc = L.mic_synth_reads_device2(C.byref(spec), 5, n_reads, read_len, int(paired), 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
-                                           d_cont.numel(), d_truth.data_ptr(), None)   # the same reads on every rank
-            assert rc == 0
-            torch.cuda.synchronize()
+            d_rp = torch.empty(n_reads + 1, dtype=torch.int32, device=dev)
+            d_cont = torch.zeros(n_reads * pitch + 64, dtype=torch.int16, device=dev)
+            generate_reads(5)                          # the same reads on every rank
             table_sharded = sharded_leg(world)
             if world >= 4:      # the 2-D layout for a table that needs two GPUs: 2 parts x world / 2 read groups
                 table_sharded["two_parts_2d"] = sharded_leg(2)
@@ -862,6 +897,8 @@ def main():
             "scaling": "strong" if db_mode else "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": w["name"], "reads_per_gpu": n_reads, "read_len": read_len, "k": k,
+                       "reads_format": "generator's fixed pitch, a 0 behind every read" if args.pitch_layout else
+                                       "the packer's: reads back to back, readsPointer[r + 1] = end of read r (CuCLARK_hh.hh:1616-1716)",
                        "mode": (f"{P} part(s) x {n_groups} read group(s): " + (PART_MODE[info["layout"]] if P > 1 else "table replicated") +
                                 " + all_to_all of sparse rows" if db_mode else
                                 ("read-sharded, table replicated" if world > 1 else "single GPU, table resident")),

@@ -1215,30 +1215,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     const uint32_t pe = cur_pe;
     RowAcc acc; acc.label1 = 0; acc.count = 0;
     uint32_t n_ent = 0, overflow = 0, total = 0;
-    bool first_part = true;
-
-    while (pp < pe) {
-      // the header of a later part - for nearly every read the 0 that ends it - is among the 24 containers of the read-ahead
-      // entry more often than not: an LDS read instead of a global load the whole wave waits for
-      uint32_t plen;
-      {
-        const uint32_t rel = pp - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);    // u16 offset inside the entry
-        if (first_part) plen = cur_hdr;
-        else if (rel < 24u) {
-          const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
-          plen = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu);
-        } else plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
-      }
-      const bool ahead_ok = first_part;
-      first_part = false;
-      if (plen == 0) break;
-      const uint32_t first = pp + 1;
-      pp = first + (plen + 7) / 8;
-      if (plen < (uint32_t)k) continue;
-      const uint32_t nk = plen - k + 1;
-      const uint32_t cend = pp;
-      for (uint32_t base = 0; base < nk; base += 128) {
-        const bool use_ahead = ahead_ok && base == 0;
+    // one chunk of one part: front half, runs, rounds (inlined twice: the straight line of a one-part, one-chunk read and the
+    // general loops)
+    auto chunk = [&](const uint32_t first, const uint32_t cend, const uint32_t base, const uint32_t nk, const bool use_ahead) __attribute__((always_inline)) {
         // lane-derived shift counts, positions and lane masks are recomputed per chunk from this opaque copy: kept across
         // the kernel they cost scalar register pairs the kernel does not have (34 -> 15 spill moves, +4 VALU, -6 SALU per read)
         int ln = lane;
@@ -1458,7 +1437,39 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             tally2(sres[0], sres[1], acc, n_ent, overflow, total, lane);
           }
         }
+    };
+    // A read that is ONE part of at most 128 k-mers in the packer's format (its part ends where the read ends): straight line - no
+    // part loop, no header of a next part, the window out of the read-ahead entry.  The scalar unit (one per CU, ~275 scalar
+    // instructions and branches per read against 240 vector instructions spread over four SIMDs) is what the kernel is short of,
+    // and the loops' bookkeeping is scalar work a 150-bp read does not need.
+    const uint32_t plen0 = cur_hdr, pp1 = pp + 1 + (plen0 + 7) / 8;
+    if (pp < pe && plen0 >= (uint32_t)k && plen0 - (uint32_t)k < 128u && pp1 >= pe) {      // (pp == pe: a read without a k-mer has no part at all)
+      chunk(pp + 1, pp1, 0u, plen0 - (uint32_t)k + 1u, true);
+    } else {
+    bool first_part = true;
+
+    while (pp < pe) {
+      // the header of a later part - for nearly every read the 0 that ends it - is among the 24 containers of the read-ahead
+      // entry more often than not: an LDS read instead of a global load the whole wave waits for
+      uint32_t plen;
+      {
+        const uint32_t rel = pp - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);    // u16 offset inside the entry
+        if (first_part) plen = cur_hdr;
+        else if (rel < 24u) {
+          const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
+          plen = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu);
+        } else plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
       }
+      const bool ahead_ok = first_part;
+      first_part = false;
+      if (plen == 0) break;
+      const uint32_t first = pp + 1;
+      pp = first + (plen + 7) / 8;
+      if (plen < (uint32_t)k) continue;
+      const uint32_t nk = plen - k + 1;
+      const uint32_t cend = pp;
+      for (uint32_t base = 0; base < nk; base += 128) chunk(first, cend, base, nk, ahead_ok && base == 0);
+    }
     }
     uint32_t t_hdr, t_pp, t_pe;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
