@@ -16,6 +16,9 @@
 
 #include <stdlib.h>
 
+#ifndef MIC_EXP
+#define MIC_EXP 0
+#endif
 #ifndef MIC_FUNNEL64
 #define MIC_FUNNEL64 1
 #endif
@@ -208,7 +211,10 @@ __device__ __forceinline__ void finish_read(const RowAcc& acc, uint32_t n_ent, u
                                             uint32_t r, const ARGS& a, int lane) {
   // (count, label + 1) pairs compared as 32-bit scalars: a 64-bit key has no scalar compare and went through the vector unit
   uint32_t bc = 0, bl = 0, sc = 0, sl = 0;       // best and second: count, label + 1 (0 = none)
-  for (uint32_t i = 0; i < n_ent; ++i) {
+  // (the first entry is the best so far without a comparison - its count is at least 1: most reads have one entry, and the
+  // comparisons are scalar work the kernel is short of)
+  if (n_ent) { bl = __builtin_amdgcn_readlane(acc.label1, 0); bc = __builtin_amdgcn_readlane(acc.count, 0); }
+  for (uint32_t i = 1; i < n_ent; ++i) {
     const uint32_t l1 = __builtin_amdgcn_readlane(acc.label1, i);
     const uint32_t c = __builtin_amdgcn_readlane(acc.count, i);
     const bool over_best = c > bc || (c == bc && l1 < bl);
@@ -248,7 +254,11 @@ __device__ __forceinline__ void finish_read(const RowAcc& acc, uint32_t n_ent, u
     out[0] = lo; out[1] = hi;
   }
   // wave-uniform branch: the wait for the atomic's return value must not sit on the common path
+#if MIC_EXP & 2
+  if (__builtin_expect(__builtin_amdgcn_readfirstlane(flags) != 0, 0)) if (a.flagged) {
+#else
   if (__builtin_amdgcn_readfirstlane(flags) && a.flagged) {
+#endif
     if (lane == 0) {
       uint32_t pos = atomicAdd(&a.flagged[0], 1u);
       if (pos < a.flagged_cap) a.flagged[1 + pos] = r;
@@ -1197,7 +1207,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     const uint32_t raw = entry[lane];
     const bool odd = (((uint64_t)(cont + pp_w)) >> 1) & 1;
     const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw, 0x101, 0xF, 0xF, true);
-    return odd ? ((up << 16) | (up >> 16)) : ((raw & 0xFFFF0000u) | (up & 0xFFFFu));
+    // odd: (up << 16) | (up >> 16); even: (raw & 0xFFFF0000) | (up & 0xFFFF) - one byte permute with a scalar selector instead of
+    // a scalar branch around either form
+    return __builtin_amdgcn_perm(up, raw, odd ? 0x05040706u : 0x03020504u);
   };
   uint32_t cur_pp, cur_pe, cur_hdr, n_pp, n_pe, ahead_sel;
   {
@@ -1336,7 +1348,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
             for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = ((const uint32_t*)stage)[8 * i + (lane >> 3)];
 #pragma unroll
             for (int i = 0; i < MIC_RMAX / 8; ++i) {
+#if !(MIC_EXP & 1)
               if (8u * i >= nrun) break;
+#endif
               if (sidx[i] != 0xFFFFFFFFu)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
                                                  (__attribute__((address_space(3))) void*)(stage + (64 + MIC_R_SKEW) * i), 16, 0, 0);
@@ -1443,7 +1457,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     // instructions and branches per read against 240 vector instructions spread over four SIMDs) is what the kernel is short of,
     // and the loops' bookkeeping is scalar work a 150-bp read does not need.
     const uint32_t plen0 = cur_hdr, pp1 = pp + 1 + (plen0 + 7) / 8;
-    if (pp < pe && plen0 >= (uint32_t)k && plen0 - (uint32_t)k < 128u && pp1 >= pe) {      // (pp == pe: a read without a k-mer has no part at all)
+    if (plen0 - (uint32_t)k < 128u && pp1 == pe) {      // (k <= plen0 < k + 128 by the unsigned wrap; pp1 == pe implies pp < pe: a read without a k-mer has pp == pe)
       chunk(pp + 1, pp1, 0u, plen0 - (uint32_t)k + 1u, true);
     } else {
     bool first_part = true;
