@@ -398,6 +398,11 @@ def main():
         # `python bench.py --gpus N` with no launcher: this process has not touched the GPU yet - it starts the N ranks as a
         # fresh child (one process per GPU under torch.distributed.run), relays their output and exits with their code
         sys.exit(launch_ranks(args, n_dev))
+    if os.environ.get("MIC_BENCH_WATCHDOG"):
+        # a rank that is still running after this many seconds prints every thread's Python stack and exits (tests of the
+        # multi-rank paths set it: a stuck rendezvous or collective then names the call instead of running into the test's timeout)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MIC_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -494,8 +499,8 @@ def main():
         """n_reads packed reads of this workload in HBM, IN THE PACKER'S FORMAT: reads back to back, readsPointer[r + 1] = the end of
         read r, no terminator (CuCLARK_hh.hh:1616-1716, the arrays queryBatch receives).  The generator writes every read at a
         fixed pitch with a 0 behind its last part (it works on all reads at once); the compaction below (device, not timed) removes
-        pitch and terminators - a terminator costs the kernel a second pass of its part loop per read (2.3 %,
-        tools/compact_reads_probe.py) that the reference's format does not have."""
+        pitch and terminators, which the reference's format does not have (the pitch form costs the kernel 2 %:
+        --pitch-layout, tools/compact_reads_probe.py)."""
         nonlocal d_rp, d_cont
         rc_ = L.mic_synth_reads_device2(C.byref(spec), seed, n_reads, read_len, int(paired), 0.2, 0.01, 0.001, d_rp.data_ptr(), d_cont.data_ptr(),
                                         d_cont.numel(), d_truth.data_ptr(), None)

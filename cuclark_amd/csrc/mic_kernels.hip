@@ -1457,7 +1457,17 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     // instructions and branches per read against 240 vector instructions spread over four SIMDs) is what the kernel is short of,
     // and the loops' bookkeeping is scalar work a 150-bp read does not need.
     const uint32_t plen0 = cur_hdr, pp1 = pp + 1 + (plen0 + 7) / 8;
-    if (plen0 - (uint32_t)k < 128u && pp1 == pe) {      // (k <= plen0 < k + 128 by the unsigned wrap; pp1 == pe implies pp < pe: a read without a k-mer has pp == pe)
+    bool simple = plen0 - (uint32_t)k < 128u && pp1 == pe;      // (k <= plen0 < k + 128 by the unsigned wrap; pp1 == pe implies pp < pe: a read without a k-mer has pp == pe)
+    if (!simple && plen0 - (uint32_t)k < 128u && pp1 < pe) {
+      // terminated formats (the device packer's reservations, the generator's pitch): one part and a 0 behind it is the same
+      // read - the header behind the part sits in the read-ahead entry for reads of up to ~170 nucleotides
+      const uint32_t rel = pp1 - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);
+      if (rel < 24u) {
+        const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
+        simple = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu) == 0;
+      }
+    }
+    if (simple) {
       chunk(pp + 1, pp1, 0u, plen0 - (uint32_t)k + 1u, true);
     } else {
     bool first_part = true;
