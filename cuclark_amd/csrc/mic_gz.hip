@@ -292,6 +292,8 @@ struct Fast {
   Scratch sc;
   uint16_t lit_fast[1 << GZ_FAST_LIT];        // len << 12 | symbol, 0 = longer code
   uint16_t dist_fast[1 << GZ_FAST_DIST];
+  uint32_t lit_wide[1 << GZ_FAST_LIT];        // the window decode's tables (fill_wide): a code's length, its extra bits and its base in one entry
+  uint32_t dist_wide[1 << GZ_FAST_DIST];
   uint32_t stage[GZ_STAGE / 4 + 4];
   uint32_t len_tab[32], dist_tab[32];         // base | extra bits << 16: the constant tables, here because a lookup with a vector index
                                               // in constant memory is a global load (hundreds of cycles on the decode's critical path)
@@ -337,6 +339,12 @@ struct WBits {                                 // the Bits of a whole wavefront:
   __device__ uint32_t get(int k) { const uint32_t v = peek(k); drop(k); return v; }
   __device__ uint64_t bitpos() const { return pos * 8 - (uint64_t)cnt; }
   __device__ void align() { drop(cnt & 7); }
+  __device__ void seek(uint64_t bit) {           // continue at this bit (the window decode hands back to the serial one)
+    pos = bit >> 3; buf = 0; cnt = 0;
+    refill();
+    const int skip = (int)(bit & 7);
+    buf >>= skip; cnt -= skip;
+  }
 };
 
 // the same Huffman walk on the wavefront's bits
@@ -386,6 +394,30 @@ __device__ uint32_t first_level(const Fast& f, int lane) {
   const uint32_t l2 = e2 >> 12;
   if (e2 && (e2 & 0xFFFu) < 256u && l1 + l2 <= 6u) return (2u << 24) | ((l1 + l2) << 16) | ((e2 & 0xFFu) << 8) | (e1 & 0xFFu);
   return (1u << 24) | (l1 << 16) | (e1 & 0xFFu);
+}
+
+// The tables of the window decode (gz_decode_body): what the serial path finds in two dependent lookups - the code, then the
+// base and the extra bits of a length or a distance - in one 32-bit entry.
+//   lit_wide:  bits of the code | extra bits << 4 | kind << 8 (0 literal, 1 length, 2 end of block) | literal or length base << 16
+//   dist_wide: bits of the code | extra bits << 4 | distance base << 16            0 = a longer code, or no valid symbol: the serial path
+__device__ void fill_wide(Fast& f, int lane) {
+  for (int i = lane; i < (1 << GZ_FAST_LIT); i += 64) {
+    const uint32_t e = f.lit_fast[i], l = e >> 12, sy = e & 0xFFFu;
+    uint32_t x = 0;
+    if (e) {
+      if (sy < 256u) x = l | (sy << 16);
+      else if (sy == 256u) x = l | (2u << 8);
+      else if (sy - 257u < 29u) { const uint32_t lt = f.len_tab[sy - 257u]; x = l | ((lt >> 16) << 4) | (1u << 8) | ((lt & 0xFFFFu) << 16); }
+    }
+    f.lit_wide[i] = x;
+  }
+  for (int i = lane; i < (1 << GZ_FAST_DIST); i += 64) {
+    const uint32_t e = f.dist_fast[i], l = e >> 12, sy = e & 0xFFFu;
+    uint32_t x = 0;
+    if (e && sy < 30u) { const uint32_t dt = f.dist_tab[sy]; x = l | ((dt >> 16) << 4) | ((dt & 0xFFFFu) << 16); }
+    f.dist_wide[i] = x;
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 // read_dynamic on the wavefront's bits (every lane the same), then the fast tables
@@ -451,6 +483,7 @@ __device__ bool read_dynamic_w(WBits& b, Fast& f, int lane) {
   __builtin_amdgcn_wave_barrier();
   fill_fast<GZ_FAST_LIT>(s.lit, s.len, f.lit_fast, lane);
   fill_fast<GZ_FAST_DIST>(s.dist, s.len + hlit, f.dist_fast, lane);
+  fill_wide(f, lane);
   return true;
 }
 
@@ -469,6 +502,7 @@ __device__ void fixed_codes_w(Fast& f, int lane) {
   __builtin_amdgcn_wave_barrier();
   fill_fast<GZ_FAST_LIT>(s.lit, s.len, f.lit_fast, lane);
   fill_fast<GZ_FAST_DIST>(s.dist, s.len + 288, f.dist_fast, lane);
+  fill_wide(f, lane);
 }
 
 // WRITE = false: the counting form (units that did not fit their region are counted exactly and decoded again)
@@ -537,12 +571,107 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
       // makes the loop's own copy of it a vector register whatever the loop does with it)
       b.buf = UNI64(b.buf); b.pos = UNI64(b.pos); b.cnt = (int)UNI((uint32_t)b.cnt); b.base = UNI64(b.base);
       w = UNI(w); wf = UNI(wf); b.over = UNI((uint32_t)b.over) != 0u;
+      // A match, one element per lane: element i comes from w - dist + i, or - where that is inside the match itself - from
+      // w - dist + (i mod dist).  In front of the unit: position 32768 - (dist - (w + i)) of the unknown window, as a marker; inside
+      // the ring (the last GZ_RING symbols, minus what this match overwrites): an LDS copy; further back: the symbol buffer, once
+      // everything the ring still holds has been written out and has arrived.
+      auto match = [&](uint32_t len, uint32_t dist) -> bool {
+        if (dist > w && (known || dist - w > 32768u)) { status = GZ_ERR_DIST; return false; }
+        const bool far = dist > (uint32_t)GZ_RING - 258u;                     // some source symbol may have left the ring
+        if (far) {
+          // Its sources lie GZ_RING - 516 symbols or more behind w: they left the ring in groups of 64 at least
+          // (GZ_RING - 516 - 385) / 64 = 17 stores ago.  Memory operations of a wavefront complete in the order of their issue for
+          // the counter, so "at most 8 still in flight" means those stores have arrived - no flush, no full wait.
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (len <= 64u && dist >= len && dist <= w && !far) {
+          // the common match in one step: at most 64 symbols, its source whole inside the ring and in front of the match (three
+          // scalar compares instead of the general loop's per-lane cases: self-overlap, markers, sources that left the ring)
+          if ((uint32_t)lane < len) f.ring[(w + (uint32_t)lane) & RM] = f.ring[(w - dist + (uint32_t)lane) & RM];
+        } else
+        for (uint32_t i = lane; i < len; i += 64) {
+          uint32_t j = i;
+          if (j >= dist) j = dist == 1 ? 0u : j % dist;      // (len > dist: a run; dist 1 is the common one)
+          const int32_t rel = (int32_t)(w - dist + j);          // (w <= 2^28, dist <= 32 Ki)
+          uint16_t x;
+          if (rel < 0) x = (uint16_t)(0x8000u | (uint32_t)(32768 + rel));
+          else if (far && (uint32_t)rel < wf) x = (uint32_t)rel < room ? __atomic_load_n(&out[rel], __ATOMIC_RELAXED) : (uint16_t)0;   // (past the region: the unit is decoded again anyway)
+          else x = f.ring[(uint32_t)rel & RM];
+          f.ring[(w + i) & RM] = x;
+        }
+        __builtin_amdgcn_wave_barrier();
+        w += len;
+        if (w - wf >= 64) flush(w & ~63u);
+        return true;
+      };
+      const uint64_t nbits = n * 8ull;
       for (;;) {
         if (!UNI(go)) break;
         // (the loop-carried state, said uniform once per symbol: the compiler keeps it in scalar registers from here to the back edge)
         b.buf = UNI64(b.buf); b.pos = UNI64(b.pos); b.cnt = (int)UNI((uint32_t)b.cnt); b.base = UNI64(b.base);
         w = UNI(w); wf = UNI(wf); b.over = UNI((uint32_t)b.over) != 0u;
         if (b.over) { status = GZ_ERR_OVER; bad = true; go = 0u; continue; }
+        // THE WINDOW DECODE.  The serial decode spends ~200 cycles on a literal and ~1 150 on a match (a wavefront on its own issues an
+        // instruction every four to five cycles, and a match is four dependent LDS round trips).  Here the 64 lanes decode
+        // SPECULATIVELY what starts at each of the next 64 bit offsets - lane i: the literal / length code at offset i with its extra
+        // bits and, behind them, a distance code with its extra bits, out of the wide tables: three LDS round trips for the whole
+        // window instead of four per match - and the scalar side then only follows the chain of the offsets that really start a
+        // symbol: v_readlane of lane p, act, p += bits used.
+        // An offset whose code is longer than the tables' (or invalid, or the end of the data near) is left to the serial path below,
+        // one symbol, after which the next window starts.
+        {
+          uint64_t P = b.bitpos();
+          uint32_t stop = 0u;                                // 1: this offset takes the serial path, 2: end of block, 3: error
+          if (P + 256u <= nbits) {
+            for (;;) {
+              P = UNI64(P); w = UNI(w); wf = UNI(wf); b.base = UNI64(b.base);
+              if (P + 256u > nbits) break;
+              if (w > (1u << 28)) { status = GZ_ERR_ROOM; stop = 3u; break; }
+              const uint64_t byte = P >> 3;
+              if (byte < b.base || byte + 24u > b.base + GZ_STAGE) b.restage(byte);
+              const uint32_t bo = (uint32_t)(P - b.base * 8ull) + (uint32_t)lane;
+              const uint32_t wi = bo >> 5, sh = bo & 31u;
+              const uint32_t a0 = f.stage[wi], a1 = f.stage[wi + 1], a2 = f.stage[wi + 2];
+              const uint64_t lo = (uint64_t)a0 | ((uint64_t)a1 << 32);
+              const uint64_t v = sh ? (lo >> sh) | ((uint64_t)a2 << (64u - sh)) : lo;          // 64 bits from this lane's offset on
+              const uint32_t e = f.lit_wide[(uint32_t)v & ((1u << GZ_FAST_LIT) - 1u)];
+              const uint32_t l = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
+              const uint32_t c1 = l + eb;
+              const uint32_t val = (e >> 16) + ((uint32_t)(v >> l) & ((1u << eb) - 1u));      // the literal, or the match's length
+              const uint64_t v2 = v >> c1;
+              const uint32_t e2 = f.dist_wide[(uint32_t)v2 & ((1u << GZ_FAST_DIST) - 1u)];
+              const uint32_t l2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
+              const uint32_t R1 = (e2 >> 16) + ((uint32_t)(v2 >> l2) & ((1u << eb2) - 1u));   // the distance, were this a match
+              uint32_t cons = c1;
+              if (kind == 1u) cons = l2 ? c1 + l2 + eb2 : 0u;
+              if (l == 0u) cons = 0u;
+              const uint32_t R0 = cons | (kind << 8) | (val << 16);
+              uint32_t p = 0u;
+              while (p < 64u) {
+                const uint32_t r0 = __builtin_amdgcn_readlane(R0, (int)p);
+                const uint32_t used = r0 & 0xFFu, kd = (r0 >> 8) & 3u;
+                if (used == 0u) { stop = 1u; break; }
+                if (kd == 0u) {
+                  if (lane == 0) f.ring[w & RM] = (uint16_t)(r0 >> 16);
+                  ++w;
+                  if ((w & 63u) == 0u && w - wf >= 64u) flush(w);
+                } else if (kd == 2u) { p += used; stop = 2u; break; }
+                else {
+                  const uint32_t r1 = __builtin_amdgcn_readlane(R1, (int)p);
+                  if (!match(r0 >> 16, r1)) { stop = 3u; break; }
+                }
+                p += used;
+              }
+              P += p;
+              if (stop) break;
+            }
+            b.seek(P);
+          }
+          if (stop == 2u) { go = 0u; continue; }
+          if (stop == 3u) { bad = true; go = 0u; continue; }
+        }
+        // one symbol by the serial decode
         const uint32_t v = b.peek(15);
         {
           const uint32_t q = __builtin_amdgcn_readlane(t6, (int)(v & 63u));
@@ -584,37 +713,7 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
         if (ds < 0 || ds >= 30) { status = GZ_ERR_CODE; bad = true; go = 0u; continue; }
         const uint32_t dt = UNI(f.dist_tab[ds]);
         const uint32_t dist = (dt & 0xFFFFu) + b.get((int)(dt >> 16));
-        if (dist > w && (known || dist - w > 32768u)) { status = GZ_ERR_DIST; bad = true; go = 0u; continue; }
-        // The match, one element per lane: element i comes from w - dist + i, or - where that is inside the match itself - from
-        // w - dist + (i mod dist).  In front of the unit: position 32768 - (dist - (w + i)) of the unknown window, as a marker; inside
-        // the ring (the last GZ_RING symbols, minus what this match overwrites): an LDS copy; further back: the symbol buffer, once
-        // everything the ring still holds has been written out and has arrived.
-        const bool far = dist > (uint32_t)GZ_RING - 258u;                     // some source symbol may have left the ring
-        if (far) {
-          // Its sources lie GZ_RING - 516 symbols or more behind w: they left the ring in groups of 64 at least
-          // (GZ_RING - 516 - 385) / 64 = 17 stores ago.  Memory operations of a wavefront complete in the order of their issue for
-          // the counter, so "at most 8 still in flight" means those stores have arrived - no flush, no full wait.
-          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (len <= 64u && dist >= len && dist <= w && !far) {
-          // the common match in one step: at most 64 symbols, its source whole inside the ring and in front of the match (three
-          // scalar compares instead of the general loop's per-lane cases: self-overlap, markers, sources that left the ring)
-          if ((uint32_t)lane < len) f.ring[(w + (uint32_t)lane) & RM] = f.ring[(w - dist + (uint32_t)lane) & RM];
-        } else
-        for (uint32_t i = lane; i < len; i += 64) {
-          uint32_t j = i;
-          if (j >= dist) j = dist == 1 ? 0u : j % dist;      // (len > dist: a run; dist 1 is the common one)
-          const int32_t rel = (int32_t)(w - dist + j);          // (w <= 2^28, dist <= 32 Ki)
-          uint16_t x;
-          if (rel < 0) x = (uint16_t)(0x8000u | (uint32_t)(32768 + rel));
-          else if (far && (uint32_t)rel < wf) x = (uint32_t)rel < room ? __atomic_load_n(&out[rel], __ATOMIC_RELAXED) : (uint16_t)0;   // (past the region: the unit is decoded again anyway)
-          else x = f.ring[(uint32_t)rel & RM];
-          f.ring[(w + i) & RM] = x;
-        }
-        __builtin_amdgcn_wave_barrier();
-        w += len;
-        if (w - wf >= 64) flush(w & ~63u);
+        if (!match(len, dist)) { bad = true; go = 0u; continue; }
       }
       if (bad) break;
     } else { status = GZ_ERR_TYPE; break; }
