@@ -741,20 +741,27 @@ gz_decode_members_kernel(const uint8_t* __restrict__ d, uint64_t n, GzUnit* __re
 }
 
 // ---- 3: windows in chain order --------------------------------------------------------------------------------------------
-// win_in[u] = the 32 KiB in front of unit u (bytes); the member starts with an empty (zero) window that nothing refers to.
-// One block per member; a step reads the unit's last 32 Ki symbols (32 per thread, loaded before any is used), resolves them
-// against the window in LDS and writes the next window.
-__global__ void __launch_bounds__(1024) gz_window_kernel(const GzUnit* __restrict__ units, uint32_t n_units, const uint16_t* __restrict__ sym,
-                                                        uint8_t* __restrict__ win_in) {
-  __shared__ uint8_t w0[32768];
-  __shared__ uint8_t w1[32768];
-  uint8_t* cur = w0; uint8_t* nxt = w1;
+// The 32 KiB in front of unit u: the last 32 Ki bytes of (the window in front of unit u - 1 ++ unit u - 1 resolved against it) - a
+// chain through all units.  One unit's step is a MAP of window positions: entry t of the new window is a byte, or position i of the
+// old one (0x8000 | i).  Maps compose, so the chain is cut into groups of ~sqrt(units) units:
+//   gz_compose_kernel   a block per group, all groups at once: the units' maps composed in chain order, from the identity on, in LDS
+//                       (two maps of 64 KiB); pmap[u] = the map from the window in front of the GROUP to the window in front of unit u,
+//                       qmap[g] = the same over the whole group;
+//   gz_chain_kernel     one block: the windows in front of the groups (wg[g]), one qmap applied per step - sqrt(units) steps where
+//                       the chain over single units took one step per unit (10.8 ms of the 53 for 2 404 units; now 0.5);
+//   gz_resolve2_kernel  looks a marker up in two steps: pmap[u], and - where that entry is a position again - wg[group of u].
+__global__ void __launch_bounds__(1024) gz_compose_kernel(const GzUnit* __restrict__ units, uint32_t n_units, uint32_t group, const uint16_t* __restrict__ sym,
+                                                         uint16_t* __restrict__ pmap, uint16_t* __restrict__ qmap) {
+  extern __shared__ uint16_t gz_lds_maps[];             // 2 x 32 Ki entries
+  uint16_t* cur = gz_lds_maps; uint16_t* nxt = gz_lds_maps + 32768;
   const int tid = threadIdx.x;
-  for (int i = tid; i < 32768; i += 1024) cur[i] = 0;
+  const uint32_t u0 = blockIdx.x * group, u1 = u0 + group < n_units ? u0 + group : n_units;
+  if (u0 >= n_units) return;
+  for (int i = tid; i < 32768; i += 1024) cur[i] = (uint16_t)(0x8000u | (uint32_t)i);
   // the unit's symbols are loaded ONE UNIT AHEAD (its descriptor two ahead): a step then waits for no global load
   uint16_t x[32];
-  unsigned long long m = n_units ? units[0].n_sym : 0, so = n_units ? units[0].sym_off : 0;
-  unsigned long long m1 = n_units > 1 ? units[1].n_sym : 0, so1 = n_units > 1 ? units[1].sym_off : 0;
+  unsigned long long m = units[u0].n_sym, so = units[u0].sym_off;
+  unsigned long long m1 = u0 + 1 < u1 ? units[u0 + 1].n_sym : 0, so1 = u0 + 1 < u1 ? units[u0 + 1].sym_off : 0;
   auto fetch = [&](unsigned long long mm, unsigned long long off) {
     const uint16_t* s = sym + off;
 #pragma unroll
@@ -763,22 +770,66 @@ __global__ void __launch_bounds__(1024) gz_window_kernel(const GzUnit* __restric
       x[j] = q >= 32768 ? s[q - 32768] : (uint16_t)0xFFFF;
     }
   };
-  if (n_units) fetch(m, so);
+  fetch(m, so);
   __syncthreads();
-  for (uint32_t u = 0; u < n_units; ++u) {
-    uint8_t* keep = win_in + (size_t)u * 32768;
-    for (int i = tid * 8; i < 32768; i += 8192) *(uint2*)(keep + i) = *(const uint2*)(cur + i);
+  for (uint32_t u = u0; u < u1; ++u) {
+    uint16_t* keep = pmap + (size_t)u * 32768;
+    for (int i = tid * 8; i < 32768; i += 8192) *(uint4*)(keep + i) = *(const uint4*)(cur + i);
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       const int t = tid + 1024 * j;
       const unsigned long long q = (unsigned long long)t + m;
-      nxt[t] = q < 32768 ? cur[q] : (x[j] < 0x8000u ? (uint8_t)x[j] : cur[x[j] & 0x7FFFu]);
+      nxt[t] = q < 32768 ? cur[q] : (x[j] < 0x8000u ? x[j] : cur[x[j] & 0x7FFFu]);
     }
     m = m1; so = so1;
-    if (u + 1 < n_units) fetch(m, so);
-    if (u + 2 < n_units) { m1 = units[u + 2].n_sym; so1 = units[u + 2].sym_off; }
+    if (u + 1 < u1) fetch(m, so);
+    if (u + 2 < u1) { m1 = units[u + 2].n_sym; so1 = units[u + 2].sym_off; }
+    __syncthreads();
+    uint16_t* t_ = cur; cur = nxt; nxt = t_;
+  }
+  uint16_t* q = qmap + (size_t)blockIdx.x * 32768;
+  for (int i = tid * 8; i < 32768; i += 8192) *(uint4*)(q + i) = *(const uint4*)(cur + i);
+}
+
+// wg[g] = the 32 KiB in front of group g (bytes); the member starts with an empty (zero) window that nothing refers to.
+__global__ void __launch_bounds__(1024) gz_chain_kernel(const uint16_t* __restrict__ qmap, uint32_t n_groups, uint8_t* __restrict__ wg) {
+  __shared__ uint8_t w0[32768];
+  __shared__ uint8_t w1[32768];
+  uint8_t* cur = w0; uint8_t* nxt = w1;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 32768; i += 1024) cur[i] = 0;
+  uint16_t x[32];
+  auto fetch = [&](uint32_t g) {
+    const uint16_t* q = qmap + (size_t)g * 32768;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) x[j] = q[tid + 1024 * j];
+  };
+  if (n_groups) fetch(0);
+  __syncthreads();
+  for (uint32_t g = 0; g < n_groups; ++g) {
+    uint8_t* keep = wg + (size_t)g * 32768;
+    for (int i = tid * 8; i < 32768; i += 8192) *(uint2*)(keep + i) = *(const uint2*)(cur + i);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) nxt[tid + 1024 * j] = x[j] < 0x8000u ? (uint8_t)x[j] : cur[x[j] & 0x7FFFu];
+    if (g + 1 < n_groups) fetch(g + 1);
     __syncthreads();
     uint8_t* t_ = cur; cur = nxt; nxt = t_;
+  }
+}
+
+__global__ void __launch_bounds__(256) gz_resolve2_kernel(const GzUnit* __restrict__ units, uint32_t n_units, uint32_t group, const uint16_t* __restrict__ sym,
+                                                         const uint16_t* __restrict__ pmap, const uint8_t* __restrict__ wg, uint8_t* __restrict__ text,
+                                                         uint32_t blocks_per_unit) {
+  const uint32_t u = blockIdx.x / blocks_per_unit, part = blockIdx.x % blocks_per_unit;
+  if (u >= n_units) return;
+  const uint64_t m = units[u].n_sym, off = units[u].out_off;
+  const uint16_t* s = sym + units[u].sym_off;
+  const uint16_t* pm = pmap + (size_t)u * 32768;
+  const uint8_t* w = wg + (size_t)(u / group) * 32768;
+  for (uint64_t i = (uint64_t)part * 256 + threadIdx.x; i < m; i += (uint64_t)blocks_per_unit * 256) {
+    uint16_t x = s[i];
+    if (x >= 0x8000u) { x = pm[x & 0x7FFFu]; if (x >= 0x8000u) x = w[x & 0x7FFFu]; }
+    text[off + i] = (uint8_t)x;
   }
 }
 
@@ -1116,7 +1167,8 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   const uint32_t isize = (uint32_t)p[n + 4] | ((uint32_t)p[n + 5] << 8) | ((uint32_t)p[n + 6] << 16) | ((uint32_t)p[n + 7] << 24);
   if (crc32_expected) *crc32_expected = crc;
   uint8_t* d_in = nullptr; unsigned long long* d_start = nullptr; GzUnit* d_units = nullptr; uint16_t* d_sym = nullptr;
-  uint8_t* d_win = nullptr; uint8_t* d_out = nullptr;
+  uint16_t* d_pmap = nullptr; uint16_t* d_qmap = nullptr; uint8_t* d_wg = nullptr; uint8_t* d_out = nullptr;
+  uint32_t group = 1, n_groups = 0;
   const uint32_t n_chunks = (uint32_t)((n + GZ_CHUNK - 1) / GZ_CHUNK);
   std::vector<unsigned long long> h_start(n_chunks);
   std::vector<GzUnit> units, chain;
@@ -1198,7 +1250,11 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   GZTRY(hipGetLastError());
   GZTRY(hipMemcpyAsync(units.data(), d_units, units.size() * sizeof(GzUnit), hipMemcpyDeviceToHost, s));
   GZTRY(dev_alloc((void**)&d_chain, units.size() * sizeof(GzUnit)));           // (while the decode runs)
-  GZTRY(dev_alloc((void**)&d_win, units.size() * (size_t)32768));
+  while ((size_t)group * group < units.size()) ++group;                          // units per group of the window chain: ~sqrt(units)
+  n_groups = (uint32_t)((units.size() + group - 1) / group);
+  GZTRY(dev_alloc((void**)&d_pmap, units.size() * (size_t)65536));
+  GZTRY(dev_alloc((void**)&d_qmap, (size_t)n_groups * 65536));
+  GZTRY(dev_alloc((void**)&d_wg, (size_t)n_groups * 32768));
   GZTRY(hipStreamSynchronize(s));
   lap("decode");
   if (timing) {
@@ -1255,10 +1311,18 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
   for (uint32_t i : chain_idx) chain.push_back(units[i]);
   GZTRY(hipMemcpyAsync(d_chain, chain.data(), chain.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
   if (!d_out) GZTRY(hipMalloc(&d_out, total + 64));
-  gz_window_kernel<<<1, 1024, 0, s>>>(d_chain, (uint32_t)chain.size(), d_sym, d_win);
+  n_groups = (uint32_t)((chain.size() + group - 1) / group);
+  {
+    static std::once_flag lds_once; static hipError_t lds_rc = hipSuccess;
+    std::call_once(lds_once, [] { lds_rc = hipFuncSetAttribute((const void*)gz_compose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536); });
+    GZTRY(lds_rc);
+  }
+  gz_compose_kernel<<<n_groups, 1024, 2 * 65536, s>>>(d_chain, (uint32_t)chain.size(), group, d_sym, d_pmap, d_qmap);
+  GZTRY(hipGetLastError());
+  gz_chain_kernel<<<1, 1024, 0, s>>>(d_qmap, n_groups, d_wg);
   GZTRY(hipGetLastError());
   lap("windows");
-  gz_resolve_kernel<<<(unsigned)chain.size() * 8u, 256, 0, s>>>(d_chain, (uint32_t)chain.size(), d_sym, d_win, d_out, 8);
+  gz_resolve2_kernel<<<(unsigned)chain.size() * 8u, 256, 0, s>>>(d_chain, (uint32_t)chain.size(), group, d_sym, d_pmap, d_wg, d_out, 8);
   GZTRY(hipGetLastError());
   {
     const size_t n_pieces = (size_t)((total + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE);
@@ -1295,10 +1359,10 @@ extern "C" int mic_gz_reserve(mic_engine* e, size_t gz_bytes, uint32_t isize) {
   const uint32_t n_chunks = (uint32_t)((n + GZ_CHUNK - 1) / GZ_CHUNK);
   GzReserve r;
   r.eng = e; r.gz_bytes = gz_bytes;
-  // input, block starts, units and chain, symbols by their bound, windows for a third of the chunks (a block of gzip's is three
+  // input, block starts, units and chain, symbols by their bound, window maps (64 KiB a unit) for a third of the chunks (a block of gzip's is three
   // chunks and more; a file of smaller blocks gets the rest of its windows from hipMalloc)
   r.scratch_bytes = up256(n + 16) + up256((size_t)n_chunks * 8) + 2 * up256((size_t)n_chunks * sizeof(GzUnit)) +
-                    up256((sym_bound_of(n, n_chunks) + 8) * 2) + up256(((size_t)n_chunks / 3 + 64) * 32768) + up256(((size_t)isize / GZ_CRC_PIECE + 2) * 4) + 4096;
+                    up256((sym_bound_of(n, n_chunks) + 8) * 2) + up256(((size_t)n_chunks / 3 + 64) * 65536) + 2 * up256(((size_t)n_chunks / 24 + 64) * 65536) + up256(((size_t)isize / GZ_CRC_PIECE + 2) * 4) + 4096;
   hipError_t he = hipMalloc(&r.scratch, r.scratch_bytes);
   if (he == hipSuccess && (unsigned long long)isize <= 1100ull * n) {
     r.text_bytes = (size_t)isize + 64;
