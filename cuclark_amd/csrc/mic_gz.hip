@@ -198,47 +198,148 @@ __device__ void fixed_codes(Scratch& s) {
 }
 
 // ---- 1: block finder ----------------------------------------------------------------------------------------------------
-__device__ bool candidate(const uint8_t* d, uint64_t n, uint64_t bit) {      // the cheap tests, every lane its own offset
-  const uint64_t byte = bit >> 3;
-  if (byte + 12 >= n) return false;
-  // 3 + 14 + 19 x 3 = 74 bits from `bit` on
-  const uint8_t* s = d + byte;
-  uint64_t lo = 0, hi = 0;
-  for (int i = 0; i < 8; ++i) lo |= (uint64_t)s[i] << (8 * i);
-  for (int i = 0; i < 4; ++i) hi |= (uint64_t)s[8 + i] << (8 * i);
-  const int sh = (int)(bit & 7);
-  uint64_t a = (lo >> sh) | (sh ? hi << (64 - sh) : 0);                        // bits 0..63 from `bit`
-  const uint64_t b2 = hi >> sh;                                                 // bits 64.. from `bit`
-  if ((a & 6u) != 4u) return false;                                             // BTYPE = 2 (BFINAL either way: the member's last block is a unit like any other)
-  const uint32_t hlit = (uint32_t)(a >> 3) & 31u, hdist = (uint32_t)(a >> 8) & 31u, hclen = ((uint32_t)(a >> 13) & 15u) + 4u;
-  if (hlit > 29u || hdist > 29u) return false;
-  uint32_t sum = 0;
-  for (uint32_t i = 0; i < hclen; ++i) {
-    const uint32_t at = 17u + 3u * i;                                           // bit offset of this 3-bit length
-    const uint32_t l = at + 3u <= 64u ? (uint32_t)(a >> at) & 7u
-                                     : (at >= 64u ? (uint32_t)(b2 >> (at - 64u)) & 7u : (uint32_t)((a >> at) | (b2 << (64u - at))) & 7u);
-    if (l) sum += 1u << (15 - l);
+// The finder's input comes out of LDS: the chunk's 8 KiB and 1 KiB behind them (a dynamic header is 562 bytes at most), staged once.
+constexpr uint32_t GZ_FIND_STAGE = GZ_CHUNK + 1024;
+struct LBits {                                 // Bits on the staged bytes [base, base + GZ_FIND_STAGE) of the data
+  const uint32_t* st; uint64_t base, n, pos, buf; int cnt; bool over;
+  __device__ void init(const uint32_t* stage, uint64_t stage_base, uint64_t len, uint64_t bitpos) {
+    st = stage; base = stage_base; n = len; pos = bitpos >> 3; buf = 0; cnt = 0; over = false;
+    refill();
+    const int skip = (int)(bitpos & 7);
+    buf >>= skip; cnt -= skip;
   }
-  return sum == (1u << 15);
+  __device__ void refill() {
+    const int add = (63 - cnt) >> 3;
+    if (pos >= n + 8 || pos + 12 > base + GZ_FIND_STAGE) { over = true; pos += (uint64_t)add; cnt += add * 8; return; }   // (behind the stage: no header reaches that far)
+    const uint32_t o = (uint32_t)(pos - base), w = o >> 2, sh = (o & 3u) * 8u;
+    const uint32_t a0 = st[w], a1 = st[w + 1], a2 = st[w + 2];
+    const uint64_t lo = (uint64_t)a0 | ((uint64_t)a1 << 32);
+    const uint64_t v = sh ? (lo >> sh) | ((uint64_t)a2 << (64u - sh)) : lo;
+    buf |= v << cnt;
+    pos += (uint64_t)add; cnt += add * 8;
+  }
+  __device__ uint32_t peek(int k) { if (cnt < k) refill(); return (uint32_t)(buf & ((1ull << k) - 1)); }
+  __device__ void drop(int k) { buf >>= k; cnt -= k; }
+  __device__ uint32_t get(int k) { const uint32_t v = peek(k); drop(k); return v; }
+};
+
+// The cheap tests, every lane its own offset, on the 74 bits of a dynamic header's fixed part (rel = the offset - 8 x the stage's
+// first byte).  first_test: BTYPE and the two counts - 17 bits, a fifth of all offsets pass.  kraft_test: the code-length code
+// exactly complete - its up to 19 lengths of 3 bits as two words of ten and nine fields, the ones behind HCLEN masked off, and
+// (0x80 >> l) & 0x7f = 2^(7 - l) for a length l, 0 for none: the sum has to be 128.  32-bit arithmetic, no loop over HCLEN.
+__device__ __forceinline__ bool first_test(const uint32_t* st, uint32_t rel) {
+  const uint32_t w = rel >> 5, sh = rel & 31u;
+  const uint32_t v = __builtin_amdgcn_alignbit(st[w + 1], st[w], sh);
+  return (v & 6u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u;     // BTYPE = 2 (BFINAL either way: the member's last block is a unit like any other)
+}
+__device__ __forceinline__ bool kraft_test(const uint32_t* st, uint32_t rel) {
+  const uint32_t w = rel >> 5, sh = rel & 31u;
+  const uint32_t a0 = st[w], a1 = st[w + 1], a2 = st[w + 2], a3 = st[w + 3];
+  const uint32_t s0 = __builtin_amdgcn_alignbit(a1, a0, sh), s1 = __builtin_amdgcn_alignbit(a2, a1, sh), s2 = __builtin_amdgcn_alignbit(a3, a2, sh);
+  const uint32_t hclen = ((s0 >> 13) & 15u) + 4u;
+  uint32_t f0 = ((s0 >> 17) | (s1 << 15)) & 0x3FFFFFFFu;                        // lengths 0..9: bits 17..46
+  uint32_t f1 = ((s1 >> 15) | (s2 << 17)) & 0x07FFFFFFu;                        // lengths 10..18: bits 47..73
+  if (hclen <= 10u) { f0 &= (1u << (3u * hclen)) - 1u; f1 = 0u; }
+  else f1 &= (1u << (3u * (hclen - 10u))) - 1u;
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) sum += (0x80u >> ((f0 >> (3 * i)) & 7u)) & 0x7Fu;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sum += (0x80u >> ((f1 >> (3 * i)) & 7u)) & 0x7Fu;
+  return sum == 128u;
 }
 
+// What read_dynamic(strict) decides, without keeping the codes: one lane, its own candidate - 64 candidates at a time.  The
+// code-length code's table is the lane's column of an LDS array (pre[v * 64]), the 19 lengths one 57-bit number, and the two codes'
+// Kraft sums, the number of distance codes and the end-of-block code's length are kept up as the lengths are read.
+__device__ bool header_holds(const uint32_t* st, uint64_t st_base, uint64_t n, uint64_t at, uint8_t* pre) {
+  LBits b; b.init(st, st_base, n, at + 3);
+  const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
+  if (hlit > 286 || hdist > 30) return false;
+  uint64_t cl = 0;
+  for (int i = 0; i < hclen; ++i) cl |= (uint64_t)b.get(3) << (3 * (int)c_cl_order[i]);
+  {
+    uint32_t ks = 0;
+    for (int sy = 0; sy < 19; ++sy) { const uint32_t l = (uint32_t)(cl >> (3 * sy)) & 7u; if (l) ks += 1u << (15 - l); }
+    if (ks != (1u << 15)) return false;                    // (complete: every 7-bit index below gets its entry)
+  }
+  {
+    uint32_t code = 0;
+    for (uint32_t l = 1; l <= 7; ++l) {
+      for (int sy = 0; sy < 19; ++sy) {
+        if (((uint32_t)(cl >> (3 * sy)) & 7u) != l) continue;
+        const uint32_t r = __builtin_bitreverse32(code) >> (32 - l);
+        for (uint32_t v = r; v < 128; v += 1u << l) pre[v * 64] = (uint8_t)((l << 5) | (uint32_t)sy);
+        ++code;
+      }
+      code <<= 1;
+    }
+  }
+  const int total = hlit + hdist;
+  int at_n = 0, prev = 0;
+  uint32_t kl = 0, kd = 0, used = 0, len256 = 0;
+  while (at_n < total) {
+    const uint32_t e = pre[b.peek(7) * 64];
+    b.drop((int)(e >> 5));
+    const int sy = (int)(e & 31u);
+    int rep = 1, val = 0;
+    if (sy < 16) val = sy;
+    else if (sy == 16) { if (at_n == 0) return false; val = prev; rep = 3 + (int)b.get(2); }
+    else if (sy == 17) rep = 3 + (int)b.get(3);
+    else rep = 11 + (int)b.get(7);
+    if (at_n + rep > total) return false;
+    if (val) {
+      const int a = at_n < hlit ? (rep < hlit - at_n ? rep : hlit - at_n) : 0;      // how many of them are literal / length codes
+      kl += (uint32_t)a << (15 - val);
+      kd += (uint32_t)(rep - a) << (15 - val);
+      used += (uint32_t)(rep - a);
+    }
+    if (at_n <= 256 && 256 < at_n + rep) len256 = (uint32_t)val;
+    at_n += rep; prev = val;
+    if (kl > (1u << 15) || kd > (1u << 15)) return false;          // (over-subscribed already: what the sums below would say at the end)
+  }
+  if (b.over || len256 == 0) return false;
+  if (kl != (1u << 15)) return false;
+  if (kd > (1u << 15)) return false;
+  if (kd < (1u << 15) && used > 1) return false;
+  return true;
+}
+
+// The finder is arithmetic: 65 536 offsets a chunk.  Every offset takes first_test (a dozen instructions); the fifth that pass are
+// COLLECTED and take kraft_test 64 at a time (all lanes busy - tested in place, three lanes in four would idle through the
+// nineteen lengths); the ~65 a chunk that pass that are collected again and go through their whole header side by side
+// (header_holds), and only those whose header holds - one in thousands is not a block - take the one-lane path with its codes and
+// the trial decode.  In the order of the offsets throughout: the first start of the chunk is the answer.
 __global__ void __launch_bounds__(64) gz_find_kernel(const uint8_t* __restrict__ d, uint64_t n, uint64_t first_bit, uint32_t n_chunks,
                                                     unsigned long long* __restrict__ start) {
   __shared__ Scratch sc;
+  __shared__ uint8_t pre_l[128 * 64];
+  __shared__ uint32_t cand[192];
+  __shared__ uint32_t pend[192];
+  __shared__ uint32_t stg[GZ_FIND_STAGE / 4 + 4];
   const uint32_t c = blockIdx.x;
   const int lane = threadIdx.x;
   if (c >= n_chunks) return;
   if (c == 0) { if (lane == 0) start[0] = first_bit; return; }
   const uint64_t from = (uint64_t)c * GZ_CHUNK * 8, to = (uint64_t)(c + 1) * GZ_CHUNK * 8 < n * 8 ? (uint64_t)(c + 1) * GZ_CHUNK * 8 : n * 8;
+  const uint64_t st_base = (uint64_t)c * GZ_CHUNK;                 // (d is 256-byte aligned, a chunk a multiple of 4 bytes)
+  for (uint32_t i = lane; i < GZ_FIND_STAGE / 4 + 4; i += 64) {
+    const uint64_t byte = st_base + 4ull * i;
+    stg[i] = byte + 4 <= n + 16 ? *(const uint32_t*)(d + byte) : 0u;
+  }
+  __builtin_amdgcn_wave_barrier();
   unsigned long long found = ~0ull;
-  for (uint64_t base = from > first_bit ? from : first_bit + 1; base < to && found == ~0ull; base += 64) {
-    const uint64_t bit = base + (uint64_t)lane;
-    const bool cand = bit < to && candidate(d, n, bit);
-    unsigned long long m = __ballot(cand);
+  uint32_t n_c = 0;
+  // the first `cnt` collected candidates, in the order of their offsets
+  auto batch = [&](uint32_t cnt) {
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t mine = from + (uint64_t)cand[(uint32_t)lane < cnt ? lane : 0];
+    const bool holds = (uint32_t)lane < cnt && header_holds(stg, st_base, n, mine, pre_l + lane);
+    unsigned long long m = __ballot(holds);
     while (m && found == ~0ull) {
       const int l = __builtin_ctzll(m);
       m &= m - 1;
-      const uint64_t at = base + (uint64_t)l;
+      const uint64_t at = from + (uint64_t)cand[l];
       int good = 0;
       if (lane == 0) {
         Bits b; b.init(d, n, at + 3);
@@ -260,7 +361,48 @@ __global__ void __launch_bounds__(64) gz_find_kernel(const uint8_t* __restrict__
       good = __shfl(good, 0);
       if (good) found = at;
     }
+    __builtin_amdgcn_wave_barrier();
+    // the rest of the list moves up
+    const uint32_t left = n_c - cnt;
+    uint32_t keep0 = 0, keep1 = 0;
+    if ((uint32_t)lane < left) keep0 = cand[cnt + (uint32_t)lane];
+    if ((uint32_t)lane + 64u < left) keep1 = cand[cnt + (uint32_t)lane + 64u];
+    __builtin_amdgcn_wave_barrier();
+    if ((uint32_t)lane < left) cand[lane] = keep0;
+    if ((uint32_t)lane + 64u < left) cand[lane + 64] = keep1;
+    n_c = left;
+    __builtin_amdgcn_wave_barrier();
+  };
+  uint32_t n_p = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // the first `cnt` offsets that passed first_test through kraft_test; what passes joins the candidates
+  auto sift = [&](uint32_t cnt) {
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t rel = pend[(uint32_t)lane < cnt ? lane : 0];
+    const bool is = (uint32_t)lane < cnt && kraft_test(stg, rel);
+    const unsigned long long m = __ballot(is);
+    if (is) cand[n_c + (uint32_t)__builtin_popcountll(m & below)] = rel;
+    n_c += (uint32_t)__builtin_popcountll(m);
+    const uint32_t left = n_p - cnt;
+    uint32_t keep0 = 0;
+    if ((uint32_t)lane < left) keep0 = pend[cnt + (uint32_t)lane];               // (left < 64: a step adds 64 at most to fewer than 64)
+    __builtin_amdgcn_wave_barrier();
+    if ((uint32_t)lane < left) pend[lane] = keep0;
+    n_p = left;
+    __builtin_amdgcn_wave_barrier();
+    if (n_c >= 64u) batch(64u);
+  };
+  for (uint64_t base = from > first_bit ? from : first_bit + 1; base < to && found == ~0ull; base += 64) {
+    const uint64_t bit = base + (uint64_t)lane;
+    const uint32_t rel = (uint32_t)(bit - from);
+    const bool is = bit < to && (bit >> 3) + 12 < n && first_test(stg, rel);
+    const unsigned long long m = __ballot(is);
+    if (is) pend[n_p + (uint32_t)__builtin_popcountll(m & below)] = rel;
+    n_p += (uint32_t)__builtin_popcountll(m);
+    if (n_p >= 64u) sift(64u);
   }
+  while (n_p && found == ~0ull) sift(n_p);
+  while (n_c && found == ~0ull) batch(n_c < 64u ? n_c : 64u);
   if (lane == 0) start[c] = found;
 }
 
