@@ -786,23 +786,43 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
               const uint32_t l2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
               const uint32_t R1 = (e2 >> 16) + ((uint32_t)(v2 >> l2) & ((1u << eb2) - 1u));   // the distance, were this a match
               uint32_t cons = c1;
-              if (kind == 1u) cons = l2 ? c1 + l2 + eb2 : 0u;
+              const bool deep = w >= (uint32_t)GZ_RING;          // (then every distance of a common match lies inside the unit's own output)
+              uint32_t kd_l = kind;                              // 0 literal, 1 match (or: the serial path), 2 end of block, 3 THE COMMON MATCH: at
+              if (kind == 1u) {                                  // most 64 symbols, its source in front of it and inside the ring - decided here,
+                cons = l2 ? c1 + l2 + eb2 : 0u;                  // by every lane for its offset
+                if (deep && val <= 64u && R1 >= val && R1 <= (uint32_t)GZ_RING - 258u) kd_l = 3u;
+              }
               if (l == 0u) cons = 0u;
-              const uint32_t R0 = cons | (kind << 8) | (val << 16);
+              if (cons == 0u) kd_l = 1u;
+              const uint32_t R0 = cons | (kd_l << 8) | (val << 16);
               uint32_t p = 0u;
-              while (p < 64u) {
-                const uint32_t r0 = __builtin_amdgcn_readlane(R0, (int)p);
-                const uint32_t used = r0 & 0xFFu, kd = (r0 >> 8) & 3u;
-                if (used == 0u) { stop = 1u; break; }
-                if (kd == 0u) {
-                  if (lane == 0) f.ring[w & RM] = (uint16_t)(r0 >> 16);
-                  ++w;
-                  if ((w & 63u) == 0u && w - wf >= 64u) flush(w);
-                } else if (kd == 2u) { p += used; stop = 2u; break; }
-                else {
-                  const uint32_t r1 = __builtin_amdgcn_readlane(R1, (int)p);
-                  if (!match(r0 >> 16, r1)) { stop = 3u; break; }
+              for (;;) {
+                // literals and common matches: a loop of its own, two branches a symbol (one loop over all kinds came out of the
+                // compiler as eight branches a symbol, and a taken branch costs a wavefront on its own ~20 cycles)
+                while (p < 64u) {
+                  const uint32_t r0 = __builtin_amdgcn_readlane(R0, (int)p);
+                  const uint32_t kd = (r0 >> 8) & 3u;
+                  if (kd == 3u) {
+                    const uint32_t r1 = __builtin_amdgcn_readlane(R1, (int)p);
+                    const uint32_t len = r0 >> 16;
+                    if ((uint32_t)lane < len) f.ring[(w + (uint32_t)lane) & RM] = f.ring[(w - r1 + (uint32_t)lane) & RM];
+                    w += len;
+                    if (w - wf >= 64u) flush(w & ~63u);
+                  } else if (kd == 0u) {
+                    if (lane == 0) f.ring[w & RM] = (uint16_t)(r0 >> 16);
+                    ++w;
+                    if ((w & 63u) == 0u && w - wf >= 64u) flush(w);
+                  } else break;
+                  p += r0 & 0xFFu;
                 }
+                if (p >= 64u) break;
+                // everything else, one symbol
+                const uint32_t r0 = __builtin_amdgcn_readlane(R0, (int)p);
+                const uint32_t used = r0 & 0xFFu;
+                if (used == 0u) { stop = 1u; break; }
+                if (((r0 >> 8) & 3u) == 2u) { p += used; stop = 2u; break; }
+                const uint32_t r1 = __builtin_amdgcn_readlane(R1, (int)p);
+                if (!match(r0 >> 16, r1)) { stop = 3u; break; }
                 p += used;
               }
               P += p;
