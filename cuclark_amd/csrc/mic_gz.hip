@@ -200,6 +200,7 @@ __device__ void fixed_codes(Scratch& s) {
 // ---- 1: block finder ----------------------------------------------------------------------------------------------------
 // The finder's input comes out of LDS: the chunk's 8 KiB and 1 KiB behind them (a dynamic header is 562 bytes at most), staged once.
 constexpr uint32_t GZ_FIND_STAGE = GZ_CHUNK + 1024;
+constexpr uint32_t GZ_PEND = 1024;          // offsets that passed the first test and wait for the second (a step adds 512 at most to fewer than 64)
 struct LBits {                                 // Bits on the staged bytes [base, base + GZ_FIND_STAGE) of the data
   const uint32_t* st; uint64_t base, n, pos, buf; int cnt; bool over;
   __device__ void init(const uint32_t* stage, uint64_t stage_base, uint64_t len, uint64_t bitpos) {
@@ -224,14 +225,10 @@ struct LBits {                                 // Bits on the staged bytes [base
 };
 
 // The cheap tests, every lane its own offset, on the 74 bits of a dynamic header's fixed part (rel = the offset - 8 x the stage's
-// first byte).  first_test: BTYPE and the two counts - 17 bits, a fifth of all offsets pass.  kraft_test: the code-length code
+// first byte).  The first test (in the kernel's loop): BTYPE = 2 (BFINAL either way: the member's last block is a unit like any other) and the two
+// counts - 17 bits, a fifth of all offsets pass.  kraft_test: the code-length code
 // exactly complete - its up to 19 lengths of 3 bits as two words of ten and nine fields, the ones behind HCLEN masked off, and
 // (0x80 >> l) & 0x7f = 2^(7 - l) for a length l, 0 for none: the sum has to be 128.  32-bit arithmetic, no loop over HCLEN.
-__device__ __forceinline__ bool first_test(const uint32_t* st, uint32_t rel) {
-  const uint32_t w = rel >> 5, sh = rel & 31u;
-  const uint32_t v = __builtin_amdgcn_alignbit(st[w + 1], st[w], sh);
-  return (v & 6u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u;     // BTYPE = 2 (BFINAL either way: the member's last block is a unit like any other)
-}
 __device__ __forceinline__ bool kraft_test(const uint32_t* st, uint32_t rel) {
   const uint32_t w = rel >> 5, sh = rel & 31u;
   const uint32_t a0 = st[w], a1 = st[w + 1], a2 = st[w + 2], a3 = st[w + 3];
@@ -315,7 +312,7 @@ __global__ void __launch_bounds__(64) gz_find_kernel(const uint8_t* __restrict__
   __shared__ Scratch sc;
   __shared__ uint8_t pre_l[128 * 64];
   __shared__ uint32_t cand[192];
-  __shared__ uint32_t pend[192];
+  __shared__ uint32_t pend[GZ_PEND];
   __shared__ uint32_t stg[GZ_FIND_STAGE / 4 + 4];
   const uint32_t c = blockIdx.x;
   const int lane = threadIdx.x;
@@ -373,35 +370,51 @@ __global__ void __launch_bounds__(64) gz_find_kernel(const uint8_t* __restrict__
     n_c = left;
     __builtin_amdgcn_wave_barrier();
   };
-  uint32_t n_p = 0;
+  uint32_t n_p = 0, head = 0;                            // pend is a ring: entries head .. head + n_p - 1 (mod GZ_PEND)
   const unsigned long long below = (1ull << lane) - 1ull;
   // the first `cnt` offsets that passed first_test through kraft_test; what passes joins the candidates
   auto sift = [&](uint32_t cnt) {
     __builtin_amdgcn_wave_barrier();
-    const uint32_t rel = pend[(uint32_t)lane < cnt ? lane : 0];
+    const uint32_t rel = pend[(head + ((uint32_t)lane < cnt ? (uint32_t)lane : 0u)) & (GZ_PEND - 1u)];
     const bool is = (uint32_t)lane < cnt && kraft_test(stg, rel);
     const unsigned long long m = __ballot(is);
     if (is) cand[n_c + (uint32_t)__builtin_popcountll(m & below)] = rel;
     n_c += (uint32_t)__builtin_popcountll(m);
-    const uint32_t left = n_p - cnt;
-    uint32_t keep0 = 0;
-    if ((uint32_t)lane < left) keep0 = pend[cnt + (uint32_t)lane];               // (left < 64: a step adds 64 at most to fewer than 64)
-    __builtin_amdgcn_wave_barrier();
-    if ((uint32_t)lane < left) pend[lane] = keep0;
-    n_p = left;
+    head += cnt; n_p -= cnt;
     __builtin_amdgcn_wave_barrier();
     if (n_c >= 64u) batch(64u);
   };
-  for (uint64_t base = from > first_bit ? from : first_bit + 1; base < to && found == ~0ull; base += 64) {
-    const uint64_t bit = base + (uint64_t)lane;
-    const uint32_t rel = (uint32_t)(bit - from);
-    const bool is = bit < to && (bit >> 3) + 12 < n && first_test(stg, rel);
-    const unsigned long long m = __ballot(is);
-    if (is) pend[n_p + (uint32_t)__builtin_popcountll(m & below)] = rel;
-    n_p += (uint32_t)__builtin_popcountll(m);
-    if (n_p >= 64u) sift(64u);
+  // first_test, a BYTE a lane: the 32 bits from its byte on hold the 17 bits of all eight offsets inside it; 64 bytes a step.  What
+  // passes is appended in the order of the offsets: lane by lane (a count over the lanes below per bit of the byte), bit by bit.
+  const uint64_t lo_bit = from > first_bit ? from : first_bit + 1;
+  const uint32_t lo_rel = (uint32_t)(lo_bit - from);
+  const uint32_t bytes_here = (uint32_t)((to - from) >> 3);
+  for (uint32_t bb = 0; bb < bytes_here && found == ~0ull; bb += 64) {
+    const uint32_t B = bb + (uint32_t)lane;
+    const bool live = B < bytes_here && st_base + B + 12 < n;
+    const uint32_t v = __builtin_amdgcn_alignbit(stg[(B >> 2) + 1], stg[B >> 2], (B & 3u) * 8u);
+    uint32_t mask8 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t t = v >> k;
+      if ((t & 6u) == 4u && ((t >> 3) & 31u) <= 29u && ((t >> 8) & 31u) <= 29u && B * 8u + (uint32_t)k >= lo_rel) mask8 |= 1u << k;
+    }
+    if (!live) mask8 = 0;
+    uint32_t at = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long m = __ballot((mask8 >> k) & 1u);
+      at += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      tot += (uint32_t)__builtin_popcountll(m);
+    }
+    at += head + n_p;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if ((mask8 >> k) & 1u) { pend[at & (GZ_PEND - 1u)] = B * 8u + (uint32_t)k; ++at; }
+    n_p += tot;
+    while (n_p >= 64u && found == ~0ull) sift(64u);
   }
-  while (n_p && found == ~0ull) sift(n_p);
+  while (n_p && found == ~0ull) sift(n_p < 64u ? n_p : 64u);
   while (n_c && found == ~0ull) batch(n_c < 64u ? n_c : 64u);
   if (lane == 0) start[c] = found;
 }
@@ -784,43 +797,47 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
               const uint64_t v2 = v >> c1;
               const uint32_t e2 = f.dist_wide[(uint32_t)v2 & ((1u << GZ_FAST_DIST) - 1u)];
               const uint32_t l2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
-              const uint32_t R1 = (e2 >> 16) + ((uint32_t)(v2 >> l2) & ((1u << eb2) - 1u));   // the distance, were this a match
+              const uint32_t dist_l = (e2 >> 16) + ((uint32_t)(v2 >> l2) & ((1u << eb2) - 1u));   // the distance, were this a match
               uint32_t cons = c1;
               const bool deep = w >= (uint32_t)GZ_RING;          // (then every distance of a common match lies inside the unit's own output)
-              uint32_t kd_l = kind;                              // 0 literal, 1 match (or: the serial path), 2 end of block, 3 THE COMMON MATCH: at
-              if (kind == 1u) {                                  // most 64 symbols, its source in front of it and inside the ring - decided here,
-                cons = l2 ? c1 + l2 + eb2 : 0u;                  // by every lane for its offset
-                if (deep && val <= 64u && R1 >= val && R1 <= (uint32_t)GZ_RING - 258u) kd_l = 3u;
+              // R0: bits used | flags << 8 | symbols << 16;  R1: the distance - of a literal: its value.  Flag 4 = HOT: a literal, or
+              // THE COMMON MATCH - at most 64 symbols, its source in front of it and inside the ring; decided here, by every lane
+              // for its offset.  Flag 1 = literal, 2 = end of block.
+              uint32_t fl = 0u, n_out = val, R1 = dist_l;
+              if (kind == 0u) { fl = 4u | 1u; n_out = 1u; R1 = val; }
+              else if (kind == 2u) fl = 2u;
+              else {
+                cons = l2 ? c1 + l2 + eb2 : 0u;
+                if (deep && val <= 64u && dist_l >= val && dist_l <= (uint32_t)GZ_RING - 258u) fl = 4u;
               }
               if (l == 0u) cons = 0u;
-              if (cons == 0u) kd_l = 1u;
-              const uint32_t R0 = cons | (kd_l << 8) | (val << 16);
+              if (cons == 0u) fl = 0u;
+              const uint32_t R0 = cons | (fl << 8) | (n_out << 16);
               uint32_t p = 0u;
               for (;;) {
-                // literals and common matches: a loop of its own, two branches a symbol (one loop over all kinds came out of the
-                // compiler as eight branches a symbol, and a taken branch costs a wavefront on its own ~20 cycles)
-                while (p < 64u) {
+                // Literals and common matches: ONE straight body in a loop of its own - a literal is a copy of one symbol whose value
+                // comes out of R1 instead of the ring.  (One loop over all kinds came out of the compiler as eight branches a symbol,
+                // and a taken branch costs a wavefront on its own ~20 cycles; so does every `if` in here.)  The loop leaves for
+                // anything else, and for the flush of a whole group of 64.
+                while (p < 64u && w - wf < 64u) {
                   const uint32_t r0 = __builtin_amdgcn_readlane(R0, (int)p);
-                  const uint32_t kd = (r0 >> 8) & 3u;
-                  if (kd == 3u) {
-                    const uint32_t r1 = __builtin_amdgcn_readlane(R1, (int)p);
-                    const uint32_t len = r0 >> 16;
-                    if ((uint32_t)lane < len) f.ring[(w + (uint32_t)lane) & RM] = f.ring[(w - r1 + (uint32_t)lane) & RM];
-                    w += len;
-                    if (w - wf >= 64u) flush(w & ~63u);
-                  } else if (kd == 0u) {
-                    if (lane == 0) f.ring[w & RM] = (uint16_t)(r0 >> 16);
-                    ++w;
-                    if ((w & 63u) == 0u && w - wf >= 64u) flush(w);
-                  } else break;
+                  if (!(r0 & 0x400u)) break;
+                  const uint32_t r1 = __builtin_amdgcn_readlane(R1, (int)p);
+                  const uint32_t cnt = r0 >> 16;
+                  const uint16_t x = f.ring[(w - r1 + (uint32_t)lane) & RM];
+                  const uint16_t y = (r0 & 0x100u) ? (uint16_t)r1 : x;
+                  if ((uint32_t)lane < cnt) f.ring[(w + (uint32_t)lane) & RM] = y;
+                  w += cnt;
                   p += r0 & 0xFFu;
                 }
+                if (w - wf >= 64u) { flush(w & ~63u); continue; }
                 if (p >= 64u) break;
                 // everything else, one symbol
                 const uint32_t r0 = __builtin_amdgcn_readlane(R0, (int)p);
                 const uint32_t used = r0 & 0xFFu;
+                if (r0 & 0x400u) continue;
                 if (used == 0u) { stop = 1u; break; }
-                if (((r0 >> 8) & 3u) == 2u) { p += used; stop = 2u; break; }
+                if (r0 & 0x200u) { p += used; stop = 2u; break; }
                 const uint32_t r1 = __builtin_amdgcn_readlane(R1, (int)p);
                 if (!match(r0 >> 16, r1)) { stop = 3u; break; }
                 p += used;
