@@ -106,7 +106,7 @@ struct Huff {
     for (int i = 0; i < n; ++i) if (len[i] & 15) { const uint16_t o = offs[len[i] & 15]++; if (o < 288) symbol[o] = (uint16_t)i; }
     return left > 0 ? 1 : 0;
   }
-  __device__ int decode(Bits& b) const {
+  template <class B> __device__ int decode(B& b) const {
     const uint32_t v = b.peek(15);
     int code = 0, first = 0, index = 0;
     for (int l = 1; l <= 15; ++l) {
@@ -133,7 +133,7 @@ __device__ uint32_t kraft(const uint8_t* len, int n) {
 }
 
 // header of a block with dynamic codes (behind BFINAL / BTYPE) -> the two codes; strict: what a real encoder emits (pgz.hpp)
-__device__ bool read_dynamic(Bits& b, Scratch& s, bool strict) {
+template <class B> __device__ bool read_dynamic(B& b, Scratch& s, bool strict) {
   const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
   if (hlit > 286 || hdist > 30) return false;
   for (int i = 0; i < 19; ++i) s.cl[i] = 0;
@@ -201,27 +201,36 @@ __device__ void fixed_codes(Scratch& s) {
 // The finder's input comes out of LDS: the chunk's 8 KiB and 1 KiB behind them (a dynamic header is 562 bytes at most), staged once.
 constexpr uint32_t GZ_FIND_STAGE = GZ_CHUNK + 1024;
 constexpr uint32_t GZ_PEND = 1024;          // offsets that passed the first test and wait for the second (a step adds 512 at most to fewer than 64)
-struct LBits {                                 // Bits on the staged bytes [base, base + GZ_FIND_STAGE) of the data
-  const uint32_t* st; uint64_t base, n, pos, buf; int cnt; bool over;
-  __device__ void init(const uint32_t* stage, uint64_t stage_base, uint64_t len, uint64_t bitpos) {
-    st = stage; base = stage_base; n = len; pos = bitpos >> 3; buf = 0; cnt = 0; over = false;
+struct LBits {                                 // Bits on the staged bytes [base, base + GZ_FIND_STAGE) of the data; behind them: the data itself
+  const uint32_t* st; const uint8_t* p; uint64_t base, n, pos, buf; int cnt; bool over;
+  __device__ void init(const uint32_t* stage, uint64_t stage_base, const uint8_t* d, uint64_t len, uint64_t bitpos) {
+    st = stage; base = stage_base; p = d; n = len; pos = bitpos >> 3; buf = 0; cnt = 0; over = false;
     refill();
     const int skip = (int)(bitpos & 7);
     buf >>= skip; cnt -= skip;
   }
   __device__ void refill() {
     const int add = (63 - cnt) >> 3;
-    if (pos >= n + 8 || pos + 12 > base + GZ_FIND_STAGE) { over = true; pos += (uint64_t)add; cnt += add * 8; return; }   // (behind the stage: no header reaches that far)
-    const uint32_t o = (uint32_t)(pos - base), w = o >> 2, sh = (o & 3u) * 8u;
-    const uint32_t a0 = st[w], a1 = st[w + 1], a2 = st[w + 2];
-    const uint64_t lo = (uint64_t)a0 | ((uint64_t)a1 << 32);
-    const uint64_t v = sh ? (lo >> sh) | ((uint64_t)a2 << (64u - sh)) : lo;
+    uint64_t v = 0;
+    if (pos >= base && pos + 12 <= base + GZ_FIND_STAGE) {
+      const uint32_t o = (uint32_t)(pos - base), w = o >> 2, sh = (o & 3u) * 8u;
+      const uint32_t a0 = st[w], a1 = st[w + 1], a2 = st[w + 2];
+      const uint64_t lo = (uint64_t)a0 | ((uint64_t)a1 << 32);
+      v = sh ? (lo >> sh) | ((uint64_t)a2 << (64u - sh)) : lo;
+    } else if (pos + 8 <= n + 16) {          // (a trial decode that runs on behind the stage)
+      const uint8_t* s = p + (pos <= n + 8 ? pos : n + 8);
+      v = (uint64_t)s[0] | ((uint64_t)s[1] << 8) | ((uint64_t)s[2] << 16) | ((uint64_t)s[3] << 24) | ((uint64_t)s[4] << 32) |
+          ((uint64_t)s[5] << 40) | ((uint64_t)s[6] << 48) | ((uint64_t)s[7] << 56);
+      if (pos > n + 8) v = 0;
+    }
+    if (pos >= n + 8) over = true;
     buf |= v << cnt;
     pos += (uint64_t)add; cnt += add * 8;
   }
   __device__ uint32_t peek(int k) { if (cnt < k) refill(); return (uint32_t)(buf & ((1ull << k) - 1)); }
   __device__ void drop(int k) { buf >>= k; cnt -= k; }
   __device__ uint32_t get(int k) { const uint32_t v = peek(k); drop(k); return v; }
+  __device__ void skip(int k) { if (cnt < k) refill(); drop(k); }
 };
 
 // The cheap tests, every lane its own offset, on the 74 bits of a dynamic header's fixed part (rel = the offset - 8 x the stage's
@@ -249,8 +258,8 @@ __device__ __forceinline__ bool kraft_test(const uint32_t* st, uint32_t rel) {
 // What read_dynamic(strict) decides, without keeping the codes: one lane, its own candidate - 64 candidates at a time.  The
 // code-length code's table is the lane's column of an LDS array (pre[v * 64]), the 19 lengths one 57-bit number, and the two codes'
 // Kraft sums, the number of distance codes and the end-of-block code's length are kept up as the lengths are read.
-__device__ bool header_holds(const uint32_t* st, uint64_t st_base, uint64_t n, uint64_t at, uint8_t* pre) {
-  LBits b; b.init(st, st_base, n, at + 3);
+__device__ bool header_holds(const uint32_t* st, uint64_t st_base, const uint8_t* d, uint64_t n, uint64_t at, uint8_t* pre) {
+  LBits b; b.init(st, st_base, d, n, at + 3);
   const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
   if (hlit > 286 || hdist > 30) return false;
   uint64_t cl = 0;
@@ -331,7 +340,7 @@ __global__ void __launch_bounds__(64) gz_find_kernel(const uint8_t* __restrict__
   auto batch = [&](uint32_t cnt) {
     __builtin_amdgcn_wave_barrier();
     const uint64_t mine = from + (uint64_t)cand[(uint32_t)lane < cnt ? lane : 0];
-    const bool holds = (uint32_t)lane < cnt && header_holds(stg, st_base, n, mine, pre_l + lane);
+    const bool holds = (uint32_t)lane < cnt && header_holds(stg, st_base, d, n, mine, pre_l + lane);
     unsigned long long m = __ballot(holds);
     while (m && found == ~0ull) {
       const int l = __builtin_ctzll(m);
@@ -339,7 +348,7 @@ __global__ void __launch_bounds__(64) gz_find_kernel(const uint8_t* __restrict__
       const uint64_t at = from + (uint64_t)cand[l];
       int good = 0;
       if (lane == 0) {
-        Bits b; b.init(d, n, at + 3);
+        LBits b; b.init(stg, st_base, d, n, at + 3);
         good = read_dynamic(b, sc, true) ? 1 : 0;
         for (int i = 0; i < GZ_TRIAL && good; ++i) {
           if (b.over) { good = 0; break; }
@@ -501,6 +510,18 @@ struct WBits {                                 // the Bits of a whole wavefront:
     buf >>= skip; cnt -= skip;
   }
 };
+
+// WBits::restage for the window decode, NOT inlined: inlined, its loads make the compiler wait for every outstanding memory
+// operation (the counter is one for loads and stores) at the top of every window - also behind a flush, whose store then costs
+// a window its whole latency.
+__device__ __attribute__((noinline)) void restage_apart(const uint8_t* p, uint64_t n, uint64_t base, uint32_t* stage, int lane) {
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < GZ_STAGE / 4 + 2; i += 64) {
+    const uint64_t byte = base + 4ull * (uint64_t)i;
+    stage[i] = byte + 4 <= n + 16 ? *(const uint32_t*)(p + byte) : 0u;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
 
 // the same Huffman walk on the wavefront's bits
 __device__ int slow_decode(const Huff& h, WBits& b, int limit) {
@@ -784,35 +805,37 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
               if (P + 256u > nbits) break;
               if (w > (1u << 28)) { status = GZ_ERR_ROOM; stop = 3u; break; }
               const uint64_t byte = P >> 3;
-              if (byte < b.base || byte + 24u > b.base + GZ_STAGE) b.restage(byte);
+              if (byte < b.base || byte + 24u > b.base + GZ_STAGE) { b.base = byte & ~3ull; restage_apart(b.p, b.n, b.base, b.stage, lane); }
               const uint32_t bo = (uint32_t)(P - b.base * 8ull) + (uint32_t)lane;
               const uint32_t wi = bo >> 5, sh = bo & 31u;
               const uint32_t a0 = f.stage[wi], a1 = f.stage[wi + 1], a2 = f.stage[wi + 2];
-              const uint64_t lo = (uint64_t)a0 | ((uint64_t)a1 << 32);
-              const uint64_t v = sh ? (lo >> sh) | ((uint64_t)a2 << (64u - sh)) : lo;          // 64 bits from this lane's offset on
-              const uint32_t e = f.lit_wide[(uint32_t)v & ((1u << GZ_FAST_LIT) - 1u)];
+              const uint32_t vlo = __builtin_amdgcn_alignbit(a1, a0, sh), vhi = __builtin_amdgcn_alignbit(a2, a1, sh);   // 64 bits from this lane's offset on
+              const uint32_t e = f.lit_wide[vlo & ((1u << GZ_FAST_LIT) - 1u)];
               const uint32_t l = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
-              const uint32_t c1 = l + eb;
-              const uint32_t val = (e >> 16) + ((uint32_t)(v >> l) & ((1u << eb) - 1u));      // the literal, or the match's length
-              const uint64_t v2 = v >> c1;
-              const uint32_t e2 = f.dist_wide[(uint32_t)v2 & ((1u << GZ_FAST_DIST) - 1u)];
-              const uint32_t l2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
-              const uint32_t dist_l = (e2 >> 16) + ((uint32_t)(v2 >> l2) & ((1u << eb2) - 1u));   // the distance, were this a match
-              uint32_t cons = c1;
+              const uint32_t c1 = l + eb;                                                        // (<= 15)
+              const uint32_t val = (e >> 16) + ((vlo >> l) & ((1u << eb) - 1u));                // the literal, or the match's length
+              const uint32_t v2 = __builtin_amdgcn_alignbit(vhi, vlo, c1);
+              const uint32_t e2 = f.dist_wide[v2 & ((1u << GZ_FAST_DIST) - 1u)];
+              const uint32_t l2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;                               // (l2 + eb2 <= 21)
+              const uint32_t dist_l = (e2 >> 16) + ((v2 >> l2) & ((1u << eb2) - 1u));           // the distance, were this a match
               const bool deep = w >= (uint32_t)GZ_RING;          // (then every distance of a common match lies inside the unit's own output)
               // R0: bits used | flags << 8 | symbols << 16;  R1: the distance - of a literal: its value.  Flag 4 = HOT: a literal, or
               // THE COMMON MATCH - at most 64 symbols, its source in front of it and inside the ring; decided here, by every lane
-              // for its offset.  Flag 1 = literal, 2 = end of block.
-              uint32_t fl = 0u, n_out = val, R1 = dist_l;
-              if (kind == 0u) { fl = 4u | 1u; n_out = 1u; R1 = val; }
-              else if (kind == 2u) fl = 2u;
-              else {
-                cons = l2 ? c1 + l2 + eb2 : 0u;
-                if (deep && val <= 64u && dist_l >= val && dist_l <= (uint32_t)GZ_RING - 258u) fl = 4u;
-              }
-              if (l == 0u) cons = 0u;
-              if (cons == 0u) fl = 0u;
+              // for its offset.  Flag 1 = literal, 2 = end of block.  (Selects, not branches: the lanes differ.)
+              const bool is_lit = kind == 0u, is_len = kind == 1u;
+              const uint32_t cons = l == 0u ? 0u : (is_len ? (l2 ? c1 + l2 + eb2 : 0u) : c1);
+              const bool common = is_len && deep && val <= 64u && dist_l >= val && dist_l <= (uint32_t)GZ_RING - 258u;
+              const uint32_t fl = cons == 0u ? 0u : (is_lit ? 5u : (kind == 2u ? 2u : (common ? 4u : 0u)));
+              const uint32_t n_out = is_lit ? 1u : val, R1 = is_lit ? val : dist_l;
               const uint32_t R0 = cons | (fl << 8) | (n_out << 16);
+              // ... and the symbol BEHIND this offset's, were it one: lane i looks at lane i + bits used.  Where both are hot and the
+              // second does not read what the first writes (distance >= both lengths), the chain takes the two in one step: N0 / N1 are
+              // the second's R0 / R1, or 0.
+              const uint32_t nx = (uint32_t)lane + cons;
+              const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nx & 63u) << 2), (int)R0);
+              const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nx & 63u) << 2), (int)R1);
+              const bool two = (fl & 4u) && nx < 64u && (b0 & 0x400u) && ((b0 & 0x100u) || b1 >= n_out + (b0 >> 16));
+              const uint32_t N0 = two ? b0 : 0u, N1 = two ? b1 : 0u;
               uint32_t p = 0u;
               for (;;) {
                 // Literals and common matches: ONE straight body in a loop of its own - a literal is a copy of one symbol whose value
@@ -823,12 +846,16 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
                   const uint32_t r0 = __builtin_amdgcn_readlane(R0, (int)p);
                   if (!(r0 & 0x400u)) break;
                   const uint32_t r1 = __builtin_amdgcn_readlane(R1, (int)p);
-                  const uint32_t cnt = r0 >> 16;
+                  const uint32_t q0 = __builtin_amdgcn_readlane(N0, (int)p), q1 = __builtin_amdgcn_readlane(N1, (int)p);
+                  const uint32_t cnt = r0 >> 16, cnt2 = q0 >> 16, w2 = w + cnt;
                   const uint16_t x = f.ring[(w - r1 + (uint32_t)lane) & RM];
+                  const uint16_t x2 = f.ring[(w2 - q1 + (uint32_t)lane) & RM];
                   const uint16_t y = (r0 & 0x100u) ? (uint16_t)r1 : x;
+                  const uint16_t y2 = (q0 & 0x100u) ? (uint16_t)q1 : x2;
                   if ((uint32_t)lane < cnt) f.ring[(w + (uint32_t)lane) & RM] = y;
-                  w += cnt;
-                  p += r0 & 0xFFu;
+                  if ((uint32_t)lane < cnt2) f.ring[(w2 + (uint32_t)lane) & RM] = y2;
+                  w = w2 + cnt2;
+                  p += (r0 & 0xFFu) + (q0 & 0xFFu);
                 }
                 if (w - wf >= 64u) { flush(w & ~63u); continue; }
                 if (p >= 64u) break;
