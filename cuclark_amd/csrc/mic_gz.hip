@@ -318,10 +318,13 @@ __device__ bool header_holds(const uint32_t* st, uint64_t st_base, const uint8_t
 // the trial decode.  In the order of the offsets throughout: the first start of the chunk is the answer.
 __global__ void __launch_bounds__(64) gz_find_kernel(const uint8_t* __restrict__ d, uint64_t n, uint64_t first_bit, uint32_t n_chunks,
                                                     unsigned long long* __restrict__ start) {
-  __shared__ Scratch sc;
-  __shared__ uint8_t pre_l[128 * 64];
-  __shared__ uint32_t cand[192];
-  __shared__ uint32_t pend[GZ_PEND];
+  // (LDS is what limits the wavefronts a CU holds here, and the finder's time goes with their number: 19.5 KB a chunk, eight a CU.
+  // The lanes' code-length tables and the one lane's codes are never live together; offsets inside a chunk fit 16 bits.)
+  __shared__ union { Scratch sc; uint8_t pre_l[128 * 64]; } un;
+  Scratch& sc = un.sc;
+  uint8_t* pre_l = un.pre_l;
+  __shared__ uint16_t cand[192];
+  __shared__ uint16_t pend[GZ_PEND];
   __shared__ uint32_t stg[GZ_FIND_STAGE / 4 + 4];
   const uint32_t c = blockIdx.x;
   const int lane = threadIdx.x;
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(64) gz_find_kernel(const uint8_t* __restrict__
     const uint32_t rel = pend[(head + ((uint32_t)lane < cnt ? (uint32_t)lane : 0u)) & (GZ_PEND - 1u)];
     const bool is = (uint32_t)lane < cnt && kraft_test(stg, rel);
     const unsigned long long m = __ballot(is);
-    if (is) cand[n_c + (uint32_t)__builtin_popcountll(m & below)] = rel;
+    if (is) cand[n_c + (uint32_t)__builtin_popcountll(m & below)] = (uint16_t)rel;
     n_c += (uint32_t)__builtin_popcountll(m);
     head += cnt; n_p -= cnt;
     __builtin_amdgcn_wave_barrier();
@@ -419,7 +422,7 @@ __global__ void __launch_bounds__(64) gz_find_kernel(const uint8_t* __restrict__
     at += head + n_p;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if ((mask8 >> k) & 1u) { pend[at & (GZ_PEND - 1u)] = B * 8u + (uint32_t)k; ++at; }
+      if ((mask8 >> k) & 1u) { pend[at & (GZ_PEND - 1u)] = (uint16_t)(B * 8u + (uint32_t)k); ++at; }
     n_p += tot;
     while (n_p >= 64u && found == ~0ull) sift(64u);
   }
