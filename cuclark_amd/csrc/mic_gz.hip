@@ -2,26 +2,30 @@
 // unit per deflate block - thousands of wavefronts - instead of sixteen threads.  BASELINE config 5 names gzip FASTQ; the
 // reference's scripts gunzip to a temporary file first (classify_metagenome.sh:116-142).  The command line's path for compressed
 // FASTQ on one engine: the text stays on the device, where the pair merge and the ingest kernels read it (mic_ingest.hip:
-// mic_pairs_*, mic_text_*).  316 MB of FASTQ out of 59 MB of gzip in 53-56 ms (pgz.hpp on the 16 allowed CPUs: 3 GB/s); a
-// block-gzip file (BGZF) of the same text, a wavefront per member, in 35-45 ms.  tests/test_gz_device.py, tools/gz_device_timing.py.
+// mic_pairs_*, mic_text_*).  316 MB of FASTQ out of 59 MB of gzip in 12 ms (pgz.hpp on the 16 allowed CPUs: 3 GB/s); a
+// block-gzip file (BGZF) of the same text, a wavefront per member, in 14-15 ms.  tests/test_gz_device.py, tools/gz_device_timing.py.
 //
-//   1  gz_find_kernel     one wavefront per 8 KiB of compressed data: the first bit offset at which a block with dynamic codes
-//                         starts - 64 offsets per step through the cheap tests (BFINAL / BTYPE bits, HLIT / HDIST in range, the
-//                         code-length code exactly complete), the survivors one by one through the whole header (every code
-//                         complete, an end-of-block code) and 300 symbols of trial decode;
+//   1  gz_find_kernel     one wavefront per 8 KiB of compressed data (staged in LDS): the first bit offset at which a block with
+//                         dynamic codes starts - a sieve: BTYPE and the two counts on every offset (a byte a lane), the
+//                         code-length code exactly complete on the fifth that pass (collected, 64 at a time), the whole header
+//                         of the ~65 a chunk that pass that (64 side by side: every code complete, an end-of-block code), and
+//                         the one-lane path with its codes and 300 symbols of trial decode for what is left;
 //   2  gz_decode_kernel   one wavefront per unit = from one found start to the first block boundary at or behind the next found
 //                         start, into a region of the symbol buffer sized by the unit's compressed span: 16-bit symbols - a
 //                         byte, or a MARKER 0x8000 | i for a back-reference to position i of the 32 KiB in front of the unit.
 //                         The host stitches the units into a chain (a unit whose start lies inside the unit in front of it was a
 //                         false find and is dropped; a gap or an error gives the file back to the caller's CPU inflater); a
 //                         unit that outgrew its region was counted exactly and is decoded again into one that fits.
-//                         The decode itself is serial; all 64 lanes run it redundantly on state the compiler is told is uniform
-//                         (scalar registers, scalar branches) and are there for what is parallel: staging the input through
-//                         LDS, filling the decode tables, copying a match inside an LDS ring of the last 2 Ki symbols, writing
-//                         symbols out 64 at a time.  First-level literal table: one vector register, looked up by v_readlane;
-//   3  gz_window_kernel   in chain order the last 32 KiB of every unit are resolved against the window handed on (one block,
-//                         the window in LDS, symbols loaded one unit ahead) and every unit's incoming window is kept;
-//   4  gz_resolve_kernel  all units at once: markers replaced, symbols narrowed to bytes at the unit's offset of the text.
+//                         THE WINDOW DECODE: the 64 lanes decode speculatively what starts at each of the next 64 bit offsets
+//                         (literal / length code, extra bits, distance code, extra bits: wide tables, three LDS round trips a
+//                         window), the scalar side follows the chain of the offsets that really start a symbol - v_readlane,
+//                         copy inside an LDS ring of the last 2 Ki symbols, two symbols a step where they do not depend on each
+//                         other.  Codes longer than the tables' and matches out of the ordinary take the serial decode (all
+//                         lanes redundantly on state the compiler is told is uniform), one symbol;
+//   3  gz_compose_kernel / gz_chain_kernel   the 32 KiB in front of every unit: a unit's step is a map of window positions, maps
+//                         compose - per group of ~sqrt(units) units in LDS, all groups at once, then one step per group;
+//   4  gz_resolve2_kernel all units at once: markers replaced through the unit's map and its group's window, symbols narrowed to
+//                         bytes at the unit's offset of the text.
 //   5  gz_crc_kernel      the CRC-32 of the text in 4-KiB pieces, combined on the host: length (ISIZE) and CRC-32 are checked against
 //                         the member's trailer, as gunzip checks them.
 // Stored and fixed-code blocks are decoded; several members, a preset dictionary or anything that does not stitch:
