@@ -46,6 +46,43 @@ def test_fastq_text_of_many_blocks(engine, level):
     assert crc == zlib.crc32(data)
 
 
+def _with_extra_field(gz, n_extra):
+    """The same member with an FEXTRA field of n_extra bytes in its header: the deflate data starts that much later."""
+    import struct
+    assert gz[3] & 4 == 0
+    sub = b"XX" + struct.pack("<H", n_extra - 4) + bytes(n_extra - 4)
+    return gz[:3] + bytes([gz[3] | 4]) + gz[4:10] + struct.pack("<H", n_extra) + sub + gz[10:]
+
+
+def test_a_header_longer_than_two_finder_chunks(engine):
+    """20 000 bytes of FEXTRA: the first block starts in the finder's third 8-KiB chunk (the chunks in front of it hold no deflate
+    data at all), and zlib reads the same member."""
+    rng = np.random.default_rng(21)
+    data = _fastq(rng, 20000)
+    gz = _with_extra_field(_gz(data, 1), 20000)
+    assert gzip.decompress(gz) == data
+    text, crc = engine.gunzip(gz)
+    assert text == data and crc == zlib.crc32(data)
+
+
+def test_texts_that_leave_the_window_decode(engine):
+    """What the decode's 64-offsets-at-a-time path hands to the serial one: codes longer than its tables (a text of many rare
+    byte values: 11- to 15-bit codes), matches longer than 64 symbols and runs (distance 1 ... 5), literals only (level 0 is
+    stored; a text without repeats at level 1 is literals), and the same FASTQ with every one of them in between."""
+    rng = np.random.default_rng(22)
+    skew = np.concatenate([np.full(40000, 65, np.uint8), rng.integers(0, 256, 3000).astype(np.uint8), np.full(40000, 67, np.uint8)])
+    rng.shuffle(skew)
+    rare = np.tile(skew, 12).tobytes()                                               # two common bytes, 254 rare ones: long codes
+    runs = b"".join(bytes([65 + i % 4]) * int(n) for i, n in enumerate(rng.integers(1, 700, 4000)))
+    period = b"".join((b"ACGTT"[: 1 + i % 5]) * int(n) for i, n in enumerate(rng.integers(20, 200, 3000)))
+    noise = rng.integers(0, 256, 400000, dtype=np.uint8).tobytes()
+    fq = _fastq(rng, 4000)
+    for level in (1, 6, 9):
+        for data in (rare, runs, period, fq + rare[:200000] + runs[:200000] + fq + noise[:50000] + period[:100000] + fq):
+            text, crc = engine.gunzip(_gz(data, level))
+            assert text == data and crc == zlib.crc32(data)
+
+
 @pytest.mark.parametrize("kind", ["empty", "one byte", "tiny (fixed codes)", "random (stored blocks)", "zeros", "period 3", "text 1 MB",
                                   "binary mix", "long header"])
 def test_block_kinds_and_sizes(engine, kind):
