@@ -233,6 +233,43 @@ def test_block_gzip_members_side_by_side(engine):
         engine.gunzip(bytes(gz) + _gz(data[:1000]))
 
 
+def _random_stream(rng):
+    """One deflate stream of a random make (tools/gz_soak.py draws from it too): (text, gzip member, what it was)."""
+    kind = int(rng.integers(6))
+    n = int(rng.choice([0, 1, 100, 5000, 70000, 400000, 1500000]))
+    if kind == 0:
+        data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].tobytes()
+    elif kind == 1:
+        data = _fastq(rng, n // 316 + 1)[:n]
+    elif kind == 2:
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    elif kind == 3:
+        data = (b"the quick brown fox jumps over the lazy dog\n" * (n // 44 + 1))[:n]
+    elif kind == 4:
+        data = bytes(n)
+    else:
+        parts, left = [], n
+        while left > 0:
+            m = int(min(left, rng.integers(1, 60000)))
+            parts.append(rng.integers(0, int(rng.choice([2, 4, 20, 256])), m, dtype=np.uint8).tobytes() if rng.random() < 0.7 else bytes([int(rng.integers(256))]) * m)
+            left -= m
+        data = b"".join(parts)
+    level = int(rng.integers(0, 10))
+    strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
+    mem = int(rng.integers(1, 10))
+    wbits = int(rng.integers(9, 16))
+    c = zlib.compressobj(level, zlib.DEFLATED, 16 + wbits, mem, strategy)
+    gz = b""
+    cuts = sorted(int(x) for x in rng.integers(0, len(data) + 1, int(rng.integers(0, 3))))
+    prev = 0
+    for cut in cuts:
+        gz += c.compress(data[prev:cut]) + c.flush(int(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH])))
+        prev = cut
+    gz += c.compress(data[prev:]) + c.flush()
+    assert zlib.decompress(gz, 31) == data
+    return data, gz, (kind, n, level, strategy, mem, wbits)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_streams_against_zlib(engine, seed):
     """Deflate streams of every make: levels 0-9, the strategies (default, filtered, Huffman only, RLE, fixed codes), memLevel 1-9
@@ -242,41 +279,11 @@ def test_random_streams_against_zlib(engine, seed):
     rng = np.random.default_rng(1000 + seed)
     took = 0
     for trial in range(40):
-        kind = int(rng.integers(6))
-        n = int(rng.choice([0, 1, 100, 5000, 70000, 400000, 1500000]))
-        if kind == 0:
-            data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].tobytes()
-        elif kind == 1:
-            data = _fastq(rng, n // 316 + 1)[:n]
-        elif kind == 2:
-            data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
-        elif kind == 3:
-            data = (b"the quick brown fox jumps over the lazy dog\n" * (n // 44 + 1))[:n]
-        elif kind == 4:
-            data = bytes(n)
-        else:
-            parts, left = [], n
-            while left > 0:
-                m = int(min(left, rng.integers(1, 60000)))
-                parts.append(rng.integers(0, int(rng.choice([2, 4, 20, 256])), m, dtype=np.uint8).tobytes() if rng.random() < 0.7 else bytes([int(rng.integers(256))]) * m)
-                left -= m
-            data = b"".join(parts)
-        level = int(rng.integers(0, 10))
-        strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
-        mem = int(rng.integers(1, 10))
-        wbits = int(rng.integers(9, 16))
-        c = zlib.compressobj(level, zlib.DEFLATED, 16 + wbits, mem, strategy)
-        gz = b""
-        cuts = sorted(int(x) for x in rng.integers(0, len(data) + 1, int(rng.integers(0, 3))))
-        prev = 0
-        for cut in cuts:
-            gz += c.compress(data[prev:cut]) + c.flush(int(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH])))
-            prev = cut
-        gz += c.compress(data[prev:]) + c.flush()
-        assert zlib.decompress(gz, 31) == data
+        data, gz, what = _random_stream(rng)
+        n, level = what[1], what[2]
         try:
             text, crc = engine.gunzip(gz)
-            assert text == data and crc == zlib.crc32(data), (trial, kind, n, level, strategy, mem, wbits)
+            assert text == data and crc == zlib.crc32(data), (trial,) + what
             took += 1
         except MiClarkUnsupported:
             pass
