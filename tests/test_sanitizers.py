@@ -152,3 +152,27 @@ def test_host_pipeline_under_sanitizers(flavour, rig):
         r = subprocess.run([exe, "--merge-pairs", f1, f2, out, *mode], capture_output=True, text=True, timeout=120,
                            env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
         assert r.returncode == 0 and "Sanitizer" not in r.stderr and open(out, "rb").read() == want, r.stderr[-2000:]
+
+
+def test_the_librarys_host_code_under_asan_against_a_mock_hip_runtime(tmp_path):
+    """mic_engine.hip, mic_build.hip, mic_ingest.hip, mic_gz.hip, mic_synth.hip, mic_dbbuild.hip and
+    mic_host.cpp compiled HOST-ONLY (hipcc --offload-host-only) under ASan + UBSan, linked against tools/sanitize/hip_mock.cpp
+    (device memory = host memory, kernels do not run, ASYNCHRONOUS COPIES DEFERRED to the next synchronisation so that a host
+    buffer that dies with a copy queued is a use-after-free the sanitizer sees), driven by tools/sanitize/host_rig.cpp through the
+    fuzzer's call sequences - engines, tables from arrays in all layouts (whole, bucket-range shards, slot-range parts), the
+    batch API, the merge over shards, ingest slots and the group ingest, the device inflate's error paths.  No report, exit 0."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / "host_rig")
+    r = subprocess.run(["bash", os.path.join(gu.ROOT, "tools", "sanitize", "build_host_rig.sh"), out], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and os.path.exists(os.path.join(out, "host_rig")), (r.stdout[-2000:], r.stderr[-3000:])
+    env = dict(os.environ, ASAN_OPTIONS="detect_stack_use_after_return=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(out, "host_rig"), "20", "5"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "host rig ok" in r.stdout, (r.stdout[-1500:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    calls = {ln.split()[0]: (int(ln.split()[1]), int(ln.split()[3])) for ln in r.stdout.splitlines() if ln.startswith("  mic_")}
+    # the rig must get INTO the code: tables load, batches run, ingest slots classify (what fails is what needs a kernel's answer)
+    for name in ("mic_db_load_host", "mic_batches_alloc", "mic_batch_query", "mic_batch_merge_shards", "mic_ingest_classify", "mic_ingest_classify_group"):
+        n, bad = calls[name]
+        assert n > 20 and bad < n // 2, (name, n, bad)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# The library's host code compiled host-only under ASan + UBSan against tools/sanitize/hip_mock.cpp, and the rig that drives it
+# on the CPU (no GPU): tools/sanitize/build_host_rig.sh <out dir>
+set -e
+R=$(cd "$(dirname "$0")/../.." && pwd)
+OUT=${1:-$R/build/host_rig}
+mkdir -p $OUT
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 --offload-host-only -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -Wno-unused-value -I$R/include -I$R/cuclark_amd/csrc"
+pids=()
+for f in mic_engine mic_kernels mic_build mic_synth mic_dbbuild mic_ingest mic_gz; do
+  $HIPCC -x hip $FLAGS -c $R/cuclark_amd/csrc/$f.hip -o $OUT/$f.o & pids+=($!)
+  if [ ${#pids[@]} -ge 4 ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); fi
+done
+wait
+$HIPCC -x hip $FLAGS -c $R/cuclark_amd/csrc/mic_host.cpp -o $OUT/mic_host.o
+$HIPCC -x hip $FLAGS -c $R/tools/sanitize/hip_mock.cpp -o $OUT/hip_mock.o
+# the fat binaries the host-only objects refer to (there is no device code in this build)
+nm --undefined-only $OUT/mic_*.o | awk '/__hip_fatbin_/ {print $2}' | sort -u | awk '{print "char " $1 "[8];"}' > $OUT/fatbins.c
+gcc -c $OUT/fatbins.c -o $OUT/fatbins.o
+$HIPCC -x hip $FLAGS -c $R/tools/sanitize/host_rig.cpp -o $OUT/host_rig.o
+$HIPCC -fsanitize=address,undefined -o $OUT/host_rig $OUT/host_rig.o $OUT/mic_*.o $OUT/hip_mock.o $OUT/fatbins.o -lpthread -lz 2>&1 | grep -v "^$" || true
+ls -la $OUT/host_rig
