@@ -20,4 +20,6 @@ nm --undefined-only $OUT/mic_*.o | awk '/__hip_fatbin_/ {print $2}' | sort -u | 
 gcc -c $OUT/fatbins.c -o $OUT/fatbins.o
 $HIPCC -x hip $FLAGS -c $R/tools/sanitize/host_rig.cpp -o $OUT/host_rig.o
 $HIPCC -fsanitize=address,undefined -o $OUT/host_rig $OUT/host_rig.o $OUT/mic_*.o $OUT/hip_mock.o $OUT/fatbins.o -lpthread -lz 2>&1 | grep -v "^$" || true
-ls -la $OUT/host_rig
+# the same objects as a shared library for tools/sanitize/py_rig.py (references bound inside: torch brings the real runtime along)
+$HIPCC -shared -fsanitize=address -shared-libasan -Wl,-Bsymbolic -o $OUT/libmi_clark_mock.so $OUT/mic_*.o $OUT/hip_mock.o $OUT/fatbins.o -lpthread
+ls -la $OUT/host_rig $OUT/libmi_clark_mock.so
