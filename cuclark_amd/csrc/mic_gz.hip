@@ -60,39 +60,8 @@ __constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49
 __constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// ---- bits, LSB first.  The data is followed by 16 readable zero bytes; positions behind the data read zeros and set `over`.
-struct Bits {
-  const uint8_t* p; uint64_t n;           // n bytes of data (p[n .. n+15] readable)
-  uint64_t pos;                           // next byte to load
-  uint64_t buf; int cnt; bool over;
-  __device__ void init(const uint8_t* d, uint64_t len, uint64_t bitpos) {
-    p = d; n = len; pos = bitpos >> 3; buf = 0; cnt = 0; over = false;
-    refill();
-    const int skip = (int)(bitpos & 7);
-    buf >>= skip; cnt -= skip;
-  }
-  __device__ void refill() {
-    uint64_t v = 0;
-    if (pos + 8 <= n + 16) {
-      const uint64_t q = pos <= n + 8 ? pos : n + 8;
-      // unaligned eight bytes: two aligned pairs of dwords would need the alignment of p; bytes are cached, this is not the hot part
-      const uint8_t* s = p + q;
-      v = (uint64_t)s[0] | ((uint64_t)s[1] << 8) | ((uint64_t)s[2] << 16) | ((uint64_t)s[3] << 24) | ((uint64_t)s[4] << 32) |
-          ((uint64_t)s[5] << 40) | ((uint64_t)s[6] << 48) | ((uint64_t)s[7] << 56);
-      if (pos > n + 8) v = 0;
-    }
-    if (pos >= n + 8) over = true;
-    buf |= v << cnt;
-    const int add = (63 - cnt) >> 3;
-    pos += (uint64_t)add; cnt += add * 8;
-  }
-  __device__ uint32_t peek(int k) { if (cnt < k) refill(); return (uint32_t)(buf & ((1ull << k) - 1)); }
-  __device__ void drop(int k) { buf >>= k; cnt -= k; }
-  __device__ uint32_t get(int k) { const uint32_t v = peek(k); drop(k); return v; }
-  __device__ void skip(int k) { if (cnt < k) refill(); drop(k); }
-  __device__ uint64_t bitpos() const { return pos * 8 - (uint64_t)cnt; }
-  __device__ void align() { drop(cnt & 7); }
-};
+// ---- bits, LSB first: the data is followed by 16 readable zero bytes; positions behind the data read zeros and set `over`
+// (LBits below for the finder, WBits for the decode).
 
 // ---- canonical Huffman code in the count / symbol form (puff.c): a few hundred bytes of LDS per code
 struct Huff {
@@ -189,16 +158,6 @@ template <class B> __device__ bool read_dynamic(B& b, Scratch& s, bool strict) {
   s.lit.build(s.len, hlit);
   s.dist.build(s.len + hlit, hdist);
   return true;
-}
-
-__device__ void fixed_codes(Scratch& s) {
-  for (int i = 0; i < 144; ++i) s.len[i] = 8;
-  for (int i = 144; i < 256; ++i) s.len[i] = 9;
-  for (int i = 256; i < 280; ++i) s.len[i] = 7;
-  for (int i = 280; i < 288; ++i) s.len[i] = 8;
-  s.lit.build(s.len, 288);
-  for (int i = 0; i < 30; ++i) s.len[i] = 5;
-  s.dist.build(s.len, 30);
 }
 
 // ---- 1: block finder ----------------------------------------------------------------------------------------------------
