@@ -755,7 +755,7 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
         w = UNI(w); wf = UNI(wf); b.over = UNI((uint32_t)b.over) != 0u;
         if (b.over) { status = GZ_ERR_OVER; bad = true; go = 0u; continue; }
         // THE WINDOW DECODE.  The serial decode spends ~200 cycles on a literal and ~1 150 on a match (a wavefront on its own issues an
-        // instruction every four to five cycles, and a match is four dependent LDS round trips).  Here the 64 lanes decode
+        // instruction every nine cycles or so - counted - and a match is four dependent LDS round trips).  Here the 64 lanes decode
         // SPECULATIVELY what starts at each of the next 64 bit offsets - lane i: the literal / length code at offset i with its extra
         // bits and, behind them, a distance code with its extra bits, out of the wide tables: three LDS round trips for the whole
         // window instead of four per match - and the scalar side then only follows the chain of the offsets that really start a
