@@ -169,9 +169,40 @@ def test_the_librarys_host_code_under_asan_against_a_mock_hip_runtime(tmp_path):
     r = subprocess.run(["bash", script, out], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and os.path.exists(os.path.join(out, "host_rig")), (r.stdout[-2000:], r.stderr[-3000:])
     env = dict(os.environ, ASAN_OPTIONS="detect_stack_use_after_return=1", UBSAN_OPTIONS="print_stacktrace=1")
+    # ... and with the engines of a sharded configuration spread over four (mock) devices: peer copies, per-device streams
+    r4 = subprocess.run([os.path.join(out, "host_rig"), "15", "6"], capture_output=True, text=True, timeout=600, env=dict(env, MOCK_HIP_DEVICES="4"))
+    assert r4.returncode == 0 and "host rig ok" in r4.stdout and "4 device(s)" in r4.stdout, (r4.stdout[-1500:], r4.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r4.stderr and "runtime error" not in r4.stderr, r4.stderr[-4000:]
     r = subprocess.run([os.path.join(out, "host_rig"), "20", "5"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "host rig ok" in r.stdout, (r.stdout[-1500:], r.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    # ... and THE COMMAND LINE ITSELF on four mock devices (classifier.cpp + cli_main.cpp on the same objects): the table-sharded
+    # modes (4 parts x 1 group, 2 parts x 2 groups: one read of the files for all devices, the peer matrix, the group ingest
+    # across devices) and the read-sharded mode (3 and 2 engines, single and paired files) - every record once, no report.  The
+    # GPU boxes of this pool have one device: this is where those paths run with every engine on a device of its own.
+    import test_cli as tc
+    import test_ingest as ti
+    tmp = str(tmp_path)
+    d, t = tc._db_dir(tmp, "light_k27_u32", light=True), tc._targets_file(tmp)
+    rng = np.random.default_rng(43)
+    genomes = ti._genomes()
+    fq = os.path.join(tmp, "r.fq")
+    open(fq, "wb").write(ti._random_reads(rng, genomes, 4000, fasta=False))
+    m1, m2 = tc._pair_files(rng, genomes, 2000)
+    p1, p2 = os.path.join(tmp, "m_1.fq"), os.path.join(tmp, "m_2.fq")
+    open(p1, "wb").write(m1)
+    open(p2, "wb").write(m2)
+    cli_env = dict(env, ASAN_OPTIONS="detect_stack_use_after_return=1:detect_leaks=0", MOCK_HIP_DEVICES="4", MIC_INGEST_KB="128")   # (libomp keeps 128 bytes)
+    for args, n_rec, said in ((["-d", "4", "--db-sharded", "--parts", "4", "-O", fq], 4000, "4 engine(s) on 4 device(s), table-sharded: 4 part(s) x 1 read group(s)"),
+                              (["-d", "4", "--db-sharded", "--parts", "2", "-O", fq], 4000, "table-sharded: 2 part(s) x 2 read group(s)"),
+                              (["-d", "3", "-O", fq], 4000, "3 engine(s) on 3 device(s), read-sharded"),
+                              (["-d", "2", "-P", p1, p2], 2000, "2 engine(s) on 2 device(s), read-sharded")):
+        res = os.path.join(tmp, "out")
+        rc = subprocess.run([os.path.join(out, "cuCLARK_mock-l"), "-T", t, "-D", d, *args, "-R", res, "-n", "5"], capture_output=True, text=True, timeout=600, env=cli_env)
+        assert rc.returncode == 0, (args, rc.stdout[-800:], rc.stderr[-3000:])
+        assert "AddressSanitizer" not in rc.stderr and "runtime error" not in rc.stderr, (args, rc.stderr[-4000:])
+        assert said in rc.stderr, (args, [ln for ln in rc.stderr.splitlines() if "Devices" in ln])
+        assert sum(1 for _ in open(res + ".csv", "rb")) == n_rec + 1, args
     calls = {ln.split()[0]: (int(ln.split()[1]), int(ln.split()[3])) for ln in r.stdout.splitlines() if ln.startswith("  mic_")}
     # the rig must get INTO the code: tables load, batches run, ingest slots classify (what fails is what needs a kernel's answer)
     for name in ("mic_db_load_host", "mic_batches_alloc", "mic_batch_query", "mic_batch_merge_shards", "mic_ingest_classify", "mic_ingest_classify_group"):

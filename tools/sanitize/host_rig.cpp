@@ -70,6 +70,8 @@ static std::string random_fasta(unsigned n_reads, unsigned L) {
   return s;
 }
 
+static unsigned n_dev = 1;      // MOCK_HIP_DEVICES: the engines of a sharded configuration are spread over that many (mock) devices
+
 static void one_round() {
   static const int ks[] = {8, 12, 16, 20, 21, 24, 25, 27, 31, 32};
   static const uint32_t Ts[] = {1, 2, 7, 40, 64, 65, 300, 4096};
@@ -94,7 +96,7 @@ static void one_round() {
   const unsigned n_eng = mode == 0 ? 1 : (unsigned)rnd(2, 5);
   std::vector<mic_engine*> eng(n_eng, nullptr);
   for (unsigned i = 0; i < n_eng; ++i) {
-    mic_config cfg; cfg.device = 0; cfg.k = k; cfg.num_targets = T; cfg.num_batches = 1; cfg.row_words = 16; cfg.layout = layout;
+    mic_config cfg; cfg.device = (int)(i % n_dev); cfg.k = k; cfg.num_targets = T; cfg.num_batches = 1; cfg.row_words = 16; cfg.layout = layout;
     CALL(mic_create(&cfg, &eng[i]));
     if (!eng[i]) { for (unsigned j = 0; j < i; ++j) mic_destroy(eng[j]); return; }
     if (mode == 2) CALL(mic_db_set_part(eng[i], i, n_eng));
@@ -104,7 +106,7 @@ static void one_round() {
     mic_db_info info;
     CALL(mic_db_get_info(eng[i], &info));
     char name[256];
-    CALL(mic_db_kernel_name(eng[i], name, sizeof(name)));
+    { const int len = mic_db_kernel_name(eng[i], name, sizeof(name)); tally("mic_db_kernel_name(", len < 0 ? len : MIC_OK); }     // (returns the name's length)
   }
   // the batch API on every engine, then the merge over shards
   for (unsigned i = 0; i < n_eng; ++i) {
@@ -178,11 +180,13 @@ int main(int argc, char** argv) {
   const double budget = argc > 1 ? atof(argv[1]) : 10.0;
   const uint64_t seed = argc > 2 ? strtoull(argv[2], nullptr, 10) : 1;
   rng.seed(seed);
+  { int c = 1; if (mic_device_count(&c) == MIC_OK && c > 0) n_dev = (unsigned)c; }
+  { std::vector<int> mat((size_t)n_dev * n_dev); tally("mic_peer_matrix(", mic_peer_matrix(mat.data(), (int)n_dev)); }
   const time_t t_end = time(nullptr) + (time_t)budget;
   unsigned long rounds = 0;
   while (time(nullptr) < t_end) { one_round(); ++rounds; }
-  printf("host rig ok: %lu rounds, %lu calls (%lu returned an error: the mock's device answers with zeros), seed %llu\n", rounds, n_calls, n_fail,
-         (unsigned long long)seed);
+  printf("host rig ok: %lu rounds, %lu calls (%lu returned an error: the mock's device answers with zeros), %u device(s), seed %llu\n", rounds, n_calls, n_fail,
+         n_dev, (unsigned long long)seed);
   for (const auto& c : by_call) printf("  %-28s %8lu calls, %8lu returned an error\n", c.first.c_str(), c.second.first, c.second.second);
   fflush(stdout);
   return 0;
