@@ -385,6 +385,8 @@ def main():
                          "describe the product library")
     ap.add_argument("--pitch-layout", action="store_true",
                     help="leave the reads as the generator writes them (fixed pitch, a 0 behind every read) instead of the packer's format")
+    ap.add_argument("--db-leg-timeout", type=float, default=300.0,
+                    help="N > 1, read mode: seconds after which the line is printed without the table-sharded extra leg")
     ap.add_argument("--no-db-leg", action="store_true",
                     help="N > 1, read mode: skip the extra table-sharded measurement reported as \"table_sharded\"")
     args = ap.parse_args()
@@ -837,6 +839,42 @@ def main():
                 e2e = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             log("end_to_end:", json.dumps(e2e))
 
+    def emit(ts):
+        """rank 0's ONE line; ts = the table-sharded extra leg's result (N > 1, read mode), or None"""
+        out = {
+            "metric": f"Mreads/sec (10M x {'2x' if paired else ''}{read_len}bp{' pairs' if paired else ''}, k={k})", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong" if db_mode else "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": w["name"], "reads_per_gpu": n_reads, "read_len": read_len, "k": k,
+                       "reads_format": "generator's fixed pitch, a 0 behind every read" if args.pitch_layout else
+                                       "the packer's: reads back to back, readsPointer[r + 1] = end of read r (CuCLARK_hh.hh:1616-1716)",
+                       "mode": (f"{P} part(s) x {n_groups} read group(s): " + (PART_MODE[info["layout"]] if P > 1 else "table replicated") +
+                                " + all_to_all of sparse rows" if db_mode else
+                                ("read-sharded, table replicated" if world > 1 else "single GPU, table resident")),
+                       "table": {"htsize": info["htsize"], "kmers": info["n_elems"], "slot_class": info["slot_class"],
+                                 "layout": {1: "direct: one 64-B slot per on-disk bucket", 2: "minimizer-keyed 128-B slots", 3: "super-k-mer 128-B slots",
+                                            4: "super-k-mer 128-B slots, both strands stored (no reverse complement in the query)"}[info["layout"]],
+                                 "minimizer_len": info["minimizer_len"], "largest_minimizer_bucket": info["max_chain"],
+                                 "hbm_GB": round(info["hbm_bytes"] / 1e9, 2), "overflow_slots": info["n_overflow"],
+                                 "max_bucket": info["max_bucket"], "on_disk_equiv_GB": round((info["htsize"] + n_el * (key_b + 2)) / 1e9, 2)},
+                       "flagged_reads_dense_path": flagged,
+                       "setup_s": {"synth_db": round(t_gen, 1), "table_build": round(t_build, 1), "table_build_stages": build_stages},
+                       "library": lib_id},
+            "roofline": roofline, "cpu_baseline": cpu, "known_answer": known,
+        }
+        if pipeline is not None:
+            out["pipeline"] = pipeline
+        if e2e is not None:
+            out["end_to_end"] = e2e
+        if proxy is not None:
+            out["table_sharded_proxy"] = proxy
+        if default_layout is not None:
+            out["default_layout"] = default_layout
+        if ts is not None:
+            out["table_sharded"] = ts
+        print(json.dumps(out), flush=True)
+
     # ---- N > 1, read mode: the reference's own multi-GPU layout as a second, separate measurement --------------------
     # (BASELINE.json configs[3]): the table is re-built as this rank's bucket range, every rank probes the SAME reads,
     # sparse rows are exchanged with all_to_all by read range, merged and finalised.  Fixed total work: "strong".
@@ -882,6 +920,22 @@ def main():
             finally:
                 eng2.close()
                 torch.cuda.empty_cache()
+        # The headline line must not depend on this leg - not on its failing (the except below) and not on its HANGING: the leg
+        # is the one place where ranks meet in collectives of sub-groups; if it has not finished in time, rank 0 prints the line
+        # without it and every rank leaves (no barrier: the others may be the ones that are stuck).
+        import threading
+        leg_done = threading.Event()
+
+        def give_up():
+            if leg_done.is_set():
+                return
+            if rank == 0:
+                emit({"error": f"the table-sharded leg did not finish within {args.db_leg_timeout} s; the line stands without it"})
+            sys.stdout.flush()
+            os._exit(0)
+        watchdog = threading.Timer(args.db_leg_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             eng.close()
             del d_res
@@ -894,41 +948,12 @@ def main():
                 table_sharded["two_parts_2d"] = sharded_leg(2)
         except Exception as ex:   # the headline line must not depend on this leg
             table_sharded = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        finally:
+            leg_done.set()
+            watchdog.cancel()
 
     if rank == 0:
-        out = {
-            "metric": f"Mreads/sec (10M x {'2x' if paired else ''}{read_len}bp{' pairs' if paired else ''}, k={k})", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong" if db_mode else "weak", "vs_baseline": None, "dtype": "u64",
-            "data": "synthetic",
-            "config": {"workload": w["name"], "reads_per_gpu": n_reads, "read_len": read_len, "k": k,
-                       "reads_format": "generator's fixed pitch, a 0 behind every read" if args.pitch_layout else
-                                       "the packer's: reads back to back, readsPointer[r + 1] = end of read r (CuCLARK_hh.hh:1616-1716)",
-                       "mode": (f"{P} part(s) x {n_groups} read group(s): " + (PART_MODE[info["layout"]] if P > 1 else "table replicated") +
-                                " + all_to_all of sparse rows" if db_mode else
-                                ("read-sharded, table replicated" if world > 1 else "single GPU, table resident")),
-                       "table": {"htsize": info["htsize"], "kmers": info["n_elems"], "slot_class": info["slot_class"],
-                                 "layout": {1: "direct: one 64-B slot per on-disk bucket", 2: "minimizer-keyed 128-B slots", 3: "super-k-mer 128-B slots",
-                                            4: "super-k-mer 128-B slots, both strands stored (no reverse complement in the query)"}[info["layout"]],
-                                 "minimizer_len": info["minimizer_len"], "largest_minimizer_bucket": info["max_chain"],
-                                 "hbm_GB": round(info["hbm_bytes"] / 1e9, 2), "overflow_slots": info["n_overflow"],
-                                 "max_bucket": info["max_bucket"], "on_disk_equiv_GB": round((info["htsize"] + n_el * (key_b + 2)) / 1e9, 2)},
-                       "flagged_reads_dense_path": flagged,
-                       "setup_s": {"synth_db": round(t_gen, 1), "table_build": round(t_build, 1), "table_build_stages": build_stages},
-                       "library": lib_id},
-            "roofline": roofline, "cpu_baseline": cpu, "known_answer": known,
-        }
-        if pipeline is not None:
-            out["pipeline"] = pipeline
-        if e2e is not None:
-            out["end_to_end"] = e2e
-        if proxy is not None:
-            out["table_sharded_proxy"] = proxy
-        if default_layout is not None:
-            out["default_layout"] = default_layout
-        if table_sharded is not None:
-            out["table_sharded"] = table_sharded
-        print(json.dumps(out), flush=True)
+        emit(table_sharded)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

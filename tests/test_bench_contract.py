@@ -181,6 +181,21 @@ def test_bench_two_ranks_on_one_gpu(mode):
 
 
 @pytest.mark.gpu
+def test_bench_line_stands_when_the_table_sharded_leg_does_not_finish():
+    """N > 1, read mode: the extra table-sharded leg has a deadline (--db-leg-timeout); past it rank 0 prints the line without the
+    leg and every rank leaves with exit code 0 - a stuck collective in that leg cannot take the headline with it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = _run_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                    "127.0.0.1", "--master-port", "29541", os.path.join(gu.ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                    "--warmup", "1", "--workload", "tiny", "--mode", "read", "--backend", "gloo", "--db-leg-timeout", "0.001"], env, port=29541)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "did not finish" in d["table_sharded"]["error"]
+
+
+@pytest.mark.gpu
 def test_bench_four_ranks_two_dimensional_layout():
     """Four ranks sharing cuda:0 over gloo, read mode: the headline leg, then the table-sharded legs - 4 parts x 1 group (the
     reference's mode) and 2 parts x 2 read groups (the 2-D layout, exchange inside process subgroups) - each must reproduce the
