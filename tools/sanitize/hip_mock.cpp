@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <deque>
+#include <map>
 #include <mutex>
 #include <set>
 #include <vector>
@@ -124,8 +125,35 @@ hipError_t hipMalloc(void** p, size_t n) {
   return hipSuccess;
 }
 hipError_t hipFree(void* p) { std::lock_guard<std::recursive_mutex> lk(g_mu); run_all(); free(p); return hipSuccess; }   // (hipFree waits for the device)
-hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipHostFree(void* p) { std::lock_guard<std::recursive_mutex> lk(g_mu); run_all(); free(p); return hipSuccess; }
+// Pinned host memory: the mock does NOT assume that hipHostFree waits for the device - a copy still queued into or out of the
+// block when it is freed is reported and the process aborts (the library must have waited for its own copies by then).
+static std::map<void*, size_t>& g_pinned = *new std::map<void*, size_t>();
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) {
+  *p = calloc(n ? n : 1, 1);
+  if (!*p) return hipErrorOutOfMemory;
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  g_pinned[*p] = n ? n : 1;
+  return hipSuccess;
+}
+static bool touches(const Op& o, const char* lo, const char* hi) {
+  if (o.kind != Op::COPY && o.kind != Op::SET) return false;
+  const char* d = (const char*)o.dst; const char* s = (const char*)o.src;
+  return (d && d < hi && d + o.n > lo) || (o.kind == Op::COPY && s && s < hi && s + o.n > lo);
+}
+hipError_t hipHostFree(void* p) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  auto it = g_pinned.find(p);
+  if (p && it != g_pinned.end()) {
+    const char* lo = (const char*)p; const char* hi = lo + it->second;
+    bool queued = false;
+    for (const Op& o : g_null.q) queued |= touches(o, lo, hi);
+    for (Stream* st : g_streams) for (const Op& o : st->q) queued |= touches(o, lo, hi);
+    if (queued) { fprintf(stderr, "hip_mock: hipHostFree(%p) with a copy into or out of the block still queued\n", p); abort(); }
+    g_pinned.erase(it);
+  }
+  free(p);
+  return hipSuccess;
+}
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   run_all();
