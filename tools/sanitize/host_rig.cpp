@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <random>
@@ -170,6 +171,93 @@ static void one_round() {
       }
       CALL(mic_gz_release(eng[0]));
     }
+  }
+  // the device-resident entry points ("device" pointers are host memory on the mock) on engine 0
+  if (rng() % 2 == 0) {
+    const size_t nr = (size_t)n_reads;
+    std::vector<uint32_t> d_rp(rp), d_res(nr * MIC_RESULT_WORDS), d_rows(nr * 16), d_rows2(nr * 16), d_out(nr * 16), d_ids(nr), d_counts(nr * (size_t)T < (1u << 22) ? nr * (size_t)T : 1);
+    std::vector<uint16_t> d_ct(cont);
+    for (size_t i = 0; i < nr; ++i) d_ids[i] = (uint32_t)i;
+    CALL(mic_query_device(eng[0], d_rp.data(), d_ct.data(), nr, d_res.data(), d_rows.data(), nullptr));
+    size_t n_res = 0;
+    CALL(mic_resolve_flagged_device(eng[0], d_rp.data(), d_ct.data(), d_res.data(), d_rows.data(), nullptr, &n_res));
+    float ms = 0;
+    CALL(mic_last_query_ms(eng[0], &ms));
+    CALL(mic_merge_rows_device(eng[0], d_rows.data(), d_rows2.data(), d_out.data(), nr, nullptr));
+    CALL(mic_result_from_rows_device(eng[0], d_out.data(), d_res.data(), nr, nullptr));
+    if (d_counts.size() > 1) {
+      CALL(mic_count_dense_device(eng[0], d_rp.data(), d_ct.data(), d_ids.data(), nr, d_counts.data(), nullptr));
+      CALL(mic_result_from_dense_device(eng[0], d_counts.data(), d_ids.data(), nr, d_res.data(), d_rows.data(), nullptr));
+    }
+    uint64_t st4[4];
+    CALL(mic_probe_stats_device(eng[0], d_rp.data(), d_ct.data(), nr, st4));
+    CALL(mic_sync(eng[0]));
+  }
+  // texts resident on the "device": a FASTQ text indexed, cut into slots, copied back; two mates paired up and merged
+  if (rng() % 2 == 0) {
+    std::string fq1, fq2;
+    const unsigned nrec = (unsigned)rnd(1, 300);
+    for (unsigned r = 0; r < nrec; ++r) {
+      const unsigned len = (unsigned)rnd(1, 200);
+      std::string a, b2;
+      for (unsigned i = 0; i < len; ++i) { a += "ACGT"[rng() & 3]; b2 += "ACGT"[rng() & 3]; }
+      fq1 += "@p" + std::to_string(r) + "/1\n" + a + "\n+\n" + std::string(len, 'I') + "\n";
+      fq2 += "@p" + std::to_string(r) + "/2\n" + b2 + "\n+\n" + std::string(len, 'I') + "\n";
+    }
+    std::vector<std::string> names(T);
+    std::vector<const char*> np(T);
+    for (uint32_t t = 0; t < T; ++t) { names[t] = "t" + std::to_string(t); np[t] = names[t].c_str(); }
+    uint8_t* raw[1] = {nullptr};
+    if (CALL(mic_ingest_alloc(eng[0], 1, (size_t)1 << 20, np.data(), T, 0, raw))) {
+      mic_text* tx = nullptr; uint64_t nrx = 0; uint32_t stx = 0;
+      if (CALL(mic_text_index_device(eng[0], fq1.data(), fq1.size(), &tx, &nrx, &stx)) && tx) {
+        const uint64_t* smp = nullptr; size_t nsmp = 0; uint32_t stride = 0;
+        CALL(mic_text_offsets(tx, &smp, &nsmp, &stride));
+        (void)mic_text_format(tx);
+        size_t nb = 0;
+        CALL(mic_text_to_slot(eng[0], tx, 0, nrx, 0, &nb));
+        std::vector<uint8_t> back(fq1.size() + 64);
+        CALL(mic_text_copy(eng[0], tx, 0, nrx, back.data(), back.size(), &nb));
+        CALL(mic_text_free(eng[0], tx));
+      }
+      mic_pairs* pr = nullptr; uint64_t npr = 0; uint32_t stp = 0;
+      if (CALL(mic_pairs_index_device(eng[0], fq1.data(), fq1.size(), fq2.data(), fq2.size(), &pr, &npr, &stp)) && pr) {
+        const uint64_t* smp = nullptr; size_t nsmp = 0; uint32_t stride = 0;
+        CALL(mic_pairs_offsets(pr, &smp, &nsmp, &stride));
+        size_t nb = 0;
+        CALL(mic_pairs_merge_to_slot(eng[0], pr, 0, npr, 0, &nb));
+        std::vector<uint8_t> back(fq1.size() + fq2.size() + 64);
+        CALL(mic_pairs_text(eng[0], pr, 0, npr, back.data(), back.size(), &nb));
+        CALL(mic_pairs_free(eng[0], pr));
+      }
+      CALL(mic_ingest_free(eng[0]));
+    }
+  }
+  // the same table from FILES: one engine, and several engines from one read of the files (mic_db_load_files_multi)
+  if (rng() % 4 == 0) {
+    char prefix[256];
+    snprintf(prefix, sizeof(prefix), "%s/host_rig_%d_db", getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp", (int)getpid());
+    bool ok = true;
+    { FILE* f = fopen((std::string(prefix) + ".sz").c_str(), "wb"); ok = ok && f && fwrite(db.sizes.data(), 1, db.sizes.size(), f) == db.sizes.size(); if (f) fclose(f); }
+    { FILE* f = fopen((std::string(prefix) + ".ky").c_str(), "wb"); ok = ok && f && fwrite(db.keys.data(), 1, db.keys.size(), f) == db.keys.size(); if (f) fclose(f); }
+    { FILE* f = fopen((std::string(prefix) + ".lb").c_str(), "wb"); ok = ok && f && fwrite(db.labels.data(), 2, db.labels.size(), f) == db.labels.size(); if (f) fclose(f); }
+    if (ok) {
+      const unsigned n2 = (unsigned)rnd(1, 4);
+      std::vector<mic_engine*> e2(n2, nullptr);
+      bool made = true;
+      for (unsigned i = 0; i < n2; ++i) {
+        mic_config cfg; cfg.device = (int)(i % n_dev); cfg.k = k; cfg.num_targets = T; cfg.num_batches = 1; cfg.row_words = 16; cfg.layout = layout;
+        made = made && CALL(mic_create(&cfg, &e2[i])) && e2[i];
+        if (made && n2 > 1) CALL(mic_db_set_part(e2[i], i, n2));
+      }
+      if (made) {
+        if (n2 == 1) CALL(mic_db_load_files(e2[0], prefix, rng() & 1 ? db.key_bytes : 0, 1, 0, 0));
+        else CALL(mic_db_load_files_multi(e2.data(), n2, prefix, db.key_bytes, 1));
+        CALL(mic_db_unload(e2[0]));
+      }
+      for (unsigned i = 0; i < n2; ++i) if (e2[i]) CALL(mic_destroy(e2[i]));
+    }
+    for (const char* ext : {".sz", ".ky", ".lb"}) remove((std::string(prefix) + ext).c_str());
   }
   // free in a random order; sometimes the batches explicitly first
   for (unsigned i = 0; i < n_eng; ++i) if (rng() & 1) CALL(mic_batches_free(eng[i]));
