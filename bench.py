@@ -201,7 +201,108 @@ def gzip_sub_leg(cmd, fqs, rec, n, res_base, tmp):
     return out
 
 
-def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res_expect, truth, threads, keep=False, paired=False):
+ASSIGN_RE = r"Assignment time: ([0-9.eE+-]+) s\. Speed: (\d+) objects/min\. \((\d+) objects\)"
+
+
+def run_cli(cmd, extra_env=None):
+    """one run of exe/cuCLARK with its timing lines on; returns (CompletedProcess, parsed dict)"""
+    import re
+    import subprocess
+    env = dict(os.environ, MIC_CLI_TIMING="1", MIC_LOAD_TIMING="1")
+    env.update(extra_env or {})
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    wall = time.time() - t0
+    out = {"process_wall_s": round(wall, 2)}
+    if r.returncode != 0:
+        out["error"] = (r.stderr or r.stdout)[-400:]
+        return r, out
+    m = re.search(ASSIGN_RE, r.stdout)
+    out["assignment_s"] = round(float(m.group(1)), 4)
+    out["objects"] = int(m.group(3))
+    out["value"] = round(int(m.group(3)) / float(m.group(1)) / 1e6, 1)
+    out["unit"] = "Mreads/s"
+    ing = re.search(r"device ingest: (\d+) batches of <= (\d+) KB on (\d+) slot\(s\), (\d+) through the host path; threads: (\d+) load, (\d+) device, (\d+) write; "
+                    r"thread-seconds: load ([0-9.e+-]+), device ([0-9.e+-]+), write ([0-9.e+-]+); input ([0-9.e+]+) MB, over the link ([0-9.e+]+) MB", r.stderr)
+    if ing:
+        out["ingest"] = {"batches": int(ing.group(1)), "slot_KB": int(ing.group(2)), "slots": int(ing.group(3)), "batches_through_host_path": int(ing.group(4)),
+                         "threads": {"load": int(ing.group(5)), "device": int(ing.group(6)), "write": int(ing.group(7))},
+                         "thread_seconds": {"load": float(ing.group(8)), "device": float(ing.group(9)), "write": float(ing.group(10))},
+                         "input_MB": float(ing.group(11)), "h2d_MB": float(ing.group(12))}
+    out["table_load_s"] = {a.strip(): float(b) for a, b in re.findall(r"\[load(?: x\d+)?\] ([^:\n]+): ([0-9.]+) s", r.stderr)}
+    kn = re.search(r"\[timing\] query kernel: (.+)", r.stderr)
+    if kn:
+        out["kernel"] = kn.group(1).strip()
+    return r, out
+
+
+def multi_engine_leg(base_cmd, res_one, tmp, paired_gz=None):
+    """the product binary's multi-device modes at FULL scale on this one GPU (MIC_SHARD_ENGINES=n puts n engines on it):
+    the same table files and the same 10 M-read FASTQ as the one-engine run; every CSV must equal that run's byte for byte.
+      --db-sharded --parts N on N = 2 / 4 / 8 engines  the reference's mode (CuClarkDB.cu:566-574, 886-1024): N parts of the table, every
+                                                       batch probed by all N, rows exchanged read-range owned over peer copies
+      --db-sharded --parts 2 on 4 engines              2-D: 2 parts x 2 read groups
+      -d 2 on 2 engines                                read-sharded: two whole tables, batches dealt
+      -P a.fq.gz b.fq.gz -d 2 on 2 engines             compressed mates inflated on the first engine's device, slots on both engines
+    Reported per run: assignment time, the table load split (one read of the files / the builds per device), and - from HIP events on
+    every engine's stream (MIC_GROUP_TIMING) - bytes and time of the packed-read fan-out and of the row exchange next to the kernels."""
+    import filecmp
+    import re
+    out = {"what": "exe/cuCLARK with n engines on ONE GPU (MIC_SHARD_ENGINES): same files as the one-engine run, CSVs compared byte for byte; "
+                   "'peer' copies are device-local here, so exchange_ms is a floor for what xGMI adds", "runs": {}}
+    runs = [("db_sharded_2", ["--db-sharded", "--parts", "2"], 2), ("db_sharded_4", ["--db-sharded", "--parts", "4"], 4),
+            ("db_sharded_8", ["--db-sharded", "--parts", "8"], 8), ("db_sharded_4_parts_2", ["--db-sharded", "--parts", "2"], 4),
+            ("read_sharded_2", ["-d", "2"], 2)]
+    for name, flags, n_eng in runs:
+        res = os.path.join(tmp, "out_" + name)
+        cmd = [res if a == res_one else a for a in base_cmd] + flags
+        r, d = run_cli(cmd, {"MIC_SHARD_ENGINES": str(n_eng), "MIC_GROUP_TIMING": "1"})
+        d["engines"] = n_eng
+        d["flags"] = " ".join(flags)
+        if "error" not in d:
+            d["csv_equals_one_engine_run"] = filecmp.cmp(res_one + ".csv", res + ".csv", shallow=False)
+            dv = re.search(r"Devices: (.+)", r.stderr)
+            d["layout"] = dv.group(1).split(";")[0] if dv else None
+            g = re.search(r"table-sharded batches: (\d+) timed, (\d+) reads, (\d+) part\(s\); packed-read fan-out ([0-9.e+-]+) MB, ([0-9.e+-]+) ms summed over the helpers "
+                          r"\(slowest helper of each batch: ([0-9.e+-]+) ms\); query kernels ([0-9.e+-]+) ms summed over the engines \(slowest engine of each batch: ([0-9.e+-]+) ms\); "
+                          r"row exchange ([0-9.e+-]+) MB, ([0-9.e+-]+) ms summed over the engines \(slowest engine of each batch: ([0-9.e+-]+) ms\)", r.stderr)
+            if g:
+                nb = max(int(g.group(1)), 1)
+                d["per_batch"] = {"batches": nb, "reads": int(g.group(2)) // nb,
+                                  "fanout_MB": round(float(g.group(4)) / nb, 2), "fanout_ms_slowest_helper": round(float(g.group(6)) / nb, 3),
+                                  "kernel_ms_all_engines": round(float(g.group(7)) / nb, 3), "kernel_ms_slowest_engine": round(float(g.group(8)) / nb, 3),
+                                  "exchange_MB": round(float(g.group(9)) / nb, 2), "exchange_ms_all_engines": round(float(g.group(10)) / nb, 3),
+                                  "exchange_ms_slowest_engine": round(float(g.group(11)) / nb, 3)}
+            try:
+                os.unlink(res + ".csv")
+            except OSError:
+                pass
+        out["runs"][name] = d
+        log("multi_engine", name + ":", json.dumps(d))
+    if paired_gz:
+        # compressed mates through one engine and through two (read-sharded): the text is inflated on the first engine's device and
+        # the slots of both engines are filled from there
+        a, b, cmd_p = paired_gz
+        res1, res2 = os.path.join(tmp, "out_gz1"), os.path.join(tmp, "out_gz2")
+        c1 = [res1 if x == res_one else x for x in cmd_p]
+        c2 = [res2 if x == res_one else x for x in cmd_p] + ["-d", "2"]
+        r1, d1 = run_cli(c1)
+        r2, d2 = run_cli(c2, {"MIC_SHARD_ENGINES": "2"})
+        d2["engines"] = 2
+        d2["flags"] = "-P a.fq.gz b.fq.gz -d 2"
+        if "error" not in d1 and "error" not in d2:
+            d2["csv_equals_one_engine_run"] = filecmp.cmp(res1 + ".csv", res2 + ".csv", shallow=False)
+            d2["one_engine_value"] = d1["value"]
+            d2["inflated_on"] = "device" if re.search(r"device inflate: [0-9.]+ MB of text", r2.stderr) else "host"
+        elif "error" in d1:
+            d2["error"] = "one-engine run: " + d1["error"]
+        out["runs"]["paired_gzip_read_sharded_2"] = d2
+        log("multi_engine paired_gzip_read_sharded_2:", json.dumps(d2))
+    out["all_csv_equal"] = all(v.get("csv_equals_one_engine_run") is True for v in out["runs"].values())
+    return out
+
+
+def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res_expect, truth, threads, keep=False, paired=False, reps=3, multi=True, multi_reads=0):
     """files in, file out, through exe/cuCLARK (reference: CuCLARK_hh.hh:550-563 times index + pack +
     GPU + CSV and prints objects/min, :1938-1944).  The table goes to disk in the reference's format, the same reads as
     FASTQ; the binary loads the table, classifies, writes the CSV.  Checked: every CSV line against the kernel's result
@@ -243,16 +344,29 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
         res_base = os.path.join(tmp, "out")
         cmd = [exe, "-k", str(k), "--htsize", str(w["htsize"]), "-T", os.path.join(tmp, "targets.txt"), "-D", dbdir,
                *(["-P", fqs[0], fqs[1]] if paired else ["-O", fqs[0]]), "-R", res_base, "-n", str(threads)]
-        t0 = time.time()
-        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MIC_CLI_TIMING="1", MIC_LOAD_TIMING="1"))
-        wall = time.time() - t0
-        if r.returncode != 0:
-            return {"error": (r.stderr or r.stdout)[-400:]}
+        # the run is repeated (--e2e-reps, default 3): `value` is the MEDIAN of the assignment rates, min and max beside it - one run
+        # is a draw from a spread of +-20 % on this pool (the loaders' rate inside the job's CPU quota moves from run to run)
+        r, first = run_cli(cmd)
+        if "error" in first:
+            return {"error": first["error"]}
         import re
-        m = re.search(r"Assignment time: ([0-9.eE+-]+) s\. Speed: (\d+) objects/min\. \((\d+) objects\)", r.stdout)
-        t_assign, opm, n_obj = float(m.group(1)), int(m.group(2)), int(m.group(3))
-        ing = re.search(r"device ingest: (\d+) batches of <= (\d+) KB on (\d+) slot\(s\), (\d+) through the host path.*?input ([0-9.e+]+) MB, over the link ([0-9.e+]+) MB", r.stderr)
-        load = {a.strip(): float(b) for a, b in re.findall(r"\[load\] ([^:\n]+): ([0-9.]+) s", r.stderr)}
+        reps_out = [first]
+        import filecmp
+        for i in range(1, max(1, reps)):
+            res_i = os.path.join(tmp, f"out_rep{i}")
+            ri, di = run_cli([res_i if a == res_base else a for a in cmd])
+            if "error" in di:
+                return {"error": di["error"]}
+            di["csv_equals_first_run"] = filecmp.cmp(res_base + ".csv", res_i + ".csv", shallow=False)
+            os.unlink(res_i + ".csv")
+            reps_out.append(di)
+        by_rate = sorted(reps_out, key=lambda d: d["value"])
+        med = by_rate[len(by_rate) // 2]
+        t_assign, n_obj = med["assignment_s"], med["objects"]
+        opm = int(n_obj / t_assign * 60)
+        ing_d = med.get("ingest")
+        load = first["table_load_s"]
+        wall = first["process_wall_s"]
         # every CSV line against the kernel's rows of the same reads
         import pandas as pd
         names = np.array(["NA"] + [f"TARGET_{t:05d}" for t in range(T)])
@@ -268,16 +382,82 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
                       df["Object_ID"].iloc[-1] == f"r{n_reads - 1:09d}")
         del df
         fq_bytes = sum(os.path.getsize(f) for f in fqs)
-        out = {"value": round(n_obj / t_assign / 1e6, 1), "unit": "Mreads/s", "objects_per_min": opm, "objects": n_obj,
-               "assignment_s": round(t_assign, 4), "process_wall_s": round(wall, 2), "table_load_s": load,
+        out = {"value": round(n_obj / t_assign / 1e6, 1), "unit": "Mreads/s", "value_is": f"median of {len(reps_out)} runs of the command",
+               "min": by_rate[0]["value"], "max": by_rate[-1]["value"], "runs": [d["value"] for d in reps_out],
+               "runs_csv_equal": all(d.get("csv_equals_first_run", True) for d in reps_out),
+               "objects_per_min": opm, "objects": n_obj,
+               "assignment_s": round(t_assign, 4), "process_wall_s": round(wall, 2), "process_wall_s_runs": [d["process_wall_s"] for d in reps_out],
+               "table_load_s": load,
                "input": (f"two FASTQ files (pairs), {fq_bytes / n_reads:.0f} bytes per pair, " if paired else f"FASTQ, {fq_bytes / n_reads:.0f} bytes per record, ") +
                         f"{fq_bytes / 1e9:.2f} GB in the page cache",
                "input_GBs": round(fq_bytes / t_assign / 1e9, 1), "csv_MB": round(os.path.getsize(res_base + ".csv") / 1e6, 1),
-               "host_threads": threads, "ingest": ({"batches": int(ing.group(1)), "slot_KB": int(ing.group(2)), "slots": int(ing.group(3)),
-                                                    "batches_through_host_path": int(ing.group(4)), "input_MB": float(ing.group(5)),
-                                                    "h2d_MB": float(ing.group(6)), "h2d_GBs": round(float(ing.group(6)) / 1e3 / t_assign, 1)} if ing else None),
+               "host_threads": threads, "ingest": (dict(ing_d, h2d_GBs=round(ing_d["h2d_MB"] / 1e3 / t_assign, 1)) if ing_d else None),
+               "kernel": first.get("kernel"),
                "command": "exe/cuCLARK -k %d -T targets.txt -D DB/ %s -R out -n %d" % (k, "-P reads_1.fq reads_2.fq" if paired else "-O reads_1.fq", threads),
                "csv_lines_equal_kernel_rows": bool(ok and lines == n_reads), "setup_files_s": round(t_files, 1)}
+        # ---- what bounds the run: every stage's busy share (thread-seconds / threads / assignment time, the median run's) and - plain FASTQ -
+        # the loaders ALONE on the same file with the same thread count and chunk size, no device work (exe/cuCLARK --strip-fastq ...
+        # loaders: pread of 256 KiB into a stage that stays in L2, AVX2 strip into a slot-sized buffer; tools/loader_rate.sh)
+        if ing_d:
+            th, ts = ing_d["threads"], ing_d["thread_seconds"]
+            shares = {st: round(ts[st] / max(th[st], 1) / t_assign, 3) for st in ("load", "device", "write")}
+            out["stage_busy_share"] = {"loaders": shares["load"], "device_threads": shares["device"], "writer": shares["write"]}
+            out["device_busy_share"], out["writer_busy_share"] = shares["device"], shares["write"]
+            out["h2d_GBs"] = round(ing_d["h2d_MB"] / 1e3 / t_assign, 1)
+            if not paired:
+                import subprocess
+                lr = subprocess.run([exe, "--strip-fastq", fqs[0], "-", "262144", "loaders", str(th["load"])], capture_output=True, text=True)
+                rates = sorted(float(x) for x in re.findall(r": ([0-9.]+) GB/s", lr.stdout))
+                if rates:
+                    alone = rates[len(rates) // 2]
+                    in_run = ing_d["input_MB"] / 1e3 / t_assign
+                    out["loaders_alone_GBs"] = round(alone, 1)
+                    out["loaders_alone_runs_GBs"] = [round(x, 1) for x in rates]
+                    out["loaders_in_run_GBs"] = round(in_run, 1)
+                    out["loaders_in_run_vs_alone"] = round(in_run / alone, 3)
+            top = max(shares, key=lambda st_: shares[st_])
+            bound = {"load": "loaders (page cache -> stripped FASTQ in pinned slots)", "device": "device threads (H2D + kernels + D2H per batch)",
+                     "write": "CSV writer (one pwrite stream)"}[top]
+            if top == "load" and "loaders_alone_GBs" in out:
+                bound += (f": {out['loaders_in_run_GBs']} GB/s of input in the run against {out['loaders_alone_GBs']} GB/s for the same {th['load']} loader threads "
+                          f"with nothing else running ({out['loaders_in_run_vs_alone']:.2f} x)")
+            out["bound"] = bound
+        if multi and not paired:
+            me_cmd, me_ref, me_n = cmd, res_base, n_reads
+            if 0 < multi_reads < n_reads:
+                # (tests: the same legs on the first multi_reads reads of the file, with a one-engine run of their own to compare against)
+                short = os.path.join(tmp, "reads_head.fq")
+                with open(fqs[0], "rb") as f, open(short, "wb") as g:
+                    g.write(f.read(multi_reads * rec))
+                me_ref, me_n = os.path.join(tmp, "out_head"), multi_reads
+                me_cmd = [short if a == fqs[0] else me_ref if a == res_base else a for a in cmd]
+                r0, d0 = run_cli(me_cmd)
+                if "error" in d0:
+                    raise RuntimeError("one-engine run on the head of the file: " + d0["error"])
+            # compressed mates for the two-engine run: the first million pairs of the same generator, as `gzip -1` files
+            pgz = None
+            try:
+                import subprocess
+                n_p = min(n_reads, 1_000_000)
+                d_t = torch.empty(n_p * rec, dtype=torch.uint8, device=d_sizes.device)
+                gz_names = []
+                for mate in (0, 1):
+                    rc = L.mic_synth_reads_text_device(C.byref(spec), 5, n_p, read_len, 0.2, 0.01, 0.001, 0, mate, d_t.data_ptr(), d_t.numel(), None)
+                    assert rc == 0
+                    torch.cuda.synchronize()
+                    name = os.path.join(tmp, f"mate_{mate + 1}.fq.gz")
+                    with open(name, "wb") as f:
+                        subprocess.run(["gzip", "-1", "-c"], input=d_t.cpu().numpy().tobytes(), stdout=f, check=True)
+                    gz_names.append(name)
+                del d_t
+                cmd_p = [exe, "-k", str(k), "--htsize", str(w["htsize"]), "-T", os.path.join(tmp, "targets.txt"), "-D", dbdir, "-P", gz_names[0], gz_names[1],
+                         "-R", me_ref, "-n", str(threads)]
+                pgz = (gz_names[0], gz_names[1], cmd_p)
+            except Exception as ex:
+                log("multi_engine: no compressed mates:", repr(ex))
+            torch.cuda.empty_cache()
+            out["multi_engine"] = multi_engine_leg(me_cmd, me_ref, tmp, pgz)
+            out["multi_engine"]["reads"] = me_n
         if paired:
             out["gzip_input"] = gzip_sub_leg(cmd, fqs, rec, min(n_reads, 1_000_000), res_base, tmp)
         elif not os.environ.get("MIC_BENCH_NO_FASTA"):
@@ -370,6 +550,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the batch-API pipeline leg (N=1)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-in, CSV-out leg through exe/cuCLARK (N=1)")
     ap.add_argument("--e2e-threads", type=int, default=12, help="-n of the end-to-end run")
+    ap.add_argument("--e2e-reps", type=int, default=3, help="runs of the end-to-end command; the leg reports their median, min and max")
+    ap.add_argument("--multi-engine-reads", type=int, default=0, help="end_to_end.multi_engine on the first N reads of the file only (tests)")
+    ap.add_argument("--no-multi-engine", action="store_true",
+                    help="N=1: skip end_to_end.multi_engine (exe/cuCLARK's multi-device modes with 2 / 4 / 8 engines on this GPU, CSVs against the one-engine run)")
     ap.add_argument("--parts", type=int, default=0,
                     help="--mode db: parts the table is cut into (default: one per rank = the reference's mode).  With fewer parts than "
                          "ranks the ranks form N / parts groups that split the reads (2-D layout, DESIGN.md 6)")
@@ -834,7 +1018,8 @@ def main():
             try:
                 del d_res, d_cont, d_rp
                 torch.cuda.empty_cache()
-                e2e = end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res, truth, args.e2e_threads, paired=paired)
+                e2e = end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res, truth, args.e2e_threads, paired=paired,
+                                      reps=args.e2e_reps, multi=not args.no_multi_engine, multi_reads=args.multi_engine_reads)
             except Exception as ex:
                 e2e = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             log("end_to_end:", json.dumps(e2e))

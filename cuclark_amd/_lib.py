@@ -96,6 +96,7 @@ SYMBOLS = [
     ("mic_ingest_classify", C.c_int, [_VP, _SZ, _SZ, C.c_int, C.POINTER(MicIngestResult)]),
     ("mic_ingest_classify_group", C.c_int, [C.POINTER(C.c_void_p), _SZ, _SZ, _SZ, _SZ, C.c_int, C.POINTER(MicIngestResult)]),
     ("mic_ingest_fetch_group_rows", C.c_int, [_VP, _SZ, _SZ, _VP, _SZ, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    ("mic_ingest_group_stats", C.c_int, [_VP, C.POINTER(C.c_double), _SZ]),
     ("mic_ingest_fetch_packed", C.c_int, [_VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("mic_ingest_free", C.c_int, [_VP]),
     ("mic_gz_inflate_device", C.c_int, [_VP, _VP, _SZ, C.POINTER(_VP), C.POINTER(_SZ), C.POINTER(C.c_uint32)]),

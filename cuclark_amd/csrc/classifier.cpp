@@ -144,72 +144,31 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
   //                     part of the table each (mic_db_set_part) and answer every batch of their group together; --parts P picks P,
   //                     the default is the smallest P that divides the engines and whose part fits a device - a part's kernel
   //                     costs nearly as much as the whole table's, so engines beyond that divide the READS
-  parts_ = 1;
-  if (opt_.db_sharded) {
-    if (opt_.parts) {
-      if (use % opt_.parts != 0) die("--parts " + std::to_string(opt_.parts) + " does not divide the " + std::to_string(use) + " device(s) in use.");
-      parts_ = opt_.parts;
-    } else {
-      struct stat sz, ky;
-      uint64_t dev_free = 0, dev_total = 0;
-      if (stat((db + ".sz").c_str(), &sz) != 0 || stat((db + ".ky").c_str(), &ky) != 0) die("Failed to open " + db + ".sz");
-      check(mic_device_memory(0, &dev_free, &dev_total), "device memory");
-      const int kb = mic_key_bytes_rule((uint64_t)sz.st_size, (int)opt_.k);
-      const uint64_t n_el = (uint64_t)ky.st_size / (uint64_t)(kb > 0 ? kb : 4);
-      const uint64_t images = (uint64_t)sz.st_size + n_el * (uint64_t)(kb + 2);          // every part is built from the whole images
-      const uint64_t table = opt_.k >= 24 ? n_el * 12 : (uint64_t)sz.st_size * 64;       // resident bytes: super-k-mer slots / direct slots
-      parts_ = use;
-      for (size_t p = 1; p <= use; ++p)
-        if (use % p == 0 && images + 2 * (table / p) + ((uint64_t)2 << 30) <= dev_total) { parts_ = p; break; }
-    }
-  }
-  groups_ = use / parts_;
-  std::cerr << "Loading database [" << db << ".*] (s=" << opt_.sampling << ")..." << std::endl;
-  const size_t per_engine_batches = std::max<size_t>(1, (opt_.batches + groups_ - 1) / groups_);
-  for (size_t d = 0; d < use; ++d) {
-    mic_config cfg;
-    memset(&cfg, 0, sizeof(cfg));
-    cfg.device = (int)(d % (size_t)n_dev); cfg.k = (int)opt_.k; cfg.num_targets = (uint32_t)(names_.size());
-    cfg.num_batches = (uint32_t)per_engine_batches;
-    cfg.row_words = opt_.extended ? (uint32_t)std::min<size_t>(names_.size() + 1, 65) : 16;
-    mic_engine* e = nullptr;
-    check(mic_create(&cfg, &e), "engine creation");
-    engines_.push_back(e);
-    if (parts_ > 1) check(mic_db_set_part(e, (uint32_t)(d % parts_), (uint32_t)parts_), "table part");
-  }
+  const int nd_used = (int)std::min<size_t>(use, (size_t)n_dev);
   gz_on_device_ = true;
+  std::vector<int> pm;
   if (use > 1) {
     // peer access between the devices in use (the reference: CuClarkDB.cu:184-208): the row exchange of the table-sharded mode and
     // the slots filled from a text inflated on another device go over it
-    const int nd = (int)std::min<size_t>(use, (size_t)n_dev);
-    std::vector<int> pm((size_t)nd * nd, 0);
-    check(mic_peer_matrix(pm.data(), nd), "peer access");
-    std::cerr << "Devices: " << use << " engine(s) on " << nd << " device(s)";
-    if (opt_.db_sharded) std::cerr << ", table-sharded: " << parts_ << " part(s) x " << groups_ << " read group(s)";
-    else std::cerr << ", read-sharded (table replicated)";
-    std::cerr << "; peer access:";
-    for (int i = 0; i < nd; ++i) {
-      std::cerr << (i ? " | " : " ");
-      for (int j = 0; j < nd; ++j) { std::cerr << pm[(size_t)i * nd + j]; if (i != j && !pm[(size_t)i * nd + j]) gz_on_device_ = false; }
-    }
-    std::cerr << std::endl;
+    pm.assign((size_t)nd_used * nd_used, 0);
+    check(mic_peer_matrix(pm.data(), nd_used), "peer access");
+    for (int i = 0; i < nd_used; ++i)
+      for (int j = 0; j < nd_used; ++j) if (i != j && !pm[(size_t)i * nd_used + j]) gz_on_device_ = false;
   }
-  // the ingest slots (pinned and device buffers of the streaming path) are set up while the database loads
-  // The slots' device memory is announced to the engines first (mic_db_reserve_hbm): the table build sizes its staging area
-  // from the free HBM, and what it sees must not depend on how far the side thread has got.
-  std::thread slots;
-  if (device_ingest() && !opt_.objects.empty()) {
-    size_t bytes = ~(size_t)0 >> 1;
+  // What the run allocates on the devices NEXT to the table: the ingest slots (pinned and device buffers of the streaming path, set
+  // up on a side thread while the database loads) and the buffers of a device inflate.  Known before the table is cut: the number
+  // of parts is chosen with them in the sum, and the builders are told (mic_db_reserve_hbm) so that the staging area they size from
+  // the free HBM does not depend on how far the side thread has got.
+  const bool want_slots = device_ingest() && !opt_.objects.empty();
+  size_t in_bytes = ~(size_t)0 >> 1, slot_bytes = 0, workers = 0;
+  struct GzFile { size_t bytes; uint32_t isize; };
+  std::vector<GzFile> gz;
+  uint64_t gz_hbm = 0;
+  if (want_slots) {
     struct stat st;
-    if (opt_.objects2.empty() && !is_gzip(opt_.objects) && stat(opt_.objects.c_str(), &st) == 0) bytes = (size_t)st.st_size;
-    size_t slot_bytes = 0, workers = 0;
-    ingest_geometry(bytes, slot_bytes, workers);
-    const size_t per_engine = (workers + engines_.size() - 1) / engines_.size();
-    // table-sharded: every engine also holds the partial rows, gathered rows and packed reads of every slot of its group (~6.5 x the slot)
-    const size_t group_extra = parts_ > 1 ? ((workers + groups_ - 1) / groups_) * 13 / 2 : 0;
-    // two compressed mates on one engine are inflated on the device (run_paired): the buffers of that are set up here as well
-    struct GzFile { size_t bytes; uint32_t isize; };
-    std::vector<GzFile> gz;
+    if (opt_.objects2.empty() && !is_gzip(opt_.objects) && stat(opt_.objects.c_str(), &st) == 0) in_bytes = (size_t)st.st_size;
+    ingest_geometry(in_bytes, slot_bytes, workers);
+    // two compressed mates (or one compressed file) on the first engine are inflated on the device (run_paired / run)
     const bool gz_pair = !opt_.objects2.empty() && is_gzip(opt_.objects) && is_gzip(opt_.objects2) && !getenv("MIC_SERIAL_PAIRS");
     const bool gz_single = opt_.objects2.empty() && is_gzip(opt_.objects);
     if (gz_on_device_ && (gz_pair || gz_single) && !getenv("MIC_GZ_HOST")) {
@@ -236,13 +195,101 @@ Classifier::Classifier(const Options& opt) : opt_(opt) {
         if (fd != -1) close(fd);
       }
     }
-    uint64_t gz_hbm = 0;
     for (const GzFile& g : gz) gz_hbm += mic_gz_reserve_bytes(g.bytes, g.isize);
-    for (mic_engine* e : engines_)      // ~6.1 x the slot size per slot (mic_ingest.hip); the inflated text lives on the first engine's device
-      mic_db_reserve_hbm(e, (uint64_t)(per_engine * 7 + group_extra) * slot_bytes + (e == engines_[0] ? gz_hbm : 0));
-    slots = std::thread([this, bytes, gz] {
-      try { ensure_ingest(bytes); } catch (const std::exception&) { release_ingest(); }
-      for (const GzFile& g : gz) if (mic_gz_reserve(engines_[0], g.bytes, g.isize) != MIC_OK) break;     // (without it the call allocates for itself)
+  }
+  // device memory engine `e` of `use` allocates next to its table when the table is cut into P parts
+  auto reserve_of = [&](size_t P, size_t e) -> uint64_t {
+    if (!want_slots) return 0;
+    const size_t G = use / P, per_engine = (workers + use - 1) / use;      // ~6.1 x the slot size per slot (mic_ingest.hip)
+    // table-sharded: every engine also holds the partial rows, gathered rows and packed reads of every slot of its group (~6.5 x the slot)
+    const size_t group_extra = P > 1 ? ((workers + G - 1) / G) * 13 / 2 : 0;
+    return (uint64_t)(per_engine * 7 + group_extra) * slot_bytes + (e == 0 ? gz_hbm : 0);   // (the inflated text lives on the first engine's device)
+  };
+  parts_ = 1;
+  if (opt_.db_sharded) {
+    if (opt_.parts && use % opt_.parts != 0) die("--parts " + std::to_string(opt_.parts) + " does not divide the " + std::to_string(use) + " device(s) in use.");
+    struct stat sz, ky;
+    if (stat((db + ".sz").c_str(), &sz) != 0 || stat((db + ".ky").c_str(), &ky) != 0) die("Failed to open " + db + ".sz");
+    // the memory a device must offer: the least free memory over the devices in use (a device may be shared with another job)
+    uint64_t free_min = ~(uint64_t)0;
+    for (int d = 0; d < nd_used; ++d) {
+      uint64_t f = 0, t = 0;
+      check(mic_device_memory(d, &f, &t), "device memory");
+      free_min = std::min(free_min, f);
+    }
+    const int kb = mic_key_bytes_rule((uint64_t)sz.st_size, (int)opt_.k);
+    const uint64_t n_el = (uint64_t)ky.st_size / (uint64_t)(kb > 0 ? kb : 4);
+    const uint64_t images = (uint64_t)sz.st_size + n_el * (uint64_t)(kb + 2);
+    // resident bytes and how a part is cut follow the layout: super-k-mer tables (k >= 24) are cut by RESIDENT slot
+    // range and every part is built from the whole images; direct and minimizer tables are cut by on-disk bucket range, and a device
+    // then holds its engines' share of the images only (mic_db_load_files_multi)
+    const char* lay = getenv("MIC_LAYOUT");
+    const bool bucket_cut = (lay && (!strcmp(lay, "direct") || !strcmp(lay, "minimizer"))) || (!lay && opt_.k < 24);
+    const uint64_t table = lay && !strcmp(lay, "minimizer") ? n_el * 30 : lay && !strcmp(lay, "super2") ? n_el * 24
+                         : bucket_cut ? (uint64_t)sz.st_size * 64 + n_el / 8 : n_el * 12;
+    const size_t epd = (use + (size_t)nd_used - 1) / (size_t)nd_used;       // engines that share a device (MIC_SHARD_ENGINES on fewer devices)
+    auto need = [&](size_t P) -> uint64_t {
+      const uint64_t part = table / P;
+      const uint64_t images_dev = bucket_cut ? images / P * std::min<uint64_t>(epd, P) + (1u << 20) : images;
+      // the device's engines' parts, the staging area of the build in progress (the builders work in passes when it is small: a
+      // quarter of a part at least), what the engines allocate next to their tables, the runtime's own
+      return images_dev + epd * part + part / 4 + epd * reserve_of(P, 0) + ((uint64_t)1 << 30);
+    };
+    auto sizes = [&](size_t P) {
+      char b[256];
+      snprintf(b, sizeof(b), "%.1f GB (images %.1f GB%s + %zu part(s) of %.1f GB + build staging + %.1f GB of ingest buffers)", need(P) / 1e9,
+               (bucket_cut ? images / P * std::min<uint64_t>(epd, P) : images) / 1e9, bucket_cut ? " of this device's bucket ranges" : ", whole: a super-k-mer part is a slot range of the resident table",
+               epd, table / P / 1e9, epd * reserve_of(P, 0) / 1e9);
+      return std::string(b);
+    };
+    if (opt_.parts) {
+      parts_ = opt_.parts;
+      if (need(parts_) > free_min)
+        std::cerr << "Note: --parts " << parts_ << " needs about " << sizes(parts_) << " per device, " << free_min / 1e9 << " GB are free." << std::endl;
+    } else {
+      // the smallest number of parts that fits: a part's kernel costs nearly as much as the whole table's, so engines
+      // beyond what capacity needs divide the READS
+      parts_ = 0;
+      for (size_t p = 1; p <= use; ++p)
+        if (use % p == 0 && need(p) <= free_min) { parts_ = p; break; }
+      if (!parts_)
+        die("The database does not fit " + std::to_string(use) + " engine(s) on " + std::to_string(nd_used) + " device(s) with " + std::to_string(free_min / 1000000 / 1000.0) +
+            " GB free each: " + std::to_string(use) + " parts need about " + sizes(use) + " per device.  Use more devices (-d), or --parts P to try a cut yourself.");
+    }
+  }
+  groups_ = use / parts_;
+  std::cerr << "Loading database [" << db << ".*] (s=" << opt_.sampling << ")..." << std::endl;
+  const size_t per_engine_batches = std::max<size_t>(1, (opt_.batches + groups_ - 1) / groups_);
+  for (size_t d = 0; d < use; ++d) {
+    mic_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.device = (int)(d % (size_t)n_dev); cfg.k = (int)opt_.k; cfg.num_targets = (uint32_t)(names_.size());
+    cfg.num_batches = (uint32_t)per_engine_batches;
+    cfg.row_words = opt_.extended ? (uint32_t)std::min<size_t>(names_.size() + 1, 65) : 16;
+    mic_engine* e = nullptr;
+    check(mic_create(&cfg, &e), "engine creation");
+    engines_.push_back(e);
+    if (parts_ > 1) check(mic_db_set_part(e, (uint32_t)(d % parts_), (uint32_t)parts_), "table part");
+  }
+  if (use > 1) {
+    std::cerr << "Devices: " << use << " engine(s) on " << nd_used << " device(s)";
+    if (opt_.db_sharded) std::cerr << ", table-sharded: " << parts_ << " part(s) x " << groups_ << " read group(s)";
+    else std::cerr << ", read-sharded (table replicated)";
+    std::cerr << "; peer access:";
+    for (int i = 0; i < nd_used; ++i) {
+      std::cerr << (i ? " | " : " ");
+      for (int j = 0; j < nd_used; ++j) std::cerr << pm[(size_t)i * nd_used + j];
+    }
+    std::cerr << std::endl;
+  }
+  std::thread slots;
+  if (want_slots) {
+    for (size_t e = 0; e < engines_.size(); ++e) mic_db_reserve_hbm(engines_[e], reserve_of(parts_, e));
+    std::vector<std::pair<size_t, uint32_t>> gzv;
+    for (const GzFile& g : gz) gzv.push_back({g.bytes, g.isize});
+    slots = std::thread([this, in_bytes, gzv] {
+      try { ensure_ingest(in_bytes); } catch (const std::exception&) { release_ingest(); }
+      for (const auto& g : gzv) if (mic_gz_reserve(engines_[0], g.first, g.second) != MIC_OK) break;     // (without it the call allocates for itself)
     });
   }
   std::string load_err;
@@ -1902,6 +1949,20 @@ bool Classifier::run_stream(Feeder& feed, const std::string& results_base, bool 
                         << (ts_alloc - t0_us) / 1e3 << ", first batch loaded " << (ts_first_loaded - t0_us) / 1e3 << ", last loaded "
                         << (ts_last_loaded - t0_us) / 1e3 << ", last off the device " << (ts_last_dev - t0_us) / 1e3 << ", last write done " << (ts_last_write - t0_us) / 1e3
                         << " (longest " << us_write_max / 1e3 << "), end " << diff * 1e3 << std::endl;
+  if (timing && parts_ > 1) {
+    // MIC_GROUP_TIMING=1: HIP events on every engine's stream around the packed-read fan-out, the query kernel and the row exchange of
+    // every batch (mic_ingest_group_stats), summed over the slots' owners
+    double tot[MIC_GROUP_STATS_FIELDS] = {0};
+    for (mic_engine* e : engines_) {
+      double v[MIC_GROUP_STATS_FIELDS];
+      if (mic_ingest_group_stats(e, v, MIC_GROUP_STATS_FIELDS) > 0) for (size_t i = 0; i < MIC_GROUP_STATS_FIELDS; ++i) tot[i] += v[i];
+    }
+    if (tot[0] > 0)
+      std::cerr << "[timing] table-sharded batches: " << (uint64_t)tot[0] << " timed, " << (uint64_t)tot[1] << " reads, " << parts_ << " part(s); packed-read fan-out "
+                << tot[2] / 1e6 << " MB, " << tot[3] << " ms summed over the helpers (slowest helper of each batch: " << tot[4] << " ms); query kernels "
+                << tot[5] << " ms summed over the engines (slowest engine of each batch: " << tot[6] << " ms); row exchange " << tot[7] / 1e6 << " MB, "
+                << tot[8] << " ms summed over the engines (slowest engine of each batch: " << tot[9] << " ms)" << std::endl;
+  }
   std::cout << " - Assignment time: " << diff << " s. Speed: ";  // CuCLARK_hh.hh:1938-1944
   std::cout << (size_t)(((double)n_objects_) / (diff) * 60.0) << " objects/min. (" << n_objects_ << " objects)." << std::endl;
   std::cout << " - Results stored in " << csv << std::endl;

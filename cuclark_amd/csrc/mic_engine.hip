@@ -13,6 +13,7 @@
 
 #include <sched.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <atomic>
@@ -40,7 +41,8 @@ int fail(int code, const char* fmt, ...) {
 thread_local uint64_t mic_build_reserved_hbm = 0;
 namespace {
 std::mutex g_report_mu;
-std::string g_report;     // stage times of the last table build of this process, one "name: seconds" per line
+std::string g_report;     // stage times of the last table build that FINISHED in this process, one "name: seconds" per line
+thread_local std::string t_report;   // ... of the build running on this thread
 
 #define HIPTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     return fail(e_ == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
@@ -148,8 +150,11 @@ int check_shard(uint64_t htsize, uint64_t& s0, uint64_t& s1) {
 // stream a byte range of a file into device memory through two pinned staging buffers; every chunk is read by several
 // threads (pread on disjoint slices): one fread stream moves ~6 GB/s out of the page cache, the link takes ~50.
 // Several destinations (mic_db_load_files_multi: one per device): every chunk is read ONCE and uploaded to each of them.
-struct UploadDst { int device; void* dst; hipStream_t stream; };
-int upload_file_range_multi(FILE* f, uint64_t off, uint64_t bytes, const std::vector<UploadDst>& dsts, const char* what) {
+// Destinations may want different byte ranges of the file (mic_db_load_files_multi: a device whose engines answer for a bucket range
+// holds that range of the images only): [lo, hi) in file offsets, dst = where byte lo goes.  Every chunk is read once and goes to the
+// destinations whose range it meets.
+struct UploadDst { int device; void* dst; hipStream_t stream; uint64_t lo, hi; };
+int upload_file_range_multi(FILE* f, const std::vector<UploadDst>& dsts, const char* what) {
   const size_t CH = 256u << 20;
   const int fd = fileno(f);
   static const int n_readers = [] { const char* e = getenv("MIC_LOAD_THREADS"); int v = e ? atoi(e) : 0; return v > 0 ? (v > 64 ? 64 : v) : 8; }();
@@ -157,7 +162,11 @@ int upload_file_range_multi(FILE* f, uint64_t off, uint64_t bytes, const std::ve
   const size_t nd = dsts.size();
   std::vector<hipEvent_t> ev(2 * nd, nullptr);
   int rc = MIC_OK;
-  if (bytes == 0 || nd == 0) return MIC_OK;
+  if (nd == 0) return MIC_OK;
+  uint64_t off = ~0ull, end = 0;
+  for (const UploadDst& d : dsts) if (d.hi > d.lo) { off = d.lo < off ? d.lo : off; end = d.hi > end ? d.hi : end; }
+  if (end <= off) return MIC_OK;
+  const uint64_t bytes = end - off;
   int dev_now = 0;
   hipGetDevice(&dev_now);
   mic_bind_thread_near_device(dsts[0].device, 1);
@@ -168,12 +177,19 @@ int upload_file_range_multi(FILE* f, uint64_t off, uint64_t bytes, const std::ve
     if (hipSetDevice(dsts[i % nd].device) != hipSuccess || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
       rc = fail(MIC_E_HIP, "event create failed");
   }
-  uint64_t done = 0; int cur = 0; bool used[2] = {false, false};
+  uint64_t done = 0; int cur = 0;
+  std::vector<char> used(2 * nd, 0);
   while (rc == MIC_OK && done < bytes) {
     size_t n = (size_t)((bytes - done) < CH ? (bytes - done) : CH);
-    if (used[cur])
-      for (size_t d = 0; d < nd; ++d)
+    const uint64_t c0 = off + done, c1 = c0 + n;
+    bool wanted = false;
+    for (const UploadDst& d : dsts) if (d.lo < c1 && d.hi > c0) wanted = true;
+    if (!wanted) { done += n; continue; }                // (a gap between the destinations' ranges)
+    for (size_t d = 0; d < nd; ++d)
+      if (used[(size_t)cur * nd + d]) {
         if (hipEventSynchronize(ev[(size_t)cur * nd + d]) != hipSuccess) { rc = fail(MIC_E_HIP, "event sync failed"); break; }
+        used[(size_t)cur * nd + d] = 0;
+      }
     if (rc != MIC_OK) break;
     {
       std::atomic<bool> short_read(false);
@@ -186,7 +202,7 @@ int upload_file_range_multi(FILE* f, uint64_t off, uint64_t bytes, const std::ve
         th.emplace_back([&, lo, len] {
           size_t got = 0;
           while (got < len) {
-            const ssize_t r = pread(fd, (char*)stage[cur] + lo + got, len - got, (off_t)(off + done + lo + got));
+            const ssize_t r = pread(fd, (char*)stage[cur] + lo + got, len - got, (off_t)(c0 + lo + got));
             if (r <= 0) { short_read = true; return; }
             got += (size_t)r;
           }
@@ -196,11 +212,14 @@ int upload_file_range_multi(FILE* f, uint64_t off, uint64_t bytes, const std::ve
       if (short_read) { rc = fail(MIC_E_IO, "%s is shorter than the bucket sizes imply", what); break; }
     }
     for (size_t d = 0; d < nd && rc == MIC_OK; ++d) {
+      const uint64_t a = dsts[d].lo > c0 ? dsts[d].lo : c0, b = dsts[d].hi < c1 ? dsts[d].hi : c1;
+      if (a >= b) continue;
       if (hipSetDevice(dsts[d].device) != hipSuccess ||
-          hipMemcpyAsync((char*)dsts[d].dst + done, stage[cur], n, hipMemcpyHostToDevice, dsts[d].stream) != hipSuccess ||
+          hipMemcpyAsync((char*)dsts[d].dst + (a - dsts[d].lo), (char*)stage[cur] + (a - c0), (size_t)(b - a), hipMemcpyHostToDevice, dsts[d].stream) != hipSuccess ||
           hipEventRecord(ev[(size_t)cur * nd + d], dsts[d].stream) != hipSuccess) rc = fail(MIC_E_HIP, "H2D copy failed");
+      used[(size_t)cur * nd + d] = 1;
     }
-    used[cur] = true; cur ^= 1; done += n;
+    cur ^= 1; done += n;
   }
   for (size_t d = 0; d < nd; ++d) { hipSetDevice(dsts[d].device); hipStreamSynchronize(dsts[d].stream); }
   for (int i = 0; i < 2; ++i) if (stage[i]) hipHostFree(stage[i]);
@@ -213,7 +232,7 @@ int upload_file_range_multi(FILE* f, uint64_t off, uint64_t bytes, const std::ve
 int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStream_t s, const char* what) {
   int dev_now = 0;
   hipGetDevice(&dev_now);
-  return upload_file_range_multi(f, off, bytes, {UploadDst{dev_now, dst, s}}, what);
+  return upload_file_range_multi(f, {UploadDst{dev_now, dst, s, off, off + bytes}}, what);
 }
 
 // layout: explicit request, else the environment (MIC_LAYOUT=direct|minimizer|super|super2), else by k
@@ -271,7 +290,7 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   MicBuildOut b;
   memset(&b, 0, sizeof(b));
   char err[256] = "";
-  { std::lock_guard<std::mutex> lk(g_report_mu); g_report.clear(); }
+  t_report.clear();                              // the stages of THIS build (mic_build_report_add appends to the calling thread's copy)
   mic_build_reserved_hbm = e->reserve_hbm;       // the builders size their staging areas from the free HBM minus this
   struct timespec t_b0; clock_gettime(CLOCK_MONOTONIC, &t_b0);
   int layout, m, m0; bool by_default;
@@ -311,6 +330,8 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
   fill_table(e, b, htsize, s0, s1, key_bytes, sampling, layout, m);
   { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
     mic_build_report_add("table build, total", (t.tv_sec - t_b0.tv_sec) + (t.tv_nsec - t_b0.tv_nsec) / 1e9); }
+  // published in one piece: builds on other threads (mic_db_load_files_multi: one per device) neither wipe nor interleave it
+  { std::lock_guard<std::mutex> lk(g_report_mu); g_report = t_report; }
   return MIC_OK;
 }
 
@@ -452,8 +473,7 @@ void mic_engine_copy_streams(mic_engine* e, hipStream_t* up, hipStream_t* down) 
 void mic_build_report_add(const char* what, double seconds) {
   char line[256];
   snprintf(line, sizeof(line), "%s: %.4f\n", what, seconds);
-  std::lock_guard<std::mutex> lk(g_report_mu);
-  g_report += line;
+  t_report += line;
 }
 
 // ---- several devices in one process -----------------------------------------------------------------------------------
@@ -939,9 +959,13 @@ int mic_db_kernel_name(const mic_engine* e, char* buf, size_t cap) {
   return mic_query_kernel_name(e->table, e->slot_class, buf, cap);
 }
 
-// The database into several engines from one read of the files: images uploaded to every device that hosts an engine, chunk by
-// chunk from the same pinned buffer; then one thread per device builds the tables of its engines (reference: one
-// read() loop over the files filling every device's parts, CuClarkDB.cu:604-808).
+// The database into several engines from one read of the files: every chunk is read once into pinned memory and uploaded to the
+// devices that need it; then one thread per device builds the tables of its engines (reference: one read() loop over the files
+// filling every device's parts, CuClarkDB.cu:604-808).  What a device needs follows the layout: engines that answer for a BUCKET
+// range (direct and minimizer layouts cut by mic_db_set_part - the reference's cut, CuClarkDB.cu:566-574) need that range of the
+// images only, so a database larger than one device's memory loads as long as its share does; a super-k-mer part is a slot range of
+// the RESIDENT table, every k-mer of the images may land in it, so those devices get the whole images - and give them back as soon
+// as their last engine is built.
 int mic_db_load_files_multi(mic_engine* const* engines, size_t n_engines, const char* prefix, int key_bytes, uint32_t sampling) {
   if (!engines || !n_engines || !prefix) return fail(MIC_E_INVALID, "null argument");
   for (size_t i = 0; i < n_engines; ++i) {
@@ -952,8 +976,14 @@ int mic_db_load_files_multi(mic_engine* const* engines, size_t n_engines, const 
   FILE* fs = fopen((p + ".sz").c_str(), "rb");
   FILE* fk = fopen((p + ".ky").c_str(), "rb");
   FILE* fl = fopen((p + ".lb").c_str(), "rb");
-  struct Dev { int device; std::vector<size_t> eng; uint8_t* d_sz = nullptr; void* d_ky = nullptr; uint16_t* d_lb = nullptr; hipStream_t stream = nullptr; };
+  struct Eng { uint64_t s0 = 0, s1 = 0, base_elems = 0, base_rank = 0; };       // bucket range, elements and non-empty buckets in front of it
+  struct Dev {
+    int device; std::vector<size_t> eng; uint8_t* d_sz = nullptr; void* d_ky = nullptr; uint16_t* d_lb = nullptr; hipStream_t stream = nullptr;
+    uint64_t lo = ~0ull, hi = 0, el_lo = 0, el_hi = 0;     // buckets [lo, hi) of the images live here = elements [el_lo, el_hi)
+    double build_s = 0;
+  };
   std::vector<Dev> devs;
+  std::vector<Eng> er(n_engines);
   uint8_t* h_sz = nullptr;
   int rc = MIC_OK;
   const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
@@ -978,30 +1008,67 @@ int mic_db_load_files_multi(mic_engine* const* engines, size_t n_engines, const 
     h_sz = (uint8_t*)malloc(htsize);
     if (!h_sz) { rc = fail(MIC_E_NOMEM, "out of host memory for bucket sizes"); break; }
     if (fread(h_sz, 1, htsize, fs) != htsize) { rc = fail(MIC_E_IO, "short read on %s.sz", prefix); break; }
-    uint64_t n_el = 0;
-    for (uint64_t i = 0; i < htsize; ++i) n_el += h_sz[i];
+    // every engine's bucket range (the whole table unless mic_db_set_part cut a bucket-range layout); elements and non-empty
+    // buckets in front of each cut from ONE pass over the sizes
+    std::vector<uint64_t> cuts;
+    for (size_t i = 0; i < n_engines && !rc; ++i) {
+      er[i].s0 = 0; er[i].s1 = htsize;
+      rc = apply_part(engines[i], htsize, er[i].s0, er[i].s1);
+      cuts.push_back(er[i].s0); cuts.push_back(er[i].s1);
+    }
+    if (rc) break;
+    cuts.push_back(0); cuts.push_back(htsize);
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    std::vector<uint64_t> el_at(cuts.size(), 0), rank_at(cuts.size(), 0);
+    {
+      uint64_t el = 0, rk = 0;
+      for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+        el_at[c] = el; rank_at[c] = rk;
+        for (uint64_t i = cuts[c]; i < cuts[c + 1]; ++i) { el += h_sz[i]; rk += h_sz[i] > 0; }
+      }
+      el_at[cuts.size() - 1] = el; rank_at[cuts.size() - 1] = rk;
+    }
+    auto at = [&](uint64_t bucket) { return (size_t)(std::lower_bound(cuts.begin(), cuts.end(), bucket) - cuts.begin()); };
     lap("read .sz, sum bucket sizes");
     for (size_t i = 0; i < n_engines; ++i) {
+      er[i].base_elems = el_at[at(er[i].s0)]; er[i].base_rank = rank_at[at(er[i].s0)];
       size_t d = 0;
       while (d < devs.size() && devs[d].device != engines[i]->device) ++d;
       if (d == devs.size()) { devs.emplace_back(); devs[d].device = engines[i]->device; devs[d].stream = engines[i]->stream; }
       devs[d].eng.push_back(i);
+      devs[d].lo = std::min(devs[d].lo, er[i].s0); devs[d].hi = std::max(devs[d].hi, er[i].s1);
     }
     for (Dev& dv : devs) {
+      dv.el_lo = el_at[at(dv.lo)]; dv.el_hi = el_at[at(dv.hi)];
       if (hipSetDevice(dv.device) != hipSuccess) { rc = fail(MIC_E_HIP, "hipSetDevice failed"); break; }
       for (size_t i : dv.eng) if (engines[i]->db_loaded) mic_db_unload(engines[i]);
-      hipError_t he = hipMalloc(&dv.d_sz, htsize);
+      const uint64_t n_el = dv.el_hi - dv.el_lo;
+      hipError_t he = hipMalloc(&dv.d_sz, dv.hi - dv.lo);
       if (he == hipSuccess) he = hipMalloc(&dv.d_ky, n_el * key_bytes + 16);
       if (he == hipSuccess) he = hipMalloc(&dv.d_lb, n_el * 2 + 16);
-      if (he != hipSuccess) { rc = fail(he == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "DB image allocation on device %d: %s", dv.device, hipGetErrorString(he)); break; }
+      if (he != hipSuccess) {
+        size_t fr = 0, tot = 0;
+        hipMemGetInfo(&fr, &tot);
+        rc = fail(he == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "DB image allocation on device %d (%.1f GB of images for buckets [%llu, %llu), %.1f GB free of %.1f): %s",
+                  dv.device, ((dv.hi - dv.lo) + n_el * (double)(key_bytes + 2)) / 1e9, (unsigned long long)dv.lo, (unsigned long long)dv.hi, fr / 1e9, tot / 1e9, hipGetErrorString(he));
+        break;
+      }
     }
     if (rc) break;
     std::vector<UploadDst> dz, dk, dl;
-    for (Dev& dv : devs) { dz.push_back({dv.device, dv.d_sz, dv.stream}); dk.push_back({dv.device, dv.d_ky, dv.stream}); dl.push_back({dv.device, dv.d_lb, dv.stream}); }
-    if ((rc = upload_file_range_multi(fs, 0, htsize, dz, "the .sz file"))) break;
-    if ((rc = upload_file_range_multi(fk, 0, n_el * key_bytes, dk, "the .ky file"))) break;
-    if ((rc = upload_file_range_multi(fl, 0, n_el * 2, dl, "the .lb file"))) break;
-    lap("images uploaded to every device");
+    uint64_t up_bytes = 0;
+    for (Dev& dv : devs) {
+      dz.push_back({dv.device, dv.d_sz, dv.stream, dv.lo, dv.hi});
+      dk.push_back({dv.device, dv.d_ky, dv.stream, dv.el_lo * (uint64_t)key_bytes, dv.el_hi * (uint64_t)key_bytes});
+      dl.push_back({dv.device, dv.d_lb, dv.stream, dv.el_lo * 2, dv.el_hi * 2});
+      up_bytes += (dv.hi - dv.lo) + (dv.el_hi - dv.el_lo) * (uint64_t)(key_bytes + 2);
+    }
+    if ((rc = upload_file_range_multi(fs, dz, "the .sz file"))) break;
+    if ((rc = upload_file_range_multi(fk, dk, "the .ky file"))) break;
+    if ((rc = upload_file_range_multi(fl, dl, "the .lb file"))) break;
+    if (timing) fprintf(stderr, "[load x%zu] images on %zu device(s): %.2f GB uploaded from one read of the files\n", n_engines, devs.size(), up_bytes / 1e9);
+    lap("images uploaded to the devices");
     // one thread per device; the engines of a device one after another (a build sizes its staging area from the free HBM)
     std::vector<int> rcs(devs.size(), MIC_OK);
     std::vector<std::string> msgs(devs.size());
@@ -1009,19 +1076,27 @@ int mic_db_load_files_multi(mic_engine* const* engines, size_t n_engines, const 
     for (size_t d = 0; d < devs.size(); ++d)
       th.emplace_back([&, d] {
         Dev& dv = devs[d];
+        struct timespec ta; clock_gettime(CLOCK_MONOTONIC, &ta);
         for (size_t i : dv.eng) {
           mic_engine* e = engines[i];
-          uint64_t s0 = 0, s1 = htsize, base_elems = 0, base_rank = 0;
           int r = set_device(e);
-          if (!r) r = apply_part(e, htsize, s0, s1);
-          if (!r && s0 > 0 && mic_reduce_sizes(dv.d_sz, s0, &base_elems, &base_rank, e->stream) != 0) r = fail(MIC_E_HIP, "size reduction failed");
-          if (!r) r = build_from_device(e, dv.d_sz + s0, htsize, s0, s1, (const char*)dv.d_ky + base_elems * key_bytes, key_bytes,
-                                        dv.d_lb + base_elems, sampling, base_rank);
-          if (r) { rcs[d] = r; msgs[d] = g_err; return; }
+          if (!r) r = build_from_device(e, dv.d_sz + (er[i].s0 - dv.lo), htsize, er[i].s0, er[i].s1,
+                                        (const char*)dv.d_ky + (er[i].base_elems - dv.el_lo) * key_bytes, key_bytes,
+                                        dv.d_lb + (er[i].base_elems - dv.el_lo), sampling, er[i].base_rank);
+          if (r) { rcs[d] = r; msgs[d] = g_err; break; }
         }
+        // the images go as soon as this device's last engine is built (the other devices may still be building)
+        hipSetDevice(dv.device);
+        if (dv.d_sz) { hipFree(dv.d_sz); dv.d_sz = nullptr; }
+        if (dv.d_ky) { hipFree(dv.d_ky); dv.d_ky = nullptr; }
+        if (dv.d_lb) { hipFree(dv.d_lb); dv.d_lb = nullptr; }
+        struct timespec tb; clock_gettime(CLOCK_MONOTONIC, &tb);
+        dv.build_s = (tb.tv_sec - ta.tv_sec) + (tb.tv_nsec - ta.tv_nsec) / 1e9;
       });
     for (auto& t : th) t.join();
     for (size_t d = 0; d < devs.size(); ++d) if (rcs[d]) { rc = fail(rcs[d], "%s", msgs[d].c_str()); break; }
+    if (timing)
+      for (Dev& dv : devs) fprintf(stderr, "[load x%zu] device %d: %zu table(s) built in %.3f s\n", n_engines, dv.device, dv.eng.size(), dv.build_s);
     lap("tables built");
   } while (0);
   if (fs) fclose(fs);

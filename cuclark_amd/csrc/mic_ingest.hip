@@ -23,6 +23,8 @@
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -485,9 +487,22 @@ struct Slot {
     uint32_t* d_flagged = nullptr;
     hipStream_t stream = nullptr;                           // helpers: a stream on their device; owner: the slot's stream
     hipEvent_t ev_q = nullptr, ev_done = nullptr;           // this engine's rows are written; its range is finished and delivered
+    // MIC_GROUP_TIMING: packed reads asked for / arrived (= kernel start) / kernel done / all other engines' rows ready / range delivered
+    hipEvent_t tv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const void* table_id = nullptr;                         // the engine's table when the buffers were set up (a reloaded engine is another peer)
   };
   std::vector<Peer> peers;
   hipEvent_t ev_pack = nullptr;
+  size_t group_owner = 0;
+  uint64_t fan_bytes = 0, x_bytes = 0;                      // MIC_GROUP_TIMING: bytes of the last batch's fan-out and row exchange
+  bool timed = false;
+};
+
+// MIC_GROUP_TIMING=1: what the table-sharded batches of an engine's slots cost, summed over its batches (mic_ingest_group_stats)
+struct GroupStats {
+  std::mutex mu;
+  uint64_t batches = 0, reads = 0, fan_bytes = 0, x_bytes = 0;
+  double fan_ms_sum = 0, fan_ms_max = 0, kernel_ms_sum = 0, kernel_ms_max = 0, x_ms_sum = 0, x_ms_max = 0, span_ms = 0;
 };
 
 struct Ingest {
@@ -496,6 +511,7 @@ struct Ingest {
   char* d_tnames = nullptr; uint32_t* d_tname_off = nullptr; uint32_t n_targets = 0;
   int want_results = 0;
   std::vector<Slot> slots;
+  GroupStats gstats;
 };
 
 const uint32_t kFlaggedCapI = 1024;
@@ -634,21 +650,66 @@ void free_peers(Slot& s) {
     if (p.stream && p.stream != s.stream) { hipStreamSynchronize(p.stream); hipStreamDestroy(p.stream); }
     if (p.ev_q) hipEventDestroy(p.ev_q);
     if (p.ev_done) hipEventDestroy(p.ev_done);
+    for (hipEvent_t e : p.tv) if (e) hipEventDestroy(e);
     if (p.block) hipFree(p.block);
   }
   s.peers.clear();
 }
 
+static bool group_timing() { static const bool on = getenv("MIC_GROUP_TIMING") != nullptr; return on; }
+
+// The engines of a group must answer for ONE database cut into disjoint pieces that cover it: the same k and target count, and
+// either slot-range parts (mic_db_set_part on a super-k-mer table) or bucket ranges (the other layouts, explicit shards) that
+// tile the whole table.  Engines that each hold the whole table, or overlapping pieces, would count every hit several times.
+int check_group(mic_engine* const* group, size_t P) {
+  struct Piece { uint64_t lo, hi; };
+  std::vector<Piece> pieces(P);
+  int k0 = 0, layout0 = 0, parted0 = 0; uint32_t nt0 = 0; uint64_t whole = 0;
+  for (size_t p = 0; p < P; ++p) {
+    MicTable t; int sc, ncu, dev, k; uint32_t nt;
+    int rc = mic_engine_table(group[p], &t, &sc, &ncu, &dev, &k, &nt);
+    if (rc) return rc;
+    if (!t.slots) return mic_set_error(MIC_E_STATE, "no database loaded on engine %zu of the group", p);
+    if (p == 0) { k0 = k; nt0 = nt; layout0 = t.layout; parted0 = t.parted; whole = t.parted ? t.n_main : t.div.d; }
+    if (k != k0 || nt != nt0) return mic_set_error(MIC_E_INVALID, "engine %zu of the group differs in k or in the number of targets (%d / %u against %d / %u)", p, k, nt, k0, nt0);
+    if (t.layout != layout0 || t.parted != parted0) return mic_set_error(MIC_E_INVALID, "engine %zu of the group holds another table layout than engine 0", p);
+    if (t.parted) {
+      if (t.n_main != whole) return mic_set_error(MIC_E_INVALID, "engine %zu of the group holds a part of another table (%llu slots against %llu)", p, (unsigned long long)t.n_main, (unsigned long long)whole);
+      pieces[p] = {t.slot_lo, (uint64_t)t.slot_lo + t.slot_cnt};
+    } else {
+      if (t.div.d != whole) return mic_set_error(MIC_E_INVALID, "engine %zu of the group holds a table of another size", p);
+      pieces[p] = {t.shard_start, t.shard_end};
+    }
+  }
+  std::sort(pieces.begin(), pieces.end(), [](const Piece& a, const Piece& b) { return a.lo < b.lo || (a.lo == b.lo && a.hi < b.hi); });
+  uint64_t at = 0;
+  for (size_t p = 0; p < P; ++p) {
+    if (pieces[p].lo == pieces[p].hi) continue;            // (an empty part answers nothing)
+    if (pieces[p].lo != at)
+      return mic_set_error(MIC_E_INVALID, "the engines of the group do not hold disjoint pieces that cover the table: piece [%llu, %llu) follows %llu%s",
+                           (unsigned long long)pieces[p].lo, (unsigned long long)pieces[p].hi, (unsigned long long)at,
+                           P > 1 && pieces[p].lo == 0 && pieces[p].hi == whole ? " (whole tables: use mic_db_set_part)" : "");
+    at = pieces[p].hi;
+  }
+  if (at != whole) return mic_set_error(MIC_E_INVALID, "the engines of the group cover %llu of %llu %s of the table", (unsigned long long)at,
+                                        (unsigned long long)whole, parted0 ? "slots" : "buckets");
+  return MIC_OK;
+}
+
 int setup_peers(Ingest* g, Slot& s, mic_engine* const* group, size_t P, size_t owner) {
   free_peers(s);
+  int rc = check_group(group, P);
+  if (rc) return rc;
   s.peers.resize(P);
+  s.group_owner = owner;
+  s.timed = group_timing();
   const size_t len_max = g->max_reads / P + 2, rw = kGroupRowWords;
   for (size_t p = 0; p < P; ++p) {
     Slot::Peer& q = s.peers[p];
     MicTable t; int sc, ncu, dev, k; uint32_t nt;
-    int rc = mic_engine_table(group[p], &t, &sc, &ncu, &dev, &k, &nt);
+    rc = mic_engine_table(group[p], &t, &sc, &ncu, &dev, &k, &nt);
     if (rc) return rc;
-    q.eng = group[p]; q.device = dev;
+    q.eng = group[p]; q.device = dev; q.table_id = t.slots;
     ITRY(hipSetDevice(dev));
     const bool own = p == owner;
     for (int pass = 0; pass < 2; ++pass) {          // pass 0 adds the sizes up, pass 1 hands the pieces out
@@ -671,6 +732,7 @@ int setup_peers(Ingest* g, Slot& s, mic_engine* const* group, size_t P, size_t o
     }
     ITRY(hipEventCreateWithFlags(&q.ev_q, hipEventDisableTiming));
     ITRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
+    if (s.timed) for (hipEvent_t& e : q.tv) ITRY(hipEventCreate(&e));
     if (own) { q.d_rp = s.d_rp; q.d_cont = s.d_cont; q.d_res = s.d_results; q.d_flagged = s.d_flagged; q.stream = s.stream; }
     else {
       ITRY(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
@@ -687,14 +749,13 @@ int setup_peers(Ingest* g, Slot& s, mic_engine* const* group, size_t P, size_t o
 // Every engine of the group probes the batch's packed reads (on the owner's device after pack_kernel) against its part; the rows
 // are summed read-range owned; the owner's d_results hold best / second-best of all reads when its stream has passed the waits
 // queued here.  Nothing blocks the host.
-int group_query(mic_engine* const* group, size_t P, size_t owner, Ingest* g, Slot& s, uint32_t n, uint32_t nb, int k) {
-  bool same = s.peers.size() == P;
-  for (size_t p = 0; same && p < P; ++p) same = s.peers[p].eng == group[p];
-  if (!same) { int rc = setup_peers(g, s, group, P, owner); if (rc) return rc; }
+int group_query_issue(mic_engine* const* group, size_t P, size_t owner, Ingest* g, Slot& s, uint32_t n, uint32_t nb, int k) {
   const size_t rw = kGroupRowWords;
   Slot::Peer& O = s.peers[owner];
   // containers the packer can have written for nb bytes in n reads (record_kernel's reservations) + what the kernel reads ahead
   const size_t cont_n = std::min<size_t>(g->cont_cap + 192, (size_t)nb / 8 + 2 * ((size_t)nb / (size_t)(k + 1)) + 10 * (size_t)n + 128);
+  const bool timed = s.timed;
+  s.fan_bytes = s.x_bytes = 0;
   ITRY(hipSetDevice(O.device));
   ITRY(hipEventRecord(s.ev_pack, s.stream));
   for (size_t p = 0; p < P; ++p) {
@@ -706,20 +767,30 @@ int group_query(mic_engine* const* group, size_t P, size_t owner, Ingest* g, Slo
     ITRY(hipSetDevice(dev));
     if (p != owner) {
       ITRY(hipStreamWaitEvent(q.stream, s.ev_pack, 0));
+      if (timed) ITRY(hipEventRecord(q.tv[0], q.stream));
       ITRY(hipMemcpyPeerAsync(q.d_rp, dev, O.d_rp, O.device, ((size_t)n + 2) * 4, q.stream));
       ITRY(hipMemcpyPeerAsync(q.d_cont, dev, O.d_cont, O.device, cont_n * 2, q.stream));
-    }
+      s.fan_bytes += ((size_t)n + 2) * 4 + cont_n * 2;
+    } else if (timed) ITRY(hipEventRecord(q.tv[0], q.stream));
     ITRY(hipMemsetAsync(q.d_flagged, 0, 4, q.stream));
+    if (timed) ITRY(hipEventRecord(q.tv[1], q.stream));
     MicQueryArgs qa;
     qa.t = t; qa.reads_ptr = q.d_rp; qa.cont = q.d_cont; qa.n_reads = n; qa.row_words = (uint32_t)rw; qa.results = q.d_res;
     qa.rows = q.d_rows; qa.flagged = q.d_flagged; qa.flagged_cap = kFlaggedCapI;
     ITRY(mic_launch_query(qa, sc, ncu, q.stream));
     ITRY(hipEventRecord(q.ev_q, q.stream));
+    if (timed) ITRY(hipEventRecord(q.tv[2], q.stream));
   }
   for (size_t j = 0; j < P; ++j) {
     Slot::Peer& q = s.peers[j];
     const size_t lo = (size_t)n * j / P, hi = (size_t)n * (j + 1) / P, len = hi - lo;
     ITRY(hipSetDevice(q.device));
+    if (timed) {
+      // measuring runs: the stream first waits for EVERY engine's rows, so that what tv[3] .. tv[4] brackets is the copies and the
+      // merges alone and not the other engines' kernels (the product form below lets a copy start as soon as its source is written)
+      for (size_t p = 0; p < P; ++p) if (p != j) ITRY(hipStreamWaitEvent(q.stream, s.peers[p].ev_q, 0));
+      ITRY(hipEventRecord(q.tv[3], q.stream));
+    }
     if (len) {
       // the running sum: this engine's own rows of the range, then the two spare buffers in turn (the partial rows stay as the
       // kernel wrote them: mic_ingest_fetch_group_rows)
@@ -729,17 +800,20 @@ int group_query(mic_engine* const* group, size_t P, size_t owner, Ingest* g, Slo
       for (size_t p = 0; p < P; ++p) {
         if (p == j) continue;
         uint32_t* in = q.d_gather + got * len * rw;
-        ITRY(hipStreamWaitEvent(q.stream, s.peers[p].ev_q, 0));
+        if (!timed) ITRY(hipStreamWaitEvent(q.stream, s.peers[p].ev_q, 0));
         ITRY(hipMemcpyPeerAsync(in, q.device, s.peers[p].d_rows + lo * rw, s.peers[p].device, len * rw * 4, q.stream));
         ITRY(mic_launch_merge_rows(cur, in, spare[c], (uint32_t)rw, len, nullptr, q.stream));
         cur = spare[c]; c ^= 1; ++got;
+        s.x_bytes += len * rw * 4;
       }
       if (j == owner) ITRY(mic_launch_result_from_rows(cur, (uint32_t)rw, O.d_res + lo * 8, len, q.stream));
       else {
         ITRY(mic_launch_result_from_rows(cur, (uint32_t)rw, q.d_res, len, q.stream));
         ITRY(hipMemcpyPeerAsync(O.d_res + lo * 8, O.device, q.d_res, q.device, len * 32, q.stream));
+        s.x_bytes += len * 32;
       }
     }
+    if (timed) ITRY(hipEventRecord(q.tv[4], q.stream));
     ITRY(hipEventRecord(q.ev_done, q.stream));
   }
   ITRY(hipSetDevice(O.device));
@@ -747,6 +821,50 @@ int group_query(mic_engine* const* group, size_t P, size_t owner, Ingest* g, Slo
   group_overflow_kernel<<<(n + 255) / 256, 256, 0, s.stream>>>(O.d_res, n, s.d_flagged);
   ITRY(hipGetLastError());
   return MIC_OK;
+}
+
+int group_query(mic_engine* const* group, size_t P, size_t owner, Ingest* g, Slot& s, uint32_t n, uint32_t nb, int k) {
+  // the slot's buffers on the engines of its group are kept from batch to batch while the group is the same: the same engines in the
+  // same order, each on the device and with the table it had (an engine destroyed and another created at its address is not the same)
+  bool same = s.peers.size() == P && s.group_owner == owner && s.timed == group_timing();
+  for (size_t p = 0; same && p < P; ++p) {
+    MicTable t; int sc, ncu, dev, kk; uint32_t nt;
+    same = s.peers[p].eng == group[p] && mic_engine_table(group[p], &t, &sc, &ncu, &dev, &kk, &nt) == MIC_OK &&
+           dev == s.peers[p].device && (const void*)t.slots == s.peers[p].table_id;
+  }
+  if (!same) { int rc = setup_peers(g, s, group, P, owner); if (rc) { free_peers(s); return rc; } }
+  const int rc = group_query_issue(group, P, owner, g, s, n, nb, k);
+  if (rc) {
+    // an error in the middle leaves work queued on the helpers' streams that reads and writes the slot's buffers: wait for it
+    // before the caller reuses or frees them (the error text is kept)
+    const std::string msg = mic_last_error();
+    for (Slot::Peer& q : s.peers) if (q.stream) { hipSetDevice(q.device); hipStreamSynchronize(q.stream); }
+    (void)hipGetLastError();
+    hipSetDevice(s.peers[owner].device);
+    return mic_set_error(rc, "%s", msg.c_str());
+  }
+  return MIC_OK;
+}
+
+// MIC_GROUP_TIMING: the slot's last table-sharded batch has finished (the owner's stream waited for every engine): its events' times
+void group_harvest(Ingest* g, Slot& s, uint32_t n) {
+  if (!s.timed || s.peers.empty()) return;
+  double fan_sum = 0, fan_max = 0, k_sum = 0, k_max = 0, x_sum = 0, x_max = 0;
+  for (size_t p = 0; p < s.peers.size(); ++p) {
+    Slot::Peer& q = s.peers[p];
+    hipSetDevice(q.device);
+    float fan = 0, kq = 0, x = 0;
+    if (hipEventElapsedTime(&fan, q.tv[0], q.tv[1]) != hipSuccess || hipEventElapsedTime(&kq, q.tv[1], q.tv[2]) != hipSuccess ||
+        hipEventElapsedTime(&x, q.tv[3], q.tv[4]) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (p != s.group_owner) { fan_sum += fan; fan_max = std::max(fan_max, (double)fan); }
+    k_sum += kq; k_max = std::max(k_max, (double)kq);
+    x_sum += x; x_max = std::max(x_max, (double)x);
+  }
+  hipSetDevice(g->device);
+  std::lock_guard<std::mutex> lk(g->gstats.mu);
+  GroupStats& G = g->gstats;
+  ++G.batches; G.reads += n; G.fan_bytes += s.fan_bytes; G.x_bytes += s.x_bytes;
+  G.fan_ms_sum += fan_sum; G.fan_ms_max += fan_max; G.kernel_ms_sum += k_sum; G.kernel_ms_max += k_max; G.x_ms_sum += x_sum; G.x_ms_max += x_max;
 }
 
 }  // namespace
@@ -939,6 +1057,7 @@ int mic_ingest_classify_group(mic_engine* const* group, size_t n_group, size_t o
   ITRY(hipEventRecord(s.ev, st));
   ITRY(wait_event(s.ev));
   const double t2 = timing ? now_s() : 0;
+  if (n_group > 1) group_harvest(g, s, n_reads);
   s.n_reads = n_reads; s.cont_used = s.h_hdr[H_CONT];
   const uint32_t csv_bytes = s.h_hdr[H_CSV_BYTES];
   uint32_t status = s.h_hdr[H_STATUS];
@@ -1319,6 +1438,18 @@ int mic_ingest_fetch_group_rows(mic_engine* owner, size_t slot_id, size_t part, 
     ITRY(hipSetDevice(g->device));
   }
   return MIC_OK;
+}
+
+int mic_ingest_group_stats(mic_engine* owner, double* out, size_t cap) {
+  if (!owner || !out || cap < MIC_GROUP_STATS_FIELDS) return mic_set_error(MIC_E_INVALID, "bad argument");
+  Ingest* g = (Ingest*)*mic_engine_ingest_slot(owner);
+  if (!g) return mic_set_error(MIC_E_STATE, "ingest slots are not allocated");
+  std::lock_guard<std::mutex> lk(g->gstats.mu);
+  const GroupStats& G = g->gstats;
+  const double v[MIC_GROUP_STATS_FIELDS] = {(double)G.batches, (double)G.reads, (double)G.fan_bytes, G.fan_ms_sum, G.fan_ms_max, G.kernel_ms_sum,
+                                            G.kernel_ms_max, (double)G.x_bytes, G.x_ms_sum, G.x_ms_max};
+  for (size_t i = 0; i < MIC_GROUP_STATS_FIELDS; ++i) out[i] = v[i];
+  return (int)MIC_GROUP_STATS_FIELDS;
 }
 
 // host build of the device formatter (tests pin it against the C library's "%g")

@@ -303,6 +303,16 @@ int mic_ingest_fetch_packed(mic_engine* e, size_t slot, uint32_t* reads_pointer,
  * computed for the slot's last table-sharded batch, as its kernel wrote them. */
 int mic_ingest_fetch_group_rows(mic_engine* owner, size_t slot, size_t part, uint32_t* rows, size_t cap_words, uint64_t* n_reads,
                                 uint32_t* row_words);
+/* mic_ingest_group_stats  what the table-sharded batches of this engine's slots cost, when the process runs with
+ * MIC_GROUP_TIMING=1 (HIP events on every engine's stream; a measuring mode: the exchange then starts when ALL engines' rows are
+ * written, so that its bracket holds copies and merges only).  out[0 .. MIC_GROUP_STATS_FIELDS): batches, reads, bytes of the
+ * packed-read fan-out (owner -> the other engines), its ms summed over the helpers and over the batches, the same with the
+ * slowest helper of each batch only, query-kernel ms summed over engines and batches, slowest engine of each batch only, bytes of
+ * the row exchange (rows of a read range from the other engines + the results to the owner), its ms summed, slowest engine only.
+ * Returns the number of fields; zeros without MIC_GROUP_TIMING.  (The reference times nothing per device; its exchange is
+ * CuClarkDB.cu:954-974.) */
+#define MIC_GROUP_STATS_FIELDS 10
+int mic_ingest_group_stats(mic_engine* owner, double* out, size_t cap);
 int mic_ingest_free(mic_engine* e);
 /* ---- compressed input: one gzip member inflated on the device ------------------------------------------------
  * Replaces the `gunzip` the reference's scripts run in front of the classifier (classify_metagenome.sh:116-142) for the

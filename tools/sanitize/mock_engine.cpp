@@ -99,6 +99,8 @@ int mic_ingest_classify_group(mic_engine* const* group, size_t n_group, size_t o
   return mic_ingest_classify(group[owner], slot, n_bytes, flags, out);
 }
 
+int mic_ingest_group_stats(mic_engine*, double* out, size_t cap) { for (size_t i = 0; i < cap && i < MIC_GROUP_STATS_FIELDS; ++i) out[i] = 0; return MIC_GROUP_STATS_FIELDS; }
+
 // the batch API is only reached when a slot is handed back (MIC_INGEST_FALLBACK): the mock never does
 int mic_batches_alloc(mic_engine*, size_t, size_t, size_t, const uint32_t*, int, uint32_t**, uint32_t**, uint32_t**, uint16_t**) { return MIC_E_NODEVICE; }
 int mic_batch_ready(mic_engine*, size_t, size_t, size_t) { return MIC_E_NODEVICE; }
