@@ -236,7 +236,7 @@ def run_cli(cmd, extra_env=None):
     return r, out
 
 
-def multi_engine_leg(base_cmd, res_one, tmp, paired_gz=None):
+def multi_engine_leg(base_cmd, res_one, tmp, paired_gz=None, only=None):
     """the product binary's multi-device modes at FULL scale on this one GPU (MIC_SHARD_ENGINES=n puts n engines on it):
     the same table files and the same 10 M-read FASTQ as the one-engine run; every CSV must equal that run's byte for byte.
       --db-sharded --parts N on N = 2 / 4 / 8 engines  the reference's mode (CuClarkDB.cu:566-574, 886-1024): N parts of the table, every
@@ -254,6 +254,8 @@ def multi_engine_leg(base_cmd, res_one, tmp, paired_gz=None):
             ("db_sharded_8", ["--db-sharded", "--parts", "8"], 8), ("db_sharded_4_parts_2", ["--db-sharded", "--parts", "2"], 4),
             ("read_sharded_2", ["-d", "2"], 2)]
     for name, flags, n_eng in runs:
+        if only and name not in only:
+            continue
         res = os.path.join(tmp, "out_" + name)
         cmd = [res if a == res_one else a for a in base_cmd] + flags
         r, d = run_cli(cmd, {"MIC_SHARD_ENGINES": str(n_eng), "MIC_GROUP_TIMING": "1"})
@@ -279,7 +281,7 @@ def multi_engine_leg(base_cmd, res_one, tmp, paired_gz=None):
                 pass
         out["runs"][name] = d
         log("multi_engine", name + ":", json.dumps(d))
-    if paired_gz:
+    if paired_gz and (not only or "paired_gzip_read_sharded_2" in only):
         # compressed mates through one engine and through two (read-sharded): the text is inflated on the first engine's device and
         # the slots of both engines are filled from there
         a, b, cmd_p = paired_gz
@@ -302,7 +304,7 @@ def multi_engine_leg(base_cmd, res_one, tmp, paired_gz=None):
     return out
 
 
-def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res_expect, truth, threads, keep=False, paired=False, reps=3, multi=True, multi_reads=0):
+def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res_expect, truth, threads, keep=False, paired=False, reps=3, multi=True, multi_reads=0, multi_only=None):
     """files in, file out, through exe/cuCLARK (reference: CuCLARK_hh.hh:550-563 times index + pack +
     GPU + CSV and prints objects/min, :1938-1944).  The table goes to disk in the reference's format, the same reads as
     FASTQ; the binary loads the table, classifies, writes the CSV.  Checked: every CSV line against the kernel's result
@@ -437,8 +439,10 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
             # compressed mates for the two-engine run: the first million pairs of the same generator, as `gzip -1` files
             pgz = None
             try:
+                if multi_only and "paired_gzip_read_sharded_2" not in multi_only:
+                    raise LookupError("not asked for")
                 import subprocess
-                n_p = min(n_reads, 1_000_000)
+                n_p = min(me_n, 1_000_000)
                 d_t = torch.empty(n_p * rec, dtype=torch.uint8, device=d_sizes.device)
                 gz_names = []
                 for mate in (0, 1):
@@ -456,7 +460,7 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
             except Exception as ex:
                 log("multi_engine: no compressed mates:", repr(ex))
             torch.cuda.empty_cache()
-            out["multi_engine"] = multi_engine_leg(me_cmd, me_ref, tmp, pgz)
+            out["multi_engine"] = multi_engine_leg(me_cmd, me_ref, tmp, pgz, only=multi_only)
             out["multi_engine"]["reads"] = me_n
         if paired:
             out["gzip_input"] = gzip_sub_leg(cmd, fqs, rec, min(n_reads, 1_000_000), res_base, tmp)
@@ -552,6 +556,7 @@ def main():
     ap.add_argument("--e2e-threads", type=int, default=12, help="-n of the end-to-end run")
     ap.add_argument("--e2e-reps", type=int, default=3, help="runs of the end-to-end command; the leg reports their median, min and max")
     ap.add_argument("--multi-engine-reads", type=int, default=0, help="end_to_end.multi_engine on the first N reads of the file only (tests)")
+    ap.add_argument("--multi-engine-runs", default="", help="comma-separated subset of end_to_end.multi_engine's runs (tests); default: all")
     ap.add_argument("--no-multi-engine", action="store_true",
                     help="N=1: skip end_to_end.multi_engine (exe/cuCLARK's multi-device modes with 2 / 4 / 8 engines on this GPU, CSVs against the one-engine run)")
     ap.add_argument("--parts", type=int, default=0,
@@ -1019,7 +1024,8 @@ def main():
                 del d_res, d_cont, d_rp
                 torch.cuda.empty_cache()
                 e2e = end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res, truth, args.e2e_threads, paired=paired,
-                                      reps=args.e2e_reps, multi=not args.no_multi_engine, multi_reads=args.multi_engine_reads)
+                                      reps=args.e2e_reps, multi=not args.no_multi_engine, multi_reads=args.multi_engine_reads,
+                                      multi_only=[x for x in args.multi_engine_runs.split(",") if x] or None)
             except Exception as ex:
                 e2e = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             log("end_to_end:", json.dumps(e2e))

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("mic_batch_dense_counts", C.c_int, [_VP, _SZ, _SZ, _VP]),
     ("mic_batch_check", C.c_int, [_VP, _SZ, C.POINTER(C.c_int)]),
     ("mic_batch_merge_shards", C.c_int, [C.POINTER(C.c_void_p), _SZ, _SZ]),
+    ("mic_batch_query_group", C.c_int, [C.POINTER(C.c_void_p), _SZ, _SZ, C.c_int]),
     ("mic_sync", C.c_int, [_VP]),
     ("mic_thread_bind_near_device", C.c_int, [_VP, C.c_int]),
     ("mic_batches_free", C.c_int, [_VP]),

@@ -2054,16 +2054,11 @@ size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, F
         check(mic_batch_query(engines_[d], lb, opt_.extended ? 1 : 0, 0), "queryBatch");
         check(mic_batch_wait(engines_[d], lb), "waitForBatch");
       } else {
-        // every engine of the group probes the same reads against its part of the table; the rows are summed read-range owned
-        // and land in the first engine's host arrays (mic_batch_merge_shards)
-        for (size_t g = 0; g < parts_; ++g) {
-          if (g) {
-            memcpy(lent_[d + g].rp[lb], L.rp[lb], (cnt + 1) * sizeof(uint32_t));
-            memcpy(lent_[d + g].ct[lb], L.ct[lb], m * sizeof(uint16_t));
-          }
-          check(mic_batch_ready(group[g], lb, cnt, m), "readyBatch");
-          check(mic_batch_query(group[g], lb, 1, 0), "queryBatch");
-        }
+        // every engine of the group probes the same reads against its part of the table - one upload into the first engine, the packed
+        // reads fanned out device to device (mic_batch_query_group; the reference uploads the host arrays to every device,
+        // CuClarkDB.cu:886-890) - and the rows are summed read-range owned into the first engine's host arrays (mic_batch_merge_shards)
+        check(mic_batch_ready(group[0], lb, cnt, m), "readyBatch");
+        check(mic_batch_query_group(group, parts_, lb, 1), "queryBatch");
         check(mic_batch_merge_shards(group, parts_, lb), "merge of the table shards");
       }
       tick(t_query);

@@ -785,9 +785,10 @@ int mic_batch_ready(mic_engine* e, size_t batch, size_t n_reads, size_t n_contai
   return MIC_OK;
 }
 
-int mic_batch_query(mic_engine* e, size_t batch, int extended, int followup) {
-  (void)followup;
-  if (!e || batch >= e->batches.size()) return fail(MIC_E_INVALID, "bad batch id");
+// queryBatch of one engine.  src == nullptr: the batch's reads come from the engine's own pinned buffers (H2D on the upload stream);
+// otherwise they are ALREADY on device src_device in another engine's batch buffers (uploaded there, `src->ev_up` says when) and come
+// over by peer copy on this batch's stream - one upload serves every engine of a table-sharded group.
+static int batch_query_impl(mic_engine* e, size_t batch, int extended, const Batch* src, int src_device) {
   if (!e->db_loaded) return fail(MIC_E_STATE, "no database loaded");
   std::lock_guard<std::mutex> lock(e->submit_mu);
   int rc = set_device(e);
@@ -795,10 +796,16 @@ int mic_batch_query(mic_engine* e, size_t batch, int extended, int followup) {
   Batch& B = e->batches[batch];
   if (extended && !B.d_rows) return fail(MIC_E_STATE, "batches were not allocated for extended results");
   hipStream_t s = B.stream, up = e->up_stream, down = e->down_stream;
-  HIPTRY(hipMemcpyAsync(B.d_rp, B.h_rp, (B.n_reads + 1) * 4, hipMemcpyHostToDevice, up));
-  HIPTRY(hipMemcpyAsync(B.d_cont, B.h_cont, (B.n_cont + 16) * 2, hipMemcpyHostToDevice, up));
-  HIPTRY(hipEventRecord(B.ev_up, up));
-  HIPTRY(hipStreamWaitEvent(s, B.ev_up, 0));
+  if (!src) {
+    HIPTRY(hipMemcpyAsync(B.d_rp, B.h_rp, (B.n_reads + 1) * 4, hipMemcpyHostToDevice, up));
+    HIPTRY(hipMemcpyAsync(B.d_cont, B.h_cont, (B.n_cont + 16) * 2, hipMemcpyHostToDevice, up));
+    HIPTRY(hipEventRecord(B.ev_up, up));
+    HIPTRY(hipStreamWaitEvent(s, B.ev_up, 0));
+  } else {
+    HIPTRY(hipStreamWaitEvent(s, src->ev_up, 0));
+    HIPTRY(hipMemcpyPeerAsync(B.d_rp, e->device, src->d_rp, src_device, (B.n_reads + 1) * 4, s));
+    HIPTRY(hipMemcpyPeerAsync(B.d_cont, e->device, src->d_cont, src_device, (B.n_cont + 16) * 2, s));
+  }
   HIPTRY(hipMemsetAsync(B.d_flagged, 0, 4, s));
   MicQueryArgs a;
   a.t = e->table; a.reads_ptr = B.d_rp; a.cont = B.d_cont; a.n_reads = (uint32_t)B.n_reads;
@@ -816,6 +823,28 @@ int mic_batch_query(mic_engine* e, size_t batch, int extended, int followup) {
   HIPTRY(hipEventRecord(B.done, down));
   B.scheduled = true; B.resolved = false; B.extended = extended != 0;
   return MIC_OK;
+}
+
+int mic_batch_query(mic_engine* e, size_t batch, int extended, int followup) {
+  (void)followup;
+  if (!e || batch >= e->batches.size()) return fail(MIC_E_INVALID, "bad batch id");
+  return batch_query_impl(e, batch, extended, nullptr, 0);
+}
+
+int mic_batch_query_group(mic_engine* const* engines, size_t n_engines, size_t batch, int extended) {
+  if (!engines || n_engines == 0 || !engines[0] || batch >= engines[0]->batches.size()) return fail(MIC_E_INVALID, "bad argument");
+  const Batch& B0 = engines[0]->batches[batch];
+  for (size_t i = 1; i < n_engines; ++i) {
+    mic_engine* e = engines[i];
+    if (!e || batch >= e->batches.size()) return fail(MIC_E_INVALID, "bad engine or batch id");
+    Batch& B = e->batches[batch];
+    if (B0.n_reads > B.max_reads || B0.n_cont > B.max_cont) return fail(MIC_E_INVALID, "engine %zu: batch %zu is smaller than engine 0's", i, batch);
+    B.n_reads = B0.n_reads; B.n_cont = B0.n_cont;
+  }
+  mic_peer_enable_engines(engines, n_engines);
+  int rc = batch_query_impl(engines[0], batch, extended, nullptr, 0);
+  for (size_t i = 1; i < n_engines && rc == MIC_OK; ++i) rc = batch_query_impl(engines[i], batch, extended, &B0, engines[0]->device);
+  return rc;
 }
 
 int mic_batch_wait(mic_engine* e, size_t batch) {

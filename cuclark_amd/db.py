@@ -130,6 +130,14 @@ class MiClarkDB:
         arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
         check(L.mic_batch_merge_shards(arr, len(engines), batch))
 
+    @staticmethod
+    def query_group(engines, batch, extended=True):
+        """queryBatch on every engine of a table-sharded group from ONE upload: the reads are engines[0]'s (its lent buffers, its
+        readyBatch); the others take the packed reads device to device (mic_batch_query_group; CuClarkDB.cu:886-890)."""
+        L = engines[0].L
+        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        check(L.mic_batch_query_group(arr, len(engines), batch, int(bool(extended))))
+
     def checkBatch(self, batch):
         d = C.c_int(0)
         check(self.L.mic_batch_check(self.h, batch, C.byref(d)))

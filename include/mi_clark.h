@@ -188,6 +188,12 @@ int mic_batch_check(mic_engine* e, size_t batch, int* done);
  * row does not fit (MIC_FLAG_ROW_OVERFLOW in its results word 6, row[0] == MIC_ROW_INVALID) is completed by the
  * caller: the sum over the engines of mic_batch_dense_counts.  Synchronous.  Engines may share a device. */
 int mic_batch_merge_shards(mic_engine* const* engines, size_t n_engines, size_t batch);
+/* queryBatch on every engine of a table-sharded group from ONE upload (the reference copies the batch's host arrays to every device,
+ * CuClarkDB.cu:886-890): the reads are engines[0]'s (filled into ITS lent buffers, mic_batch_ready on engines[0]); engines[0]
+ * uploads them, the other engines take the packed reads from engines[0]'s device buffers by peer copy on their batch's stream and
+ * run their kernel; all asynchronous, as mic_batch_query.  Follow with mic_batch_merge_shards.  The other engines' host buffers
+ * for this batch are not read. */
+int mic_batch_query_group(mic_engine* const* engines, size_t n_engines, size_t batch, int extended);
 /* (How the rows are summed: READ-RANGE OWNED, all engines at once - engine j fetches the rows of the j-th 1/n of the batch's
  * reads from the other n - 1 engines (n - 1 peer copies of 1/n of the rows each, hipMemcpyPeerAsync over xGMI with peer access
  * enabled), sums them, finishes best / second-best for its range and writes results and rows of the range straight into

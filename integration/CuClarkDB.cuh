@@ -20,13 +20,13 @@
 template <typename HKMERr> class CuClarkDB {
   // numDevices engines, each holding one part of the table (the reference's multi-device mode, CuClarkDB.cu:104-208, 566-574,
   // 886-974): every engine gets the batch's reads, the sparse rows are summed read-range owned (mic_batch_merge_shards)
-  std::vector<mic_engine*> e_; size_t nb_; uint8_t k_; bool ext_ = false; uint32_t rw_ = 16;   // rw_: u32 words per sparse row
+  std::vector<mic_engine*> e_; size_t nb_; uint8_t k_; bool ext_ = false; uint32_t rw_ = 16, nt_ = 0;   // rw_: u32 words per sparse row
   uint32_t *res32_ = nullptr, *rows32_ = nullptr; RESULTS *final_ = nullptr, *full_ = nullptr;
   std::vector<ITYPE> index_; std::vector<size_t> nreads_, ncont_; size_t rowSize_ = 0, finalRowSize_ = 5;
   std::vector<std::vector<uint32_t*> > rp_; std::vector<std::vector<uint16_t*> > ct_;   // [engine][batch]
   static void ck(int rc) { if (rc) { std::cerr << mic_last_error() << std::endl; exit(1); } }   // CUERR behaviour
  public:
-  CuClarkDB(size_t numDevices, uint8_t k, size_t numBatches, size_t numTargets) : nb_(numBatches), k_(k) {
+  CuClarkDB(size_t numDevices, uint8_t k, size_t numBatches, size_t numTargets) : nb_(numBatches), k_(k), nt_((uint32_t)numTargets) {
     int have = 0; ck(mic_device_count(&have));                                              // CuClarkDB.cu:104-181
     if (numDevices == 0 || numDevices > (size_t)have) numDevices = have > 0 ? (size_t)have : 1;
     if (const char* env = getenv("MIC_SHARD_ENGINES")) { long v = atol(env); if (v >= 1 && v <= 64) numDevices = (size_t)v; }
@@ -72,27 +72,51 @@ template <typename HKMERr> class CuClarkDB {
   }
   bool readyBatch(size_t b, size_t nReads, size_t nCont) {
     nreads_[b] = nReads; ncont_[b] = nCont;
-    for (size_t d = 0; d < e_.size(); ++d) ck(mic_batch_ready(e_[d], b, nReads, nCont));
+    ck(mic_batch_ready(e_[0], b, nReads, nCont));                 // the reads live in the first engine's lent buffers
     return true;
   }
   bool queryBatch(size_t b, bool isExtended, bool isFollowup = false) {                     // CuClarkDB.cu:878-1033
-    for (size_t d = 0; d < e_.size(); ++d) {
-      if (d) { memcpy(rp_[d][b], rp_[0][b], (nreads_[b] + 1) * sizeof(uint32_t));           // every device sees all reads, :886-890
-               memcpy(ct_[d][b], ct_[0][b], ncont_[b] * sizeof(uint16_t)); }
-      ck(mic_batch_query(e_[d], b, isExtended || e_.size() > 1, isFollowup));
-    }
+    // every device sees all reads (:886-890): ONE upload into the first engine, the packed reads fanned out device to device
+    if (e_.size() > 1) ck(mic_batch_query_group(e_.data(), e_.size(), b, 1));
+    else ck(mic_batch_query(e_[0], b, isExtended, isFollowup));
     return true;
+  }
+  // A read whose sparse row did not fit (more targets than a row holds - MAXHITS in the reference, whose kernel then prints "Too
+  // many different tagets hit by a sequence. Results will be corrupted." and leaves a row count beyond the row, CuClarkDB.cu:1200-1211)
+  // is completed EXACTLY from dense counts summed over the devices: sum / best / second-best under the reference's order
+  // (:1440-1459), and the row gets as many (target, count) pairs, ascending by target, as rowSize holds, with n = the pairs stored.
+  void complete(size_t b, size_t r, uint32_t T) {
+    std::vector<uint32_t> dense(T, 0), part(T);
+    for (size_t d = 0; d < e_.size(); ++d) {
+      ck(mic_batch_dense_counts(e_[d], b, r - index_[b], part.data()));
+      for (uint32_t t = 0; t < T; ++t) dense[t] += part[t];
+    }
+    uint32_t sum = 0, best = 0, ib = 0, sb = 0, is = 0, n = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+      const uint32_t c = dense[t];
+      if (!c) continue;
+      sum += c;
+      if (c > best) { sb = best; is = ib; best = c; ib = t + 1; } else if (c > sb) { sb = c; is = t + 1; }
+      if (ext_ && 2 * n + 2 < rowSize_) { full_[r * rowSize_ + 2 * n + 1] = (RESULTS)t; full_[r * rowSize_ + 2 * n + 2] = (RESULTS)c; ++n; }
+    }
+    const uint32_t five[5] = {sum, ib, best, is, sb};
+    for (int w = 0; w < 5; ++w) final_[r * finalRowSize_ + w] = (RESULTS)five[w];
+    if (ext_) full_[r * rowSize_] = (RESULTS)n;
   }
   bool waitForBatch(size_t b) {                                                             // CuClarkDB.cu:440-445
     if (e_.size() > 1) ck(mic_batch_merge_shards(e_.data(), e_.size(), b));                 // peer copies + mergeKernel + resultKernel, :954-1024
     else ck(mic_batch_wait(e_[0], b));
     for (size_t r = index_[b]; r < index_[b] + nreads_[b]; ++r) {      // u32 -> RESULTS, the layout CuCLARK_hh.hh reads
+      const uint32_t* row = rows32_ ? rows32_ + r * rw_ : nullptr;
+      const bool over = (res32_[r * MIC_RESULT_WORDS + 6] & MIC_FLAG_ROW_OVERFLOW) || (row && row[0] == MIC_ROW_INVALID) ||
+                        (ext_ && row && 2 * (size_t)row[0] + 2 > rowSize_);
+      if (over) { complete(b, r, nt_); continue; }
       for (int w = 0; w < 5; ++w) final_[r * finalRowSize_ + w] = (RESULTS)res32_[r * MIC_RESULT_WORDS + w];
       if (ext_) {
-        const uint32_t* row = rows32_ + r * rw_; uint32_t n = row[0] == MIC_ROW_INVALID ? 0 : row[0];
+        const uint32_t n = row[0];
         full_[r * rowSize_] = (RESULTS)n;
-        for (uint32_t i = 0; i < n && 2 * i + 2 < rowSize_; ++i) { full_[r * rowSize_ + 2 * i + 1] = row[1 + i] & 0xFFFF;
-                                                                   full_[r * rowSize_ + 2 * i + 2] = row[1 + i] >> 16; }
+        for (uint32_t i = 0; i < n; ++i) { full_[r * rowSize_ + 2 * i + 1] = row[1 + i] & 0xFFFF;
+                                           full_[r * rowSize_ + 2 * i + 2] = row[1 + i] >> 16; }
       }
     }
     return true;

@@ -2,7 +2,8 @@
 // (CuCLARK_hh.hh:608 ctor, :621 read, :514-515 swapDbParts+sync, :1600-1606 malloc, :1735 readyBatch, :1743 queryBatch,
 // :1997 waitForBatch, :335 freeBatchMemory).  Reads a packed batch (reads_pointer u32, containers u16) from two binary
 // files, prints "sum idxBest best idxSecond second" per read.
-//   shim_driver <db prefix> <k> <num targets> <reads_pointer.bin> <containers.bin> [numDevices [extended]]
+//   shim_driver <db prefix> <k> <num targets> <reads_pointer.bin> <containers.bin> [numDevices [extended [rowSize]]]
+// rowSize: u16 words per sparse row the caller allocates (the reference: 2 * MAXHITS + 2, CuCLARK_hh.hh:1587-1590)
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -32,7 +33,7 @@ int main(int argc, char** argv) {
   RESULTS *full = nullptr, *fin = nullptr;
   std::vector<uint32_t*> readsPointer;
   std::vector<CONTAINER*> readsInContainers;
-  const size_t rowSize = 2 * MAXHITS + 2, finalRowSize = 5;
+  const size_t rowSize = argc > 8 ? (size_t)atol(argv[8]) : 2 * MAXHITS + 2, finalRowSize = 5;
   db.malloc(numReads, numReads, numCont, indexBatches, full, rowSize, fin, finalRowSize, extended, readsPointer, readsInContainers);
   memcpy(readsPointer[0], b1.data(), b1.size());
   memcpy(readsInContainers[0], b2.data(), b2.size());

@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
+# ORACLE_LIB_PATH: another build of the same sources (tools/sanitize/oracle_rig.sh: AddressSanitizer + UBSan)
+_LIB_OVERRIDE = os.environ.get("ORACLE_LIB_PATH")
 
 
 class _OrcDb(C.Structure):
@@ -38,8 +40,9 @@ def _ptr(a, t):
 
 class Oracle:
     def __init__(self):
-        build()
-        L = C.CDLL(_LIB)
+        if not _LIB_OVERRIDE:
+            build()
+        L = C.CDLL(_LIB_OVERRIDE or _LIB)
         self.L = L
         L.orc_nt_code.restype = C.c_int
         L.orc_nt_code.argtypes = [C.c_uint8]

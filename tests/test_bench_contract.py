@@ -71,15 +71,26 @@ def test_bench_full_config3():
     """BASELINE.json configs[2]: 10 M x 150 bp against the 36 GB-scale k = 31 table resident in HBM: oracle parity on a
     sample, constructive known answer on all genome reads, batch-API pipeline equal to the device path, CLI CSV equal to
     the kernel's rows on all 10 M reads."""
-    d = _bench("--workload", "full", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000")
+    d = _bench("--workload", "full", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000", "--no-parts-proxy", "--no-default-layout",
+               "--e2e-reps", "1", "--multi-engine-reads", "2000000", "--multi-engine-runs", "db_sharded_8,read_sharded_2")
     _check_config(d, 10_000_000)
     assert d["config"]["table"]["htsize"] == 1610612741 and d["config"]["table"]["kmers"] > 5_700_000_000
+    # the product binary's multi-device modes against the 36 GB-scale database (the other shapes: test_bench_light27_config2_proper):
+    # 8 parts of the table on 8 engines, and two whole tables read-sharded, 2 M reads, CSVs equal to the one-engine run's
+    me = d["end_to_end"]["multi_engine"]
+    assert me["reads"] == 2_000_000 and me["all_csv_equal"] is True, me
+    r8 = me["runs"]["db_sharded_8"]
+    assert r8["csv_equals_one_engine_run"] is True and r8["ingest"]["batches_through_host_path"] == 0
+    assert "query_kernel_r<31, 20, false, true," in r8["kernel"] and "8 part(s) x 1 read group(s)" in r8["layout"]
+    assert r8["per_batch"]["exchange_MB"] > 0 and r8["per_batch"]["fanout_MB"] > 0 and r8["per_batch"]["kernel_ms_slowest_engine"] > 0
+    assert me["runs"]["read_sharded_2"]["csv_equals_one_engine_run"] is True
 
 
 @pytest.mark.gpu
 def test_bench_light_config2():
     """BASELINE.json configs[1]: the same 10 M reads against the CuCLARK-l-scale table."""
-    d = _bench("--workload", "light", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000")
+    d = _bench("--workload", "light", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000", "--no-parts-proxy", "--no-default-layout",
+               "--e2e-reps", "1", "--no-multi-engine")
     _check_config(d, 10_000_000)
     assert d["config"]["table"]["htsize"] == 57777779
 
@@ -90,7 +101,8 @@ def test_bench_paired_config5_shape():
     end-to-end leg feeds the two FASTQ files to exe/cuCLARK -P."""
     d = _bench("--workload", "tiny_paired", "--steps", "2", "--warmup", "1")
     _check_config(d, 100_000)
-    d = _bench("--workload", "paired", "--steps", "2", "--warmup", "1", "--cpu-sample", "100000", "--reads", "2000000")
+    d = _bench("--workload", "paired", "--steps", "2", "--warmup", "1", "--cpu-sample", "100000", "--reads", "2000000", "--no-parts-proxy",
+               "--no-default-layout", "--e2e-reps", "1")
     _check_config(d, 2_000_000)
     assert "pairs" in d["end_to_end"]["input"]
     # config 5 names gzip input: plain gzip and block gzip of the same pairs give the plain run's CSV
@@ -115,8 +127,22 @@ def test_bench_table_sharded_mode_under_rccl_on_one_gpu():
 @pytest.mark.gpu
 def test_bench_light27_config2_proper():
     """SURVEY.md 8d config 2 as cuCLARK-l builds it: HTSIZE 57 777 779, k = 27, u32 keys, ~90 M k-mers, 10 M reads."""
-    d = _bench("--workload", "light27", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000")
+    d = _bench("--workload", "light27", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000", "--no-parts-proxy", "--no-default-layout",
+               "--multi-engine-reads", "2000000")
     _check_config(d, 10_000_000, random_hits_possible=True)
+    # end_to_end: the median of three runs of the command, every run's CSV the same, the stages' busy shares and a named bound
+    e2e = d["end_to_end"]
+    assert len(e2e["runs"]) == 3 and e2e["min"] <= e2e["value"] <= e2e["max"] and e2e["runs_csv_equal"] is True
+    assert e2e["bound"] and set(e2e["stage_busy_share"]) == {"loaders", "device_threads", "writer"} and e2e["loaders_alone_GBs"] > 0
+    # every multi-device mode of the product binary on this one GPU (MIC_SHARD_ENGINES), 2 M reads, CSVs equal to the one-engine run's
+    me = e2e["multi_engine"]
+    assert set(me["runs"]) == {"db_sharded_2", "db_sharded_4", "db_sharded_8", "db_sharded_4_parts_2", "read_sharded_2", "paired_gzip_read_sharded_2"}
+    for name, run in me["runs"].items():
+        assert "error" not in run and run["csv_equals_one_engine_run"] is True, (name, run)
+        if name.startswith("db_sharded"):
+            assert run["ingest"]["batches_through_host_path"] == 0 and "query_kernel_r<27, 20, false, true," in run["kernel"], (name, run)
+            assert run["per_batch"]["exchange_MB"] > 0, (name, run)
+    assert me["runs"]["paired_gzip_read_sharded_2"]["inflated_on"] == "device"
     t = d["config"]["table"]
     assert t["htsize"] == 57777779 and d["config"]["k"] == 27 and 80_000_000 < t["kmers"] < 95_000_000
     assert "k=27" in d["metric"]
@@ -131,21 +157,15 @@ def test_bench_has_the_contract_flags():
 
 def _run_ranks(cmd, env, port=None):
     """Runs a multi-rank bench command with the ranks' watchdog on (MIC_BENCH_WATCHDOG: a rank still running after 240 s prints
-    its threads' stacks and exits).  Once in some tens of runs two gloo ranks sharing one GPU do not get past their start; what
-    the watchdog printed then goes to gpurun_out/bench_rank_hang.log and the command runs once more, on another port.  A wrong
-    RESULT or any other failure is not retried."""
+    every thread's Python stack and exits non-zero).  Nothing is retried: a rank that does not get past its start FAILS the test, and
+    what the watchdog printed is kept under gpurun_out/ for the post-mortem."""
     env = dict(env, MIC_BENCH_WATCHDOG="240")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     if r.returncode != 0 and "Timeout (" in r.stderr:
-        import warnings
         out_dir = os.path.join(gu.ROOT, "gpurun_out")
         os.makedirs(out_dir, exist_ok=True)
         with open(os.path.join(out_dir, "bench_rank_hang.log"), "a") as f:
             f.write(f"--- {' '.join(cmd)}\n{r.stderr[-20000:]}\n")
-        warnings.warn("a bench rank hit its watchdog (stacks: gpurun_out/bench_rank_hang.log); running the command once more")
-        if port is not None:
-            cmd = [str(int(c) + 101) if c == str(port) else c for c in cmd]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     return r
 
 

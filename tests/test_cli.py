@@ -16,6 +16,15 @@ def _run(args, **kw):
     return subprocess.run(args, capture_output=True, text=True, timeout=600, **kw)
 
 
+def _run_many(jobs, workers=4):
+    """Independent runs of the command line side by side (each its own process; at most `workers` of them use the GPU at once, next
+    to the test process itself - the pool allows six).  jobs: callables; returns their results in order.  What is checked is
+    unchanged - the suite's wall time is what this buys (GPUTEST budget)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        return list(ex.map(lambda j: j(), jobs))
+
+
 def _targets_file(tmp):
     p = os.path.join(tmp, "targets.txt")
     with open(p, "w") as f:
@@ -380,14 +389,15 @@ def multi_engine_rig(tmp_path_factory):
         out = os.path.join(tmp, f"{tag}_{name}")
         res = ["-R", out]
         if name == "list":
-            open(rig["lr"], "w").write(out + "_a\n" + out + "_b\n")
-            res = ["-R", rig["lr"]]
+            lr = rig["lr"] + "." + tag
+            open(lr, "w").write(out + "_a\n" + out + "_b\n")
+            res = ["-R", lr]
         r = _run([EXE_L, "-T", t, "-D", d, *cases[name], *res, "-n", "5"], env=env)
         assert r.returncode == 0, (name, r.stderr)
         return r, [open(out + sfx + ".csv", "rb").read() for sfx in (("_a", "_b") if name == "list" else ("",))]
     rig["run"] = run
     one = dict(os.environ, MIC_CLI_TIMING="1", MIC_INGEST_KB="24")
-    rig["one"] = {name: run(name, "one", one)[1] for name in cases}
+    rig["one"] = dict(zip(cases, (x[1] for x in _run_many([lambda name=name: run(name, "one", one) for name in cases]))))
     return rig
 
 
@@ -401,8 +411,8 @@ def test_read_sharded_cli_with_several_engines_on_one_gpu(multi_engine_rig, engi
     compressed mates, list-of-files."""
     rig = multi_engine_rig
     multi = dict(os.environ, MIC_SHARD_ENGINES=str(engines), MIC_CLI_TIMING="1", MIC_INGEST_KB="24")
-    for name in rig["cases"]:
-        r, got = rig["run"](name, f"multi{engines}", multi)
+    names = list(rig["cases"])
+    for name, (r, got) in zip(names, _run_many([lambda name=name: rig["run"](name, f"multi{engines}", multi) for name in names], workers=3)):
         assert f"{engines} engine(s) on 1 device(s), read-sharded (table replicated)" in r.stderr, r.stderr
         assert f"on {engines} device(s)" in r.stderr
         if name in ("gz", "bgzf", "gzpairs"):      # inflated on the device although the slots sit on several engines
@@ -439,24 +449,27 @@ def test_device_ingest_equals_host_ingest_over_many_batches(tmp_path):
         open(os.path.join(tmp, name), "wb").write(data)
     with gzip.open(os.path.join(tmp, "a.fq.gz"), "wb") as f:
         f.write(files["a.fq"])
-    for name in list(files) + ["a.fq.gz"]:
-        src = os.path.join(tmp, name)
-        ref = os.path.join(tmp, "host_" + name)
-        r = _run([EXE_L, "-T", t, "-D", d, "-O", src, "-R", ref, "-n", "4"], env=dict(os.environ, MIC_HOST_INGEST="1"))
+    names = list(files) + ["a.fq.gz"]
+
+    def host_run(name):
+        r = _run([EXE_L, "-T", t, "-D", d, "-O", os.path.join(tmp, name), "-R", os.path.join(tmp, "host_" + name), "-n", "4"], env=dict(os.environ, MIC_HOST_INGEST="1"))
         assert r.returncode == 0, r.stderr
-        n_obj = re.search(r"\((\d+) objects\)", r.stdout).group(1)
-        for kb, n in (("16", "4"), ("300", "3"), ("0", "1")):
-            out = os.path.join(tmp, f"dev{kb}_{name}")
-            env = dict(os.environ, MIC_CLI_TIMING="1")
-            if kb != "0":
-                env["MIC_INGEST_KB"] = kb
-            r = _run([EXE_L, "-T", t, "-D", d, "-O", src, "-R", out, "-n", n], env=env)
-            assert r.returncode == 0, r.stderr
-            assert f"({n_obj} objects)" in r.stdout
-            assert "device ingest:" in r.stderr
-            if name == "d.fa":
-                assert re.search(r", [1-9]\d* through the host path", r.stderr), r.stderr
-            assert open(out + ".csv", "rb").read() == open(ref + ".csv", "rb").read(), (name, kb)
+        return re.search(r"\((\d+) objects\)", r.stdout).group(1)
+
+    def dev_run(name, kb, n):
+        env = dict(os.environ, MIC_CLI_TIMING="1")
+        if kb != "0":
+            env["MIC_INGEST_KB"] = kb
+        return _run([EXE_L, "-T", t, "-D", d, "-O", os.path.join(tmp, name), "-R", os.path.join(tmp, f"dev{kb}_{name}"), "-n", n], env=env)
+    n_obj = dict(zip(names, _run_many([lambda name=name: host_run(name) for name in names])))
+    combos = [(name, kb, n) for name in names for kb, n in (("16", "4"), ("300", "3"), ("0", "1"))]
+    for (name, kb, n), r in zip(combos, _run_many([lambda c=c: dev_run(*c) for c in combos])):
+        assert r.returncode == 0, r.stderr
+        assert f"({n_obj[name]} objects)" in r.stdout
+        assert "device ingest:" in r.stderr
+        if name == "d.fa":
+            assert re.search(r", [1-9]\d* through the host path", r.stderr), r.stderr
+        assert open(os.path.join(tmp, f"dev{kb}_{name}.csv"), "rb").read() == open(os.path.join(tmp, "host_" + name + ".csv"), "rb").read(), (name, kb)
 
 
 def _pair_files(rng, genomes, n, crlf=False):
@@ -566,12 +579,14 @@ def test_compressed_mates_inflated_and_merged_on_the_device_equal_the_host_path(
         r0 = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", ref, "-n", "4"], env=dict(os.environ, MIC_GZ_HOST="1", MIC_CLI_TIMING="1"))
         assert r0.returncode == 0 and "device inflate" not in r0.stderr, r0.stderr
         n_obj = re.search(r"\((\d+) objects\)", r0.stdout).group(1)
-        for kb, n in (("16", "4"), ("300", "6"), ("0", "3")):
-            out = os.path.join(tmp, f"dev{kb}_{name}")
+        def dev_pair(kb, n, name=name, p1=p1, p2=p2):
             env = dict(os.environ, MIC_CLI_TIMING="1")
             if kb != "0":
                 env["MIC_INGEST_KB"] = kb
-            r = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", out, "-n", n], env=env)
+            return _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", os.path.join(tmp, f"dev{kb}_{name}"), "-n", n], env=env)
+        combos = (("16", "4"), ("300", "6"), ("0", "3"))
+        for (kb, n), r in zip(combos, _run_many([lambda c=c: dev_pair(*c) for c in combos], workers=3)):
+            out = os.path.join(tmp, f"dev{kb}_{name}")
             assert r.returncode == 0, r.stderr
             assert f"({n_obj} objects)" in r.stdout and r.stdout.count("Assignment time") == 1
             assert open(out + ".csv", "rb").read() == open(ref + ".csv", "rb").read(), (name, kb)

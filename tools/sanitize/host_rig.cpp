@@ -109,7 +109,8 @@ static void one_round() {
     char name[256];
     { const int len = mic_db_kernel_name(eng[i], name, sizeof(name)); tally("mic_db_kernel_name(", len < 0 ? len : MIC_OK); }     // (returns the name's length)
   }
-  // the batch API on every engine, then the merge over shards
+  // the batch API on every engine (or: one upload into the first engine and the group query), then the merge over shards
+  const bool group_query = n_eng > 1 && (rng() & 1);
   for (unsigned i = 0; i < n_eng; ++i) {
     const uint32_t ib[2] = {0, (uint32_t)n_reads};
     uint32_t *res = nullptr, *rows = nullptr, *brp[1] = {nullptr};
@@ -117,6 +118,11 @@ static void one_round() {
     if (!CALL(mic_batches_alloc(eng[i], (size_t)n_reads, (size_t)n_reads, n_cont ? n_cont : 1, ib, 1, &res, &rows, brp, bct))) continue;
     memcpy(brp[0], rp.data(), rp.size() * 4);
     memcpy(bct[0], cont.data(), n_cont * 2);
+    if (group_query) {
+      if (i == 0) CALL(mic_batch_ready(eng[0], 0, (size_t)n_reads, n_cont));
+      if (i + 1 == n_eng) CALL(mic_batch_query_group(eng.data(), n_eng, 0, 1));
+      continue;
+    }
     CALL(mic_batch_ready(eng[i], 0, (size_t)n_reads, n_cont));
     CALL(mic_batch_query(eng[i], 0, 1, 0));
     if (rng() & 1) { int done = 0; CALL(mic_batch_check(eng[i], 0, &done)); }

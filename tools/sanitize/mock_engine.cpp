@@ -108,6 +108,7 @@ int mic_batch_query(mic_engine*, size_t, int, int) { return MIC_E_NODEVICE; }
 int mic_batch_wait(mic_engine*, size_t) { return MIC_E_NODEVICE; }
 int mic_batch_dense_counts(mic_engine*, size_t, size_t, uint32_t*) { return MIC_E_NODEVICE; }
 int mic_batch_merge_shards(mic_engine* const*, size_t, size_t) { return MIC_E_NODEVICE; }
+int mic_batch_query_group(mic_engine* const*, size_t, size_t, int) { return MIC_E_NODEVICE; }
 int mic_batches_free(mic_engine*) { return MIC_OK; }
 // ---- compressed input "on the device": the same entry points on the CPU, so that the command line's DeviceGzFeeder (batch
 // arithmetic over the sampled offsets, slots filled in place, the hand-back path) runs under the sanitizers too.  "Device" memory
