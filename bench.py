@@ -304,7 +304,7 @@ def multi_engine_leg(base_cmd, res_one, tmp, paired_gz=None, only=None):
     return out
 
 
-def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res_expect, truth, threads, keep=False, paired=False, reps=3, multi=True, multi_reads=0, multi_only=None):
+def end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res_expect, truth, threads, keep=False, paired=False, reps=3, multi=True, multi_reads=0, multi_only=None):
     """files in, file out, through exe/cuCLARK (reference: CuCLARK_hh.hh:550-563 times index + pack +
     GPU + CSV and prints objects/min, :1938-1944).  The table goes to disk in the reference's format, the same reads as
     FASTQ; the binary loads the table, classifies, writes the CSV.  Checked: every CSV line against the kernel's result
@@ -317,6 +317,8 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
     out = {}
     try:
         t0 = time.time()
+        d_sizes, d_keys, d_labels = images
+        dev = d_sizes.device
         dbdir = os.path.join(tmp, "DB")
         os.makedirs(dbdir)
         base = os.path.join(dbdir, f"db_central_k{k}_t{T}_s{w['htsize']}_m0.tsk")
@@ -326,13 +328,18 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
             with open(base + ext, "wb") as f:
                 for o in range(0, n_el, CH):
                     arr[o:min(n_el, o + CH)].cpu().numpy().tofile(f)
+        # the table's images are on disk now: this process gives their 36 GB of HBM back before the command line loads and builds
+        # its own table next to it (the build takes its fast road when the memory is there)
+        del d_sizes, d_keys, d_labels
+        images.clear()
+        torch.cuda.empty_cache()
         dummy = os.path.join(tmp, "genome.fa")
         open(dummy, "w").write(">g\nACGT\n")
         with open(os.path.join(tmp, "targets.txt"), "w") as f:
             for t in range(T):
                 f.write(f"{dummy} TARGET_{t:05d}\n")
         rec = int(L.mic_synth_text_record_bytes(read_len, 0))
-        d_text = torch.empty(n_reads * rec, dtype=torch.uint8, device=d_sizes.device)
+        d_text = torch.empty(n_reads * rec, dtype=torch.uint8, device=dev)
         fqs = []
         for mate in ((0, 1) if paired else (-1,)):
             rc = L.mic_synth_reads_text_device(C.byref(spec), 5, n_reads, read_len, 0.2, 0.01, 0.001, 0, mate, d_text.data_ptr(), d_text.numel(), None)
@@ -443,7 +450,7 @@ def end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_le
                     raise LookupError("not asked for")
                 import subprocess
                 n_p = min(me_n, 1_000_000)
-                d_t = torch.empty(n_p * rec, dtype=torch.uint8, device=d_sizes.device)
+                d_t = torch.empty(n_p * rec, dtype=torch.uint8, device=dev)
                 gz_names = []
                 for mate in (0, 1):
                     rc = L.mic_synth_reads_text_device(C.byref(spec), 5, n_p, read_len, 0.2, 0.01, 0.001, 0, mate, d_t.data_ptr(), d_t.numel(), None)
@@ -1022,8 +1029,10 @@ def main():
         if not args.no_e2e:
             try:
                 del d_res, d_cont, d_rp
+                images = [d_sizes, d_keys, d_labels]
+                del d_sizes, d_keys, d_labels
                 torch.cuda.empty_cache()
-                e2e = end_to_end_leg(L, spec, w, d_sizes, d_keys, d_labels, n_el, n_reads, read_len, res, truth, args.e2e_threads, paired=paired,
+                e2e = end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res, truth, args.e2e_threads, paired=paired,
                                       reps=args.e2e_reps, multi=not args.no_multi_engine, multi_reads=args.multi_engine_reads,
                                       multi_only=[x for x in args.multi_engine_runs.split(",") if x] or None)
             except Exception as ex:

@@ -602,6 +602,146 @@ __global__ void __launch_bounds__(TILE) s_scatter_kernel(MBuildArgs a, const uns
   });
 }
 
+// ---- the sorted build (round 5): candidates once, ordered by their slot hash, then counted and staged with LOCAL traffic ------------
+// The classic form above walks the database three times with one thread per on-disk BUCKET (buckets hold 0 .. 255 k-mers: a
+// wavefront runs as long as its fullest bucket), evaluates the sampling scheme of every k-mer each time (~400 vector operations),
+// and ends every k-mer in a random atomic or a random write somewhere in gigabytes of counters / staging: count (twice: the table
+// is sized from a first count), scatter.  Here:
+//   s_expand_kernel   a tile's k-mers are spread over the block's threads through LDS (one k-mer per thread whatever the bucket
+//                     sizes); every k-mer's candidates are computed ONCE: record = (h = slot hash of the minimizer, oriented k-mer,
+//                     position | label), written at the k-mer's own index (coalesced); a HyperLogLog sketch of the minimizer values
+//                     (LDS registers, merged at the end) sizes the table - it replaces the first counting pass of the classic form too;
+//   radix sort        (hipcub, chunks of <= 2^30 records) by the top 16 bits of h: slot = floor(h n / 2^32) is monotone in h, so
+//                     a chunk's records now sweep the slots in order, ~1/65536 of the table at a time;
+//   s_rec_count / s_rec_place   the counting and the staging of the classic form over the RECORDS: a streaming read, atomics and
+//                     writes that stay inside a window of counters / staging the caches hold.
+// The staging arrays that come out are the classic form's (the same candidates per slot, in another order: s_merge_kernel sorts
+// them anyway).  One-strand tables that fit the memory below take this road; everything else the classic one.
+// a record = a 64-bit sort key ((minimizer position | label << 8) << 32 | slot hash; ~0: no record) and the oriented k-mer.
+// The hash sits in the LOW word and the sort takes bits [16, 32): rocPRIM 4.2 (ROCm 7.2) tears pairs apart and leaves them unsorted
+// when a 64-bit key is sorted by a bit range that starts at bit 32 or above and there are fewer than ~2^24 pairs
+// (tools/radix_sort_probe.hip, profiles/r05_radix_sort_probe.log); ranges inside the low word sort correctly at every size.
+typedef unsigned long long SKey;
+typedef unsigned long long SVal;
+#define S_NOREC (~0ull)
+#define S_HLL_BITS 12
+#define S_XCAP 2048                                   // k-mers of a tile staged per round
+
+template <typename RAW, bool EMIT>
+__global__ void __launch_bounds__(TILE) s_expand_kernel(MBuildArgs a, uint32_t tile_lo, uint32_t tile_hi, unsigned long long elem0,
+                                                        SKey* __restrict__ out_h, SVal* __restrict__ out_v,
+                                                        SKey* __restrict__ ex_h, SVal* __restrict__ ex_v, uint32_t ex_cap,
+                                                        unsigned long long* __restrict__ counters,      // [0] kept k-mers, [1] extra records, [2] extras dropped
+                                                        uint32_t* __restrict__ hll) {
+  __shared__ unsigned long long s_c[S_XCAP];
+  __shared__ unsigned short s_lb[S_XCAP];
+  __shared__ uint32_t s_hll[1 << S_HLL_BITS];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (1 << S_HLL_BITS); i += TILE) s_hll[i] = 0;
+  unsigned long long kept_mine = 0;
+  for (uint32_t tile = tile_lo + blockIdx.x; tile < tile_hi; tile += gridDim.x) {
+    const uint64_t i = (uint64_t)tile * TILE + tid;
+    const uint32_t sz = i < a.n_buckets ? a.sizes[i] : 0;
+    uint32_t ea, eb, ta, tb;
+    block_scan2(sz, sz > 0, ea, eb, ta, tb);
+    const bool keep = sz > 0 && kept_bucket(sz, a.rank_base + a.base_a[tile].nonzero + eb + 1, a.sampling);
+    const uint64_t off = a.base_a[tile].elems + ea;
+    const uint64_t last = keep ? raw_key<RAW>(a.keys, off + sz - 1) : 0;
+    uint32_t e = 0; uint64_t run = 0; bool first = true;
+    for (uint32_t base = 0; base < ta; base += S_XCAP) {
+      // the bucket's thread puts its k-mers of this round into LDS: the canonical k-mer, or ~0 for what the reference's scan cannot
+      // reach (CuClarkDB.cu:1291-1307) and for buckets the sampling drops
+      while (e < sz && ea + e < base + S_XCAP) {
+        unsigned long long cv = ~0ull;
+        if (keep) {
+          const uint64_t kv = raw_key<RAW>(a.keys, off + e);
+          const bool reach = (first || kv > run) && kv <= last;
+          if (first || kv > run) { run = kv; first = false; }
+          if (reach) cv = kv * a.htsize + (a.bucket0 + i);
+        }
+        s_c[ea + e - base] = cv;
+        s_lb[ea + e - base] = keep ? a.labels[off + e] : (unsigned short)0;
+        ++e;
+      }
+      __syncthreads();
+      const uint32_t n_here = ta - base < S_XCAP ? ta - base : S_XCAP;
+      for (uint32_t j = tid; j < n_here; j += TILE) {
+        const unsigned long long c = s_c[j];
+        SKey h0 = S_NOREC; SVal r0 = 0;
+        if (c != ~0ull) {
+          ++kept_mine;
+          const uint32_t lb = s_lb[j];
+          int n_c = 0;
+          auto put = [&](uint64_t K, int p, uint64_t x) {
+            const unsigned long long g = x * 0x9E3779B97F4A7C15ull;              // the sketch's own hash of x
+            const uint32_t rank = (uint32_t)__builtin_clzll((g << S_HLL_BITS) | (1ull << (S_HLL_BITS - 1))) + 1u;
+            atomicMax(&s_hll[(uint32_t)(g >> (64 - S_HLL_BITS))], rank);
+            if (!EMIT) return;
+            const uint32_t h = sslot_hash(x);
+            const uint32_t cm = (uint32_t)p | (lb << 8);
+            const SKey key = ((SKey)cm << 32) | h;
+            if (n_c++ == 0) { h0 = key; r0 = K; }
+            else {
+              // a k-mer stored under several positions (tied t-mers: low complexity; a palindromic m-mer): the extras' own list
+              const unsigned long long at = atomicAdd(&counters[1], 1ull);
+              if (at < ex_cap) { ex_h[at] = key; ex_v[at] = K; }
+              else atomicAdd(&counters[2], 1ull);
+            }
+          };
+          if (a.fwd) s_candidates_fwd(c, a.k, a.m, put); else s_candidates(c, a.k, a.m, put);
+        }
+        if (EMIT) {
+          const unsigned long long at = a.base_a[tile].elems + base + j - elem0;
+          out_h[at] = h0; out_v[at] = r0;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < (1 << S_HLL_BITS); i += TILE) if (s_hll[i]) atomicMax(&hll[i], s_hll[i]);
+  for (int o = 32; o > 0; o >>= 1) kept_mine += __shfl_down(kept_mine, o);
+  if ((tid & 63) == 0 && kept_mine) atomicAdd(&counters[0], kept_mine);
+}
+
+// counts / stages the records of the slots [slot_lo, slot_hi) (see s_count_kernel / s_scatter_kernel); grid-stride: a launch
+// holds fewer than 2^32 threads, a database more records
+__global__ void __launch_bounds__(256) s_rec_count_kernel(const SKey* __restrict__ h, uint64_t n, uint32_t n_slots,
+                                                          uint32_t slot_lo, uint32_t slot_hi, uint32_t* __restrict__ cnt) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const SKey key = h[i];
+    if (key == S_NOREC) continue;
+    const uint32_t s = __umulhi((uint32_t)key, n_slots);
+    if (s >= slot_lo && s < slot_hi) atomicAdd(&cnt[s], 1u);
+  }
+}
+__global__ void __launch_bounds__(256) s_rec_place_kernel(const SKey* __restrict__ h, const SVal* __restrict__ v, uint64_t n, uint32_t n_slots,
+                                                          const unsigned long long* __restrict__ off, uint32_t* __restrict__ cursor,
+                                                          unsigned long long* __restrict__ cand_k, uint32_t* __restrict__ cand_m,
+                                                          uint32_t slot_lo, uint32_t slot_hi, unsigned long long base) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const SKey key = h[i];
+    if (key == S_NOREC) continue;
+    const uint32_t s = __umulhi((uint32_t)key, n_slots);
+    if (s < slot_lo || s >= slot_hi) continue;
+    const unsigned long long pos = off[s] - base + atomicAdd(&cursor[s], 1u);
+    cand_k[pos] = v[i]; cand_m[pos] = (uint32_t)(key >> 32);
+  }
+}
+
+static unsigned rec_grid(uint64_t n) { const uint64_t b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : b > (1u << 20) ? (1u << 20) : b); }
+
+// distinct values seen by a HyperLogLog sketch of 2^S_HLL_BITS registers (Flajolet et al. 2007, with the small-range correction)
+static double hll_estimate(const uint32_t* reg) {
+  const int mreg = 1 << S_HLL_BITS;
+  double sum = 0; int zeros = 0;
+  for (int j = 0; j < mreg; ++j) { sum += ldexp(1.0, -(int)reg[j]); zeros += reg[j] == 0; }
+  const double alpha = 0.7213 / (1.0 + 1.079 / mreg);
+  double E = alpha * mreg * (double)mreg / sum;
+  if (E <= 2.5 * mreg && zeros) E = mreg * log((double)mreg / zeros);
+  return E;
+}
+
 __global__ void s_nonzero_kernel(const uint32_t* __restrict__ cnt, uint64_t n, unsigned long long* __restrict__ out) {
   unsigned long long mine = 0;     // grid-stride: one atomic per wave of a small grid, not one per 64 slots
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mine += cnt[i] != 0;
@@ -1121,6 +1261,10 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   unsigned long long h_scal[2] = {0, 0}, h_entries = 0; uint32_t h_max = 0; double avail_b = 0;
   uint32_t* d_nent = nullptr; uint64_t stage_cap = 0; size_t n_ranges = 0; bool one_pass = false; uint64_t alloc_slots = 0;
   std::vector<uint64_t> range_lo; std::vector<unsigned long long> range_base;
+  // the sorted build (see s_expand_kernel): sketch, counters, the records of all chunks (sorted), one chunk unsorted, the extras' list
+  uint32_t* d_hll = nullptr; unsigned long long* d_ctr = nullptr; SKey* d_sh = nullptr; SVal* d_sv = nullptr;
+  SKey* d_th = nullptr; SVal* d_tv = nullptr; SKey* d_xh = nullptr; SVal* d_xv = nullptr; void* d_sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0; uint32_t ex_cap = 0; uint64_t n_extra = 0; bool sorted = false, staged = false;
   MBuildArgs a;
   const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
   struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
@@ -1149,39 +1293,127 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   HIPCK(hipMemcpyAsync(d_a, h_a.data(), sizeof(TileA) * n_tiles, hipMemcpyHostToDevice, s));
   a.sizes = d_sizes; a.n_buckets = n_buckets; a.bucket0 = bucket0; a.htsize = htsize; a.keys = d_keys; a.labels = d_labels;
   a.base_a = d_a; a.sampling = sampling; a.rank_base = rank_base; a.k = k; a.m = m; a.fwd = both_strands ? 1 : 0;
-  // Sizing: the number of entries is about the number of distinct minimizers D among the stored k-mers.  A first
-  // counting pass over G provisional slots leaves N non-empty ones, so D ~ -G ln(1 - N/G); the table then gets
-  // D / 1.5 slots (6 entries each: P(overflow) ~ 2e-4 for Poisson(1.5)).  MIC_SSLOT_LOAD overrides the 1.5.
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 0) {
-      // provisional slots of the counting pass that sizes the table; the occupancy estimate below works at any load
-      // factor short of saturation, so the count is capped where the scans' item count would overflow
-      n_slots = (both_strands ? 2 : 1) * (tot_elems / (sampling > 1 ? 4ull * sampling : 4ull)) + 64;
-      if (n_slots > 0x7FF00000ull) n_slots = 0x7FF00000ull;
+  // Sizing: the number of entries is about the number of distinct minimizer values D among the stored k-mers' candidates; the
+  // table gets D / 1.5 slots (6 entries each: P(overflow) ~ 2e-4 for Poisson(1.5)); MIC_SSLOT_LOAD overrides the 1.5.  D comes from
+  // a HyperLogLog sketch (4096 registers: +-1.6 %) filled by s_expand_kernel - on the sorted road in the same pass that writes the
+  // records, on the classic road in a pass of its own (it replaces the classic form's first counting pass; until round 5 D was
+  // read off the occupancy of 1.4 G provisional counters).  The sketch is a function of the SET of minimizer values: every engine
+  // of a table-sharded run, whichever road it takes, sizes the table identically.
+  {
+    const uint64_t CHUNK = [] { const char* e = getenv("MIC_S_SORT_CHUNK"); const long long v = e ? atoll(e) : 0; return v >= 1024 ? (uint64_t)v : (uint64_t)1 << 28; }();
+    bool want_sorted = !both_strands && tot_elems > 0 && !getenv("MIC_S_CLASSIC");
+    std::vector<uint32_t> cut;                 // chunk c = tiles [cut[c], cut[c + 1]): at most CHUNK k-mers (or one tile)
+    uint64_t chunk_max = 0;
+    {
+      uint32_t t0 = 0;
+      cut.push_back(0);
+      for (unsigned tl = 0; tl < n_tiles; ++tl) {
+        const uint64_t end = tl + 1 < n_tiles ? h_a[tl + 1].elems : tot_elems;
+        if (end - h_a[t0].elems > CHUNK && tl > t0) { cut.push_back(tl); t0 = tl; }
+        const uint64_t here = end - h_a[t0].elems;
+        if (here > chunk_max) chunk_max = here;
+      }
+      cut.push_back(n_tiles);
+      if (chunk_max > 0x7FFFFF00ull) want_sorted = false;       // (one tile of more k-mers than a sort call takes: no such table)
     }
+    ex_cap = (uint32_t)std::min<uint64_t>(tot_elems / 16 + (1u << 20), 0x7FFFFF00ull);
+    if (want_sorted) {
+      hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp_bytes, (const SKey*)nullptr, (SKey*)nullptr, (const SVal*)nullptr, (SVal*)nullptr,
+                                         (int)chunk_max, 16, 32, s);
+      size_t free_b = 0, total_b = 0;
+      HIPCK(hipMemGetInfo(&free_b, &total_b));
+      double avail = (double)free_b - 1.5e9 - (double)mic_build_reserved_hbm;
+      if (const char* env = getenv("MIC_HBM_LIMIT_GB")) { const double lim = atof(env) * 1e9; if (lim > 0 && avail > lim) avail = lim; }
+      // records of every k-mer + one chunk unsorted + the sort's scratch + the extras' list, and - while the records are still
+      // there - the staging area of this engine's slots and the per-slot arrays (the table itself comes after the records went)
+      const double need = (double)tot_elems * 16 + (double)chunk_max * 16 + (double)sort_tmp_bytes + (double)ex_cap * 16 +
+                          (double)tot_elems * 12 / (n_parts > 1 ? n_parts : 1) + (double)tot_elems * 4 + 128e6;
+      if (need > avail) want_sorted = false;
+      if (timing) fprintf(stderr, "[load]   sorted build: %.2f GB needed, %.2f GB available -> %s\n", need / 1e9, avail / 1e9, want_sorted ? "taken" : "classic build");
+    }
+    HIPCK(hipMalloc(&d_hll, sizeof(uint32_t) << S_HLL_BITS));
+    HIPCK(hipMalloc(&d_ctr, 3 * 8));
+    HIPCK(hipMemsetAsync(d_hll, 0, sizeof(uint32_t) << S_HLL_BITS, s));
+    HIPCK(hipMemsetAsync(d_ctr, 0, 3 * 8, s));
+    if (want_sorted) {
+      hipError_t e_ = hipMalloc(&d_sh, (tot_elems + 1) * sizeof(SKey));
+      if (e_ == hipSuccess) e_ = hipMalloc(&d_sv, (tot_elems + 1) * sizeof(SVal));
+      if (e_ == hipSuccess) e_ = hipMalloc(&d_th, (chunk_max + 1) * sizeof(SKey));
+      if (e_ == hipSuccess) e_ = hipMalloc(&d_tv, (chunk_max + 1) * sizeof(SVal));
+      if (e_ == hipSuccess) e_ = hipMalloc(&d_xh, (size_t)(ex_cap + 1) * sizeof(SKey));
+      if (e_ == hipSuccess) e_ = hipMalloc(&d_xv, (size_t)(ex_cap + 1) * sizeof(SVal));
+      if (e_ == hipSuccess) e_ = hipMalloc(&d_sort_tmp, sort_tmp_bytes ? sort_tmp_bytes : 16);
+      if (e_ != hipSuccess) { (void)hipGetLastError(); want_sorted = false; }
+    }
+#define EXPAND(EMIT, T0, T1, E0) do { const unsigned g_ = (unsigned)std::min<uint64_t>((uint64_t)(T1) - (T0), 2048); \
+    if (key_bytes == 8) s_expand_kernel<uint64_t, EMIT><<<g_, TILE, 0, s>>>(a, T0, T1, E0, d_th, d_tv, d_xh, d_xv, ex_cap, d_ctr, d_hll); \
+    else if (key_bytes == 4) s_expand_kernel<uint32_t, EMIT><<<g_, TILE, 0, s>>>(a, T0, T1, E0, d_th, d_tv, d_xh, d_xv, ex_cap, d_ctr, d_hll); \
+    else s_expand_kernel<uint16_t, EMIT><<<g_, TILE, 0, s>>>(a, T0, T1, E0, d_th, d_tv, d_xh, d_xv, ex_cap, d_ctr, d_hll); } while (0)
+    a.n_mslots = 0;
+    if (want_sorted) {
+      for (size_t c = 0; c + 1 < cut.size(); ++c) {
+        const uint32_t t0 = cut[c], t1 = cut[c + 1];
+        const uint64_t e0 = h_a[t0].elems, e1 = t1 < n_tiles ? h_a[t1].elems : tot_elems;
+        if (e1 == e0) continue;
+        EXPAND(true, t0, t1, e0);
+        HIPCK(hipGetLastError());
+        size_t tb = sort_tmp_bytes;
+        if (getenv("MIC_S_NOSORT")) {          // (debugging: the records as they come, unsorted)
+          HIPCK(hipMemcpyAsync(d_sh + e0, d_th, (e1 - e0) * sizeof(SKey), hipMemcpyDeviceToDevice, s));
+          HIPCK(hipMemcpyAsync(d_sv + e0, d_tv, (e1 - e0) * sizeof(SVal), hipMemcpyDeviceToDevice, s));
+        } else
+        HIPCK(hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, tb, (const SKey*)d_th, d_sh + e0, (const SVal*)d_tv, d_sv + e0, (int)(e1 - e0), 16, 32, s));
+      }
+      unsigned long long h_ctr[3] = {0, 0, 0};
+      HIPCK(hipMemcpyAsync(h_ctr, d_ctr, 24, hipMemcpyDeviceToHost, s));
+      HIPCK(hipStreamSynchronize(s));
+      if (h_ctr[2]) {          // more tied candidates than the extras' list holds (a database of low complexity): the classic road
+        want_sorted = false;
+        if (timing) fprintf(stderr, "[load]   sorted build given up: %llu extra candidates beyond the list of %u\n", h_ctr[2], ex_cap);
+      } else { sorted = true; n_extra = h_ctr[1]; h_scal[0] = h_ctr[0]; }
+      if (timing) fprintf(stderr, "[load]   sorted build: %llu k-mers kept of %llu, %llu extra candidates\n", h_ctr[0], (unsigned long long)tot_elems, h_ctr[1]);
+      hipFree(d_th); d_th = nullptr; hipFree(d_tv); d_tv = nullptr; hipFree(d_sort_tmp); d_sort_tmp = nullptr;
+      if (sorted) lap("candidates of every k-mer once + sketch of the minimizers + radix sort by slot hash (sorted build)");
+    }
+    if (!sorted) {
+      if (d_sh) { hipFree(d_sh); d_sh = nullptr; } if (d_sv) { hipFree(d_sv); d_sv = nullptr; }
+      if (d_xh) { hipFree(d_xh); d_xh = nullptr; } if (d_xv) { hipFree(d_xv); d_xv = nullptr; }
+      if (d_th) { hipFree(d_th); d_th = nullptr; } if (d_tv) { hipFree(d_tv); d_tv = nullptr; }
+      if (d_sort_tmp) { hipFree(d_sort_tmp); d_sort_tmp = nullptr; }
+      HIPCK(hipMemsetAsync(d_hll, 0, sizeof(uint32_t) << S_HLL_BITS, s));
+      HIPCK(hipMemsetAsync(d_ctr, 0, 3 * 8, s));
+      EXPAND(false, 0u, n_tiles, 0ull);
+      HIPCK(hipGetLastError());
+    }
+#undef EXPAND
+    std::vector<uint32_t> h_hll((size_t)1 << S_HLL_BITS);
+    HIPCK(hipMemcpyAsync(h_hll.data(), d_hll, sizeof(uint32_t) << S_HLL_BITS, hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    const double D = hll_estimate(h_hll.data());
+    double load = 1.5;
+    if (const char* env = getenv("MIC_SSLOT_LOAD")) { double v = atof(env); if (v > 0.05 && v < 6) load = v; }
+    n_slots = (uint64_t)(D / load) + 64;
     // the scans below take an int item count; a table this large (> 2^31 slots = 275 GB) does not fit one GPU anyway
     if (n_slots > 0x7FFFFF00ull) { snprintf(err, err_cap, "the super-k-mer table would need %llu slots", (unsigned long long)n_slots); rc = -3; goto done; }
-    if (d_cnt) { hipFree(d_cnt); d_cnt = nullptr; }
     HIPCK(hipMalloc(&d_cnt, n_slots * 4));
     HIPCK(hipMemsetAsync(d_cnt, 0, n_slots * 4, s));
-    HIPCK(hipMemsetAsync(d_scal, 0, 16, s));
     a.n_mslots = n_slots;
-    BY_RAW(s_count_kernel, a, d_cnt, d_scal);
-    HIPCK(hipGetLastError());
-    if (pass == 0) {
-      s_nonzero_kernel<<<4096, 256, 0, s>>>(d_cnt, n_slots, d_scal + 1);
+    if (sorted) {
+      // (a slot-range part counts - and later stages - its own slots only)
+      const uint32_t c_lo = n_parts > 1 ? (uint32_t)((unsigned __int128)n_slots * part / n_parts) : 0u;
+      const uint32_t c_hi = n_parts > 1 ? (uint32_t)((unsigned __int128)n_slots * (part + 1) / n_parts) : (uint32_t)n_slots;
+      s_rec_count_kernel<<<rec_grid(tot_elems), 256, 0, s>>>(d_sh, tot_elems, (uint32_t)n_slots, c_lo, c_hi, d_cnt);
+      if (n_extra) s_rec_count_kernel<<<rec_grid(n_extra), 256, 0, s>>>(d_xh, n_extra, (uint32_t)n_slots, c_lo, c_hi, d_cnt);
       HIPCK(hipGetLastError());
-      HIPCK(hipMemcpyAsync(h_scal, d_scal, 16, hipMemcpyDeviceToHost, s));
       HIPCK(hipStreamSynchronize(s));
-      const double G = (double)n_slots, N = (double)h_scal[1];
-      double D = N >= G ? 8.0 * G : -G * log(1.0 - N / G);
-      double load = 1.5;
-      if (const char* env = getenv("MIC_SSLOT_LOAD")) { double v = atof(env); if (v > 0.05 && v < 6) load = v; }
-      n_slots = (uint64_t)(D / load) + 64;
+    } else {
+      HIPCK(hipMemsetAsync(d_scal, 0, 16, s));
+      BY_RAW(s_count_kernel, a, d_cnt, d_scal);
+      HIPCK(hipGetLastError());
+      HIPCK(hipMemcpyAsync(h_scal, d_scal, 8, hipMemcpyDeviceToHost, s));
+      HIPCK(hipStreamSynchronize(s));
     }
   }
-  HIPCK(hipMemcpyAsync(h_scal, d_scal, 8, hipMemcpyDeviceToHost, s));
-  HIPCK(hipStreamSynchronize(s));
   lap("bucket sums + slot counts (sizing)");
   HIPCK(hipMalloc(&d_off, (n_slots + 1) * 8));
   HIPCK(scan_u32_to_u64(d_cnt, d_off, n_slots, s));
@@ -1205,12 +1437,25 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     size_t free_b = 0, total_b = 0;
     HIPCK(hipMemGetInfo(&free_b, &total_b));
     avail_b = (double)free_b - 1.5e9 - (double)mic_build_reserved_hbm;
+    // sorted build: the records are resident now and are freed after the staging is filled, before the table is allocated
+    const double rec_bytes = sorted ? (double)tot_elems * 16 + (double)ex_cap * 16 : 0.0;
     if (const char* env = getenv("MIC_HBM_LIMIT_GB")) {   // test hook: pretend only this much is available
       const double lim = atof(env) * 1e9;
-      if (lim > 0 && avail_b > lim) avail_b = lim;
+      if (lim > 0 && avail_b + rec_bytes > lim) avail_b = lim - rec_bytes;
     }
     const double fixed = (double)n_part * (128 * 1.02) + (double)n_slots * 24 + 64e6;    // table + chain offsets / cursors / entry counts (counts and offsets exist already)
-    double budget = avail_b - fixed;
+    double budget = avail_b + rec_bytes - fixed;
+    if (sorted && ((double)(off_hi - off_lo) * 12 > avail_b - (double)n_slots * 24 - 64e6 || (double)(off_hi - off_lo) * 12 > budget)) {
+      // the staging area does not fit next to the records (or would need several passes): the classic road from here on - the
+      // counts and offsets are the same on both
+      if (timing) fprintf(stderr, "[load]   sorted build given up: no room for the staging area next to the records\n");
+      hipFree(d_sh); d_sh = nullptr; hipFree(d_sv); d_sv = nullptr; hipFree(d_xh); d_xh = nullptr; hipFree(d_xv); d_xv = nullptr;
+      sorted = false;
+      HIPCK(hipMemGetInfo(&free_b, &total_b));
+      avail_b = (double)free_b - 1.5e9 - (double)mic_build_reserved_hbm;
+      if (const char* env = getenv("MIC_HBM_LIMIT_GB")) { const double lim = atof(env) * 1e9; if (lim > 0 && avail_b > lim) avail_b = lim; }
+      budget = avail_b - fixed;
+    }
     if (const char* env = getenv("MIC_S_STAGING_LIMIT_MB")) {           // test hook: a small staging area forces several passes
       const double lim = atof(env) * 1e6;
       if (lim > 0 && budget > lim) budget = lim;
@@ -1255,7 +1500,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       (void)hipGetLastError();
       snprintf(err, err_cap, "the super-k-mer build needs %.2f GB of staging", (double)biggest * 12 / 1e9); rc = -3; goto done;
     }
-    if (timing) fprintf(stderr, "[load]   %zu pass(es) over slot ranges, staging %.2f GB for %.2f G candidates\n", n_ranges, (double)biggest * 12 / 1e9, n_cand / 1e9);
+    if (timing) fprintf(stderr, "[load]   %zu pass(es) over slot ranges, staging %.2f GB for %.2f G candidates (%llu)\n", n_ranges, (double)biggest * 12 / 1e9, n_cand / 1e9, (unsigned long long)n_cand);
   }
   HIPCK(hipMalloc(&d_cur, n_slots * 4));      // scatter cursors
   HIPCK(hipMalloc(&d_nent, n_slots * 4));     // entries per slot
@@ -1267,6 +1512,25 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   // for a table built in several ranges no second scatter + sort either.  A pool that runs out (a database of crowded
   // minimizers, which the rule below hands to the minimizer layout anyway) or an allocation that fails falls back to the
   // two-pass form: count the entries, size the chains exactly, write.  MIC_S_TWO_PASS=1 forces that form.
+  if (sorted) {
+    // sorted build: the staging area is filled from the records (a streaming read; the writes stay inside the window of the
+    // staging area the records' order sweeps), then the records go - before the table is allocated
+    if (n_ranges != 1) {       // (a staging area cut into ranges - MIC_S_STAGING_LIMIT_MB - is the classic road's)
+      hipFree(d_sh); d_sh = nullptr; hipFree(d_sv); d_sv = nullptr; hipFree(d_xh); d_xh = nullptr; hipFree(d_xv); d_xv = nullptr;
+      sorted = false;
+    }
+  }
+  if (sorted) {
+    s_rec_place_kernel<<<rec_grid(tot_elems), 256, 0, s>>>(d_sh, d_sv, tot_elems, (uint32_t)n_slots, d_off, d_cur, d_ck, d_cm,
+                                                                     (uint32_t)range_lo[0], (uint32_t)range_lo[1], range_base[0]);
+    if (n_extra) s_rec_place_kernel<<<rec_grid(n_extra), 256, 0, s>>>(d_xh, d_xv, n_extra, (uint32_t)n_slots, d_off, d_cur, d_ck, d_cm,
+                                                                                 (uint32_t)range_lo[0], (uint32_t)range_lo[1], range_base[0]);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(s));
+    hipFree(d_sh); d_sh = nullptr; hipFree(d_sv); d_sv = nullptr; hipFree(d_xh); d_xh = nullptr; hipFree(d_xv); d_xv = nullptr;
+    staged = true;
+    lap("records counted per slot, offsets, staged (sorted build)");
+  }
   if (!getenv("MIC_S_TWO_PASS")) {
     uint64_t pool_cap = n_part / 50 + 65536;
     if (const char* env = getenv("MIC_S_POOL_SLOTS")) { long v = atol(env); if (v > 0) pool_cap = (uint64_t)v; }   // test hook: a pool that runs out
@@ -1279,7 +1543,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     if (e_ == hipSuccess) {
       for (size_t r = 0; r < n_ranges && e_ == hipSuccess; ++r) {
         const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
-        BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
+        if (!staged) BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
         s_merge_kernel<2><<<(unsigned)((hi - lo + S_TPB - 1) / S_TPB), S_TPB, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, nullptr, slots - part_lo * 32,
                                                                            d_max, lo, hi, range_base[r], 1, d_pool, (uint32_t)pool_cap);
         e_ = hipGetLastError();
@@ -1301,7 +1565,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
   // phase A (two-pass form): entries per slot (scatter + sort + merge without writing), range by range
   for (size_t r = 0; r < n_ranges && !one_pass; ++r) {
     const uint64_t lo = range_lo[r], hi = range_lo[r + 1];
-    BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
+    if (!staged) BY_RAW(s_scatter_kernel, a, d_off, d_cur, d_ck, d_cm, (uint32_t)lo, (uint32_t)hi, range_base[r]);
     HIPCK(hipGetLastError());
     s_merge_kernel<0><<<(unsigned)((hi - lo + S_TPB - 1) / S_TPB), S_TPB, 0, s>>>(d_off, d_cnt, part_hi, d_ck, d_cm, k, m, d_nent, nullptr,
                                                                        nullptr, d_max, lo, hi, range_base[r], 1, nullptr, 0);
@@ -1448,6 +1712,15 @@ done:
   if (d_cm) hipFree(d_cm);
   if (d_dem) hipFree(d_dem);
   if (d_nent) hipFree(d_nent);
+  if (d_hll) hipFree(d_hll);
+  if (d_ctr) hipFree(d_ctr);
+  if (d_sh) hipFree(d_sh);
+  if (d_sv) hipFree(d_sv);
+  if (d_th) hipFree(d_th);
+  if (d_tv) hipFree(d_tv);
+  if (d_xh) hipFree(d_xh);
+  if (d_xv) hipFree(d_xv);
+  if (d_sort_tmp) hipFree(d_sort_tmp);
   if (slots) hipFree(slots);
   if (side) hipFree(side);
   return rc;

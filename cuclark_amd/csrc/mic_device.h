@@ -168,14 +168,17 @@ __device__ __forceinline__ void s_sampled(uint64_t K, int k, int m, bool canon, 
   }
 }
 
-__device__ __forceinline__ uint32_t sslot_of_x(uint64_t x, uint32_t n_slots) {
+// slot of a minimizer value x: a 32-bit hash of x, scaled to the table - slot = floor(h * n_slots / 2^32), monotone in h (the sorted
+// build of mic_build.hip orders its records by h before the number of slots is known)
+__device__ __forceinline__ uint32_t sslot_hash(uint64_t x) {
   const uint32_t hi = (uint32_t)(x >> 32);
   uint32_t h = (uint32_t)x * 0x85EBCA77u + __umul24(hi ^ (hi >> 24), 0xC2B2AFu);
 #if !(MIC_HASH_LITE & 2)
   h ^= h >> 15; h *= 0x165667B1u;
 #endif
-  return __umulhi(h, n_slots);
+  return h;
 }
+__device__ __forceinline__ uint32_t sslot_of_x(uint64_t x, uint32_t n_slots) { return __umulhi(sslot_hash(x), n_slots); }
 
 // the same function of x given as (low word, bits above it): 32-bit operations only (query_kernel_r)
 __device__ __forceinline__ uint32_t sslot_of_x32(uint32_t lo, uint32_t hi, uint32_t n_slots) {

@@ -68,7 +68,7 @@ def test_shim_completes_a_read_of_80_targets_exactly_on_three_engines(tmp_path):
     import re
     from cuclark_amd import host
     rng = np.random.default_rng(3)
-    k, T, htsize = 27, 80, 99991
+    k, T, htsize = 27, 80, 57777779           # (cuCLARK-l's table size: u32 keys for k = 27, the driver's CuClarkDB<uint32_t>)
     o = gu.oracle()
     seqs = ["".join(rng.choice(list("ACGT"), k + 4)) for _ in range(T)]
     canon = {}

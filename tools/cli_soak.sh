@@ -49,6 +49,7 @@ while [ "$(date +%s)" -lt "$t_end" ]; do
     fi
   done
   rounds=$((rounds + 1))
+  echo "... round $rounds done, $runs runs, $(( t_end - $(date +%s) )) s left"
 done
 echo "cli soak ok: $rounds rounds of 7 inputs, $runs runs of exe/cuCLARK on the hardened library, every CSV equal to the one-engine run's (seeds $SEED..$((SEED + rounds - 1)))"
 rm -rf "$W"
