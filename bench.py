@@ -496,8 +496,10 @@ def end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res_expect, trut
             else:
                 out["fasta_input"] = {"error": (r2.stderr or r2.stdout)[-300:]}
     finally:
-        if not keep:
+        if not keep and not os.environ.get("MIC_BENCH_KEEP"):
             shutil.rmtree(tmp, ignore_errors=True)
+        elif os.environ.get("MIC_BENCH_KEEP"):
+            log("end_to_end: files kept in", tmp)
     return out
 
 

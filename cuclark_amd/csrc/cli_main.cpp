@@ -5,6 +5,7 @@
 // fixes it at compile time, parameters.hh:39 / parameters_light_hh:40).
 #include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <string.h>
 
 #include <sys/time.h>
@@ -258,13 +259,22 @@ int main(int argc, char** argv) {
   o.objects = argv[i_objects];
   if (i_objects2 > 0) o.objects2 = argv[i_objects2];
   o.results = argv[i_results];
+  mic::Classifier* classifier = nullptr;
   try {
-    mic::Classifier classifier(o);
-    if (i_objects2 > 0) classifier.run_paired(o.objects, o.objects2, o.results);
-    else classifier.run(o.objects, o.results);
+    classifier = new mic::Classifier(o);
+    if (i_objects2 > 0) classifier->run_paired(o.objects, o.objects2, o.results);
+    else classifier->run(o.objects, o.results);
   } catch (const std::exception& ex) {
     std::cerr << ex.what() << std::endl;
+    delete classifier;
     return 1;
   }
+  // The results are written and closed.  Taking the engines apart in order - tens of gigabytes of table, staging and pinned slots
+  // freed one allocation at a time - took the headline run a second (4.46 s of process for 3.45 s of work); the process ends here and
+  // the driver takes everything back at once.  MIC_CLI_ORDERLY_EXIT=1 keeps the orderly teardown (the sanitizer builds run with it).
+  std::cout.flush(); std::cerr.flush();
+  fflush(nullptr);
+  if (!getenv("MIC_CLI_ORDERLY_EXIT")) _exit(0);
+  delete classifier;
   return 0;
 }

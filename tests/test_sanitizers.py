@@ -93,7 +93,7 @@ def _run(exe, rig, objects, env_extra=(), threads="4", extra_args=()):
     if os.path.exists(out + ".csv"):
         os.remove(out + ".csv")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1",
-               **dict(env_extra))
+               MIC_CLI_ORDERLY_EXIT="1", **dict(env_extra))      # (orderly teardown: the destructors run under the sanitizer too)
     cmd = [exe, "-k", "31", "--htsize", "64", "-T", os.path.join(tmp, "targets.txt"), "-D", os.path.join(tmp, "DB"),
            *objects, "-R", out, "-n", threads, *extra_args]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
@@ -192,7 +192,7 @@ def test_the_librarys_host_code_under_asan_against_a_mock_hip_runtime(tmp_path):
     p1, p2 = os.path.join(tmp, "m_1.fq"), os.path.join(tmp, "m_2.fq")
     open(p1, "wb").write(m1)
     open(p2, "wb").write(m2)
-    cli_env = dict(env, ASAN_OPTIONS="detect_stack_use_after_return=1:detect_leaks=0", MOCK_HIP_DEVICES="4", MIC_INGEST_KB="128")   # (libomp keeps 128 bytes)
+    cli_env = dict(env, ASAN_OPTIONS="detect_stack_use_after_return=1:detect_leaks=0", MOCK_HIP_DEVICES="4", MIC_INGEST_KB="128", MIC_CLI_ORDERLY_EXIT="1")   # (libomp keeps 128 bytes)
     for args, n_rec, said in ((["-d", "4", "--db-sharded", "--parts", "4", "-O", fq], 4000, "4 engine(s) on 4 device(s), table-sharded: 4 part(s) x 1 read group(s)"),
                               (["-d", "4", "--db-sharded", "--parts", "2", "-O", fq], 4000, "table-sharded: 2 part(s) x 2 read group(s)"),
                               (["-d", "3", "-O", fq], 4000, "3 engine(s) on 3 device(s), read-sharded"),
