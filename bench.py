@@ -70,6 +70,18 @@ WORKLOADS = {
                         n_reads=10_000_000, read_len=150,
                         name="10M x 150bp synthetic reads vs 36GB-scale k=31 table with 65535 targets (HTSIZE 1610612741, u32 keys, ~5.7e9 k-mers) "
                              "resident in HBM"),
+    # Databases of DISCRIMINATIVE k-mers: the same 5.73 G candidate k-mers, of which the removal of k-mers common to
+    # several targets (HashTableStorage_hh.hh:241-292) leaves 50 % / 25 % in runs of geometric length, mean 8 (mic_synth_spec.keep_ppm)
+    "full_frag50": dict(htsize=1610612741, genome_nt=5_730_000_000, n_genomes=8192, n_targets=4096, k=31, key_bytes=4, n_reads=10_000_000, read_len=150,
+                        keep_ppm=500_000, run_len=8,
+                        name="10M x 150bp synthetic reads vs a FRAGMENTED 36GB-scale k=31 table: 50 % of ~5.7e9 candidate k-mers kept in runs of mean length 8 "
+                             "(HTSIZE 1610612741, u32 keys, 4096 targets)"),
+    "full_frag25": dict(htsize=1610612741, genome_nt=5_730_000_000, n_genomes=8192, n_targets=4096, k=31, key_bytes=4, n_reads=10_000_000, read_len=150,
+                        keep_ppm=250_000, run_len=8,
+                        name="10M x 150bp synthetic reads vs a FRAGMENTED 36GB-scale k=31 table: 25 % of ~5.7e9 candidate k-mers kept in runs of mean length 8 "
+                             "(HTSIZE 1610612741, u32 keys, 4096 targets)"),
+    "tiny_frag": dict(htsize=999983, genome_nt=1_500_000, n_genomes=64, n_targets=50, k=31, key_bytes=8, n_reads=100_000, read_len=100, keep_ppm=500_000, run_len=8,
+                      name="100k x 100bp synthetic reads vs a fragmented 50-target toy table (plumbing)"),
     "tiny_paired": dict(htsize=999983, genome_nt=1_500_000, n_genomes=64, n_targets=50, k=31, key_bytes=8,
                         n_reads=100_000, read_len=100, paired=True,
                         name="100k pairs of 2x100bp synthetic reads vs 50-target toy table (plumbing)"),
@@ -653,7 +665,7 @@ def main():
 
     # ---- synthetic table in the on-disk layout (.sz/.ky/.lb images), in HBM
     spec = _lib.MicSynthSpec(seed=4, htsize=w["htsize"], genome_nt=w["genome_nt"], n_targets=T, n_genomes=w["n_genomes"], k=k,
-                             key_bytes=w["key_bytes"])
+                             key_bytes=w["key_bytes"], keep_ppm=w.get("keep_ppm", 0), run_len=w.get("run_len", 0))
     cap = int(w["genome_nt"]) + 1024
     d_sizes = torch.empty(w["htsize"], dtype=torch.uint8, device=dev)
     d_keys = torch.empty(cap, dtype=torch.int32 if w["key_bytes"] == 4 else torch.int64, device=dev)

@@ -870,10 +870,33 @@ __global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long
   const bool live = s < slot_hi;
   const unsigned long long c0 = off[s_first] - base, c1 = off[s_end - 1] + cnt[s_end - 1] - base;
   const bool in_lds = c1 - c0 <= S_LDS_CAND;
+  // Round 5: a candidate staged in LDS is re-packed by the thread that loads it (the loads are spread evenly over the block) into ITS
+  // SORT KEY - minimizer value as the slot orders it (low 32 bits, then the bits above), minimizer position, label: 60 bits - and the
+  // 2 (k - m) bits of the k-mer around the minimizer: the same 12 bytes, but the shell sort below compares two 64-bit words where
+  // it extracted two minimizers out of two k-mers per comparison (~55 % of the kernel's instructions), and the merge loop reads
+  // value, position and label off the key.  (m <= 20: 40 bits of minimizer; other m and blocks that do not fit LDS keep the old form.)
+  const bool packed = in_lds && m <= 20;
   if (in_lds) {
-    for (uint32_t i = threadIdx.x; i < (uint32_t)(c1 - c0); i += S_TPB) { s_k[i] = cand_k[c0 + i]; s_m[i] = cand_m[c0 + i]; }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(c1 - c0); i += S_TPB) {
+      const unsigned long long Kv = cand_k[c0 + i]; const uint32_t Mv = cand_m[c0 + i];
+      if (packed) {
+        const uint32_t j = Mv & 0xFF, lb = Mv >> 8;
+        const int r = 2 * (k - m - (int)j);
+        const unsigned long long x = (Kv >> r) & ((1ULL << (2 * m)) - 1);
+        const unsigned long long left = r + 2 * m >= 64 ? 0ULL : Kv >> (r + 2 * m);        // (k = 32, position 0: nothing to the left)
+        const unsigned long long F = (left << r) | (Kv & ((1ULL << r) - 1));
+        s_k[i] = ((unsigned long long)(uint32_t)x << 28) | ((x >> 32) << 20) | ((unsigned long long)j << 16) | lb;
+        s_m[i] = (uint32_t)F;
+      } else { s_k[i] = Kv; s_m[i] = Mv; }
+    }
     __syncthreads();
   }
+  auto unpack = [&](unsigned long long key, uint32_t F, unsigned long long& kv, uint32_t& j, uint32_t& lb, uint64_t& x) {
+    x = (key >> 28) | (((key >> 20) & 0xFF) << 32); j = (uint32_t)(key >> 16) & 15u; lb = (uint32_t)key & 0xFFFFu;
+    const int r = 2 * (k - m - (int)j);
+    const unsigned long long left = (unsigned long long)F >> r;
+    kv = (r + 2 * m >= 64 ? 0ULL : left << (r + 2 * m)) | (x << r) | ((unsigned long long)F & ((1ULL << r) - 1));
+  };
   const uint32_t n = live ? cnt[s] : 0;
   const unsigned long long my = live ? off[s] - base : c0;
   unsigned long long* K = in_lds ? s_k + (my - c0) : cand_k + my;
@@ -906,7 +929,7 @@ __global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long
       for (uint32_t i = gap; i < n; ++i) {
         const unsigned long long kv = K[i]; const uint32_t mv = M[i];
         uint32_t j = i;
-        while (j >= gap && s_less(kv, mv, K[j - gap], M[j - gap], k, m)) { K[j] = K[j - gap]; M[j] = M[j - gap]; j -= gap; }
+        while (j >= gap && (packed ? kv < K[j - gap] : s_less(kv, mv, K[j - gap], M[j - gap], k, m))) { K[j] = K[j - gap]; M[j] = M[j - gap]; j -= gap; }
         K[j] = kv; M[j] = mv;
       }
     }
@@ -918,9 +941,10 @@ __global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long
   for (int o = 0; o < S_MAXOPEN; ++o) { open[o].S = 0; open[o].known = 0; open[o].pmask = 0; open[o].label = 0; }
   const u128 kmask = (((u128)1) << (2 * k)) - 1;
   for (uint32_t i = 0; i < n; ++i) {
-    const unsigned long long kv = K[i]; const uint32_t mv = M[i];
-    const uint32_t j = mv & 0xFF, lb = mv >> 8;
-    const uint64_t x = s_x_of(kv, j, k, m);
+    unsigned long long kv = K[i]; const uint32_t mv = M[i];
+    uint32_t j, lb; uint64_t x;
+    if (packed) unpack(kv, mv, kv, j, lb, x);
+    else { j = mv & 0xFF; lb = mv >> 8; x = s_x_of(kv, j, k, m); }
     if (n_open && x != cur_x) {
 #pragma unroll
       for (int o = 0; o < S_MAXOPEN; ++o) if (o < n_open) s_emit<MODE>(open[o], cur_x, L, wr);
@@ -955,7 +979,11 @@ __global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long
   __syncthreads();
   // the counting pass of the two-pass form leaves the candidates sorted for the writing pass (one range: it does not sort again)
   if (MODE == 0 && sort_now && in_lds)
-    for (uint32_t i = threadIdx.x; i < (uint32_t)(c1 - c0); i += S_TPB) { cand_k[c0 + i] = s_k[i]; cand_m[c0 + i] = s_m[i]; }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(c1 - c0); i += S_TPB) {
+      unsigned long long kv = s_k[i]; uint32_t mv = s_m[i];
+      if (packed) { uint32_t j, lb; uint64_t x; unpack(kv, mv, kv, j, lb, x); mv = j | (lb << 8); }
+      cand_k[c0 + i] = kv; cand_m[c0 + i] = mv;
+    }
   // the block's main slots: one contiguous piece of the table
   if (MODE != 0) {
     const uint32_t words = (uint32_t)(s_end - s_first) * 32u;

@@ -154,10 +154,26 @@ int check_shard(uint64_t htsize, uint64_t& s0, uint64_t& s1) {
 // holds that range of the images only): [lo, hi) in file offsets, dst = where byte lo goes.  Every chunk is read once and goes to the
 // destinations whose range it meets.
 struct UploadDst { int device; void* dst; hipStream_t stream; uint64_t lo, hi; };
-int upload_file_range_multi(FILE* f, const std::vector<UploadDst>& dsts, const char* what) {
-  const size_t CH = 256u << 20;
+// The two pinned staging buffers of a load: allocated once for its three files (pinning 2 x 256 MB costs ~0.1 s a time)
+struct UploadStage {
+  static constexpr size_t CH = 256u << 20;
+  void* buf[2] = {nullptr, nullptr};
+  bool get(int near_device) {
+    if (buf[0]) return true;
+    mic_bind_thread_near_device(near_device, 1);
+    // (HIP has one context per process: pinned host memory is reachable from every device, whatever device was current)
+    const bool ok = hipHostMalloc(&buf[0], CH, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&buf[1], CH, hipHostMallocDefault) == hipSuccess;
+    mic_bind_thread_near_device(near_device, 0);
+    return ok;
+  }
+  ~UploadStage() { for (void* b : buf) if (b) hipHostFree(b); }
+};
+int upload_file_range_multi(FILE* f, const std::vector<UploadDst>& dsts, const char* what, UploadStage* shared = nullptr) {
+  const size_t CH = UploadStage::CH;
   const int fd = fileno(f);
   static const int n_readers = [] { const char* e = getenv("MIC_LOAD_THREADS"); int v = e ? atoi(e) : 0; return v > 0 ? (v > 64 ? 64 : v) : 8; }();
+  UploadStage own;
+  UploadStage* st = shared ? shared : &own;
   void* stage[2] = {nullptr, nullptr};
   const size_t nd = dsts.size();
   std::vector<hipEvent_t> ev(2 * nd, nullptr);
@@ -169,10 +185,9 @@ int upload_file_range_multi(FILE* f, const std::vector<UploadDst>& dsts, const c
   const uint64_t bytes = end - off;
   int dev_now = 0;
   hipGetDevice(&dev_now);
+  if (!st->get(dsts[0].device)) rc = fail(MIC_E_NOMEM, "pinned staging alloc failed");
+  stage[0] = st->buf[0]; stage[1] = st->buf[1];
   mic_bind_thread_near_device(dsts[0].device, 1);
-  for (int i = 0; i < 2 && rc == MIC_OK; ++i)
-    // (HIP has one context per process: pinned host memory is reachable from every device, whatever device was current)
-    if (hipHostMalloc(&stage[i], CH, hipHostMallocDefault) != hipSuccess) rc = fail(MIC_E_NOMEM, "pinned staging alloc failed");
   for (size_t i = 0; i < 2 * nd && rc == MIC_OK; ++i) {
     if (hipSetDevice(dsts[i % nd].device) != hipSuccess || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
       rc = fail(MIC_E_HIP, "event create failed");
@@ -222,17 +237,16 @@ int upload_file_range_multi(FILE* f, const std::vector<UploadDst>& dsts, const c
     cur ^= 1; done += n;
   }
   for (size_t d = 0; d < nd; ++d) { hipSetDevice(dsts[d].device); hipStreamSynchronize(dsts[d].stream); }
-  for (int i = 0; i < 2; ++i) if (stage[i]) hipHostFree(stage[i]);
   for (hipEvent_t e : ev) if (e) hipEventDestroy(e);
   mic_bind_thread_near_device(dsts[0].device, 0);
   hipSetDevice(dev_now);
   return rc;
 }
 
-int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStream_t s, const char* what) {
+int upload_file_range(FILE* f, uint64_t off, uint64_t bytes, void* dst, hipStream_t s, const char* what, UploadStage* shared = nullptr) {
   int dev_now = 0;
   hipGetDevice(&dev_now);
-  return upload_file_range_multi(f, {UploadDst{dev_now, dst, s, off, off + bytes}}, what);
+  return upload_file_range_multi(f, {UploadDst{dev_now, dst, s, off, off + bytes}}, what, shared);
 }
 
 // The .sz image (one byte per bucket, 1.6 GB for the reference's table size) read by several threads at once into one block, and
@@ -711,6 +725,7 @@ int mic_db_load_files(mic_engine* e, const char* prefix, int key_bytes, uint32_t
   FILE* fk = fopen((p + ".ky").c_str(), "rb");
   FILE* fl = fopen((p + ".lb").c_str(), "rb");
   uint8_t* h_sz = nullptr; uint8_t* d_sz = nullptr; void* d_ky = nullptr; uint16_t* d_lb = nullptr;
+  UploadStage stage;
   const bool timing = getenv("MIC_LOAD_TIMING") != nullptr;
   struct timespec t_prev; clock_gettime(CLOCK_MONOTONIC, &t_prev);
   auto lap = [&](const char* what) {
@@ -739,7 +754,7 @@ int mic_db_load_files(mic_engine* e, const char* prefix, int key_bytes, uint32_t
       // summing them with one thread each were 0.68 s of the command line's start (0.44 s with eight threads each)
       hipError_t he = hipMalloc(&d_sz, s1);
       if (he != hipSuccess) { rc = fail(he == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "DB image allocation: %s", hipGetErrorString(he)); break; }
-      if ((rc = upload_file_range(fs, 0, s1, d_sz, e->stream, "the .sz file"))) break;
+      if ((rc = upload_file_range(fs, 0, s1, d_sz, e->stream, "the .sz file", &stage))) break;
       if (mic_reduce_sizes(d_sz, s1, &n_el, &nz, e->stream) != 0) { rc = fail(MIC_E_HIP, "size reduction failed"); break; }
       lap("read + upload .sz, bucket sizes summed on the device");
       he = hipMalloc(&d_ky, n_el * key_bytes + 16);
@@ -760,9 +775,9 @@ int mic_db_load_files(mic_engine* e, const char* prefix, int key_bytes, uint32_t
       if (he != hipSuccess) { rc = fail(he == hipErrorOutOfMemory ? MIC_E_NOMEM : MIC_E_HIP, "DB image allocation: %s", hipGetErrorString(he)); break; }
     }
     lap("allocate + upload .sz");
-    if ((rc = upload_file_range(fk, base_elems * key_bytes, n_el * key_bytes, d_ky, e->stream, "the .ky file"))) break;
+    if ((rc = upload_file_range(fk, base_elems * key_bytes, n_el * key_bytes, d_ky, e->stream, "the .ky file", &stage))) break;
     lap("upload .ky");
-    if ((rc = upload_file_range(fl, base_elems * 2, n_el * 2, d_lb, e->stream, "the .lb file"))) break;
+    if ((rc = upload_file_range(fl, base_elems * 2, n_el * 2, d_lb, e->stream, "the .lb file", &stage))) break;
     lap("upload .lb");
     rc = build_from_device(e, d_sz, htsize, s0, s1, d_ky, key_bytes, d_lb, sampling, base_rank);
     lap("table build");
@@ -1151,9 +1166,10 @@ int mic_db_load_files_multi(mic_engine* const* engines, size_t n_engines, const 
       dl.push_back({dv.device, dv.d_lb, dv.stream, dv.el_lo * 2, dv.el_hi * 2});
       up_bytes += (dv.hi - dv.lo) + (dv.el_hi - dv.el_lo) * (uint64_t)(key_bytes + 2);
     }
-    if ((rc = upload_file_range_multi(fs, dz, "the .sz file"))) break;
-    if ((rc = upload_file_range_multi(fk, dk, "the .ky file"))) break;
-    if ((rc = upload_file_range_multi(fl, dl, "the .lb file"))) break;
+    UploadStage stage;
+    if ((rc = upload_file_range_multi(fs, dz, "the .sz file", &stage))) break;
+    if ((rc = upload_file_range_multi(fk, dk, "the .ky file", &stage))) break;
+    if ((rc = upload_file_range_multi(fl, dl, "the .lb file", &stage))) break;
     if (timing) fprintf(stderr, "[load x%zu] images on %zu device(s): %.2f GB uploaded from one read of the files\n", n_engines, devs.size(), up_bytes / 1e9);
     lap("images uploaded to the devices");
     // one thread per device; the engines of a device one after another (a build sizes its staging area from the free HBM)

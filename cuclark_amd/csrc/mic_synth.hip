@@ -49,23 +49,39 @@ struct SynthDev {
   uint32_t n_genomes, n_targets;
   int k;
   MicDiv div;
+  uint32_t keep_ppm, run_len;      // fragmented database: see kept_position
 };
 
-__device__ inline void kmer_at(const SynthDev& sp, uint64_t idx, uint64_t& rem, uint64_t& quot, uint32_t& label) {
+// A database of DISCRIMINATIVE k-mers holds stretches of a genome's k-mers and lacks others (CLARK removes every k-mer two targets
+// share, HashTableStorage_hh.hh:241-292; what overlaps a shared region goes in runs).  keep_ppm != 0: the k-mer start positions of a
+// genome fall into segments whose ends are drawn with probability 1 / run_len per position (geometric lengths, mean run_len), and a
+// segment is kept with probability keep_ppm / 1e6; a function of (seed, genome, position), like the genomes themselves.
+__host__ __device__ inline bool kept_position(uint64_t seed, uint64_t g, uint64_t p, uint32_t keep_ppm, uint32_t run_len) {
+  if (!keep_ppm) return true;
+  const uint64_t gs = mix64(seed ^ 0x5EED5EEDull) + g * 0xA24BAED4963EE407ULL;
+  uint64_t q = p;
+  for (uint32_t back = 0; back < 16 * run_len && q > 0; ++back, --q)
+    if (mix64(gs + q * 0x9FB21C651E98DF25ULL) % run_len == 0) break;             // q starts a segment
+  return mix64(gs ^ (q * 0xD6E8FEB86659FD93ULL + 1)) % 1000000ull < keep_ppm;
+}
+
+__device__ inline bool kmer_at(const SynthDev& sp, uint64_t idx, uint64_t& rem, uint64_t& quot, uint32_t& label) {
   uint64_t g = idx / sp.kmers_per_genome, p = idx - g * sp.kmers_per_genome;
+  if (!kept_position(sp.seed, g, p, sp.keep_ppm, sp.run_len)) return false;
   uint64_t km = genome_kmer(sp.seed, g, p, sp.k);
   uint64_t rc = revcomp_bits(km, sp.k);
   uint64_t c = km < rc ? km : rc;
   quot = mic_div(c, sp.div);
   rem = c - quot * sp.div.d;
   label = (uint32_t)(g % sp.n_targets);
+  return true;
 }
 
 __global__ void count_kernel(SynthDev sp, uint32_t* __restrict__ cnt) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i < sp.n_kmers; i += stride) {
     uint64_t rem, quot; uint32_t label;
-    kmer_at(sp, i, rem, quot, label);
+    if (!kmer_at(sp, i, rem, quot, label)) continue;
     atomicAdd(&cnt[rem], 1u);
   }
 }
@@ -114,7 +130,7 @@ __global__ void scatter_kernel(SynthDev sp, const unsigned long long* __restrict
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i < sp.n_kmers; i += stride) {
     uint64_t rem, quot; uint32_t label;
-    kmer_at(sp, i, rem, quot, label);
+    if (!kmer_at(sp, i, rem, quot, label)) continue;
     uint32_t pos = atomicAdd(&cursor[rem], 1u);
     if (pos < 255) { uint64_t d = offsets[rem] + pos; keys[d] = (KEY)quot; labels[d] = (uint16_t)label; }
   }
@@ -142,6 +158,7 @@ struct ReadGen {
   uint32_t n_genomes, n_targets, read_len, pitch;
   int k;
   uint32_t random_thr, sub_thr, n_thr;  // thresholds on a 32-bit uniform
+  uint32_t keep_ppm, run_len;           // fragmented database (kept_position): the expected hits count kept windows only
 };
 
 // One read (or the two reads of a pair), nucleotide by nucleotide; shared by the packed and the text generators so that
@@ -207,7 +224,13 @@ __global__ void reads_kernel(ReadGen rg, size_t n_reads, int paired, uint32_t* _
       else if (i < L) code = draw_nt(rg, d, 0, i, &cl);
       else if (i > L) code = draw_nt(rg, d, 1, i - L - 1, &cl);
       clean = (cl && code >= 0) ? clean + 1 : 0;
-      if (code >= 0 && clean >= (uint32_t)rg.k) ++expect;
+      if (code >= 0 && clean >= (uint32_t)rg.k) {
+        if (!rg.keep_ppm) ++expect;
+        else if (!paired) {      // the k-mer that ends here starts at genome position p0 + i - k + 1 (forward) or its mirror
+          const uint64_t a = d.p0 + (d.rev ? (uint64_t)(d.span - 1 - i) : (uint64_t)(i + 1 - (uint32_t)rg.k));
+          if (kept_position(rg.seed, d.g, a, rg.keep_ppm, rg.run_len)) ++expect;
+        }
+      }
     }
     if (code >= 0) {
       if (!open) { hdr = w++; open = true; run = 0; cur = 0; ncur = 0; }
@@ -279,6 +302,7 @@ int mic_synth_db_device(const mic_synth_spec* spec, uint8_t* d_sizes, void* d_ke
   sp.kmers_per_genome = sp.genome_len - spec->k + 1;
   sp.n_kmers = sp.kmers_per_genome * spec->n_genomes;
   sp.n_genomes = spec->n_genomes; sp.n_targets = spec->n_targets; sp.k = spec->k;
+  sp.keep_ppm = spec->keep_ppm; sp.run_len = spec->run_len ? spec->run_len : 8;
   sp.div = mic_make_div(spec->htsize);
   const uint64_t H = spec->htsize;
   const unsigned n_tiles = (unsigned)((H + STILE - 1) / STILE);
@@ -341,6 +365,7 @@ int mic_synth_reads_device2(const mic_synth_spec* spec, uint64_t read_seed, size
   rg.genome_len = spec->genome_nt / spec->n_genomes;
   if (rg.genome_len < (paired ? 2ull : 1ull) * read_len) return MIC_E_INVALID;
   rg.n_genomes = spec->n_genomes; rg.n_targets = spec->n_targets; rg.read_len = read_len; rg.k = spec->k;
+  rg.keep_ppm = spec->keep_ppm; rg.run_len = spec->run_len ? spec->run_len : 8;
   rg.pitch = mic_synth_read_pitch(paired ? 2 * read_len + 1 : read_len, spec->k);
   if ((uint64_t)n_reads * rg.pitch > containers_cap || (uint64_t)n_reads * rg.pitch > 0xFFFFFFF0ull) return MIC_E_NOMEM;
   auto thr = [](double p) { double v = p * 4294967296.0; return v <= 0 ? 0u : (v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v); };
@@ -360,6 +385,7 @@ int mic_synth_reads_text_device(const mic_synth_spec* spec, uint64_t read_seed, 
   rg.genome_len = spec->genome_nt / spec->n_genomes;
   if (rg.genome_len < 2ull * read_len) return MIC_E_INVALID;
   rg.n_genomes = spec->n_genomes; rg.n_targets = spec->n_targets; rg.read_len = read_len; rg.k = spec->k;
+  rg.keep_ppm = spec->keep_ppm; rg.run_len = spec->run_len ? spec->run_len : 8;
   rg.pitch = 0;
   if ((uint64_t)n_reads * mic_synth_text_record_bytes(read_len, fasta) > text_cap) return MIC_E_NOMEM;
   auto thr = [](double p) { double v = p * 4294967296.0; return v <= 0 ? 0u : (v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v); };

@@ -444,6 +444,11 @@ typedef struct mic_synth_spec {
   uint32_t n_genomes;
   int32_t k;
   int32_t key_bytes;      /* 4 or 8                                                         */
+  uint32_t keep_ppm;      /* 0: every k-mer of the genomes is in the database.  Otherwise a FRAGMENTED database, as the removal
+                             of k-mers common to several targets leaves one (HashTableStorage_hh.hh:241-292): the k-mer start
+                             positions of a genome fall into segments of geometric length (mean run_len), and a segment's k-mers
+                             are kept with probability keep_ppm / 1e6                                                         */
+  uint32_t run_len;       /* mean segment length in k-mer positions (0: 8)                                                    */
 } mic_synth_spec;
 /* Builds the on-disk-format arrays of a synthetic database in device memory the caller owns:
  *   d_sizes u8[htsize], d_keys key_bytes*[capacity], d_labels u16[capacity]; *n_elems out. */

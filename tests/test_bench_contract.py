@@ -271,3 +271,16 @@ def test_bench_refuses_more_rccl_ranks_than_devices():
     # a launcher that started another number of ranks than --gpus says
     r = _refusal(["--gpus", "4", "--workload", "tiny"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_fragmented_database_known_answer():
+    """A database of discriminative k-mers (mic_synth_spec.keep_ppm: half of the genomes' k-mer positions kept, in runs of geometric
+    length - what the removal of common k-mers leaves, HashTableStorage_hh.hh:241-292): oracle parity on the sample, the constructive
+    known answer counts the KEPT windows only, the one-strand and the two-strand table agree on every read."""
+    d = _bench("--workload", "tiny_frag", "--steps", "2", "--warmup", "1", "--no-e2e", "--no-pipeline", "--no-parts-proxy")
+    assert d["cpu_baseline"]["parity_with_gpu_on_sample"] is True
+    ka = d["known_answer"]
+    assert ka["label_and_count_ok"] == 1.0 and ka["random_reads_no_hit"] == 1.0
+    assert 0.3 < d["config"]["table"]["kmers"] / 1_500_000 < 0.7
+    assert d["default_layout"]["results_equal_headline_table"] is True
