@@ -16,7 +16,7 @@ import pytest
 import golden_util as gu
 
 CSRC = os.path.join(gu.ROOT, "cuclark_amd", "csrc")
-SRCS = [os.path.join(CSRC, f) for f in ("classifier.cpp", "cli_main.cpp", "mic_host.cpp")] + [os.path.join(gu.ROOT, "tools", "sanitize", "mock_engine.cpp")]
+SRCS = [os.path.join(CSRC, f) for f in ("classifier.cpp", "classifier_stream.cpp", "classifier_batch.cpp", "cli_main.cpp", "mic_host.cpp")] + [os.path.join(gu.ROOT, "tools", "sanitize", "mock_engine.cpp")]
 
 
 def _build(tmp, flavour):

@@ -21,11 +21,11 @@ nm --undefined-only $OUT/mic_*.o | awk '/__hip_fatbin_/ {print $2}' | sort -u | 
 gcc -c $OUT/fatbins.c -o $OUT/fatbins.o
 $HIPCC -x hip $FLAGS -c $R/tools/sanitize/host_rig.cpp -o $OUT/host_rig.o
 $HIPCC $SANF -o $OUT/host_rig $OUT/host_rig.o $OUT/mic_*.o $OUT/hip_mock.o $OUT/fatbins.o -lpthread -lz 2>&1 | grep -v "^$" || true
-# the command line itself (classifier.cpp, cli_main.cpp) on the same objects: exe/cuCLARK's multi-device paths on MOCK_HIP_DEVICES devices
-for f in classifier cli_main; do
+# the command line itself (classifier*.cpp, cli_main.cpp) on the same objects: exe/cuCLARK's multi-device paths on MOCK_HIP_DEVICES devices
+for f in classifier classifier_stream classifier_batch cli_main; do
   $HIPCC -x c++ -O1 -g -std=c++17 -fopenmp $SANF -fno-omit-frame-pointer -I$R/include -I$R/cuclark_amd/csrc -c $R/cuclark_amd/csrc/$f.cpp -o $OUT/cli_$f.o
 done
-$HIPCC $SANF -fopenmp -o $OUT/cuCLARK_mock $OUT/cli_classifier.o $OUT/cli_cli_main.o $OUT/mic_*.o $OUT/hip_mock.o $OUT/fatbins.o -lpthread -lz
+$HIPCC $SANF -fopenmp -o $OUT/cuCLARK_mock $OUT/cli_classifier.o $OUT/cli_classifier_stream.o $OUT/cli_classifier_batch.o $OUT/cli_cli_main.o $OUT/mic_*.o $OUT/hip_mock.o $OUT/fatbins.o -lpthread -lz
 ln -sf cuCLARK_mock $OUT/cuCLARK_mock-l
 # the same objects as a shared library for tools/sanitize/py_rig.py (references bound inside: torch brings the real runtime along)
 if [ "${SAN:-address}" != thread ]; then $HIPCC -shared -fsanitize=address -shared-libasan -Wl,-Bsymbolic -o $OUT/libmi_clark_mock.so $OUT/mic_*.o $OUT/hip_mock.o $OUT/fatbins.o -lpthread; fi

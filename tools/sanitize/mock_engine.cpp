@@ -1,6 +1,6 @@
 // mock_engine.cpp - a stand-in for libmi_clark.so's DEVICE entry points, for sanitizer builds of the host code only
 // (tests/test_sanitizers.py: AddressSanitizer + UBSan, ThreadSanitizer; there is no GPU sanitizer on this pool).
-// exe-side code under test, unchanged: classifier.cpp (FileFeeder, SegmentFeeder, PairedFileFeeder, DeviceGzFeeder, PairedSource, GzSource,
+// exe-side code under test, unchanged: classifier*.cpp / classifier_feeders.hpp (FileFeeder, SegmentFeeder, PairedFileFeeder, DeviceGzFeeder, PairedSource, GzSource,
 // InflateStream, strip_fastq, run_stream's loader / device / writer threads), cli_main.cpp, and mic_host.cpp (indexer, packer,
 // CSV).  What is mocked: the engine.  mic_ingest_classify here "classifies" a slot on the CPU: it walks the records of the
 // slot's bytes and writes one CSV line "<name>,<length>" per record - a pure function of the input, so the test can check
