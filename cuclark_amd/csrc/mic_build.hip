@@ -1704,8 +1704,16 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     HIPCK(hipMemcpyAsync(h_crowd, d_scal, 16, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     if (h_crowd[1] > 0) {
-      uint64_t cells = 1024;
-      while (cells < 2 * h_crowd[0]) cells <<= 1;
+      // open addressing with linear probing, probed by all 64 lanes of a wavefront in lockstep: the wavefront pays the LONGEST probe
+      // sequence of its lanes, so the table is kept sparse (at 1/2 full, the round-3 setting, the unluckiest of 64 lanes walks 8
+      // cells and more).  MIC_S_SIDE_SPARSE overrides the factor (cells >= factor x k-mers).
+      // Measured on the 5 %-tandem-repeat database (tools/nonideal_bench.py, 4 M reads, one-strand / two-strand table): factor 2:
+      // 1 188 / 1 321 Mreads/s, 4: 1 318 / 1 510, 8: 1 420 / 1 578 (random genomes: 1 787 / 1 917).  16 by default, less when the side
+      // table would outgrow an eighth of the main table.
+      uint64_t cells = 1024, sparse = 16;
+      if (const char* env = getenv("MIC_S_SIDE_SPARSE")) { const long v = atol(env); if (v >= 2 && v <= 64) sparse = (uint64_t)v; }
+      while (sparse > 2 && sparse * h_crowd[0] * 16 > n_part * 128 / 8) sparse >>= 1;
+      while (cells < sparse * h_crowd[0]) cells <<= 1;
       if (cells <= 0x80000000ull && hipMalloc(&side, cells * 16) == hipSuccess) {
         HIPCK(hipMemsetAsync(side, 0, cells * 16, s));
         HIPCK(hipMemsetAsync(d_max, 0, 4, s));
