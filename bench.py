@@ -605,7 +605,7 @@ def main():
         sys.exit("bench.py: MIC_LIB_PATH is set (a measuring build of the library); unset it or pass --allow-variant-lib")
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
-    n_dev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    n_dev = torch.cuda.device_count()          # (on this image counting devices does not initialise the GPU; the ranks are a fresh child either way)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` with no launcher: this process has not touched the GPU yet - it starts the N ranks as a
         # fresh child (one process per GPU under torch.distributed.run), relays their output and exits with their code
@@ -1065,10 +1065,20 @@ def main():
                 e2e = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             log("end_to_end:", json.dumps(e2e))
 
+    import threading
+    emit_lock = threading.Lock()
+    emitted = [False]
+
     def emit(ts):
-        """rank 0's ONE line; ts = the table-sharded extra leg's result (N > 1, read mode), or None"""
+        """rank 0's ONE line; ts = the table-sharded extra leg's result (N > 1, read mode), or None.  Printed once whoever calls
+        first (the main path or the extra leg's deadline): the lock and the flag keep the one-line contract."""
+        with emit_lock:
+            if emitted[0]:
+                return
+            emitted[0] = True
+        reads_label = f"{n_reads / 1e6:g}M" + (" per GPU" if world > 1 and args.mode == "read" else "")
         out = {
-            "metric": f"Mreads/sec (10M x {'2x' if paired else ''}{read_len}bp{' pairs' if paired else ''}, k={k})", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
+            "metric": f"Mreads/sec ({reads_label} x {'2x' if paired else ''}{read_len}bp{' pairs' if paired else ''}, k={k})", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if db_mode else "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
@@ -1153,6 +1163,9 @@ def main():
         leg_done = threading.Event()
 
         def give_up():
+            # (the main path may be finishing the leg this very moment: emit() prints once, whoever gets there first; a rank that
+            # gives up leaves at once - no barrier, no destroy_process_group: the others may be the ones that are stuck.  Exit code 0
+            # on every rank so that the launcher relays rank 0's line; the line's "error" field is what says the leg is missing)
             if leg_done.is_set():
                 return
             if rank == 0:

@@ -1,4 +1,4 @@
-"""A 40-second seeded slice of tools/fuzz_parity.py under -m gpu: random tables (size, k, key width, labels), random reads, all
+"""A 30-second seeded slice of tools/fuzz_parity.py under -m gpu: random tables (size, k, key width, labels), random reads, all
 four layouts, whole table / bucket-range shards / parts of the table merged through the batch API and through the command line's
 table-sharded ingest - against the oracle.  PRODUCT AND ORACLE RUN IN TWO PROCESSES (--split): this test's child loads the
 HARDENED build of the library (cuclark_amd/lib/libmi_clark_hard.so: libstdc++ assertions, fortified libc, stack protectors -
@@ -18,11 +18,11 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
-def test_forty_seconds_of_random_configurations_product_and_oracle_in_separate_processes():
+def test_thirty_seconds_of_random_configurations_product_and_oracle_in_separate_processes():
     hard = os.path.join(gu.ROOT, "cuclark_amd", "lib", "libmi_clark_hard.so")
     assert os.path.exists(hard), "the hardened library is built by __graft_entry__.build() (make -C cuclark_amd/csrc)"
     env = dict(os.environ, MIC_LIB_PATH=hard, MALLOC_CHECK_="3", MALLOC_PERTURB_="165")
-    cmd = [sys.executable, os.path.join(gu.ROOT, "tools", "fuzz_parity.py"), "40", "20261004", "--split"]
+    cmd = [sys.executable, os.path.join(gu.ROOT, "tools", "fuzz_parity.py"), "30", "20261004", "--split"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     if r.returncode != 0:
         out_dir = os.path.join(gu.ROOT, "gpurun_out")
