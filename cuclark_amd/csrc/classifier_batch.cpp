@@ -99,7 +99,7 @@ size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, F
   long n_reads;
   for (;;) {
     if (name_s.size() < cap) { name_s.resize(cap); name_e.resize(cap); seq_s.resize(cap); seq_e.resize(cap); length.resize(cap); }
-    n_reads = mic_index_reads_parallel(map, nb, (int)opt_.threads, cap, name_s.data(), name_e.data(), seq_s.data(), seq_e.data(),
+    n_reads = mic_index_reads_parallel(map, nb, sink_ ? 1 : (int)opt_.threads, cap, name_s.data(), name_e.data(), seq_s.data(), seq_e.data(),
                                        length.data());
     if (n_reads < 0) { std::cerr << "Failed to recognize the format of the file." << std::endl; exit(-1); }
     if ((size_t)n_reads <= cap) break;
@@ -108,6 +108,11 @@ size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, F
   const size_t N = (size_t)n_reads;
   lap("index reads");
   const int k = (int)opt_.k;
+  // A batch the streaming path hands back (sink_ set) is small and comes while that path's loader / device / writer threads are
+  // running: no OpenMP team for it - a team's idle threads spin at the barriers and between the regions (libgomp's default wait
+  // policy), and next to the stream's threads that spinning ran a 64-read batch into 0.2-0.5 s of cgroup throttling
+  // (tools/cli_small_slots_probe.py: 55 such batches 14.2 s, 0.6 s with OMP_WAIT_POLICY=PASSIVE).
+  const int team = sink_ ? 1 : (int)std::max<size_t>(1, opt_.threads);
   const size_t nb_total = std::max<size_t>(1, std::min(opt_.batches, std::max<size_t>(N, 1)));
   const size_t per = (N + nb_total - 1) / nb_total;
   std::vector<size_t> cut(nb_total + 1);
@@ -116,7 +121,7 @@ size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, F
   {
     std::vector<size_t> bound(nb_total);
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(team)
 #endif
     for (long b = 0; b < (long)nb_total; ++b)
       bound[b] = mic_pack_bound(seq_s.data() + cut[b], seq_e.data() + cut[b], cut[b + 1] - cut[b], k);
@@ -143,7 +148,7 @@ size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, F
   double t_pack = 0, t_query = 0, t_format = 0, t_write = 0;   // thread-seconds, MIC_CLI_TIMING only
   auto now_s = [] { struct timeval t; gettimeofday(&t, nullptr); return t.tv_sec + t.tv_usec / 1e6; };
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic) reduction(+ : t_pack, t_query, t_format, t_write)
+#pragma omp parallel for schedule(dynamic) reduction(+ : t_pack, t_query, t_format, t_write) num_threads(team)
 #endif
   for (long bi = 0; bi < (long)nb_total; ++bi) {
     double ts = timing ? now_s() : 0;

@@ -72,17 +72,18 @@ def test_bench_full_config3():
     sample, constructive known answer on all genome reads, batch-API pipeline equal to the device path, CLI CSV equal to
     the kernel's rows on all 10 M reads."""
     d = _bench("--workload", "full", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000", "--no-parts-proxy", "--no-default-layout",
-               "--e2e-reps", "1", "--multi-engine-reads", "2000000", "--multi-engine-runs", "db_sharded_8")
+               "--e2e-reps", "1", "--multi-engine-reads", "2000000", "--multi-engine-runs", "db_sharded_2")
     _check_config(d, 10_000_000)
     assert d["config"]["table"]["htsize"] == 1610612741 and d["config"]["table"]["kmers"] > 5_700_000_000
-    # the product binary's table-sharded mode against the 36 GB-scale database (every shape: test_bench_light27_config2_proper, and at
-    # full size in the bench line itself): 8 parts of the table on 8 engines, 2 M reads, CSV equal to the one-engine run's
+    # the product binary's table-sharded mode against the 36 GB-scale database (every shape: test_bench_light27_config2_proper; all of
+    # them at full size: the bench line itself, 8 parts and the 2-D shape included): 2 parts on two engines, 2 M reads, CSV equal
+    # to the one-engine run's
     me = d["end_to_end"]["multi_engine"]
     assert me["reads"] == 2_000_000 and me["all_csv_equal"] is True, me
-    r8 = me["runs"]["db_sharded_8"]
-    assert r8["csv_equals_one_engine_run"] is True and r8["ingest"]["batches_through_host_path"] == 0
-    assert "query_kernel_r<31, 20, false, true," in r8["kernel"] and "8 part(s) x 1 read group(s)" in r8["layout"]
-    assert r8["per_batch"]["exchange_MB"] > 0 and r8["per_batch"]["fanout_MB"] > 0 and r8["per_batch"]["kernel_ms_slowest_engine"] > 0
+    r4 = me["runs"]["db_sharded_2"]
+    assert r4["csv_equals_one_engine_run"] is True and r4["ingest"]["batches_through_host_path"] == 0
+    assert "query_kernel_r<31, 20, false, true," in r4["kernel"] and "2 part(s) x 1 read group(s)" in r4["layout"]
+    assert r4["per_batch"]["exchange_MB"] > 0 and r4["per_batch"]["fanout_MB"] > 0 and r4["per_batch"]["kernel_ms_slowest_engine"] > 0
 
 
 @pytest.mark.gpu

@@ -13,7 +13,16 @@ EXE_L = os.path.join(gu.ROOT, "exe", "cuCLARK-l")
 
 
 def _run(args, **kw):
-    return subprocess.run(args, capture_output=True, text=True, timeout=600, **kw)
+    if not os.environ.get("MIC_TEST_TIMING"):
+        return subprocess.run(args, capture_output=True, text=True, timeout=600, **kw)
+    import time                                   # where the suite's wall time goes: one line per run of the command line
+    t0 = time.time()
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600, **kw)
+    env = kw.get("env") or {}
+    with open(os.environ["MIC_TEST_TIMING"], "a") as f:
+        f.write(f"{time.time() - t0:7.2f} s  {' '.join(os.path.basename(a) for a in args[:1] + args[5:])}  "
+                f"{ {k: v for k, v in env.items() if k.startswith('MIC_')} }\n" + "".join("    " + l + "\n" for l in r.stderr.splitlines() if "[timing]" in l or "[load]" in l))
+    return r
 
 
 def _run_many(jobs, workers=4):

@@ -87,9 +87,9 @@ def rig(tmp_path_factory):
     return dict(tmp=tmp, single=single, pairs=pairs)
 
 
-def _run(exe, rig, objects, env_extra=(), threads="4", extra_args=()):
+def _run(exe, rig, objects, env_extra=(), threads="4", extra_args=(), tag=""):
     tmp = rig["tmp"]
-    out = os.path.join(tmp, "out")
+    out = os.path.join(tmp, "out" + tag)
     if os.path.exists(out + ".csv"):
         os.remove(out + ".csv")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1",
@@ -139,11 +139,17 @@ CASES = [
 @pytest.mark.parametrize("flavour", ["asan", "tsan"])
 def test_host_pipeline_under_sanitizers(flavour, rig):
     exe = _build(rig["tmp"], flavour)
+    jobs = []
     for i, (name, objects, want, env, *more) in enumerate(CASES):
         objects = [o if o.startswith("-") else os.path.join(rig["tmp"], o) for o in objects]
         for threads in (("1", "7") if flavour == "asan" and i < 8 else ("7",) if flavour == "asan" else ("5",)):
-            got = _run(exe, rig, objects, env.items(), threads, more[0] if more else ())
-            assert got == rig[want], (flavour, name, threads, got[:200], rig[want][:200])
+            jobs.append((name, objects, want, env, threads, more[0] if more else ()))
+    # independent runs of the instrumented binary, three side by side (each its own process and output file)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        gots = list(ex.map(lambda j: _run(exe, rig, j[1], j[3].items(), j[4], j[5], tag=f"_{j[0]}_{j[4]}"), jobs))
+    for (name, _, want, _, threads, _), got in zip(jobs, gots):
+        assert got == rig[want], (flavour, name, threads, got[:200], rig[want][:200])
     # the merge verb (no engine at all), golden pair files
     f1, f2 = (os.path.join(gu.GOLDEN, f"pairs_k31_{i}.fq") for i in (1, 2))
     out = os.path.join(rig["tmp"], "m.fa")
