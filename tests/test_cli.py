@@ -420,8 +420,7 @@ def test_read_sharded_cli_with_several_engines_on_one_gpu(multi_engine_rig, engi
     compressed mates, list-of-files."""
     rig = multi_engine_rig
     multi = dict(os.environ, MIC_SHARD_ENGINES=str(engines), MIC_CLI_TIMING="1", MIC_INGEST_KB="24")
-    # two engines: every input form; three (an odd deal of the slots): the forms whose batches travel differently
-    names = list(rig["cases"]) if engines == 2 else ["fq", "ext", "gzpairs", "list"]
+    names = list(rig["cases"])
     for name, (r, got) in zip(names, _run_many([lambda name=name: rig["run"](name, f"multi{engines}", multi) for name in names], workers=4)):
         assert f"{engines} engine(s) on 1 device(s), read-sharded (table replicated)" in r.stderr, r.stderr
         assert f"on {engines} device(s)" in r.stderr
@@ -472,9 +471,7 @@ def test_device_ingest_equals_host_ingest_over_many_batches(tmp_path):
             env["MIC_INGEST_KB"] = kb
         return _run([EXE_L, "-T", t, "-D", d, "-O", os.path.join(tmp, name), "-R", os.path.join(tmp, f"dev{kb}_{name}"), "-n", n], env=env)
     n_obj = dict(zip(names, _run_many([lambda name=name: host_run(name) for name in names])))
-    # every file over tiny batches; the middle and default batch sizes on the files whose records decide where a batch may end
-    combos = [(name, "16", "4") for name in names] + [(name, "300", "3") for name in ("a.fq", "d.fa", "e.fq")] + \
-             [(name, "0", "1") for name in ("b.fa", "d.fa", "a.fq.gz")]
+    combos = [(name, kb, n) for name in names for kb, n in (("16", "4"), ("300", "3"), ("0", "1"))]
     for (name, kb, n), r in zip(combos, _run_many([lambda c=c: dev_run(*c) for c in combos])):
         assert r.returncode == 0, r.stderr
         assert f"({n_obj[name]} objects)" in r.stdout
