@@ -1349,6 +1349,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
       if (chunk_max > 0x7FFFFF00ull) want_sorted = false;       // (one tile of more k-mers than a sort call takes: no such table)
     }
     ex_cap = (uint32_t)std::min<uint64_t>(tot_elems / 16 + (1u << 20), 0x7FFFFF00ull);
+    if (const char* env = getenv("MIC_S_EXTRA_CAP")) { const long v = atol(env); if (v > 0) ex_cap = (uint32_t)v; }   // test hook: a list that runs over
     if (want_sorted) {
       hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp_bytes, (const SKey*)nullptr, (SKey*)nullptr, (const SVal*)nullptr, (SVal*)nullptr,
                                          (int)chunk_max, 16, 32, s);

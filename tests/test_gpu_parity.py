@@ -697,6 +697,20 @@ def test_super_table_with_crowded_slots(monkeypatch):
     info3, res3 = run()
     assert info3["n_slots"] == base_info["n_slots"] and info3["n_entries"] == base_info["n_entries"]
     assert (res3 == base).all()
+    monkeypatch.delenv("MIC_S_STAGING_LIMIT_MB")
+    # the one-strand table's sorted build (candidates once, radix sort by slot hash; mic_build.hip: s_expand_kernel) against the
+    # classic three-walk build, records sorted in many small chunks, and a list of tied candidates that runs over (test hook: the
+    # build then takes the classic road): the same table, the same answers
+    for name, value in (("MIC_S_CLASSIC", "1"), ("MIC_S_SORT_CHUNK", "4096"), ("MIC_S_EXTRA_CAP", "1")):
+        monkeypatch.setenv(name, value)
+        info4, res4 = run()
+        monkeypatch.delenv(name)
+        if info4["layout"] == 3:                 # which road the build took, from its report of stage times
+            from cuclark_amd import _lib
+            report = _lib.load().mic_db_last_build_report().decode()
+            assert ("(sorted build)" in report) == (name == "MIC_S_SORT_CHUNK"), (name, report)
+        assert info4["n_slots"] == base_info["n_slots"] and info4["n_entries"] == base_info["n_entries"] and info4["n_overflow"] == base_info["n_overflow"], name
+        assert (res4 == base).all(), name
 
 
 def test_table_adapts_to_the_free_hbm(monkeypatch):
