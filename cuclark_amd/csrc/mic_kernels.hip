@@ -357,6 +357,9 @@ __global__ void __launch_bounds__(256) query_kernel(const MicQueryArgs a) {
 #ifndef MIC_R_SKEW
 #define MIC_R_SKEW 2
 #endif
+#ifndef MIC_R_PIPE
+#define MIC_R_PIPE 1     /* query_kernel_r software-pipelined across reads (0: the loop of rounds 2-4, for comparison) */
+#endif
 __device__ __forceinline__ uint32_t staged_at(uint32_t i) { return i * MIC_MSTRIDE + (i >> 3) * MIC_R_SKEW; }   // uint4 offset of staged slot i
 // the minimizer kernel reads its staged keys as 64-bit words and loses 5 % with the skew (11.5 against 11.0 ms): none there
 #ifndef MIC_M_SKEW
@@ -1222,6 +1225,320 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     ahead_issue(ahead1, n_pp, wave0 + 2 * n_waves);
     ahead_sel = 1;
   }
+#if MIC_R_PIPE
+  // ---- the loop over the wave's reads, SOFTWARE-PIPELINED across reads (round 5) --------------------------------------------------
+  // With 8 wavefronts per SIMD and ~2-3 us between the issue of a read's slot loads and their arrival, the vector unit stood idle
+  // ~15 % of the time: every wavefront waited for ITS slots with nothing else to do (a closed queue of 8 customers around one
+  // server: utilisation 0.85-0.89 at that think time).  Now a read's slot loads are issued and the wavefront goes on to the FRONT
+  // HALF of its next read (window, sampled positions, runs, regions, slot hashes: ~60 % of a read's vector work, no memory access
+  // of its own); only then it waits, compares and tallies the earlier read.  What lives across: the run lanes' region words, sort
+  // key, range of positions, slot (8 VGPRs) and three scalars.  ONE stage area still: the next read's slot list is written after
+  // the earlier read's slots have been consumed.  Reads that are not one round of one chunk of one part (long reads, several
+  // parts, more than 32 runs) drain the pipeline and run as before.
+  struct Round {
+    uint32_t G0, G1, G2, cur;
+    int jmax, jmin, remaining;
+    int i0, n; bool rev;                   // SIDE: the run's k-mers and strand (the crowded path's bitmaps)
+  };
+  // front half of a chunk: window word, sampled positions, run records in LDS; returns the number of runs
+  auto front = [&](const uint32_t first, const uint32_t cend, const uint32_t base, const uint32_t nk, const bool use_ahead, uint32_t& wd_out) __attribute__((always_inline)) -> uint32_t {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const uint32_t wd = use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp)
+                                  : window_word_w(cont, first, cend, base, ln, false, 0u);
+    wd_out = wd;
+    const uint32_t n_act = nk - base < 128u ? nk - base : 128u;
+    const bool past = n_act + (uint32_t)(k - s_tlen(k, m)) >= 129u;
+    uint32_t qa0, qa1;
+    sampled_positions<!FWD>(wd, ln, lane, k, m, past, qa0, qa1);
+    qa0 = (uint32_t)lane < n_act ? qa0 : 0xFFu;
+    qa1 = 64u + (uint32_t)lane < n_act ? qa1 : 0xFFu;
+    const uint32_t last0 = __builtin_amdgcn_readlane(qa0, 63);
+    uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)qa0, 0x138, 0xF, 0xF, false);
+    uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)last0, (int)qa1, 0x138, 0xF, 0xF, false);
+    const bool f0 = qa0 != p0, f1 = qa1 != p1;
+    const uint64_t b0 = wballot(f0), b1 = wballot(f1);
+    const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1) - (n_act < 128u ? 1u : 0u);
+    __builtin_amdgcn_wave_barrier();
+    if (f0) rec[below(b0)] = (uint16_t)(qa0 | ((uint32_t)lane << 8));
+    if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
+    if (__builtin_expect(n_act == 128u, 0)) {
+      asm volatile("" ::: "memory");
+      if (ln == 0) rec[R] = (uint16_t)(128u << 8);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return R;
+  };
+  // one round of runs (<= MIC_RMAX, one lane each): region, minimizer, slot
+  const uint32_t xsh = (64u - 2u * (uint32_t)k) & 31u;                              // k > 16: 0 .. 30
+  auto region_x = [&](uint32_t A0, uint32_t A1, uint32_t& lo, uint32_t& hi) {
+    if (k > 16) {
+      lo = __builtin_amdgcn_alignbit(A0, A1, xsh) & (m >= 16 ? 0xFFFFFFFFu : (1u << ((2 * m) & 31)) - 1u);
+      hi = m > 16 ? (A0 >> xsh) & ((1u << ((2 * m - 32) & 31)) - 1u) : 0u;
+    } else {
+      const uint64_t x = ((((uint64_t)A0 << 32) | A1) << (2 * ctx)) >> (64 - 2 * m);
+      lo = (uint32_t)x; hi = (uint32_t)(x >> 32);
+    }
+  };
+  auto setup = [&](const uint32_t wd, const uint32_t rbase, const uint32_t R, Round& L, uint32_t& nrun_out) __attribute__((always_inline)) {
+    const uint32_t nrun = R - rbase < MIC_RMAX ? R - rbase : MIC_RMAX;
+    nrun_out = nrun;
+    const bool vr = (uint32_t)lane < nrun;
+    const uint32_t ri = vr ? rbase + (uint32_t)lane : 0u;
+    const uint32_t rc0 = rec[ri], rc1 = rec[ri + 1];
+    const int qa = (int)(rc0 & 255u), i0 = (int)(rc0 >> 8);
+    const int n = (int)(rc1 >> 8) - i0;
+    const int s1 = qa - ctx - 1;
+    const int D = s1 >> 4;
+    const uint32_t tsh = 30u - 2u * (uint32_t)(s1 & 15);
+    const int a0 = D << 2;
+    const uint32_t W0 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0, (int)wd), W1 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 4, (int)wd),
+                   W2 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 8, (int)wd), W3 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 12, (int)wd);
+    uint32_t G0 = __builtin_amdgcn_alignbit(W0, W1, tsh), G1 = __builtin_amdgcn_alignbit(W1, W2, tsh), G2 = __builtin_amdgcn_alignbit(W2, W3, tsh);
+    uint32_t key, xhi;
+    region_x(G0, G1, key, xhi);
+    bool rev = false;
+    if (!FWD) {
+      const uint32_t sh = 96u - 2u * (uint32_t)(k + ctx);
+      const uint32_t r0 = __builtin_bitreverse32(G2), r1 = __builtin_bitreverse32(G1), r2 = __builtin_bitreverse32(G0);
+      uint32_t q0 = sh ? __builtin_amdgcn_alignbit(r0, r1, 32u - sh) : r0;
+      uint32_t q1 = sh ? __builtin_amdgcn_alignbit(r1, r2, 32u - sh) : r1;
+      uint32_t q2 = r2 << sh;
+      q0 = ~(((q0 >> 1) & 0x55555555u) | ((q0 << 1) & 0xAAAAAAAAu));
+      q1 = ~(((q1 >> 1) & 0x55555555u) | ((q1 << 1) & 0xAAAAAAAAu));
+      q2 = ~(((q2 >> 1) & 0x55555555u) | ((q2 << 1) & 0xAAAAAAAAu));
+      uint32_t kr, hr;
+      region_x(q0, q1, kr, hr);
+      rev = hr < xhi || (hr == xhi && kr < key);
+      G0 = rev ? q0 : G0; G1 = rev ? q1 : G1; G2 = rev ? q2 : G2;
+      key = rev ? kr : key; xhi = rev ? hr : xhi;
+    }
+    const int jmaxf = qa - i0, jminf = jmaxf - n + 1;
+    const int jmax = rev ? ctx - jminf : jmaxf, jmin = rev ? ctx - jmaxf : jminf;
+    uint32_t cur = vr ? sslot_of_x32(key, xhi, (uint32_t)t.n_main) : 0xFFFFFFFFu;
+    bool mine = vr;
+    if (PART) {
+      mine = vr && cur - s_part[wv][0] < s_part[wv][1];
+      cur = mine ? cur : 0xFFFFFFFFu;
+    }
+    L.G0 = G0; L.G1 = G1; L.G2 = G2; L.cur = cur;
+    L.jmax = jmax; L.jmin = jmin; L.remaining = mine ? n : 0;
+    L.i0 = i0; L.n = n; L.rev = rev;
+  };
+  // the slots of a round from HBM into the stage area (LDS-DMA; the list of slots sits in the stage area itself: it is consumed
+  // before the DMA lands)
+  auto issue = [&](const uint32_t cur, const uint32_t nrun) __attribute__((always_inline)) {
+    uint32_t sidx[MIC_RMAX / 8];
+    int ln = lane;
+    asm volatile("" : "+v"(ln));           // (a lane mask recomputed here instead of a scalar register pair kept across the kernel)
+    __builtin_amdgcn_wave_barrier();
+    if (ln < MIC_RMAX) ((uint32_t*)stage)[lane] = cur;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = ((const uint32_t*)stage)[8 * i + (lane >> 3)];
+#pragma unroll
+    for (int i = 0; i < MIC_RMAX / 8; ++i) {
+      if (8u * i >= nrun) break;
+      if (sidx[i] != 0xFFFFFFFFu)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
+                                         (__attribute__((address_space(3))) void*)(stage + (64 + MIC_R_SKEW) * i), 16, 0, 0);
+    }
+  };
+  // wait for the slots, entries against regions, tally; continuation slots and the crowded runs' side-table lookups
+  auto consume = [&](Round& L, const uint32_t wd, RowAcc& acc, uint32_t& n_ent, uint32_t& overflow, uint32_t& total) __attribute__((always_inline)) {
+    const uint32_t G0 = L.G0, G1 = L.G1, G2 = L.G2;
+    uint32_t key, xhi_;
+    region_x(G0, G1, key, xhi_);            // (the sort key again from the region: cheaper than a register across the front half)
+    const int jmax = L.jmax, jmin = L.jmin;
+    uint32_t cur = L.cur;
+    int remaining = L.remaining;
+    bool crowded = false, again = false;
+    do {
+      if (again) issue(cur, MIC_RMAX);      // (continuation slots: rare; every group of eight under its lanes' mask)
+      again = true;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const bool vl = cur != 0xFFFFFFFFu;
+      const uint32_t* q = (const uint32_t*)(stage + (vl ? staged_at((uint32_t)lane) : 0));
+      const uint4 ka = *(const uint4*)q;
+      const uint2 kb = *(const uint2*)(q + 4);
+      uint32_t e = (ka.x < key) + (ka.y < key) + (ka.z < key) + (ka.w < key) + (kb.x < key) + (kb.y < key);
+      const uint32_t mz = q[30];
+      bool more = vl && e < 6;
+      e = e < 5 ? e : 5;
+      for (;;) {
+        uint32_t e3 = e + (e << 1);
+        asm volatile("" : "+v"(e3));
+        uint32_t g = q[e], S0 = q[6 + e3], S1 = q[7 + e3], S2 = q[8 + e3], pl = q[24 + e];
+        asm volatile("" : "+v"(S2));
+        const bool same = more && g == key;
+        const uint32_t d0 = G0 ^ S0, d1 = G1 ^ S1, d2 = G2 ^ S2;
+        const bool mineq = k > 16
+                               ? ((d0 & ((1u << ((32 - 2 * ctx) & 31)) - 1u)) | (d1 >> xsh)) == 0
+                               : (((((uint64_t)d0 << 32) | d1) << (2 * ctx)) >> (64 - 2 * m)) == 0;
+        const uint32_t dl = d0 >> (32 - 2 * ctx);
+        const uint32_t dr = k > 16 ? __builtin_amdgcn_alignbit(d1, d2, xsh)
+                                        : (uint32_t)((((((uint64_t)d0 << 32) | d1)) << ((2 * k) & 63)) >> 32);
+        const int left = __builtin_ctz(dl | (1u << (2 * ctx))) >> 1;
+        const int right = __builtin_clz(dr | (1u << (31 - 2 * ctx))) >> 1;
+        const int hi = left < jmax ? left : jmax, lo = ctx - right > jmin ? ctx - right : jmin;
+        const uint32_t range = ((2u << (hi & 31)) - 1u) & (~0u << (lo & 31));
+        const uint32_t hits = (same && mineq) ? (uint32_t)__popc((pl >> 16) & range) : 0u;
+        if (SIDE && same && mineq && (pl >> 16) == 0) { crowded = true; remaining = 0; }
+        const uint32_t lab_new = (pl & 0xFFFFu) + 1u;
+        tally_counts(hits ? lab_new : 0u, hits, acc, n_ent, overflow, total, lane);
+        remaining -= (int)hits;
+        more = same && remaining > 0 && e < 5;
+        e += more ? 1u : 0u;
+        if (!wballot(more)) break;
+      }
+      const bool nx = vl && remaining > 0 && (mz & MIC_S_NEXT);
+      cur = 0xFFFFFFFFu;
+      if (wballot(nx)) { if (nx && q[5] <= key) cur = q[31]; }
+    } while (wballot(cur != 0xFFFFFFFFu));
+    if (SIDE && wballot(crowded)) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      __builtin_amdgcn_wave_barrier();
+      uint32_t* bm = (uint32_t*)stage;
+      if (ln < 8) bm[lane] = 0u;
+      __builtin_amdgcn_wave_barrier();
+      if (crowded) {
+        for (int bpos = L.i0; bpos < L.i0 + L.n; ++bpos) {
+          atomicOr(&bm[bpos >> 5], 1u << (bpos & 31));
+          if (!FWD && L.rev) atomicOr(&bm[4 + (bpos >> 5)], 1u << (bpos & 31));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));
+      const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+      const uint4* __restrict__ side = kc->t.side;
+      const uint32_t smask = kc->t.side_mask;
+      uint32_t sres[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        sres[h] = 0;
+        if (__builtin_amdgcn_readfirstlane(bm[2 * h] | bm[2 * h + 1]) == 0) continue;
+        const uint32_t pos = 64u * h + (uint32_t)lane;
+        bool go = (bm[pos >> 5] >> (pos & 31)) & 1u;
+        const bool rv = !FWD && ((bm[4 + (pos >> 5)] >> (pos & 31)) & 1u);
+        const int idx = 4 * h + (lane >> 4);
+        const uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
+        uint64_t K = kmer_from_dwords(d0, d1, d2, ln & 15, k);
+        if (rv) K = revcomp_bits(K, k);
+        uint32_t hsh = s_side_hash(K, smask), got = 0;
+        while (wballot(go)) {
+          uint4 c = make_uint4(0, 0, 0, 0);
+          if (go) c = load_slot_quarter(side + hsh);
+          if (go) {
+            if (c.z == 0) go = false;
+            else if (c.x == (uint32_t)K && c.y == (uint32_t)(K >> 32)) { got = c.z; go = false; }
+            else hsh = (hsh + 1) & smask;
+          }
+        }
+        sres[h] = got;
+      }
+      __builtin_amdgcn_wave_barrier();
+      tally2(sres[0], sres[1], acc, n_ent, overflow, total, lane);
+    }
+  };
+  auto finish = [&](const RowAcc& acc, uint32_t n_ent, uint32_t total, uint32_t overflow, uint32_t r) __attribute__((always_inline)) {
+    uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+    struct { uint32_t* results; uint32_t* rows; uint32_t* flagged; uint32_t row_words, flagged_cap; } fa;
+    fa.results = kc->results; fa.rows = kc->rows; fa.flagged = kc->flagged; fa.row_words = kc->row_words; fa.flagged_cap = kc->flagged_cap;
+    finish_read(acc, n_ent, total, overflow, r, fa, lane);
+  };
+
+  // One step = one read taken up (N) and the read before it finished (P: its slots are on their way).  The loop below calls it
+  // with the two sets of registers in alternating roles: no copy of the run lanes' state from "next" to "pending".
+  uint32_t r = wave0; bool p_valid = false;
+  auto step = [&](Round& P, uint32_t& p_wd, Round& N, uint32_t& n_wd) __attribute__((always_inline)) -> bool {
+    const bool have = r < a.n_reads;
+    uint32_t pp = cur_pp;
+    const uint32_t pe = cur_pe;
+    bool simple = false;
+    uint32_t n_nrun = 0;
+    if (have) {
+      // A read that is ONE part of at most 128 k-mers (its part ends where the read ends, or a 0 follows): the pipelined road
+      const uint32_t plen0 = cur_hdr, pp1 = pp + 1 + (plen0 + 7) / 8;
+      simple = plen0 - (uint32_t)k < 128u && pp1 == pe;
+      if (!simple && plen0 - (uint32_t)k < 128u && pp1 < pe) {
+        const uint32_t rel = pp1 - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);
+        if (rel < 24u) {
+          const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
+          simple = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu) == 0;
+        }
+      }
+      if (simple) {
+        const uint32_t R = front(pp + 1, pp1, 0u, plen0 - (uint32_t)k + 1u, true, n_wd);
+        if (R <= MIC_RMAX) setup(n_wd, 0u, R, N, n_nrun);
+        else simple = false;                                  // more runs than one round holds: the general road below
+      }
+    }
+    // the earlier read: its slots have had the front half above to arrive
+    if (p_valid) {
+      RowAcc acc; acc.label1 = 0; acc.count = 0;
+      uint32_t n_ent = 0, overflow = 0, total = 0;
+      consume(P, p_wd, acc, n_ent, overflow, total);
+      finish(acc, n_ent, total, overflow, r - n_waves);      // (a pending read is the one before this one)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the read-ahead entry taken below)
+    }
+    if (!have) return false;
+    if (!simple) {
+      RowAcc acc; acc.label1 = 0; acc.count = 0;
+      uint32_t n_ent = 0, overflow = 0, total = 0;
+      bool first_part = true;
+      while (pp < pe) {
+        uint32_t plen;
+        {
+          const uint32_t rel = pp - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);    // u16 offset inside the entry
+          if (first_part) plen = cur_hdr;
+          else if (rel < 24u) {
+            const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
+            plen = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu);
+          } else plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
+        }
+        const bool ahead_ok = first_part;
+        first_part = false;
+        if (plen == 0) break;
+        const uint32_t first = pp + 1;
+        pp = first + (plen + 7) / 8;
+        if (plen < (uint32_t)k) continue;
+        const uint32_t nk = plen - k + 1;
+        const uint32_t cend = pp;
+        for (uint32_t base = 0; base < nk; base += 128) {
+          uint32_t wd;
+          const uint32_t R = front(first, cend, base, nk, ahead_ok && base == 0, wd);
+          for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
+            Round L; uint32_t nrun;
+            setup(wd, rbase, R, L, nrun);
+            issue(L.cur, nrun);
+            consume(L, wd, acc, n_ent, overflow, total);
+          }
+        }
+      }
+      finish(acc, n_ent, total, overflow, r);
+    }
+    uint32_t t_hdr, t_pp, t_pe;
+    __builtin_amdgcn_wave_barrier();
+    ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_pp, t_pe);
+    __builtin_amdgcn_wave_barrier();
+    ahead_issue(ahead_sel ? ahead0 : ahead1, t_pp, r + 3 * n_waves);
+    ahead_sel ^= 1;
+    cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; n_pp = t_pp; n_pe = t_pe;
+    p_valid = simple;
+    if (simple) issue(N.cur, n_nrun);
+    r += n_waves;
+    return true;
+  };
+  Round Ra, Rb; uint32_t wa = 0, wb = 0;
+  while (step(Ra, wa, Rb, wb) && step(Rb, wb, Ra, wa)) {}
+}
+#else
   for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
     uint32_t pp = cur_pp;
     const uint32_t pe = cur_pe;
@@ -1513,6 +1830,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; n_pp = t_pp; n_pe = t_pe;
   }
 }
+#endif
 
 
 // ---- merge / result on sparse rows ----------------------------------------------------------------
