@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) query_kernel(const MicQueryArgs a) {
 #define MIC_R_SKEW 2
 #endif
 #ifndef MIC_R_PIPE
-#define MIC_R_PIPE 1     /* query_kernel_r software-pipelined across reads (0: the loop of rounds 2-4, for comparison) */
+#define MIC_R_PIPE 2     /* query_kernel_r software-pipelined across reads: 0 no instantiation, 1 the two-strand table's, 2 the one-strand table's too */
 #endif
 __device__ __forceinline__ uint32_t staged_at(uint32_t i) { return i * MIC_MSTRIDE + (i >> 3) * MIC_R_SKEW; }   // uint4 offset of staged slot i
 // the minimizer kernel reads its staged keys as 64-bit words and loses 5 % with the skew (11.5 against 11.0 ms): none there
@@ -1225,7 +1225,11 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     ahead_issue(ahead1, n_pp, wave0 + 2 * n_waves);
     ahead_sel = 1;
   }
-#if MIC_R_PIPE
+  // Which instantiations run the software-pipelined loop (below): those with k and m as constants and without the side table's
+  // rare path - the others are at the register budget as they are (pipelined they spill into scratch memory and lose 10-17 %)
+  // and keep the loop of rounds 2-4.  MIC_R_PIPE: 0 none, 1 the two-strand table's only, 2 (default) the one-strand table's too.
+  constexpr bool PIPE = KK != 0 && !SIDE && (MIC_R_PIPE >= 2 || (MIC_R_PIPE == 1 && FWD));
+  if constexpr (PIPE) {
   // ---- the loop over the wave's reads, SOFTWARE-PIPELINED across reads (round 5) --------------------------------------------------
   // With 8 wavefronts per SIMD and ~2-3 us between the issue of a read's slot loads and their arrival, the vector unit stood idle
   // ~15 % of the time: every wavefront waited for ITS slots with nothing else to do (a closed queue of 8 customers around one
@@ -1234,11 +1238,14 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
   // of its own); only then it waits, compares and tallies the earlier read.  What lives across: the run lanes' region words, sort
   // key, range of positions, slot (8 VGPRs) and three scalars.  ONE stage area still: the next read's slot list is written after
   // the earlier read's slots have been consumed.  Reads that are not one round of one chunk of one part (long reads, several
-  // parts, more than 32 runs) drain the pipeline and run as before.
+  // parts, more than 32 runs) drain the pipeline and run as before.  The phases are the ones of the plain loop in the else branch
+  // below, cut into lambdas (front / setup / issue / consume); the comments on WHY each instruction is what it is stand there.
+  // Measured (headline, 10 M x 150 bp, 119 GB table): 4.63 -> 4.37-4.45 ms by HIP events, 241 VALU + 172 SALU + 45 branches per read
+  // against 240 + 167 + 40: the vector unit 89 % busy instead of 85 %.  One-strand table: 4.97 -> 4.83 ms.
   struct Round {
     uint32_t G0, G1, G2, cur;
     int jmax, jmin, remaining;
-    int i0, n; bool rev;                   // SIDE: the run's k-mers and strand (the crowded path's bitmaps)
+    uint32_t side;                         // SIDE: first k-mer of the run | k-mers << 8 | strand << 16 (the crowded path's bitmaps)
   };
   // front half of a chunk: window word, sampled positions, run records in LDS; returns the number of runs
   auto front = [&](const uint32_t first, const uint32_t cend, const uint32_t base, const uint32_t nk, const bool use_ahead, uint32_t& wd_out) __attribute__((always_inline)) -> uint32_t {
@@ -1323,7 +1330,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     }
     L.G0 = G0; L.G1 = G1; L.G2 = G2; L.cur = cur;
     L.jmax = jmax; L.jmin = jmin; L.remaining = mine ? n : 0;
-    L.i0 = i0; L.n = n; L.rev = rev;
+    if (SIDE) L.side = (uint32_t)i0 | ((uint32_t)n << 8) | (rev ? 0x10000u : 0u);
   };
   // the slots of a round from HBM into the stage area (LDS-DMA; the list of slots sits in the stage area itself: it is consumed
   // before the DMA lands)
@@ -1404,9 +1411,11 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
       if (ln < 8) bm[lane] = 0u;
       __builtin_amdgcn_wave_barrier();
       if (crowded) {
-        for (int bpos = L.i0; bpos < L.i0 + L.n; ++bpos) {
+        const int i0 = (int)(L.side & 255u), n = (int)((L.side >> 8) & 255u);
+        const bool rev = (L.side >> 16) != 0;
+        for (int bpos = i0; bpos < i0 + n; ++bpos) {
           atomicOr(&bm[bpos >> 5], 1u << (bpos & 31));
-          if (!FWD && L.rev) atomicOr(&bm[4 + (bpos >> 5)], 1u << (bpos & 31));
+          if (!FWD && rev) atomicOr(&bm[4 + (bpos >> 5)], 1u << (bpos & 31));
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -1537,8 +1546,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
   };
   Round Ra, Rb; uint32_t wa = 0, wb = 0;
   while (step(Ra, wa, Rb, wb) && step(Rb, wb, Ra, wa)) {}
-}
-#else
+  } else {
   for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
     uint32_t pp = cur_pp;
     const uint32_t pe = cur_pe;
@@ -1829,8 +1837,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     ahead_sel ^= 1;
     cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; n_pp = t_pp; n_pe = t_pe;
   }
+  }
 }
-#endif
 
 
 // ---- merge / result on sparse rows ----------------------------------------------------------------
