@@ -403,7 +403,7 @@ def end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res_expect, trut
                       df["Object_ID"].iloc[-1] == f"r{n_reads - 1:09d}")
         del df
         fq_bytes = sum(os.path.getsize(f) for f in fqs)
-        out = {"value": round(n_obj / t_assign / 1e6, 1), "unit": "Mreads/s", "value_is": f"median of {len(reps_out)} runs of the command",
+        out = {"value": med["value"], "unit": "Mreads/s", "value_is": f"median of {len(reps_out)} runs of the command",
                "min": by_rate[0]["value"], "max": by_rate[-1]["value"], "runs": [d["value"] for d in reps_out],
                "runs_csv_equal": all(d.get("csv_equals_first_run", True) for d in reps_out),
                "objects_per_min": opm, "objects": n_obj,
