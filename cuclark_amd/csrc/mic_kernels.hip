@@ -2140,6 +2140,9 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     unsigned want = by_work > fill ? by_work : fill;
     if (blocks > want) blocks = want;
   }
+  // test hook: a grid of this many blocks, so that a small parity case runs hundreds of reads of every shape through each wavefront
+  // (the software-pipelined loop's transitions between its pipelined and its plain road)
+  if (const char* e = getenv("MIC_QUERY_BLOCKS")) { const int v = atoi(e); if (v > 0) blocks = (unsigned)v; }
   if (a.t.layout == 2) {
     const unsigned g = (blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, b = 64 * MIC_M_WPB;
     static const bool generic = getenv("MIC_S_GENERIC") != nullptr;

@@ -341,6 +341,42 @@ def test_long_reads_and_part_splitting():
     assert expect[0, 0] > 60000
 
 
+@pytest.mark.parametrize("k", [31, 27, 24])
+def test_few_wavefronts_many_reads_of_every_shape(k, monkeypatch):
+    """The per-run kernel's loop is software-pipelined across the reads of a wavefront: a read that is one part of at most 128 k-mers
+    has its slot loads in flight during the next read's front half; every other read (several parts, several chunks, no k-mer)
+    drains the pipeline and takes the plain road.  The small cases above give a wavefront one read at most; here MIC_QUERY_BLOCKS (test
+    hook) cuts the grid to 2 and 5 blocks, so that each wavefront runs hundreds of reads of mixed shapes back to back - every
+    transition between the two roads, the first and the last read of a wavefront - against the oracle.  k = 24: the instantiation
+    with k and m from the table (plain loop)."""
+    from cuclark_amd import host
+    rng = np.random.default_rng(1000 + k)
+    htsize, T = 65537, 40
+    sizes, keys, labels, canon = gu.random_db(rng, htsize, 60000, k, 8, T)
+    o = gu.oracle()
+    odb = o.db_from_arrays(sizes, keys, labels)
+    # lengths 10 .. 320: no k-mer / one chunk / two and three chunks; N every ~100 nt in a third of the reads (several parts)
+    recs = []
+    for part in range(6):
+        recs.append(_random_reads(rng, canon, k, 500, (20, 150, 157, 158, 320, 150)[part], hit_frac=0.7, n_rate=(0.0, 0.0, 0.01, 0.0, 0.01, 0.0)[part]))
+    lines = b"".join(recs).split(b">")[1:]
+    order = rng.permutation(len(lines))
+    data = b"".join(b">" + lines[i] for i in order)
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    counts, expect = _oracle_results(odb, k, rp, cont, T)
+    assert (expect[:, 0] > 0).sum() > 1500
+    with _engine(k, T) as e:
+        e.read_arrays(sizes, keys, labels)
+        base = e.classify_packed(rp, cont)
+        assert (base[:, :5] == expect).all()
+        for blocks in ("2", "5"):
+            monkeypatch.setenv("MIC_QUERY_BLOCKS", blocks)
+            res = e.classify_packed(rp, cont)
+            monkeypatch.delenv("MIC_QUERY_BLOCKS")
+            assert (res == base).all(), blocks
+
+
 def _canonical_np(v, k):
     """canonical k-mer values of a uint64 array (A=3 C=2 G=1 T=0: the complement is the bitwise NOT)"""
     x = ~v
