@@ -1044,7 +1044,7 @@ __global__ void __launch_bounds__(256) s_crowd_count_kernel(const uint32_t* __re
 }
 
 __device__ inline void s_side_insert(uint4* __restrict__ side, uint32_t mask, uint64_t K, uint32_t label1) {
-  uint32_t h = (uint32_t)((K * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+  uint32_t h = s_side_hash(K, mask);
   for (;;) {
     uint32_t* cell = (uint32_t*)(side + h);
     if (atomicCAS(&cell[2], 0u, label1) == 0u) { cell[0] = (uint32_t)K; cell[1] = (uint32_t)(K >> 32); return; }

@@ -226,7 +226,15 @@ __device__ __forceinline__ void s_candidates_fwd(uint64_t c, int k, int m, F&& f
 }
 
 // Side table of the crowded minimizers' k-mers (mic_build.hip: s_crowd_move_kernel): cells {k-mer lo, hi, label + 1, 0}, linear probing
-__device__ __forceinline__ uint32_t s_side_hash(uint64_t K, uint32_t mask) { return (uint32_t)((K * 0x9E3779B97F4A7C15ull) >> 32) & mask; }
+// The cell of a k-mer: the TOP bits of a two-round multiply-xorshift of K.  (Until round 5: bits 32 .. of K * phi under the mask -
+// the middle of the product, which the top nucleotides of K barely reach: the k-mers of one microsatellite with different left
+// flanks - exactly what a crowded minimizer collects - fell into a handful of cells and were walked one after the other.)
+__device__ __forceinline__ uint32_t s_side_hash(uint64_t K, uint32_t mask) {
+  uint64_t x = K * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 29;
+  x *= 0xBF58476D1CE4E5B9ull;
+  return (uint32_t)(x >> 32) >> __builtin_clz(mask | 1u);      // mask = 2^b - 1: the top b bits
+}
 __device__ inline uint32_t s_side_probe(const uint4* __restrict__ side, uint32_t mask, uint64_t K) {
   uint32_t h = s_side_hash(K, mask);
   for (;;) {

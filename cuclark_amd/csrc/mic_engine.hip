@@ -53,6 +53,7 @@ struct Batch {
   uint32_t* d_results = nullptr; uint32_t* d_rows = nullptr;
   uint32_t* d_flagged = nullptr; uint32_t* h_flagged = nullptr;
   uint32_t* d_peer = nullptr; uint32_t* d_acc = nullptr;   // table-sharded merge: another engine's rows, the running sum
+  uint32_t* d_crowd = nullptr;   // work area of the crowded runs' follow-up (mic_internal.h: mic_crowd_dims)
   size_t first_read = 0, n_reads = 0, n_cont = 0, max_reads = 0, max_cont = 0;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr, ev_up = nullptr, ev_k = nullptr;   // batch finished; its upload finished; its kernels finished
@@ -85,6 +86,7 @@ struct mic_engine {
   std::mutex submit_mu;
   // device-API state
   uint32_t* d_flagged = nullptr; uint32_t flagged_cap = 0;
+  uint32_t* d_crowd = nullptr; size_t crowd_reads = 0;     // work area of the crowded runs' follow-up, sized for crowd_reads reads
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   size_t last_n_reads = 0;
@@ -622,6 +624,7 @@ int mic_destroy(mic_engine* e) {
   if (e->side) hipFree(e->side);
   if (e->d_sizes) hipFree(e->d_sizes);
   if (e->d_flagged) hipFree(e->d_flagged);
+  if (e->d_crowd) hipFree(e->d_crowd);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   if (e->stream) hipStreamDestroy(e->stream);
@@ -807,9 +810,10 @@ int mic_batches_alloc(mic_engine* e, size_t num_reads_total, size_t max_reads, s
   // sizes of the per-batch pieces
   const size_t sz_rp = up((max_reads + 2) * 4), sz_ct = up((max_containers + 64) * 2), sz_fl = up((size_t)(kFlaggedCap + 1) * 4);
   const size_t sz_res = up((max_reads + 1) * MIC_RESULT_WORDS * 4), sz_rows = extended ? up((max_reads + 1) * (size_t)rw * 4) : 0;
+  const size_t sz_crowd = up(mic_crowd_dims(max_reads).words * 4);
   const size_t h_res = up((num_reads_total + 1) * MIC_RESULT_WORDS * 4), h_rows = extended ? up((num_reads_total + 1) * (size_t)rw * 4) : 0;
   const size_t h_total = h_res + h_rows + nb * (sz_rp + sz_ct + sz_fl);
-  const size_t d_total = nb * (sz_rp + sz_ct + sz_res + sz_rows + sz_fl);
+  const size_t d_total = nb * (sz_rp + sz_ct + sz_res + sz_rows + sz_fl + sz_crowd);
   {
     mic_bind_thread_near_device(e->device, 1);      // pinned memory on the device's socket
     hipError_t he = hipHostMalloc(&e->h_block, h_total, hipHostMallocDefault);
@@ -835,6 +839,7 @@ int mic_batches_alloc(mic_engine* e, size_t num_reads_total, size_t max_reads, s
     B.d_results = (uint32_t*)dp; dp += sz_res;
     if (extended) { B.d_rows = (uint32_t*)dp; dp += sz_rows; }
     B.d_flagged = (uint32_t*)dp; dp += sz_fl;
+    B.d_crowd = (uint32_t*)dp; dp += sz_crowd;
     HIPTRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
     HIPTRY(hipEventCreateWithFlags(&B.done, hipEventDisableTiming));
     HIPTRY(hipEventCreateWithFlags(&B.ev_up, hipEventDisableTiming));
@@ -882,6 +887,7 @@ static int batch_query_impl(mic_engine* e, size_t batch, int extended, const Bat
   a.t = e->table; a.reads_ptr = B.d_rp; a.cont = B.d_cont; a.n_reads = (uint32_t)B.n_reads;
   a.row_words = e->cfg.row_words; a.results = B.d_results; a.rows = extended ? B.d_rows : nullptr;
   a.flagged = B.d_flagged; a.flagged_cap = kFlaggedCap;
+  mic_crowd_attach(a, B.d_crowd, B.max_reads);
   HIPTRY(mic_launch_query(a, e->slot_class, e->n_cu, s));
   HIPTRY(hipEventRecord(B.ev_k, s));
   HIPTRY(hipStreamWaitEvent(down, B.ev_k, 0));
@@ -1264,6 +1270,13 @@ int mic_query_device(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont
   a.t = e->table; a.reads_ptr = d_rp; a.cont = d_cont; a.n_reads = (uint32_t)n_reads;
   a.row_words = e->cfg.row_words; a.results = d_results; a.rows = d_rows;
   a.flagged = e->d_flagged; a.flagged_cap = e->flagged_cap;
+  if (e->table.side && n_reads > e->crowd_reads) {      // (first call, or a larger one: the engine's launches are one at a time)
+    HIPTRY(hipStreamSynchronize(s));
+    if (e->d_crowd) { hipFree(e->d_crowd); e->d_crowd = nullptr; e->crowd_reads = 0; }
+    HIPTRY(hipMalloc(&e->d_crowd, mic_crowd_dims(n_reads).words * 4));
+    e->crowd_reads = n_reads;
+  }
+  mic_crowd_attach(a, e->table.side ? e->d_crowd : nullptr, e->crowd_reads);
   HIPTRY(hipEventRecord(e->ev0, s));
   HIPTRY(mic_launch_query(a, e->slot_class, e->n_cu, s));
   HIPTRY(hipEventRecord(e->ev1, s));
@@ -1277,6 +1290,17 @@ int mic_last_query_ms(mic_engine* e, float* ms) {
   if (!e->timed) return fail(MIC_E_STATE, "no query was launched");
   HIPTRY(hipEventSynchronize(e->ev1));
   HIPTRY(hipEventElapsedTime(ms, e->ev0, e->ev1));
+  return MIC_OK;
+}
+
+int mic_last_crowd_stats(mic_engine* e, uint32_t out[4]) {
+  if (!e || !out) return fail(MIC_E_INVALID, "null argument");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!e->timed || !e->d_crowd || !e->table.side) return MIC_OK;
+  int rc = set_device(e);
+  if (rc) return rc;
+  HIPTRY(hipEventSynchronize(e->ev1));
+  HIPTRY(hipMemcpy(out, e->d_crowd, 16, hipMemcpyDeviceToHost));
   return MIC_OK;
 }
 

@@ -470,6 +470,7 @@ struct Slot {
   uint32_t* d_flag = nullptr; uint32_t* d_rec_of_line = nullptr; uint32_t* d_hdr_line = nullptr;
   RecArrays rec{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t* d_rp = nullptr; uint16_t* d_cont = nullptr; uint32_t* d_results = nullptr; uint32_t* d_flagged = nullptr;
+  uint32_t* d_crowd = nullptr;   // work area of the crowded runs' follow-up (mic_internal.h: mic_crowd_dims)
   uint32_t* d_line_len = nullptr; uint32_t* d_line_off = nullptr; char* d_csv = nullptr; uint32_t* d_hdr = nullptr;
   void* d_tmp = nullptr; size_t tmp_bytes = 0;
   hipStream_t stream = nullptr;
@@ -484,7 +485,7 @@ struct Slot {
     uint32_t* d_rows = nullptr;                             // this engine's partial rows of ALL reads of the batch
     uint32_t* d_gather = nullptr; uint32_t* d_acc = nullptr; uint32_t* d_acc2 = nullptr;  // rows of this engine's read range from the others; the running sum's two buffers
     uint32_t* d_res = nullptr;                              // helpers: results of all reads from the query kernel, then of the range
-    uint32_t* d_flagged = nullptr;
+    uint32_t* d_flagged = nullptr; uint32_t* d_crowd = nullptr;
     hipStream_t stream = nullptr;                           // helpers: a stream on their device; owner: the slot's stream
     hipEvent_t ev_q = nullptr, ev_done = nullptr;           // this engine's rows are written; its range is finished and delivered
     // MIC_GROUP_TIMING: packed reads asked for / arrived (= kernel start) / kernel done / all other engines' rows ready / range delivered
@@ -576,6 +577,7 @@ void carve_slot(Ingest* g, Slot& s, Arena& dv, Arena& hs, size_t tmp) {
   dv.take(&s.d_cont, g->cont_cap + 192);
   dv.take(&s.d_results, (g->max_reads + 1) * 8);
   dv.take(&s.d_flagged, (size_t)kFlaggedCapI + 1);
+  dv.take(&s.d_crowd, mic_crowd_dims(g->max_reads).words);
   dv.take(&s.d_line_len, g->max_reads + 1);
   dv.take(&s.d_line_off, g->max_reads + 1);
   dv.take(&s.d_csv, g->csv_cap);
@@ -724,6 +726,7 @@ int setup_peers(Ingest* g, Slot& s, mic_engine* const* group, size_t P, size_t o
         a.take(&q.d_cont, g->cont_cap + 192);
         a.take(&q.d_res, (g->max_reads + 1) * 8);
         a.take(&q.d_flagged, (size_t)kFlaggedCapI + 1);
+        a.take(&q.d_crowd, mic_crowd_dims(g->max_reads).words);
       }
       if (!pass) {
         hipError_t e = hipMalloc(&q.block, a.off + 256);
@@ -733,7 +736,7 @@ int setup_peers(Ingest* g, Slot& s, mic_engine* const* group, size_t P, size_t o
     ITRY(hipEventCreateWithFlags(&q.ev_q, hipEventDisableTiming));
     ITRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
     if (s.timed) for (hipEvent_t& e : q.tv) ITRY(hipEventCreate(&e));
-    if (own) { q.d_rp = s.d_rp; q.d_cont = s.d_cont; q.d_res = s.d_results; q.d_flagged = s.d_flagged; q.stream = s.stream; }
+    if (own) { q.d_rp = s.d_rp; q.d_cont = s.d_cont; q.d_res = s.d_results; q.d_flagged = s.d_flagged; q.d_crowd = s.d_crowd; q.stream = s.stream; }
     else {
       ITRY(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
       ITRY(hipMemsetAsync(q.d_cont, 0, (g->cont_cap + 192) * 2, q.stream));     // (the query kernel's read-ahead looks past the last read)
@@ -777,6 +780,7 @@ int group_query_issue(mic_engine* const* group, size_t P, size_t owner, Ingest* 
     MicQueryArgs qa;
     qa.t = t; qa.reads_ptr = q.d_rp; qa.cont = q.d_cont; qa.n_reads = n; qa.row_words = (uint32_t)rw; qa.results = q.d_res;
     qa.rows = q.d_rows; qa.flagged = q.d_flagged; qa.flagged_cap = kFlaggedCapI;
+    mic_crowd_attach(qa, q.d_crowd, g->max_reads);
     ITRY(mic_launch_query(qa, sc, ncu, q.stream));
     ITRY(hipEventRecord(q.ev_q, q.stream));
     if (timed) ITRY(hipEventRecord(q.tv[2], q.stream));
@@ -1040,6 +1044,7 @@ int mic_ingest_classify_group(mic_engine* const* group, size_t n_group, size_t o
     MicQueryArgs qa;
     qa.t = t; qa.reads_ptr = s.d_rp; qa.cont = s.d_cont; qa.n_reads = n_reads; qa.row_words = 0; qa.results = s.d_results;
     qa.rows = nullptr; qa.flagged = s.d_flagged; qa.flagged_cap = kFlaggedCapI;
+    mic_crowd_attach(qa, s.d_crowd, g->max_reads);
     ITRY(mic_launch_query(qa, sc, ncu, st));
   } else {
     // table-sharded: all engines of the group probe the batch against their parts, the rows are summed read-range owned

@@ -116,7 +116,42 @@ struct MicQueryArgs {
   uint32_t* rows;       // n_reads * row_words or nullptr
   uint32_t* flagged;    // [0] = count, [1..] = read ids needing the dense path (or nullptr)
   uint32_t flagged_cap;
+  // layout 2 with a side table: the work area through which query_kernel_r hands the runs of crowded minimizers (and the rows
+  // of their reads) to crowd_finish_kernel - mic_crowd_dims / mic_crowd_attach below - or nullptr: such reads take the dense path
+  uint32_t* crowd;
+  uint32_t* crowd_items; uint32_t* crowd_pool;      // = crowd + MIC_CROWD_HDR + 8 pend_cap, ... + 8 item_cap (the kernels do no address arithmetic with the capacities)
+  uint32_t crowd_pend_cap, crowd_item_cap, crowd_pool_cap;
 };
+
+// ---- work area of the crowded runs' follow-up (mic_kernels.hip: query_kernel_r -> crowd_finish_kernel) ----------------------
+// One per query launch in flight, any 16-byte aligned device memory; mic_launch_query zeroes the header.  Words:
+//   [0] pending reads  [1] items  [2] pool words  [3] reads sent to the dense path for lack of room  [4..7] unused
+//   pending read p (8 words): read, hits so far, entries | overflow << 8 (0xFFFFFFFF: skipped), pool offset of its row, last group
+//   item i (8 words): the run's region (3 words, oriented as the table stores it), jmin | jmax << 8, the group in front (first item of a group)
+//   pool: the rows so far, (label + 1, count) per entry
+// A group = the crowded runs of one round of one read, adjacent items: first item | (runs - 1) << 27.
+#define MIC_CROWD_HDR 8
+#define MIC_CG_NONE 0xFFFFFFFFu
+#define MIC_CG_DENSE 0xFFFFFFFEu
+struct MicCrowdDims { uint32_t pend_cap, item_cap, pool_cap; size_t words; };
+static inline MicCrowdDims mic_crowd_dims(size_t max_reads) {
+  // a quarter of the reads pending with four crowded runs and eight row words each (48 bytes per read of capacity); what does
+  // not fit takes the dense path (exact, slow: real data has a few per cent of such reads, a run or two each)
+  MicCrowdDims d;
+  const size_t cap27 = (1u << 27) - 64;
+  size_t pend = max_reads / 4 + 1024, item = max_reads + 4096, pool = max_reads * 2 + 8192;
+  d.pend_cap = (uint32_t)(pend < cap27 ? pend : cap27);
+  d.item_cap = (uint32_t)(item < cap27 ? item : cap27);
+  d.pool_cap = (uint32_t)(pool < 0xFFFFFF00u ? pool : 0xFFFFFF00u);
+  d.words = MIC_CROWD_HDR + 8 * ((size_t)d.pend_cap + d.item_cap) + d.pool_cap;
+  return d;
+}
+static inline void mic_crowd_attach(MicQueryArgs& a, uint32_t* area, size_t max_reads) {
+  const MicCrowdDims d = mic_crowd_dims(max_reads);
+  a.crowd = area; a.crowd_pend_cap = area ? d.pend_cap : 0; a.crowd_item_cap = area ? d.item_cap : 0; a.crowd_pool_cap = area ? d.pool_cap : 0;
+  a.crowd_items = area ? area + MIC_CROWD_HDR + 8 * (size_t)d.pend_cap : nullptr;
+  a.crowd_pool = area ? a.crowd_items + 8 * (size_t)d.item_cap : nullptr;
+}
 
 // stage times of the table build in progress (mic_engine.hip; read back with mic_db_last_build_report)
 void mic_build_report_add(const char* what, double seconds);

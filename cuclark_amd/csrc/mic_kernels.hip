@@ -1135,6 +1135,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
 __device__ __forceinline__ uint64_t wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 static_assert(MIC_RMAX <= 32, "tally_counts sums the first two rows of lanes");
+#define MIC_R_CROWDED (-(1 << 24))     /* `remaining` of a run that met the marker of a crowded minimizer */
 __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, RowAcc& acc, uint32_t& n_ent, uint32_t& overflow,
                                              uint32_t& total, int lane) {
   uint64_t mm = wballot(lab1 != 0);
@@ -1160,7 +1161,7 @@ __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, RowAcc
   }
 }
 
-template <int KK, int MM, bool FWD, bool PART, bool SIDE>
+template <int KK, int MM, bool FWD, bool PART>
 __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r(const MicQueryArgs a) {
   // staged slots: 8 per LDS-DMA instruction, 128 bytes apart (the DMA's own layout: lane L lands at base + 16 L); each
   // group of 8 starts MIC_R_SKEW uint4 further so that the run lanes' reads of the same word of their slots spread over
@@ -1192,11 +1193,17 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     // two LDS-DMA instructions under their lanes' masks, scalar base + 4 * lane each (lane L lands at entry + 4 L whatever
     // the mask): 12 window dwords, 2 pointers - 14 loads instead of 64, and none of the selects of the one-instruction form
     // (the pointers are loaded by lanes 0, 1 into entry + 12: with one destination the compiler merges the two loads again)
-    if (lane < 12)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));           // (the two lane masks recomputed per read instead of two scalar register pairs kept across the kernel)
+    if (ln < 12)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const uint32_t*)abase + lane),
                                        (__attribute__((address_space(3))) void*)entry, 4, 0, 0);
-    if (lane < 2)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const uint32_t*)(pbase + 48) + lane),
+    // (the scalar base opaque: reassociated into (reads_ptr + lane) + rr the lane part is hoisted out of the loop as a 64-bit
+    // vector address - two registers the kernel does not have; this way it is scalar base + the 32-bit lane offset of the load above)
+    uint64_t pb = pbase + 48;
+    asm volatile("" : "+s"(pb));
+    if (ln < 2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const uint32_t*)pb + lane),
                                        (__attribute__((address_space(3))) void*)(entry + 12), 4, 0, 0);
   };
   auto ahead_take = [&](const uint32_t* entry, uint32_t pp_w, uint32_t& hdr, uint32_t& npp, uint32_t& npe) {
@@ -1225,27 +1232,33 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     ahead_issue(ahead1, n_pp, wave0 + 2 * n_waves);
     ahead_sel = 1;
   }
-  // Which instantiations run the software-pipelined loop (below): those with k and m as constants and without the side table's
-  // rare path - the others are at the register budget as they are (pipelined they spill into scratch memory and lose 10-17 %)
-  // and keep the loop of rounds 2-4.  MIC_R_PIPE: 0 none, 1 the two-strand table's only, 2 (default) the one-strand table's too.
-  constexpr bool PIPE = KK != 0 && !SIDE && (MIC_R_PIPE >= 2 || (MIC_R_PIPE == 1 && FWD));
-  if constexpr (PIPE) {
+  // Which instantiations run the software-pipelined road of the loop below: those with k and m as constants - the others are at
+  // the register budget as they are (pipelined they spill into scratch memory and lose 10-17 %) and take every read through the
+  // plain road.  MIC_R_PIPE: 0 none, 1 the two-strand table's only, 2 (default) the one-strand table's too.
+  constexpr bool PIPE = KK != 0 && (MIC_R_PIPE >= 2 || (MIC_R_PIPE == 1 && FWD));
   // ---- the loop over the wave's reads, SOFTWARE-PIPELINED across reads (round 5) --------------------------------------------------
   // With 8 wavefronts per SIMD and ~2-3 us between the issue of a read's slot loads and their arrival, the vector unit stood idle
   // ~15 % of the time: every wavefront waited for ITS slots with nothing else to do (a closed queue of 8 customers around one
   // server: utilisation 0.85-0.89 at that think time).  Now a read's slot loads are issued and the wavefront goes on to the FRONT
   // HALF of its next read (window, sampled positions, runs, regions, slot hashes: ~60 % of a read's vector work, no memory access
-  // of its own); only then it waits, compares and tallies the earlier read.  What lives across: the run lanes' region words, sort
-  // key, range of positions, slot (8 VGPRs) and three scalars.  ONE stage area still: the next read's slot list is written after
+  // of its own); only then it waits, compares and tallies the earlier read.  What lives across: the run lanes' region words,
+  // range of positions, slot (7 VGPRs) and three scalars.  ONE stage area still: the next read's slot list is written after
   // the earlier read's slots have been consumed.  Reads that are not one round of one chunk of one part (long reads, several
-  // parts, more than 32 runs) drain the pipeline and run as before.  The phases are the ones of the plain loop in the else branch
-  // below, cut into lambdas (front / setup / issue / consume); the comments on WHY each instruction is what it is stand there.
+  // parts, more than 32 runs) drain the pipeline and take the plain road: front / setup / issue / consume one after the other.
   // Measured (headline, 10 M x 150 bp, 119 GB table): 4.63 -> 4.37-4.45 ms by HIP events, 241 VALU + 172 SALU + 45 branches per read
   // against 240 + 167 + 40: the vector unit 89 % busy instead of 85 %.  One-strand table: 4.97 -> 4.83 ms.
+  //
+  // CROWDED MINIMIZERS (round 6).  A run whose minimizer is a crowded one (mic_build.hip: s_crowd_move_kernel) meets a marker
+  // entry; its k-mers live in the side table, keyed by the k-mer.  Until round 5 a table with a side table selected an
+  // instantiation of this kernel that carried the per-k-mer side lookups as a rare path - at the register budget, so without
+  // the pipelined road, for EVERY read of every real database.  Now the kernel only hands such a run over: its region words and
+  // range of positions (everything the follow-up needs: the run's k-mers are substrings of the region) go to a work list in HBM
+  // (`crowd_emit`), the read's row so far is spilled instead of finished (`finish`), and crowd_finish_kernel - launched behind
+  // this kernel on the same stream - probes the side table one lane per k-mer, adds the hits to the row and finishes the read.
+  // The common path pays one compare per entry and one scalar test per read.
   struct Round {
     uint32_t G0, G1, G2, cur;
     int jmax, jmin, remaining;
-    uint32_t side;                         // SIDE: first k-mer of the run | k-mers << 8 | strand << 16 (the crowded path's bitmaps)
   };
   // front half of a chunk: window word, sampled positions, run records in LDS; returns the number of runs
   auto front = [&](const uint32_t first, const uint32_t cend, const uint32_t base, const uint32_t nk, const bool use_ahead, uint32_t& wd_out) __attribute__((always_inline)) -> uint32_t {
@@ -1330,7 +1343,6 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     }
     L.G0 = G0; L.G1 = G1; L.G2 = G2; L.cur = cur;
     L.jmax = jmax; L.jmin = jmin; L.remaining = mine ? n : 0;
-    if (SIDE) L.side = (uint32_t)i0 | ((uint32_t)n << 8) | (rev ? 0x10000u : 0u);
   };
   // the slots of a round from HBM into the stage area (LDS-DMA; the list of slots sits in the stage area itself: it is consumed
   // before the DMA lands)
@@ -1351,15 +1363,16 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
                                          (__attribute__((address_space(3))) void*)(stage + (64 + MIC_R_SKEW) * i), 16, 0, 0);
     }
   };
-  // wait for the slots, entries against regions, tally; continuation slots and the crowded runs' side-table lookups
-  auto consume = [&](Round& L, const uint32_t wd, RowAcc& acc, uint32_t& n_ent, uint32_t& overflow, uint32_t& total) __attribute__((always_inline)) {
+  // wait for the slots, entries against regions, tally; continuation slots; crowded runs are handed to the follow-up kernel
+  // (cg: the read's last group of crowded runs in the work list - first item | (runs - 1) << 27 -, MIC_CG_NONE, or MIC_CG_DENSE)
+  auto consume = [&](Round& L, RowAcc& acc, uint32_t& n_ent, uint32_t& overflow, uint32_t& total, uint32_t& cg) __attribute__((always_inline)) {
     const uint32_t G0 = L.G0, G1 = L.G1, G2 = L.G2;
     uint32_t key, xhi_;
     region_x(G0, G1, key, xhi_);            // (the sort key again from the region: cheaper than a register across the front half)
     const int jmax = L.jmax, jmin = L.jmin;
     uint32_t cur = L.cur;
     int remaining = L.remaining;
-    bool crowded = false, again = false;
+    bool again = false;
     do {
       if (again) issue(cur, MIC_RMAX);      // (continuation slots: rare; every group of eight under its lanes' mask)
       again = true;
@@ -1367,6 +1380,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
       __builtin_amdgcn_wave_barrier();
       const bool vl = cur != 0xFFFFFFFFu;
       const uint32_t* q = (const uint32_t*)(stage + (vl ? staged_at((uint32_t)lane) : 0));
+      // all six sort keys in one LDS round trip (the slot is 16-byte aligned); rank = number of keys below ours
       const uint4 ka = *(const uint4*)q;
       const uint2 kb = *(const uint2*)(q + 4);
       uint32_t e = (ka.x < key) + (ka.y < key) + (ka.z < key) + (ka.w < key) + (kb.x < key) + (kb.y < key);
@@ -1375,87 +1389,102 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
       e = e < 5 ? e : 5;
       for (;;) {
         uint32_t e3 = e + (e << 1);
-        asm volatile("" : "+v"(e3));
+        asm volatile("" : "+v"(e3));     // (the compiler would turn 3 e into a 64-bit multiply-add of the LDS address: quarter rate)
         uint32_t g = q[e], S0 = q[6 + e3], S1 = q[7 + e3], S2 = q[8 + e3], pl = q[24 + e];
-        asm volatile("" : "+v"(S2));
+        asm volatile("" : "+v"(S2));     // read with the others: the compiler would sink it into the branch below, one more LDS round trip
         const bool same = more && g == key;
         const uint32_t d0 = G0 ^ S0, d1 = G1 ^ S1, d2 = G2 ^ S2;
+        // the whole minimizer, not only its low 32 bits: its nucleotides are the low 32 - 2 ctx bits of word 0 and the top
+        // 2 (ctx + m) - 32 bits of word 1 (32-bit operations: the 64-bit form shifts and compares at half rate)
         const bool mineq = k > 16
                                ? ((d0 & ((1u << ((32 - 2 * ctx) & 31)) - 1u)) | (d1 >> xsh)) == 0
                                : (((((uint64_t)d0 << 32) | d1) << (2 * ctx)) >> (64 - 2 * m)) == 0;
-        const uint32_t dl = d0 >> (32 - 2 * ctx);
+        const uint32_t dl = d0 >> (32 - 2 * ctx);                                      // left context, nucleotide ctx-1 in the low bits
         const uint32_t dr = k > 16 ? __builtin_amdgcn_alignbit(d1, d2, xsh)
-                                        : (uint32_t)((((((uint64_t)d0 << 32) | d1)) << ((2 * k) & 63)) >> 32);
-        const int left = __builtin_ctz(dl | (1u << (2 * ctx))) >> 1;
+                                        : (uint32_t)((((((uint64_t)d0 << 32) | d1)) << ((2 * k) & 63)) >> 32);   // right context, its first nucleotide on top
+        const int left = __builtin_ctz(dl | (1u << (2 * ctx))) >> 1;                   // equal nucleotides next to the minimizer
         const int right = __builtin_clz(dr | (1u << (31 - 2 * ctx))) >> 1;
         const int hi = left < jmax ? left : jmax, lo = ctx - right > jmin ? ctx - right : jmin;
-        const uint32_t range = ((2u << (hi & 31)) - 1u) & (~0u << (lo & 31));
+        const uint32_t range = ((2u << (hi & 31)) - 1u) & (~0u << (lo & 31));         // empty when hi < lo
         const uint32_t hits = (same && mineq) ? (uint32_t)__popc((pl >> 16) & range) : 0u;
-        if (SIDE && same && mineq && (pl >> 16) == 0) { crowded = true; remaining = 0; }
+        // the marker of a crowded minimizer (presence mask 0): nothing of this minimizer is in the chains, the lane's walk ends
+        // (kept in `remaining`, as a value no count reaches: a lane mask of its own would cost the loop a scalar register pair)
+        remaining = (same && mineq && (pl >> 16) == 0) ? MIC_R_CROWDED : remaining;
+        // The run's hits are tallied ONCE per round: a lane keeps (label, count) of its run; a second entry with ANOTHER
+        // label (the same minimizer in two targets' genomes, both contexts matching parts of the run) is tallied on the
+        // spot - a wave-uniform branch that is virtually never taken.
         const uint32_t lab_new = (pl & 0xFFFFu) + 1u;
         tally_counts(hits ? lab_new : 0u, hits, acc, n_ent, overflow, total, lane);
         remaining -= (int)hits;
-        more = same && remaining > 0 && e < 5;
+        more = same && remaining > 0 && e < 5;                        // another entry of the same minimizer?
         e += more ? 1u : 0u;
         if (!wballot(more)) break;
       }
+      // continuation slot (rare): entries are sorted across the chain, so only if this slot's last key is not above ours
       const bool nx = vl && remaining > 0 && (mz & MIC_S_NEXT);
       cur = 0xFFFFFFFFu;
       if (wballot(nx)) { if (nx && q[5] <= key) cur = q[31]; }
     } while (wballot(cur != 0xFFFFFFFFu));
-    if (SIDE && wballot(crowded)) {
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      __builtin_amdgcn_wave_barrier();
-      uint32_t* bm = (uint32_t*)stage;
-      if (ln < 8) bm[lane] = 0u;
-      __builtin_amdgcn_wave_barrier();
-      if (crowded) {
-        const int i0 = (int)(L.side & 255u), n = (int)((L.side >> 8) & 255u);
-        const bool rev = (L.side >> 16) != 0;
-        for (int bpos = i0; bpos < i0 + n; ++bpos) {
-          atomicOr(&bm[bpos >> 5], 1u << (bpos & 31));
-          if (!FWD && rev) atomicOr(&bm[4 + (bpos >> 5)], 1u << (bpos & 31));
-        }
+    if (__builtin_expect(wballot(remaining < MIC_R_CROWDED / 2) != 0, 0)) {
+      // Rare (a database with microsatellites, a read that overlaps one): the crowded runs of this round become items of the
+      // follow-up's work list - the region as the table orients it and the run's range of minimizer positions; the k-mer with
+      // its minimizer at position j is the region's nucleotides [ctx - j, ctx - j + k).  One reservation per round.
+      // Everything here is kept in VECTOR registers on purpose (the kernarg pointer made opaque, so that the loads from it are
+      // vector loads): the entry loop's temporaries are dead at this point, while the scalar file is full - what this block
+      // would take of it, the common path would spill and reload per read.
+      const bool crowded = remaining < MIC_R_CROWDED / 2;
+      const uint32_t n_c = (uint32_t)__popcll(wballot(crowded));
+      uint64_t kpv = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+v"(kpv));
+      const MicQueryArgs* kv = (const MicQueryArgs*)kpv;
+      uint32_t* cw = kv->crowd;
+      uint32_t* itb = kv->crowd_items;
+      const uint32_t icap = kv->crowd_item_cap;
+      uint32_t ib = 0xFFFFFFFFu;
+      if (cw != nullptr && cg != MIC_CG_DENSE) {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&cw[1], n_c);
+        ib = __builtin_amdgcn_readfirstlane(v);
       }
-      __builtin_amdgcn_wave_barrier();
-      uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
-      asm volatile("" : "+s"(kp));
-      const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
-      const uint4* __restrict__ side = kc->t.side;
-      const uint32_t smask = kc->t.side_mask;
-      uint32_t sres[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        sres[h] = 0;
-        if (__builtin_amdgcn_readfirstlane(bm[2 * h] | bm[2 * h + 1]) == 0) continue;
-        const uint32_t pos = 64u * h + (uint32_t)lane;
-        bool go = (bm[pos >> 5] >> (pos & 31)) & 1u;
-        const bool rv = !FWD && ((bm[4 + (pos >> 5)] >> (pos & 31)) & 1u);
-        const int idx = 4 * h + (lane >> 4);
-        const uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
-        uint64_t K = kmer_from_dwords(d0, d1, d2, ln & 15, k);
-        if (rv) K = revcomp_bits(K, k);
-        uint32_t hsh = s_side_hash(K, smask), got = 0;
-        while (wballot(go)) {
-          uint4 c = make_uint4(0, 0, 0, 0);
-          if (go) c = load_slot_quarter(side + hsh);
-          if (go) {
-            if (c.z == 0) go = false;
-            else if (c.x == (uint32_t)K && c.y == (uint32_t)(K >> 32)) { got = c.z; go = false; }
-            else hsh = (hsh + 1) & smask;
-          }
-        }
-        sres[h] = got;
+      asm volatile("" : "+v"(ib));
+      const bool room = ib <= icap && n_c <= icap - ib;
+      if (crowded && room) {
+        uint32_t* it = itb + 8 * ((size_t)ib + below(wballot(crowded)));
+        it[0] = G0; it[1] = G1; it[2] = G2; it[3] = (uint32_t)jmin | ((uint32_t)jmax << 8);
+        it[4] = cg;                        // (the group in front of this one: read from the group's first item)
       }
-      __builtin_amdgcn_wave_barrier();
-      tally2(sres[0], sres[1], acc, n_ent, overflow, total, lane);
+      // no work area, or no room in it: the read is recounted by the dense path
+      cg = __builtin_amdgcn_readfirstlane(room ? (ib | ((n_c - 1u) << 27)) : MIC_CG_DENSE);
     }
   };
-  auto finish = [&](const RowAcc& acc, uint32_t n_ent, uint32_t total, uint32_t overflow, uint32_t r) __attribute__((always_inline)) {
+  // end of a read: best / second and the result row - or, for a read with crowded runs, its row so far into the work area
+  auto finish = [&](const RowAcc& acc, uint32_t n_ent, uint32_t total, uint32_t overflow, uint32_t r, const uint32_t cg) __attribute__((always_inline)) {
     uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
     const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+    if (__builtin_expect(cg != MIC_CG_NONE, 0)) {
+      if (cg != MIC_CG_DENSE) {          // (vector registers throughout, as in the block above)
+        uint64_t kpv = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+v"(kpv));
+        const MicQueryArgs* kv = (const MicQueryArgs*)kpv;
+        uint32_t* cw = kv->crowd;
+        uint32_t* pool = kv->crowd_pool;
+        const uint32_t pcap = kv->crowd_pend_cap, wcap = kv->crowd_pool_cap;
+        uint32_t p = 0, off = 0;
+        if (lane == 0) { p = atomicAdd(&cw[0], 1u); off = atomicAdd(&cw[2], 2u * n_ent); }
+        p = __builtin_amdgcn_readfirstlane(p); off = __builtin_amdgcn_readfirstlane(off);
+        asm volatile("" : "+v"(p), "+v"(off));
+        const bool room = off <= wcap && 2u * n_ent <= wcap - off;
+        if (p < pcap) {
+          uint32_t* pd = cw + MIC_CROWD_HDR + 8 * (size_t)p;
+          if (lane == 0) { pd[0] = r; pd[1] = total; pd[2] = room ? (n_ent | (overflow << 8)) : 0xFFFFFFFFu; pd[3] = off; pd[4] = cg; }
+          if (room && (uint32_t)lane < n_ent) { uint32_t* pe_ = pool + (size_t)off + 2 * lane; pe_[0] = acc.label1; pe_[1] = acc.count; }
+        }
+        if (__builtin_amdgcn_readfirstlane((p < pcap && room) ? 1u : 0u)) return;
+        if (lane == 0) atomicAdd(&cw[3], 1u);
+      }
+      overflow = 1;                        // -> flagged: the dense path recounts the read, side table and all
+    }
     struct { uint32_t* results; uint32_t* rows; uint32_t* flagged; uint32_t row_words, flagged_cap; } fa;
     fa.results = kc->results; fa.rows = kc->rows; fa.flagged = kc->flagged; fa.row_words = kc->row_words; fa.flagged_cap = kc->flagged_cap;
     finish_read(acc, n_ent, total, overflow, r, fa, lane);
@@ -1464,73 +1493,83 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
   // One step = one read taken up (N) and the read before it finished (P: its slots are on their way).  The loop below calls it
   // with the two sets of registers in alternating roles: no copy of the run lanes' state from "next" to "pending".
   uint32_t r = wave0; bool p_valid = false;
-  auto step = [&](Round& P, uint32_t& p_wd, Round& N, uint32_t& n_wd) __attribute__((always_inline)) -> bool {
+  auto step = [&](Round& P, Round& N) __attribute__((always_inline)) -> bool {
     const bool have = r < a.n_reads;
     uint32_t pp = cur_pp;
     const uint32_t pe = cur_pe;
-    bool simple = false;
-    uint32_t n_nrun = 0;
+    // A read that is ONE part of at most 128 k-mers in the packer's format (its part ends where the read ends, or a 0 follows -
+    // the device packer's reservations, the generator's pitch; the header behind the part sits in the read-ahead entry for reads
+    // of up to ~170 nucleotides): no part loop, no chunk loop, the window out of the read-ahead entry.  The scalar unit (one
+    // per CU) is what the kernel is short of, and the loops' bookkeeping is scalar work a 150-bp read does not need.
+    bool shape = false, simple = false;
+    uint32_t n_nrun = 0, plen0 = 0, pp1 = 0;
     if (have) {
-      // A read that is ONE part of at most 128 k-mers (its part ends where the read ends, or a 0 follows): the pipelined road
-      const uint32_t plen0 = cur_hdr, pp1 = pp + 1 + (plen0 + 7) / 8;
-      simple = plen0 - (uint32_t)k < 128u && pp1 == pe;
-      if (!simple && plen0 - (uint32_t)k < 128u && pp1 < pe) {
+      plen0 = cur_hdr; pp1 = pp + 1 + (plen0 + 7) / 8;
+      shape = plen0 - (uint32_t)k < 128u && pp1 == pe;       // (k <= plen0 < k + 128 by the unsigned wrap; pp1 == pe implies pp < pe)
+      if (!shape && plen0 - (uint32_t)k < 128u && pp1 < pe) {
         const uint32_t rel = pp1 - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);
         if (rel < 24u) {
           const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
-          simple = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu) == 0;
+          shape = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu) == 0;
         }
       }
-      if (simple) {
+      if (PIPE && shape) {                                    // ... and at most one round of runs: the pipelined road
+        uint32_t n_wd;
         const uint32_t R = front(pp + 1, pp1, 0u, plen0 - (uint32_t)k + 1u, true, n_wd);
-        if (R <= MIC_RMAX) setup(n_wd, 0u, R, N, n_nrun);
-        else simple = false;                                  // more runs than one round holds: the general road below
+        if (R <= MIC_RMAX) { setup(n_wd, 0u, R, N, n_nrun); simple = true; }
       }
     }
     // the earlier read: its slots have had the front half above to arrive
-    if (p_valid) {
+    if (PIPE && p_valid) {
       RowAcc acc; acc.label1 = 0; acc.count = 0;
-      uint32_t n_ent = 0, overflow = 0, total = 0;
-      consume(P, p_wd, acc, n_ent, overflow, total);
-      finish(acc, n_ent, total, overflow, r - n_waves);      // (a pending read is the one before this one)
+      uint32_t n_ent = 0, overflow = 0, total = 0, cg = MIC_CG_NONE;
+      consume(P, acc, n_ent, overflow, total, cg);
+      finish(acc, n_ent, total, overflow, r - n_waves, cg);  // (a pending read is the one before this one)
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the read-ahead entry taken below)
     }
     if (!have) return false;
     if (!simple) {
       RowAcc acc; acc.label1 = 0; acc.count = 0;
-      uint32_t n_ent = 0, overflow = 0, total = 0;
-      bool first_part = true;
-      while (pp < pe) {
-        uint32_t plen;
-        {
-          const uint32_t rel = pp - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);    // u16 offset inside the entry
-          if (first_part) plen = cur_hdr;
-          else if (rel < 24u) {
-            const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
-            plen = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu);
-          } else plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
+      uint32_t n_ent = 0, overflow = 0, total = 0, cg = MIC_CG_NONE;
+      auto chunk = [&](const uint32_t first, const uint32_t cend, const uint32_t base, const uint32_t nk, const bool use_ahead) __attribute__((always_inline)) {
+        uint32_t wd;
+        const uint32_t R = front(first, cend, base, nk, use_ahead, wd);
+        for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
+          Round L; uint32_t nrun;
+          setup(wd, rbase, R, L, nrun);
+          issue(L.cur, nrun);
+          consume(L, acc, n_ent, overflow, total, cg);
         }
-        const bool ahead_ok = first_part;
-        first_part = false;
-        if (plen == 0) break;
-        const uint32_t first = pp + 1;
-        pp = first + (plen + 7) / 8;
-        if (plen < (uint32_t)k) continue;
-        const uint32_t nk = plen - k + 1;
-        const uint32_t cend = pp;
-        for (uint32_t base = 0; base < nk; base += 128) {
-          uint32_t wd;
-          const uint32_t R = front(first, cend, base, nk, ahead_ok && base == 0, wd);
-          for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
-            Round L; uint32_t nrun;
-            setup(wd, rbase, R, L, nrun);
-            issue(L.cur, nrun);
-            consume(L, wd, acc, n_ent, overflow, total);
+      };
+      // (the straight line only where it is the common road: next to the pipelined road it would be a third copy of the back half)
+      if (!PIPE && shape) chunk(pp + 1, pp1, 0u, plen0 - (uint32_t)k + 1u, true);
+      else {
+        bool first_part = true;
+        while (pp < pe) {
+          // the header of a later part - for nearly every read the 0 that ends it - is among the 24 containers of the read-ahead
+          // entry more often than not: an LDS read instead of a global load the whole wave waits for
+          uint32_t plen;
+          {
+            const uint32_t rel = pp - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);    // u16 offset inside the entry
+            if (first_part) plen = cur_hdr;
+            else if (rel < 24u) {
+              const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
+              plen = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu);
+            } else plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
           }
+          const bool ahead_ok = first_part;
+          first_part = false;
+          if (plen == 0) break;
+          const uint32_t first = pp + 1;
+          pp = first + (plen + 7) / 8;
+          if (plen < (uint32_t)k) continue;
+          const uint32_t nk = plen - k + 1;
+          const uint32_t cend = pp;
+          for (uint32_t base = 0; base < nk; base += 128) chunk(first, cend, base, nk, ahead_ok && base == 0);
         }
       }
-      finish(acc, n_ent, total, overflow, r);
+      finish(acc, n_ent, total, overflow, r, cg);
     }
     uint32_t t_hdr, t_pp, t_pe;
     __builtin_amdgcn_wave_barrier();
@@ -1544,299 +1583,66 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     r += n_waves;
     return true;
   };
-  Round Ra, Rb; uint32_t wa = 0, wb = 0;
-  while (step(Ra, wa, Rb, wb) && step(Rb, wb, Ra, wa)) {}
-  } else {
-  for (uint32_t r = wave0; r < a.n_reads; r += n_waves) {
-    uint32_t pp = cur_pp;
-    const uint32_t pe = cur_pe;
+  Round Ra, Rb;
+  while (step(Ra, Rb) && step(Rb, Ra)) {}
+}
+
+// ---- crowded runs: the follow-up of query_kernel_r ---------------------------------------------------------------------------------
+// One wavefront per read that met a crowded minimizer (the pending list of the work area): its row so far comes back into
+// registers (lane i = entry i), its crowded runs are probed in the side table four at a time - 16 lanes per run, one lane per
+// k-mer: the k-mer with its minimizer at position j is the region's nucleotides [ctx - j, ctx - j + k), oriented as the table
+// stores it - the hits are tallied into the row and the read is finished exactly as query_kernel_r finishes the others
+// (best / second: CuClarkDB.cu:1440-1459).  Every k-mer occurrence is counted once: the run's k-mers are in the side table
+// or nowhere (s_crowd_move_kernel takes ALL entries of a crowded minimizer out of the chains).
+__global__ void __launch_bounds__(256) crowd_finish_kernel(const MicQueryArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = gridDim.x * 4;
+  const uint32_t* __restrict__ cw = a.crowd;
+  const uint32_t pcap = a.crowd_pend_cap;
+  uint32_t np = cw[0];
+  np = np < pcap ? np : pcap;
+  const uint32_t* __restrict__ pend = cw + MIC_CROWD_HDR;
+  const uint32_t* __restrict__ items = a.crowd_items;
+  const uint32_t* __restrict__ pool = a.crowd_pool;
+  const uint4* __restrict__ side = a.t.side;
+  const uint32_t smask = a.t.side_mask;
+  const int k = a.t.k, ctx = k - a.t.m;
+  for (uint32_t p = wave0; p < np; p += n_waves) {
+    const uint4 h = *(const uint4*)(pend + 8 * (size_t)p);
+    const uint32_t r = __builtin_amdgcn_readfirstlane(h.x), meta = __builtin_amdgcn_readfirstlane(h.z), off = __builtin_amdgcn_readfirstlane(h.w);
+    uint32_t total = __builtin_amdgcn_readfirstlane(h.y);
+    uint32_t g = __builtin_amdgcn_readfirstlane(pend[8 * (size_t)p + 4]);
+    if (meta == 0xFFFFFFFFu) continue;                       // (no room for its row: the main kernel sent the read to the dense path)
+    uint32_t n_ent = meta & 0xFFu, overflow = (meta >> 8) & 1u;
     RowAcc acc; acc.label1 = 0; acc.count = 0;
-    uint32_t n_ent = 0, overflow = 0, total = 0;
-    // one chunk of one part: front half, runs, rounds (inlined twice: the straight line of a one-part, one-chunk read and the
-    // general loops)
-    auto chunk = [&](const uint32_t first, const uint32_t cend, const uint32_t base, const uint32_t nk, const bool use_ahead) __attribute__((always_inline)) {
-        // lane-derived shift counts, positions and lane masks are recomputed per chunk from this opaque copy: kept across
-        // the kernel they cost scalar register pairs the kernel does not have (34 -> 15 spill moves, +4 VALU, -6 SALU per read)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        // The first window of a part comes out of the read-ahead entry AS IT IS: what lies behind the part's last nucleotide
-        // (the next part's header, the next read, lanes 12+ of the entry) is never part of a k-mer that is counted - the active
-        // k-mers end inside the part, the keys of m-mers behind them only reach lanes that are not active, and a run's region is
-        // compared within the run's own k-mers only - so the two compares, two selects and the masks of window_word_w are spared
-        // (8 VALU per read).  Later chunks are loaded container by container and stay bounded by the part's end.
-        const uint32_t wd = use_ahead ? ahead_word(ahead_sel ? ahead0 : ahead1, cur_pp)
-                                      : window_word_w(cont, first, cend, base, ln, false, 0u);
-        // position in the chunk of the sampled m-mer of the k-mers at positions lane and 64 + lane (mod-sampling, mic_device.h)
-        const uint32_t n_act = nk - base < 128u ? nk - base : 128u;
-        const bool past = n_act + (uint32_t)(k - s_tlen(k, m)) >= 129u;   // the last k-mers' windows reach t-mers past position 127
-        uint32_t qa0, qa1;
-        sampled_positions<!FWD>(wd, ln, lane, k, m, past, qa0, qa1);
-        // runs: k-mers next to each other whose sampled m-mer sits at the same position of the chunk (one-strand table: the
-        // strand is that of the m-mer, so a run has one)
-        // k-mers behind the last one of the chunk get a position no m-mer has: the first of them then "leads a run" whose record
-        // is exactly the closing record (first k-mer = n_act) - no compound predicates for the ballots, no extra write
-        qa0 = (uint32_t)lane < n_act ? qa0 : 0xFFu;
-        qa1 = 64u + (uint32_t)lane < n_act ? qa1 : 0xFFu;
-        const uint32_t last0 = __builtin_amdgcn_readlane(qa0, 63);
-        uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)qa0, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 keeps -1
-        uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)last0, (int)qa1, 0x138, 0xF, 0xF, false);
-        const bool f0 = qa0 != p0, f1 = qa1 != p1;
-        const uint64_t b0 = wballot(f0), b1 = wballot(f1);
-        const uint32_t R0 = __popcll(b0), R = R0 + __popcll(b1) - (n_act < 128u ? 1u : 0u);
-        __builtin_amdgcn_wave_barrier();
-        // record: position of the sampled m-mer (8 bits) | first k-mer << 8; the closing record holds n_act
-        if (f0) rec[below(b0)] = (uint16_t)(qa0 | ((uint32_t)lane << 8));
-        if (f1) rec[R0 + below(b1)] = (uint16_t)(qa1 | ((64u + (uint32_t)lane) << 8));
-        if (__builtin_expect(n_act == 128u, 0)) {     // a full chunk has no k-mer behind its last one (reads longer than 157 nt)
-          asm volatile("" ::: "memory");              // (keeps the scalar test a branch of its own)
-          if (ln == 0) rec[R] = (uint16_t)(128u << 8);
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        for (uint32_t rbase = 0; rbase < R; rbase += MIC_RMAX) {
-          const uint32_t nrun = R - rbase < MIC_RMAX ? R - rbase : MIC_RMAX;
-          const bool vr = (uint32_t)lane < nrun;
-          const uint32_t ri = vr ? rbase + (uint32_t)lane : 0u;
-          const uint32_t rc0 = rec[ri], rc1 = rec[ri + 1];
-          const int qa = (int)(rc0 & 255u), i0 = (int)(rc0 >> 8);
-          const int n = (int)(rc1 >> 8) - i0;
-          // the region [qa - ctx, qa + k) of the chunk, left-aligned in three words like the entry's super-k-mer: it starts
-          // off = 1..16 nucleotides into window dword D (off = 16 instead of 0 keeps the alignbit shift below 32)
-          const int s1 = qa - ctx - 1;
-          const int D = s1 >> 4;                                  // -1 (the region starts in front of the chunk) .. 8
-          const uint32_t tsh = 30u - 2u * (uint32_t)(s1 & 15);
-          // ds_bpermute takes its lane from bits 7..2 of the byte address: D = -1 (the region starts in front of the chunk) wraps
-          // to lane 63 by itself, and D + 1 .. D + 3 are the same address plus 4, 8, 12 - no masking, one shift
-          const int a0 = D << 2;
-          const uint32_t W0 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0, (int)wd), W1 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 4, (int)wd),
-                         W2 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 8, (int)wd), W3 = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 12, (int)wd);
-          uint32_t G0 = __builtin_amdgcn_alignbit(W0, W1, tsh), G1 = __builtin_amdgcn_alignbit(W1, W2, tsh), G2 = __builtin_amdgcn_alignbit(W2, W3, tsh);
-          // minimizer value x = nucleotides ctx .. ctx + m - 1 of the region: its low word is one funnel shift of (G0, G1), the
-          // bits above it (m > 16) one bit-field extract of G0 - 64-bit shifts run at half rate
-          // (k > 16: the region's first two words hold bits behind the minimizer; shorter k-mers take the 64-bit form)
-          const uint32_t xsh = (64u - 2u * (uint32_t)k) & 31u;                              // k > 16: 0 .. 30
-          auto region_x = [&](uint32_t A0, uint32_t A1, uint32_t& lo, uint32_t& hi) {
-            if (k > 16) {
-              lo = __builtin_amdgcn_alignbit(A0, A1, xsh) & (m >= 16 ? 0xFFFFFFFFu : (1u << ((2 * m) & 31)) - 1u);
-              hi = m > 16 ? (A0 >> xsh) & ((1u << ((2 * m - 32) & 31)) - 1u) : 0u;
-            } else {
-              const uint64_t x = ((((uint64_t)A0 << 32) | A1) << (2 * ctx)) >> (64 - 2 * m);
-              lo = (uint32_t)x; hi = (uint32_t)(x >> 32);
-            }
-          };
-          uint32_t key, xhi;
-          region_x(G0, G1, key, xhi);
-          bool rev = false;
-          if (!FWD) {
-            // One-strand table: the run is looked up in the strand in which its sampled m-mer is the smaller of itself and its
-            // reverse complement - as the reverse complement of the SAME region (the m-mer sits ctx nucleotides from either
-            // end): reverse the 96 bits, drop the 96 - 2 (k + ctx) bits that were behind the region, swap the two bits of every
-            // nucleotide back, complement - once per run, not twice per k-mer; the m-mer of that region is the reverse complement
-            const uint32_t sh = 96u - 2u * (uint32_t)(k + ctx);                  // 0 .. 31 (the launcher checks)
-            const uint32_t r0 = __builtin_bitreverse32(G2), r1 = __builtin_bitreverse32(G1), r2 = __builtin_bitreverse32(G0);
-            uint32_t q0 = sh ? __builtin_amdgcn_alignbit(r0, r1, 32u - sh) : r0;
-            uint32_t q1 = sh ? __builtin_amdgcn_alignbit(r1, r2, 32u - sh) : r1;
-            uint32_t q2 = r2 << sh;
-            q0 = ~(((q0 >> 1) & 0x55555555u) | ((q0 << 1) & 0xAAAAAAAAu));
-            q1 = ~(((q1 >> 1) & 0x55555555u) | ((q1 << 1) & 0xAAAAAAAAu));
-            q2 = ~(((q2 >> 1) & 0x55555555u) | ((q2 << 1) & 0xAAAAAAAAu));
-            uint32_t kr, hr;
-            region_x(q0, q1, kr, hr);
-            rev = hr < xhi || (hr == xhi && kr < key);
-            G0 = rev ? q0 : G0; G1 = rev ? q1 : G1; G2 = rev ? q2 : G2;
-            key = rev ? kr : key; xhi = rev ? hr : xhi;
-          }
-          // minimizer position inside the run's first / last k-mer; in the reverse complement position j becomes ctx - j
-          const int jmaxf = qa - i0, jminf = jmaxf - n + 1;
-          const int jmax = rev ? ctx - jminf : jmaxf, jmin = rev ? ctx - jmaxf : jminf;
-          uint32_t cur = vr ? sslot_of_x32(key, xhi, (uint32_t)t.n_main) : 0xFFFFFFFFu;
-          bool mine = vr;
-          if (PART) {
-            // Slot-range part of a table-sharded run: a run (one minimizer occurrence -> one slot) belongs to exactly one
-            // part, so the filter is ONE compare per run in front of the slot load; slot indices are global, the table
-            // pointer is the allocation minus the slots in front of this part (mic_engine.hip: fill_table).  The bounds sit in
-            // LDS (the kernel has no scalar registers to spare, and a scalar load here would wait in front of the slot
-            // loads): they arrive with the run records the lane reads anyway.
-            mine = vr && cur - s_part[wv][0] < s_part[wv][1];
-            cur = mine ? cur : 0xFFFFFFFFu;
-          }
-          int remaining = mine ? n : 0;
-          bool crowded = false;                     // SIDE: the run's minimizer is a crowded one (marker entry): its k-mers are in the side table
-          do {
-            uint32_t sidx[MIC_RMAX / 8];
-            // the list of slots to load sits in the stage area itself: it is consumed before the DMA lands.  (Handing the
-            // indices to the DMA lanes by ds_bpermute instead: +8 VALU, +22 SALU per read, slower.)
-            __builtin_amdgcn_wave_barrier();
-            if (ln < MIC_RMAX) ((uint32_t*)stage)[lane] = cur;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = ((const uint32_t*)stage)[8 * i + (lane >> 3)];
-#pragma unroll
-            for (int i = 0; i < MIC_RMAX / 8; ++i) {
-#if !(MIC_EXP & 1)
-              if (8u * i >= nrun) break;
-#endif
-              if (sidx[i] != 0xFFFFFFFFu)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
-                                                 (__attribute__((address_space(3))) void*)(stage + (64 + MIC_R_SKEW) * i), 16, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const bool vl = cur != 0xFFFFFFFFu;
-            const uint32_t* q = (const uint32_t*)(stage + (vl ? staged_at((uint32_t)lane) : 0));
-            // all six sort keys in one LDS round trip (the slot is 16-byte aligned); rank = number of keys below ours
-            const uint4 ka = *(const uint4*)q;
-            const uint2 kb = *(const uint2*)(q + 4);
-            uint32_t e = (ka.x < key) + (ka.y < key) + (ka.z < key) + (ka.w < key) + (kb.x < key) + (kb.y < key);
-            const uint32_t mz = q[30];
-            bool more = vl && e < 6;
-            e = e < 5 ? e : 5;
-            for (;;) {
-              uint32_t e3 = e + (e << 1);
-              asm volatile("" : "+v"(e3));     // (the compiler would turn 3 e into a 64-bit multiply-add of the LDS address: quarter rate)
-              uint32_t g = q[e], S0 = q[6 + e3], S1 = q[7 + e3], S2 = q[8 + e3], pl = q[24 + e];
-              asm volatile("" : "+v"(S2));     // read with the others: the compiler would sink it into the branch below, one more LDS round trip
-              const bool same = more && g == key;
-              const uint32_t d0 = G0 ^ S0, d1 = G1 ^ S1, d2 = G2 ^ S2;
-              // the whole minimizer, not only its low 32 bits: its nucleotides are the low 32 - 2 ctx bits of word 0 and the top
-              // 2 (ctx + m) - 32 bits of word 1 (32-bit operations: the 64-bit form shifts and compares at half rate)
-              const bool mineq = k > 16
-                                     ? ((d0 & ((1u << ((32 - 2 * ctx) & 31)) - 1u)) | (d1 >> xsh)) == 0
-                                     : (((((uint64_t)d0 << 32) | d1) << (2 * ctx)) >> (64 - 2 * m)) == 0;
-              const uint32_t dl = d0 >> (32 - 2 * ctx);                                      // left context, nucleotide ctx-1 in the low bits
-              const uint32_t dr = k > 16 ? __builtin_amdgcn_alignbit(d1, d2, xsh)
-                                              : (uint32_t)((((((uint64_t)d0 << 32) | d1)) << ((2 * k) & 63)) >> 32);   // right context, its first nucleotide on top
-              const int left = __builtin_ctz(dl | (1u << (2 * ctx))) >> 1;                   // equal nucleotides next to the minimizer
-              const int right = __builtin_clz(dr | (1u << (31 - 2 * ctx))) >> 1;
-              const int hi = left < jmax ? left : jmax, lo = ctx - right > jmin ? ctx - right : jmin;
-              const uint32_t range = ((2u << (hi & 31)) - 1u) & (~0u << (lo & 31));         // empty when hi < lo
-              const uint32_t hits = (same && mineq) ? (uint32_t)__popc((pl >> 16) & range) : 0u;
-              if (SIDE && same && mineq && (pl >> 16) == 0) { crowded = true; remaining = 0; }     // the marker: nothing of this minimizer is in the chains
-              // The run's hits are tallied ONCE per round: a lane keeps (label, count) of its run; a second entry with ANOTHER
-              // label (the same minimizer in two targets' genomes, both contexts matching parts of the run) is tallied on the
-              // spot - a wave-uniform branch that is virtually never taken.
-              const uint32_t lab_new = (pl & 0xFFFFu) + 1u;
-              tally_counts(hits ? lab_new : 0u, hits, acc, n_ent, overflow, total, lane);
-              remaining -= (int)hits;
-              more = same && remaining > 0 && e < 5;                        // another entry of the same minimizer?
-              e += more ? 1u : 0u;
-              if (!wballot(more)) break;
-            }
-            // continuation slot (rare): entries are sorted across the chain, so only if this slot's last key is not above ours
-            const bool nx = vl && remaining > 0 && (mz & MIC_S_NEXT);
-            cur = 0xFFFFFFFFu;
-            if (wballot(nx)) { if (nx && q[5] <= key) cur = q[31]; }
-          } while (wballot(cur != 0xFFFFFFFFu));
-          if (SIDE && wballot(crowded)) {
-            // Rare path (a database with microsatellites, a read that overlaps one): the k-mers of the crowded runs are looked
-            // up ONE BY ONE in the side table, keyed by the k-mer as the table stores it (as it reads; the one-strand table: in
-            // the strand of its run).  Two bitmaps over the chunk's 128 k-mers are built in the (idle) stage area: which k-mers,
-            // and which of them are taken as the reverse complement.
-            __builtin_amdgcn_wave_barrier();
-            uint32_t* bm = (uint32_t*)stage;
-            if (ln < 8) bm[lane] = 0u;
-            __builtin_amdgcn_wave_barrier();
-            if (crowded) {
-              for (int bpos = i0; bpos < i0 + n; ++bpos) {
-                atomicOr(&bm[bpos >> 5], 1u << (bpos & 31));
-                if (!FWD && rev) atomicOr(&bm[4 + (bpos >> 5)], 1u << (bpos & 31));
-              }
-            }
-            __builtin_amdgcn_wave_barrier();
-            uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(kp));
-            const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
-            const uint4* __restrict__ side = kc->t.side;
-            const uint32_t smask = kc->t.side_mask;
-            uint32_t sres[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              sres[h] = 0;
-              if (__builtin_amdgcn_readfirstlane(bm[2 * h] | bm[2 * h + 1]) == 0) continue;      // no crowded k-mer in this half of the chunk
-              const uint32_t pos = 64u * h + (uint32_t)lane;
-              bool go = (bm[pos >> 5] >> (pos & 31)) & 1u;
-              const bool rv = !FWD && ((bm[4 + (pos >> 5)] >> (pos & 31)) & 1u);
-              const int idx = 4 * h + (lane >> 4);
-              const uint32_t d0 = bperm(idx, wd), d1 = bperm(idx + 1, wd), d2 = bperm(idx + 2, wd);
-              uint64_t K = kmer_from_dwords(d0, d1, d2, ln & 15, k);
-              if (rv) K = revcomp_bits(K, k);
-              uint32_t hsh = s_side_hash(K, smask), got = 0;
-              while (wballot(go)) {
-                uint4 c = make_uint4(0, 0, 0, 0);
-                if (go) c = load_slot_quarter(side + hsh);
-                if (go) {
-                  if (c.z == 0) go = false;
-                  else if (c.x == (uint32_t)K && c.y == (uint32_t)(K >> 32)) { got = c.z; go = false; }
-                  else hsh = (hsh + 1) & smask;
-                }
-              }
-              sres[h] = got;
-            }
-            __builtin_amdgcn_wave_barrier();
-            tally2(sres[0], sres[1], acc, n_ent, overflow, total, lane);
+    if ((uint32_t)lane < n_ent) { const uint2 e = *(const uint2*)(pool + off + 2 * lane); acc.label1 = e.x; acc.count = e.y; }
+    while (g != MIC_CG_NONE) {
+      const uint32_t ib = g & 0x7FFFFFFu, n_c = (g >> 27) + 1u;
+      g = __builtin_amdgcn_readfirstlane(items[8 * (size_t)ib + 4]);
+      for (uint32_t b = 0; b < n_c; b += 4) {
+        const uint32_t idx = b + ((uint32_t)lane >> 4);
+        const bool valid = idx < n_c;
+        uint4 it = make_uint4(0, 0, 0, 0);
+        if (valid) it = *(const uint4*)(items + 8 * (size_t)(ib + idx));
+        const int jmin = (int)(it.w & 0xFFu), jmax = (int)((it.w >> 8) & 0xFFu);
+        int j = jmin + (lane & 15);
+        bool go = valid && j <= jmax;
+        j = go ? j : jmin;
+        const uint64_t K = s_extract(it.x, it.y, it.z, ctx - j, k);
+        uint32_t hsh = s_side_hash(K, smask), got = 0;
+        while (wballot(go)) {
+          uint4 c = make_uint4(0, 0, 0, 0);
+          if (go) c = load_slot_quarter(side + hsh);
+          if (go) {
+            if (c.z == 0) go = false;
+            else if (c.x == (uint32_t)K && c.y == (uint32_t)(K >> 32)) { got = c.z; go = false; }
+            else hsh = (hsh + 1) & smask;
           }
         }
-    };
-    // A read that is ONE part of at most 128 k-mers in the packer's format (its part ends where the read ends): straight line - no
-    // part loop, no header of a next part, the window out of the read-ahead entry.  The scalar unit (one per CU, ~275 scalar
-    // instructions and branches per read against 240 vector instructions spread over four SIMDs) is what the kernel is short of,
-    // and the loops' bookkeeping is scalar work a 150-bp read does not need.
-    const uint32_t plen0 = cur_hdr, pp1 = pp + 1 + (plen0 + 7) / 8;
-    bool simple = plen0 - (uint32_t)k < 128u && pp1 == pe;      // (k <= plen0 < k + 128 by the unsigned wrap; pp1 == pe implies pp < pe: a read without a k-mer has pp == pe)
-    if (!simple && plen0 - (uint32_t)k < 128u && pp1 < pe) {
-      // terminated formats (the device packer's reservations, the generator's pitch): one part and a 0 behind it is the same
-      // read - the header behind the part sits in the read-ahead entry for reads of up to ~170 nucleotides
-      const uint32_t rel = pp1 - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);
-      if (rel < 24u) {
-        const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
-        simple = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu) == 0;
+        tally2(got, 0u, acc, n_ent, overflow, total, lane);
       }
     }
-    if (simple) {
-      chunk(pp + 1, pp1, 0u, plen0 - (uint32_t)k + 1u, true);
-    } else {
-    bool first_part = true;
-
-    while (pp < pe) {
-      // the header of a later part - for nearly every read the 0 that ends it - is among the 24 containers of the read-ahead
-      // entry more often than not: an LDS read instead of a global load the whole wave waits for
-      uint32_t plen;
-      {
-        const uint32_t rel = pp - cur_pp + (uint32_t)((((uint64_t)(cont + cur_pp)) >> 1) & 1);    // u16 offset inside the entry
-        if (first_part) plen = cur_hdr;
-        else if (rel < 24u) {
-          const uint32_t v = (ahead_sel ? ahead0 : ahead1)[rel >> 1];
-          plen = __builtin_amdgcn_readfirstlane((rel & 1u) ? v >> 16 : v & 0xFFFFu);
-        } else plen = __builtin_amdgcn_readfirstlane((uint32_t)cont[pp]);
-      }
-      const bool ahead_ok = first_part;
-      first_part = false;
-      if (plen == 0) break;
-      const uint32_t first = pp + 1;
-      pp = first + (plen + 7) / 8;
-      if (plen < (uint32_t)k) continue;
-      const uint32_t nk = plen - k + 1;
-      const uint32_t cend = pp;
-      for (uint32_t base = 0; base < nk; base += 128) chunk(first, cend, base, nk, ahead_ok && base == 0);
-    }
-    }
-    uint32_t t_hdr, t_pp, t_pe;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    ahead_take(ahead_sel ? ahead1 : ahead0, n_pp, t_hdr, t_pp, t_pe);
-    __builtin_amdgcn_wave_barrier();
-    {
-      uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
-      asm volatile("" : "+s"(kp));
-      const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
-      struct { uint32_t* results; uint32_t* rows; uint32_t* flagged; uint32_t row_words, flagged_cap; } fa;
-      fa.results = kc->results; fa.rows = kc->rows; fa.flagged = kc->flagged; fa.row_words = kc->row_words; fa.flagged_cap = kc->flagged_cap;
-      finish_read(acc, n_ent, total, overflow, r, fa, lane);
-    }
-    ahead_issue(ahead_sel ? ahead0 : ahead1, t_pp, r + 3 * n_waves);
-    ahead_sel ^= 1;
-    cur_pp = n_pp; cur_pe = n_pe; cur_hdr = t_hdr; n_pp = t_pp; n_pe = t_pe;
-  }
+    finish_read(acc, n_ent, total, overflow, r, a, lane);
   }
 }
 
@@ -2122,8 +1928,19 @@ hipError_t mic_kernels_warm(hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hipStream_t s) {
-  if (a.n_reads == 0) return hipSuccess;
+hipError_t mic_launch_query(const MicQueryArgs& a_in, int slot_class, int n_cu, hipStream_t s) {
+  if (a_in.n_reads == 0) return hipSuccess;
+  MicQueryArgs a = a_in;
+  // test hook: a work area of the crowded runs' follow-up that holds this many pending reads / runs / row words at most, so that
+  // a small parity case overflows it (it can only shrink the capacities: what does not fit takes the dense path)
+  if (a.crowd) if (const char* e = getenv("MIC_CROWD_CAP")) {
+    const long v = atol(e);
+    if (v >= 0) {
+      if ((uint32_t)v < a.crowd_pend_cap) a.crowd_pend_cap = (uint32_t)v;
+      if ((uint32_t)v < a.crowd_item_cap) a.crowd_item_cap = (uint32_t)v;
+      if ((uint32_t)v < a.crowd_pool_cap) a.crowd_pool_cap = (uint32_t)v;
+    }
+  }
   unsigned blocks = (a.n_reads + 3) / 4;
   // Resident blocks per CU are 8; the grid is much larger so that each wave strides over only ~20 reads: reads differ in
   // cost (rounds, parts) and the hardware's block scheduler then evens the waves out.  Measured on the headline
@@ -2142,7 +1959,8 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
   }
   // test hook: a grid of this many blocks, so that a small parity case runs hundreds of reads of every shape through each wavefront
   // (the software-pipelined loop's transitions between its pipelined and its plain road)
-  if (const char* e = getenv("MIC_QUERY_BLOCKS")) { const int v = atoi(e); if (v > 0) blocks = (unsigned)v; }
+  // (it can only shrink the grid: a stray value in a user's environment costs speed, never a launch dimension out of range)
+  if (const char* e = getenv("MIC_QUERY_BLOCKS")) { const int v = atoi(e); if (v > 0 && (unsigned)v < blocks) blocks = (unsigned)v; }
   if (a.t.layout == 2) {
     const unsigned g = (blocks * 4 + MIC_M_WPB - 1) / MIC_M_WPB, b = 64 * MIC_M_WPB;
     static const bool generic = getenv("MIC_S_GENERIC") != nullptr;
@@ -2157,10 +1975,14 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     // realignment is a single funnel shift when the region is longer than 32 nucleotides (always for cuCLARK's k and m)
     const bool run_ok = 2 * a.t.k - a.t.m > 32 && 2 * a.t.k - a.t.m <= 48;
     static const unsigned extra_lds = [] { const char* e = getenv("MIC_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();   // occupancy experiments
-    const bool sd = a.t.side != nullptr;    // crowded minimizers in a side table: the instantiation with the rare per-k-mer path
+    // crowded minimizers in a side table: the per-run kernel hands their runs to crowd_finish_kernel through the work area
+    // (without one such reads take the dense path: exact, slow); the per-k-mer kernel looks them up itself
+    const bool crowd = a.t.side != nullptr && a.crowd != nullptr;
+    bool ran_r = false;
+    if (crowd) { const hipError_t ce = hipMemsetAsync(a.crowd, 0, MIC_CROWD_HDR * 4, s); if (ce != hipSuccess) return ce; }
 #define LAUNCH_R(KK_, MM_, FW_) do { \
-      if (pt) { if (sd) query_kernel_r<KK_, MM_, FW_, true, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, FW_, true, false><<<g, b, extra_lds, s>>>(a); } \
-      else { if (sd) query_kernel_r<KK_, MM_, FW_, false, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, FW_, false, false><<<g, b, extra_lds, s>>>(a); } } while (0)
+      if (pt) query_kernel_r<KK_, MM_, FW_, true><<<g, b, extra_lds, s>>>(a); else query_kernel_r<KK_, MM_, FW_, false><<<g, b, extra_lds, s>>>(a); \
+      ran_r = true; } while (0)
 #define LAUNCH_S(KK_, MM_) do { \
       if (fw && !sh && !per_kmer) LAUNCH_R(KK_, MM_, true); \
       else if (!fw && !sh && !per_kmer && run_ok) LAUNCH_R(KK_, MM_, false); \
@@ -2172,6 +1994,14 @@ hipError_t mic_launch_query(const MicQueryArgs& a, int slot_class, int n_cu, hip
     else LAUNCH_S(0, 0);
 #undef LAUNCH_S
 #undef LAUNCH_R
+    if (ran_r && crowd) {
+      // the number of pending reads is on the device only: a grid for the most there can be, at most two generations of resident
+      // blocks; a launch with nothing to do costs a few microseconds behind the main kernel
+      const unsigned most = a.n_reads < a.crowd_pend_cap ? a.n_reads : a.crowd_pend_cap;
+      unsigned cg = (most + 3) / 4, ccap = (unsigned)n_cu * 16u;
+      if (cg > ccap) cg = ccap;
+      if (cg) crowd_finish_kernel<<<cg, 256, 0, s>>>(a);
+    }
   }
   else if (a.t.layout) {
     {
@@ -2193,12 +2023,11 @@ int mic_query_kernel_name(const MicTable& t, int slot_class, char* buf, size_t c
     const bool pt = t.parted != 0, fw = t.fwd != 0, per_kmer = per_kmer_env();
     const bool run_ok = 2 * t.k - t.m > 32 && 2 * t.k - t.m <= 48;
     const bool sh = t.sharded != 0 || (pt && (per_kmer || (!fw && !run_ok)));
-    const bool sd = t.side != nullptr;
     const bool spec = !generic && t.m == 20 && (t.k == 31 || t.k == 27 || t.k == 32);
     const int kk = spec ? t.k : 0, mm = spec ? t.m : 0;
     const char* b[2] = {"false", "true"};
     if (!sh && !per_kmer && (fw || run_ok))
-      return snprintf(buf, cap, "query_kernel_r<%d, %d, %s, %s, %s>", kk, mm, b[fw], b[pt], b[sd]);
+      return snprintf(buf, cap, "query_kernel_r<%d, %d, %s, %s>", kk, mm, b[fw], b[pt]);
     return snprintf(buf, cap, "query_kernel_s<%d, %d, %s, %s>", kk, mm, b[sh], b[fw]);
   }
   if (t.layout) {

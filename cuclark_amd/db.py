@@ -359,3 +359,9 @@ class MiClarkDB:
         ms = C.c_float(0)
         check(self.L.mic_last_query_ms(self.h, C.byref(ms)))
         return float(ms.value)
+
+    def last_crowd_stats(self):
+        """reads / runs of crowded minimizers the last query_device launch handed to its follow-up kernel"""
+        out = (C.c_uint32 * 4)()
+        check(self.L.mic_last_crowd_stats(self.h, out))
+        return dict(reads=int(out[0]), runs=int(out[1]), row_words=int(out[2]), reads_to_dense_path=int(out[3]))

@@ -245,6 +245,11 @@ int mic_probe_stats_device(mic_engine* e, const uint32_t* d_reads_pointer, const
 /* Duration in ms of the last mic_query_device launch on this engine, measured with HIP events on the
  * stream it ran on (blocks until it finished). */
 int mic_last_query_ms(mic_engine* e, float* ms);
+/* Bookkeeping of the last mic_query_device launch on a super-k-mer table with a side table of crowded minimizers
+ * (microsatellites; see mic_db_info.side_kmers): out = {reads that met a crowded minimizer and were finished by the
+ * follow-up kernel, crowded runs handed to it, words of spilled rows, reads sent to the dense path for lack of room in
+ * the work area}.  All zero for any other table.  Synchronous. */
+int mic_last_crowd_stats(mic_engine* e, uint32_t out[4]);
 
 /* ---- device-side ingest: raw FASTA / FASTQ bytes in, result-CSV text out ----------------------------------------
  * The reference does the read indexing (CuCLARK_hh.hh:1339-1534), the 2-bit packing with its N-splitting

@@ -137,3 +137,70 @@ def test_crowded_minimizers_go_to_the_side_table(layout, monkeypatch):
     assert (hits == expect[:, 0]).all() and abs(side_total - info["side_kmers"]) <= 0.05 * info["side_kmers"]
     fits = acc[:, 0].cpu().numpy() != -1
     assert (results.cpu().numpy().view(np.uint32)[fits, :5] == expect[fits]).all() and fits.mean() > 0.9
+
+
+def _long_reads(rng, seqs, n):
+    """reads of 300 .. 3000 nt stitched from database sequences (several chunks, many rounds, crowded runs in several of them),
+    some with an N in the middle (two parts)"""
+    comp = str.maketrans("ACGT", "TGCA")
+    out = []
+    for i in range(n):
+        s = ""
+        while len(s) < int(rng.integers(300, 3000)):
+            src = seqs[int(rng.integers(0, len(seqs)))]
+            a = int(rng.integers(0, max(1, len(src) - 100)))
+            s += src[a:a + int(rng.integers(50, 160))]
+            if rng.random() < 0.1:
+                s += "N"
+        if i % 3 == 0:
+            s = s[::-1].translate(comp)
+        out.append(f">L{i}\n{s}\n")
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("layout", ["super", "super2"])
+def test_crowded_runs_go_through_the_follow_up_kernel(layout, monkeypatch):
+    """query_kernel_r hands the runs of crowded minimizers to crowd_finish_kernel (work list in HBM): short reads through the
+    pipelined road, long reads (several groups of crowded runs per read), a grid so small that every wavefront takes hundreds of
+    reads, and a work area too small for the batch (what does not fit takes the dense path) - all equal to the oracle."""
+    from cuclark_amd import MiClarkDB, host
+    import torch
+    monkeypatch.setenv("MIC_LAYOUT", layout)
+    rng = np.random.default_rng(43)
+    k, T, htsize = 31, 12, 1 << 18
+    seqs, sizes, keys, labels = _microsatellite_db(rng, k, htsize, T)
+    odb = gu.oracle().db_from_arrays(sizes, keys, labels)
+    dev = torch.device("cuda:0")
+    # (the work area is sized for a few crowded runs per read of a batch: random reads around the microsatellite ones)
+    filler = lambda n: b"".join(b">f%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 150)) + b"\n" for i in range(n))
+    cases = {"short": _reads(rng, seqs, 3000) + filler(30000), "long": _long_reads(rng, seqs, 200) + filler(40000)}
+    with MiClarkDB(k, T, row_words=16) as e:
+        e.read_arrays(sizes, keys, labels)
+        assert e.info()["side_kmers"] > 500
+        for name, data in cases.items():
+            idx = host.index_reads(data)
+            rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+            n = rp.size - 1
+            counts, expect = _oracle_results(odb, k, rp, cont, T)
+            d_rp = torch.from_numpy(rp.view(np.int32)).to(dev)
+            d_ct = torch.from_numpy(np.concatenate([cont, np.zeros(64, np.uint16)]).view(np.int16)).to(dev)
+            for env, val in ((None, None), ("MIC_QUERY_BLOCKS", "2"), ("MIC_CROWD_CAP", "40"), ("MIC_CROWD_CAP", "0")):
+                if env:
+                    monkeypatch.setenv(env, val)
+                d_res = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+                e.query_device(d_rp.data_ptr(), d_ct.data_ptr(), n, d_res.data_ptr())
+                st = e.last_crowd_stats()
+                dense = e.resolve_flagged_device(d_rp.data_ptr(), d_ct.data_ptr(), d_res.data_ptr())
+                res = d_res.cpu().numpy().view(np.uint32)
+                if env:
+                    monkeypatch.delenv(env)
+                assert (res[:, :5] == expect).all(), (name, env, val, int((res[:, :5] != expect).any(axis=1).sum()))
+                if env == "MIC_CROWD_CAP":
+                    assert dense > 0, (name, val, st, dense)
+                    if val == "0":
+                        assert st["reads"] == 0 or st["reads_to_dense_path"] > 0
+                else:
+                    # every read with a crowded run is finished by the follow-up, none by the dense path
+                    assert st["reads"] > 150 and st["runs"] >= st["reads"] and st["reads_to_dense_path"] == 0 and dense == 0, (name, st, dense)
+                    if name == "long":
+                        assert st["runs"] > 3 * st["reads"], st

@@ -130,6 +130,8 @@ def run_case(name, args, L, rng):
         names = [f"T{g}" for g in range(n_genomes)]
         layouts = {}
         for layout_name, layout in (("auto", 0), ("super2", 4), ("super", 3), ("minimizer", 2), ("direct", 1)):
+            if layout_name not in args.layouts.split(","):
+                continue
             with MiClarkDB(k, n_genomes, layout=layout) as e:
                 t0 = time.time()
                 e.read(prefix)
@@ -159,6 +161,7 @@ def run_case(name, args, L, rng):
                 for it in range(6):
                     e.query_device(d_rp.data_ptr(), d_ct.data_ptr(), args.reads, d_res.data_ptr())
                     ms.append(e.last_query_ms())
+                crowd = e.last_crowd_stats()
                 flagged = e.resolve_flagged_device(d_rp.data_ptr(), d_ct.data_ptr(), d_res.data_ptr())
                 st = e.probe_stats_device(d_rp.data_ptr(), d_ct.data_ptr(), args.reads)
                 kern = float(np.median(ms[1:])) / 1e3
@@ -174,15 +177,19 @@ def run_case(name, args, L, rng):
                     "continuation_slot_rate": round(info["n_overflow"] / max(info["n_slots"], 1), 5),
                     "entries": info["n_entries"], "kmers_per_entry": round(info["n_elems"] / max(info["n_entries"], 1), 2),
                     "fullest_chain_entries": info["max_chain"], "mean_continuation_slots_before_a_kmer": info["reserved"] / 1e6, "reads_through_dense_path": flagged, "load_s": round(t_load, 1),
-                    "classified": float((res[:, 0] > 0).mean())}
+                    "classified": float((res[:, 0] > 0).mean()),
+                    "side_table_kmers": info["side_kmers"], "reads_with_crowded_runs": crowd["reads"], "crowded_runs": crowd["runs"],
+                    "kernel_ms_runs": [round(x, 3) for x in ms]}
                 layouts[layout_name]["layout_built"] = {1: "direct", 2: "minimizer", 3: "super", 4: "super2"}[info["layout"]]
                 if layout_name == "auto":
                     ref = res[:, :5].copy()
                 else:
                     layouts[layout_name]["equal_to_auto_layout"] = bool((res[:, :5] == ref).all())
         out["layouts"] = layouts
-        out["auto_over_direct"] = round(layouts["auto"]["Mreads_s"] / layouts["direct"]["Mreads_s"], 2)
-        out["auto_over_best"] = round(layouts["auto"]["Mreads_s"] / max(l["Mreads_s"] for l in layouts.values()), 3)
+        if "direct" in layouts and "auto" in layouts:
+            out["auto_over_direct"] = round(layouts["auto"]["Mreads_s"] / layouts["direct"]["Mreads_s"], 2)
+        if "auto" in layouts:
+            out["auto_over_best"] = round(layouts["auto"]["Mreads_s"] / max(l["Mreads_s"] for l in layouts.values()), 3)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
@@ -195,6 +202,7 @@ def main():
     ap.add_argument("--reads", type=int, default=4_000_000)
     ap.add_argument("--htsize", type=int, default=268435399)
     ap.add_argument("--cases", default="ideal,homology10,homology20_repeats,repeats5,light")
+    ap.add_argument("--layouts", default="auto,super2,super,minimizer,direct", help="'auto' first: the others are compared with it")
     args = ap.parse_args()
     from cuclark_amd import _lib
     L = _lib.load()
