@@ -9,8 +9,8 @@ per-target hit counts + best/second) over one batch of synthetic reads that is a
 Workloads, all synthetic, generated in HBM by libmi_clark.so's generators:
   full   config 3: 10 M x 150 bp reads (80 % sampled from the genomes with 1 % substitutions and 0.1 % N, 20 % random)
          vs. a 36 GB-on-disk-equivalent k=31 table: HTSIZE 1610612741, u32 keys, ~5.7e9 k-mers, 4096 targets,
-         resident as 119 GB of 128-byte super-k-mer slots, both strands stored (--layout super2, the bench's default; the
-         command line's default is the one-strand table, 59 GB: `default_layout` in the JSON line times its kernel too). [default]
+         resident as 59 GB of 128-byte super-k-mer slots, one strand stored (--layout auto: the table exe/cuCLARK builds; the
+         two-strand table - 119 GB, no reverse complement in the query - is timed beside it: `two_strand_table`). [default]
   light27 config 2 proper: the CuCLARK-l table as cuCLARK-l builds it: HTSIZE 57777779, k=27 (forced, main.cc:241-249), u32 keys,
          ~90 M k-mers; 10 M x 150 bp reads.
   light  config 2, k=31 side variant: same reads vs. HTSIZE 57777779, k=31 (u64 keys), ~54 M k-mers (not reachable through the
@@ -80,6 +80,23 @@ WORKLOADS = {
                         keep_ppm=250_000, run_len=8,
                         name="10M x 150bp synthetic reads vs a FRAGMENTED 36GB-scale k=31 table: 25 % of ~5.7e9 candidate k-mers kept in runs of mean length 8 "
                              "(HTSIZE 1610612741, u32 keys, 4096 targets)"),
+    # Genomes that are NOT uniformly random (mic_synth_spec.repeat_ppm / mosaic_ppm):
+    #   full_repeats  2 % of every genome is tandem repeats, the short units shared by all genomes (microsatellites): crowded minimizers,
+    #                 a side table, reads with several times the usual number of runs
+    #   full_homolog  15 % of the 2-kb segments of every genome carry mosaic labels (the label of a k-mer changes every 1 / 2 / 4 / 8
+    #                 positions): ties between best and second, rows of more than 15 and more than 64 targets (the dense path)
+    "full_repeats": dict(htsize=1610612741, genome_nt=5_730_000_000, n_genomes=8192, n_targets=4096, k=31, key_bytes=4, n_reads=10_000_000, read_len=150,
+                         repeat_ppm=20_000,
+                         name="10M x 150bp synthetic reads vs 36GB-scale k=31 table whose genomes are 2 % tandem repeats, short units shared across genomes "
+                              "(HTSIZE 1610612741, u32 keys, 4096 targets) resident in HBM"),
+    "full_homolog": dict(htsize=1610612741, genome_nt=5_730_000_000, n_genomes=8192, n_targets=4096, k=31, key_bytes=4, n_reads=10_000_000, read_len=150,
+                         mosaic_ppm=150_000,
+                         name="10M x 150bp synthetic reads vs 36GB-scale k=31 table with 15 % of every genome in segments of mosaic labels "
+                              "(HTSIZE 1610612741, u32 keys, 4096 targets) resident in HBM"),
+    "tiny_repeats": dict(htsize=999983, genome_nt=3_000_000, n_genomes=64, n_targets=50, k=31, key_bytes=8, n_reads=100_000, read_len=100, repeat_ppm=50_000,
+                         name="100k x 100bp synthetic reads vs a 50-target toy table with 5 % tandem repeats (plumbing)"),
+    "tiny_homolog": dict(htsize=9999991, genome_nt=8_000_000, n_genomes=1000, n_targets=1000, k=31, key_bytes=8, n_reads=100_000, read_len=150, mosaic_ppm=150_000,
+                         name="100k x 150bp synthetic reads vs a 1000-target toy table with 15 % mosaic-label segments (plumbing)"),
     "tiny_frag": dict(htsize=999983, genome_nt=1_500_000, n_genomes=64, n_targets=50, k=31, key_bytes=8, n_reads=100_000, read_len=100, keep_ppm=500_000, run_len=8,
                       name="100k x 100bp synthetic reads vs a fragmented 50-target toy table (plumbing)"),
     "tiny_paired": dict(htsize=999983, genome_nt=1_500_000, n_genomes=64, n_targets=50, k=31, key_bytes=8,
@@ -93,6 +110,7 @@ PART_MODE = {1: "table-sharded by on-disk bucket range", 2: "table-sharded by on
              3: "table-sharded by resident slot range (a run of a read belongs to one rank)",
              4: "table-sharded by resident slot range (a run of a read belongs to one rank)"}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CLOCK_HZ = 2.4e9               # MI355X engine clock (MI355X_MICROARCH.md)
 RANDOM_SECTOR_GREQ = 51.4      # measured: random 64-B nontemporal requests/s this chip sustains (tools/gather_runs_bench.hip)
 
 
@@ -316,7 +334,8 @@ def multi_engine_leg(base_cmd, res_one, tmp, paired_gz=None, only=None):
     return out
 
 
-def end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res_expect, truth, threads, keep=False, paired=False, reps=3, multi=True, multi_reads=0, multi_only=None):
+def end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res_expect, truth, threads, keep=False, paired=False, reps=3, multi=True, multi_reads=0, multi_only=None,
+                   leg_allowed=lambda name, est: True, partial=None, current_leg=None):
     """files in, file out, through exe/cuCLARK (reference: CuCLARK_hh.hh:550-563 times index + pack +
     GPU + CSV and prints objects/min, :1938-1944).  The table goes to disk in the reference's format, the same reads as
     FASTQ; the binary loads the table, classifies, writes the CSV.  Checked: every CSV line against the kernel's result
@@ -416,6 +435,9 @@ def end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res_expect, trut
                "kernel": first.get("kernel"),
                "command": "exe/cuCLARK -k %d -T targets.txt -D DB/ %s -R out -n %d" % (k, "-P reads_1.fq reads_2.fq" if paired else "-O reads_1.fq", threads),
                "csv_lines_equal_kernel_rows": bool(ok and lines == n_reads), "setup_files_s": round(t_files, 1)}
+        if partial is not None:
+            partial["end_to_end"] = out          # (the sub-legs below add to it: what is there when the time budget cuts the run short)
+        full_scale = n_reads >= 5_000_000
         # ---- what bounds the run: every stage's busy share (thread-seconds / threads / assignment time, the median run's) and - plain FASTQ -
         # the loaders ALONE on the same file with the same thread count and chunk size, no device work (exe/cuCLARK --strip-fastq ...
         # loaders: pread of 256 KiB into a stage that stays in L2, AVX2 strip into a slot-sized buffer; tools/loader_rate.sh)
@@ -443,7 +465,9 @@ def end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res_expect, trut
                 bound += (f": {out['loaders_in_run_GBs']} GB/s of input in the run against {out['loaders_alone_GBs']} GB/s for the same {th['load']} loader threads "
                           f"with nothing else running ({out['loaders_in_run_vs_alone']:.2f} x)")
             out["bound"] = bound
-        if multi and not paired:
+        if multi and not paired and leg_allowed("end_to_end.multi_engine", 110 if full_scale else 40):
+            if current_leg is not None:
+                current_leg[0] = "end_to_end.multi_engine"
             me_cmd, me_ref, me_n = cmd, res_base, n_reads
             if 0 < multi_reads < n_reads:
                 # (tests: the same legs on the first multi_reads reads of the file, with a one-engine run of their own to compare against)
@@ -482,8 +506,13 @@ def end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res_expect, trut
             out["multi_engine"] = multi_engine_leg(me_cmd, me_ref, tmp, pgz, only=multi_only)
             out["multi_engine"]["reads"] = me_n
         if paired:
-            out["gzip_input"] = gzip_sub_leg(cmd, fqs, rec, min(n_reads, 1_000_000), res_base, tmp)
-        elif not os.environ.get("MIC_BENCH_NO_FASTA"):
+            if leg_allowed("end_to_end.gzip_input", 40 if full_scale else 15):
+                if current_leg is not None:
+                    current_leg[0] = "end_to_end.gzip_input"
+                out["gzip_input"] = gzip_sub_leg(cmd, fqs, rec, min(n_reads, 1_000_000), res_base, tmp)
+        elif not os.environ.get("MIC_BENCH_NO_FASTA") and leg_allowed("end_to_end.fasta_input", 20 if full_scale else 8):
+            if current_leg is not None:
+                current_leg[0] = "end_to_end.fasta_input"
             # the same reads as FASTA (header + sequence, no quality lines: 163 instead of 316 bytes per record): the run is bound by
             # the rate at which the loaders take the file out of the page cache, so half the bytes are nearly twice the reads per second
             text = np.fromfile(fqs[0], np.uint8).reshape(n_reads, rec)
@@ -568,15 +597,23 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the row exchange through host memory (validation on a box with fewer GPUs than ranks)")
-    ap.add_argument("--layout", default="super2", choices=["auto", "direct", "minimizer", "super", "super2"],
-                    help="resident table layout (DESIGN.md 3): super2 = super-k-mer slots with both strands stored, the fastest query "
-                         "kernel at twice the table (150 GB for the headline); falls back to super when it does not fit. "
-                         "The command line's default (auto) is super: half the load time, and it is host-bound anyway")
+    ap.add_argument("--layout", default="auto", choices=["auto", "direct", "minimizer", "super", "super2"],
+                    help="resident table layout (DESIGN.md 3).  auto (default) = what exe/cuCLARK builds: super-k-mer slots, one strand "
+                         "(k >= 24).  super2 = both strands stored: the fastest query kernel at twice the table and 2 s more build "
+                         "(timed beside the headline as `two_strand_table`); falls back to super when it does not fit")
+    ap.add_argument("--time-budget", type=float, default=420.0,
+                    help="seconds from the start of this process after which no further extra leg (pipeline, table_sharded_proxy, "
+                         "two_strand_table, cross_layouts, end_to_end and its sub-legs) is STARTED; the line names them in \"skipped_legs\". "
+                         "A leg still running 90 s past the budget is abandoned and the line is printed without it")
+    ap.add_argument("--cross-layouts", default="",
+                    help="N=1: comma-separated layouts whose result rows (all reads) are compared with the headline table's, each in a "
+                         "process of its own (e.g. super2,direct): `cross_layouts` in the line")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the batch-API pipeline leg (N=1)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-in, CSV-out leg through exe/cuCLARK (N=1)")
     ap.add_argument("--e2e-threads", type=int, default=12, help="-n of the end-to-end run")
     ap.add_argument("--e2e-reps", type=int, default=3, help="runs of the end-to-end command; the leg reports their median, min and max")
-    ap.add_argument("--multi-engine-reads", type=int, default=0, help="end_to_end.multi_engine on the first N reads of the file only (tests)")
+    ap.add_argument("--multi-engine-reads", type=int, default=2_000_000,
+                    help="end_to_end.multi_engine runs on the first N reads of the file (0: all of them - 8 more runs of the command at full size)")
     ap.add_argument("--multi-engine-runs", default="", help="comma-separated subset of end_to_end.multi_engine's runs (tests); default: all")
     ap.add_argument("--no-multi-engine", action="store_true",
                     help="N=1: skip end_to_end.multi_engine (exe/cuCLARK's multi-device modes with 2 / 4 / 8 engines on this GPU, CSVs against the one-engine run)")
@@ -589,7 +626,8 @@ def main():
                          "the instantiation one rank of a table-sharded run executes; results are partial, the checks that need the whole table are skipped")
     ap.add_argument("--no-parts-proxy", action="store_true",
                     help="N=1: skip \"table_sharded_proxy\" (kernel time of part 0 of 2/4/8 of the table against all reads)")
-    ap.add_argument("--no-default-layout", action="store_true", help="N=1: skip the kernel leg on the engine's default (one-strand) table")
+    ap.add_argument("--no-default-layout", "--no-two-strand", dest="no_default_layout", action="store_true",
+                    help="N=1: skip the kernel leg on the two-strand table (`two_strand_table`)")
     ap.add_argument("--allow-variant-lib", action="store_true",
                     help="accept MIC_LIB_PATH (a measuring build of the library, tools/*_sweep.sh); refused otherwise: the line must "
                          "describe the product library")
@@ -600,6 +638,16 @@ def main():
     ap.add_argument("--no-db-leg", action="store_true",
                     help="N > 1, read mode: skip the extra table-sharded measurement reported as \"table_sharded\"")
     args = ap.parse_args()
+    t_main0 = time.time()
+    skipped_legs, cut_off_legs = [], []
+
+    def leg_allowed(name, est_s):
+        """extra legs are started only while they are expected to end inside the time budget"""
+        if time.time() - t_main0 + est_s <= args.time_budget:
+            return True
+        skipped_legs.append(name)
+        log(f"bench.py: leg '{name}' skipped: {time.time() - t_main0:.0f} s gone, ~{est_s:.0f} s needed, budget {args.time_budget:.0f} s")
+        return False
 
     if os.environ.get("MIC_LIB_PATH") and not args.allow_variant_lib:
         sys.exit("bench.py: MIC_LIB_PATH is set (a measuring build of the library); unset it or pass --allow-variant-lib")
@@ -665,7 +713,8 @@ def main():
 
     # ---- synthetic table in the on-disk layout (.sz/.ky/.lb images), in HBM
     spec = _lib.MicSynthSpec(seed=4, htsize=w["htsize"], genome_nt=w["genome_nt"], n_targets=T, n_genomes=w["n_genomes"], k=k,
-                             key_bytes=w["key_bytes"], keep_ppm=w.get("keep_ppm", 0), run_len=w.get("run_len", 0))
+                             key_bytes=w["key_bytes"], keep_ppm=w.get("keep_ppm", 0), run_len=w.get("run_len", 0),
+                             repeat_ppm=w.get("repeat_ppm", 0), mosaic_ppm=w.get("mosaic_ppm", 0))
     cap = int(w["genome_nt"]) + 1024
     d_sizes = torch.empty(w["htsize"], dtype=torch.uint8, device=dev)
     d_keys = torch.empty(cap, dtype=torch.int32 if w["key_bytes"] == 4 else torch.int64, device=dev)
@@ -747,6 +796,7 @@ def main():
     generate_reads(read_seed)
     d_res = torch.zeros((n_reads, 8), dtype=torch.int32, device=dev)
     n_flagged = [0]
+    n_cu_bench = torch.cuda.get_device_properties(dev).multi_processor_count
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
 
@@ -840,6 +890,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    crowd_stats = eng.last_crowd_stats() if not db_mode else None
     ms_per_step = elapsed / args.steps * 1e3
     total_reads = n_reads * (world if args.mode == "read" else 1)
     value = total_reads / (elapsed / args.steps) / 1e6
@@ -860,6 +911,7 @@ def main():
     # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, tools/profile_bench.sh); the
     # counters cannot be read from inside this process, so the committed summary of the same workload is used.
     traffic, traffic_src, rdreq, traffic_note = None, None, None, None
+    issue = None       # instruction counters of the committed profile of this very instantiation (they do not depend on the box's clock)
     import glob
     kname = {1: "query_kernel<", 2: "query_kernel_m<", 3: "query_kernel_s<", 4: "query_kernel_s<"}[info["layout"]]
     if info["layout"] in (3, 4):      # the instantiation the launcher picks (mic_kernels.hip: mic_launch_query)
@@ -868,8 +920,7 @@ def main():
         two = info["layout"] == 4
         kname = f"query_kernel_s<{km[0]}, {km[1]}, {'true' if parted else 'false'}, {'true' if two else 'false'}>"
         if not os.environ.get("MIC_S_PER_KMER") and (two or 32 < 2 * k - info["minimizer_len"] <= 48):
-            kname = (f"query_kernel_r<{km[0]}, {km[1]}, {'true' if two else 'false'}, {'true' if parted else 'false'}, "
-                     f"{'true' if info['side_kmers'] else 'false'}>")   # super-k-mer tables are probed per run
+            kname = f"query_kernel_r<{km[0]}, {km[1]}, {'true' if two else 'false'}, {'true' if parted else 'false'}>"   # super-k-mer tables are probed per run
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_query_kernel.json")), reverse=True):
         try:
             pj = json.load(open(f))
@@ -883,6 +934,15 @@ def main():
         if kname not in pj.get("kernel", ""):
             traffic_note = f"{os.path.basename(f)} was taken on '{pj.get('kernel', '?')[:60]}', this run timed '{kname}'"
             continue
+        if issue is None and pj.get("pmc_per_launch", {}).get("SQ_INSTS_VALU"):
+            pm, nrl = pj["pmc_per_launch"], float(pj["reads_per_launch"])
+            # a wave64 vector instruction holds its SIMD for 4 cycles, a CU has 4 SIMDs: one vector instruction per CU-cycle at
+            # most; the CU's ONE scalar unit issues one scalar instruction or branch per cycle (MI355X_MICROARCH.md)
+            cu_cycles = n_cu_bench * CLOCK_HZ * kern_s
+            issue = {"source": os.path.basename(f), "valu_per_read": round(pm["SQ_INSTS_VALU"] / nrl, 1), "salu_per_read": round(pm.get("SQ_INSTS_SALU", 0) / nrl, 1),
+                     "branches_per_read": round(pm.get("SQ_INSTS_BRANCH", 0) / nrl, 1), "lds_per_read": round(pm.get("SQ_INSTS_LDS", 0) / nrl, 1),
+                     "valu_issue_frac": round(pm["SQ_INSTS_VALU"] / nrl * q_n / cu_cycles, 3),
+                     "scalar_issue_frac": round((pm.get("SQ_INSTS_SALU", 0) + pm.get("SQ_INSTS_BRANCH", 0) + pm.get("SQ_INSTS_SMEM", 0)) / nrl * q_n / cu_cycles, 3)}
         ev_ms = pj.get("bench_hip_event_ms") or pj.get("rocprof_avg_ms", 0)
         off_self = abs(pj.get("rocprof_avg_ms", 0) / max(ev_ms, 1e-9) - 1)
         off = abs(ev_ms / (kern_s * 1e3) - 1)
@@ -898,6 +958,12 @@ def main():
         traffic_note = None
         break
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # `bound` and `frac` are the contract's figures (bytes of the REFERENCE's layout against the HBM peak).  What the counters
+                # say limits this kernel is instruction issue: `bound_by_counters` and the per-read instruction counts are the progress
+                # meter once `frac` saturates (it passes 1.0 on small tables: the kernel moves fewer bytes than the reference's layout)
+                "bound_by_counters": (None if issue is None else "valu_issue" if issue["valu_issue_frac"] >= issue["scalar_issue_frac"] else "scalar_issue"),
+                "valu_per_read": issue and issue["valu_per_read"], "salu_per_read": issue and issue["salu_per_read"],
+                "valu_issue_frac": issue and issue["valu_issue_frac"], "issue": issue,
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": round(traffic, 1) if traffic else None,
                 # what the counters saw against the same peak: the kernel moves FEWER bytes than the reference's layout would
                 # (~6 k-mers share one 128-byte request), so this is the honest HBM utilisation; `frac` is the contract's figure
@@ -978,104 +1044,24 @@ def main():
                "parity_with_gpu_on_sample": equal}
         assert equal, "GPU results differ from the CPU oracle on the sample"
 
-    # ---- N = 1: the pipeline through the batch API and the end-to-end run through the CLI (SURVEY.md 8d ii, iii) -------
-    pipeline, e2e, proxy, default_layout = None, None, None, None
-    if rank == 0 and world == 1 and not db_mode:
-        if not args.no_pipeline:
-            try:
-                pipeline = pipeline_leg(eng, L, d_rp, d_cont, n_reads, res, max(2, min(args.steps, 5)), PIPE_BATCHES)
-            except Exception as ex:
-                pipeline = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-            log("pipeline:", json.dumps(pipeline))
-        eng.close()
-        torch.cuda.empty_cache()
-
-        def kernel_ms_of(e, reps=3):
-            """HIP-event time of the query kernel of engine e on the bench's reads (mean of reps after one warm-up)"""
-            ms = []
-            for i in range(reps + 1):
-                e.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), 0, sptr)
-                e.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), d_res.data_ptr(), 0, sptr)
-                if i:
-                    ms.append(e.last_query_ms())
-            return float(np.mean(ms))
-        if not args.no_parts_proxy and info["layout"] in (3, 4):
-            # BASELINE config 4 on one GPU: what ONE rank of an N-GPU table-sharded run does - part 0 of N of the table
-            # (mic_db_set_part: a slot range of the resident table), ALL reads.  Per-rank kernel time is what the exchange and
-            # the merges are added to (DESIGN.md 6); hits_share says the part really answers for ~1/N of the k-mers.
-            try:
-                proxy = {"what": "HIP-event time of the query kernel of ONE rank of an N-way table-sharded run (part 0 of N of the table, "
-                                 "all reads), next to the whole table's", "whole_table_ms": round(kern_s * 1e3, 3), "parts": {}}
-                hits_whole = int(res[:, 0].astype(np.int64).sum())
-                for n_parts in (2, 4, 8):
-                    with MiClarkDB(k, T, device=local_rank, row_words=row_words, layout=layout) as ep:
-                        ep.set_part(0, n_parts)
-                        t0 = time.time()
-                        ep.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr())
-                        tb = time.time() - t0
-                        ms = kernel_ms_of(ep)
-                        pi = ep.info()
-                        hits = int(d_res[:, 0].to(torch.int64).sum().item())
-                    proxy["parts"][str(n_parts)] = {"kernel_ms": round(ms, 3), "vs_whole": round(ms / (kern_s * 1e3), 3),
-                                                     "part_hbm_GB": round(pi["hbm_bytes"] / 1e9, 2), "part_build_s": round(tb, 1),
-                                                     "hits_share": round(hits / max(hits_whole, 1), 4)}
-                    torch.cuda.empty_cache()
-            except Exception as ex:
-                proxy = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-            log("table_sharded_proxy:", json.dumps(proxy))
-        if info["layout"] == 4 and not os.environ.get("MIC_LAYOUT") and not args.no_default_layout:
-            # `value` is quoted on the two-strand table; the command line (the end_to_end leg) builds the engine's AUTO layout,
-            # the one-strand table: its kernel on the same reads, so both legs of this line can be read against their own kernel.
-            # Measured in a process of its OWN (this script with --layout super, same seeds: the same table images and reads): a
-            # table allocated in this process right behind the 119 GB one ran the same kernel 9 % slower (5.44 against 4.98 ms -
-            # what the command line, a fresh process, gets is the latter; profiles/r05d_*).  Rows are compared by their digest.
-            try:
-                import subprocess
-                t0 = time.time()
-                cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--layout", "super", "--steps", "5", "--warmup", "2", "--no-cpu",
-                       "--no-pipeline", "--no-e2e", "--no-parts-proxy", "--no-default-layout", "--reads", str(n_reads), "--read-len", str(args.read_len)]
-                if args.pitch_layout:
-                    cmd.append("--pitch-layout")
-                r = subprocess.run(cmd, capture_output=True, text=True)
-                dl = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) if r.returncode == 0 else None
-                if dl is None:
-                    default_layout = {"error": (r.stderr or r.stdout)[-300:]}
-                else:
-                    default_layout = {"layout": "super (one strand)" if dl["config"]["table"]["layout"].startswith("super-k-mer 128-B slots") and
-                                                "both strands" not in dl["config"]["table"]["layout"] else dl["config"]["table"]["layout"],
-                                      "value": dl["value"], "unit": "Mreads/s", "ms_per_step": dl["ms_per_step"], "kernel_ms": dl["roofline"]["kernel_ms"],
-                                      "kernel": dl["roofline"]["kernel"], "roofline_frac": dl["roofline"]["frac"], "hbm_GB": dl["config"]["table"]["hbm_GB"],
-                                      "table_build_stages": dl["config"]["setup_s"]["table_build_stages"],
-                                      "results_equal_headline_table": dl["config"]["results_sha256_16"] == results_digest,
-                                      "measured_in": "a process of its own (bench.py --layout super, same seeds)", "leg_s": round(time.time() - t0, 1)}
-            except Exception as ex:
-                default_layout = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-            log("default_layout:", json.dumps(default_layout))
-            torch.cuda.empty_cache()
-        if not args.no_e2e:
-            try:
-                del d_res, d_cont, d_rp
-                images = [d_sizes, d_keys, d_labels]
-                del d_sizes, d_keys, d_labels
-                torch.cuda.empty_cache()
-                e2e = end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res, truth, args.e2e_threads, paired=paired,
-                                      reps=args.e2e_reps, multi=not args.no_multi_engine, multi_reads=args.multi_engine_reads,
-                                      multi_only=[x for x in args.multi_engine_runs.split(",") if x] or None)
-            except Exception as ex:
-                e2e = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-            log("end_to_end:", json.dumps(e2e))
-
     import threading
     emit_lock = threading.Lock()
     emitted = [False]
+    legs = {}                  # the extra legs' results as they finish (what the line carries if the time budget cuts the run short)
+    current_leg = [None]
 
     def emit(ts):
         """rank 0's ONE line; ts = the table-sharded extra leg's result (N > 1, read mode), or None.  Printed once whoever calls
         first (the main path or the extra leg's deadline): the lock and the flag keep the one-line contract."""
-        with emit_lock:
+        with emit_lock:        # (held until the line is out: whoever comes second waits for the print, then returns)
             if emitted[0]:
                 return
             emitted[0] = True
+            _emit_locked(ts)
+
+    def _emit_locked(ts):
+        pipeline, e2e, proxy = legs.get("pipeline"), legs.get("end_to_end"), legs.get("table_sharded_proxy")
+        two_strand, cross = legs.get("two_strand_table"), legs.get("cross_layouts")
         reads_label = f"{n_reads / 1e6:g}M" + (" per GPU" if world > 1 and args.mode == "read" else "")
         out = {
             "metric": f"Mreads/sec ({reads_label} x {'2x' if paired else ''}{read_len}bp{' pairs' if paired else ''}, k={k})", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
@@ -1095,6 +1081,11 @@ def main():
                                  "hbm_GB": round(info["hbm_bytes"] / 1e9, 2), "overflow_slots": info["n_overflow"],
                                  "max_bucket": info["max_bucket"], "on_disk_equiv_GB": round((info["htsize"] + n_el * (key_b + 2)) / 1e9, 2)},
                        "flagged_reads_dense_path": flagged, "results_sha256_16": results_digest,
+                       "crowded": (None if crowd_stats is None else
+                                   {"side_table_kmers": info["side_kmers"], "reads_with_crowded_runs": crowd_stats["reads"], "crowded_runs": crowd_stats["runs"],
+                                    "reads_to_dense_path_for_lack_of_room": crowd_stats["reads_to_dense_path"],
+                                    "what": "reads that met a crowded minimizer (microsatellites: one minimizer in thousands of contexts, its k-mers in a side "
+                                            "table) are finished by crowd_finish_kernel behind the query kernel, inside the timed step"}),
                        "setup_s": {"synth_db": round(t_gen, 1), "table_build": round(t_build, 1), "table_build_stages": build_stages},
                        "library": lib_id},
             "roofline": roofline, "cpu_baseline": cpu, "known_answer": known,
@@ -1105,11 +1096,148 @@ def main():
             out["end_to_end"] = e2e
         if proxy is not None:
             out["table_sharded_proxy"] = proxy
-        if default_layout is not None:
-            out["default_layout"] = default_layout
+        if two_strand is not None:
+            out["two_strand_table"] = two_strand
+        if cross is not None:
+            out["cross_layouts"] = cross
+        if world == 1 and not db_mode:
+            out["skipped_legs"] = list(skipped_legs)
+            out["cut_off_legs"] = list(cut_off_legs)
+            out["time_budget_s"] = args.time_budget
+            out["wall_s"] = round(time.time() - t_main0, 1)
         if ts is not None:
             out["table_sharded"] = ts
         print(json.dumps(out), flush=True)
+
+    # A leg that is still running 90 s past the time budget (a slow box, a stuck child process) does not take the headline with it:
+    # rank 0 prints the line with the legs finished so far and leaves.
+    def budget_over():
+        if emitted[0]:
+            return
+        if current_leg[0]:
+            cut_off_legs.append(current_leg[0])
+        log(f"bench.py: time budget exceeded by 90 s in leg '{current_leg[0]}': the line is printed without it")
+        emit(None)
+        sys.stdout.flush()
+        os._exit(0)
+    budget_timer = None
+    if rank == 0 and world == 1 and not db_mode:
+        budget_timer = threading.Timer(max(1.0, args.time_budget + 90.0 - (time.time() - t_main0)), budget_over)
+        budget_timer.daemon = True
+        budget_timer.start()
+
+    # ---- N = 1: the pipeline through the batch API and the end-to-end run through the CLI (SURVEY.md 8d ii, iii) -------
+    if rank == 0 and world == 1 and not db_mode:
+        if not args.no_pipeline and leg_allowed("pipeline", 20):
+            current_leg[0] = "pipeline"
+            try:
+                legs["pipeline"] = pipeline_leg(eng, L, d_rp, d_cont, n_reads, res, max(2, min(args.steps, 5)), PIPE_BATCHES)
+            except Exception as ex:
+                legs["pipeline"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            log("pipeline:", json.dumps(legs["pipeline"]))
+        eng.close()
+        torch.cuda.empty_cache()
+
+        def kernel_ms_of(e, reps=3):
+            """HIP-event time of the query kernel of engine e on the bench's reads (mean of reps after one warm-up)"""
+            ms = []
+            for i in range(reps + 1):
+                e.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n_reads, d_res.data_ptr(), 0, sptr)
+                e.resolve_flagged_device(d_rp.data_ptr(), d_cont.data_ptr(), d_res.data_ptr(), 0, sptr)
+                if i:
+                    ms.append(e.last_query_ms())
+            return float(np.mean(ms))
+        full_scale = w["genome_nt"] > 1_000_000_000
+        if not args.no_parts_proxy and info["layout"] in (3, 4) and leg_allowed("table_sharded_proxy", 50 if full_scale else 10):
+            # BASELINE config 4 on one GPU: what ONE rank of an N-GPU table-sharded run does - part 0 of N of the table
+            # (mic_db_set_part: a slot range of the resident table), ALL reads.  Per-rank kernel time is what the exchange and
+            # the merges are added to (DESIGN.md 6); hits_share says the part really answers for ~1/N of the k-mers.
+            current_leg[0] = "table_sharded_proxy"
+            try:
+                proxy = {"what": "HIP-event time of the query kernel of ONE rank of an N-way table-sharded run (part 0 of N of the table, "
+                                 "all reads), next to the whole table's", "whole_table_ms": round(kern_s * 1e3, 3), "parts": {}}
+                hits_whole = int(res[:, 0].astype(np.int64).sum())
+                for n_parts in (2, 4, 8):
+                    with MiClarkDB(k, T, device=local_rank, row_words=row_words, layout=layout) as ep:
+                        ep.set_part(0, n_parts)
+                        t0 = time.time()
+                        ep.read_device(d_sizes.data_ptr(), w["htsize"], d_keys.data_ptr(), w["key_bytes"], d_labels.data_ptr())
+                        tb = time.time() - t0
+                        ms = kernel_ms_of(ep)
+                        pi = ep.info()
+                        hits = int(d_res[:, 0].to(torch.int64).sum().item())
+                    proxy["parts"][str(n_parts)] = {"kernel_ms": round(ms, 3), "vs_whole": round(ms / (kern_s * 1e3), 3),
+                                                     "part_hbm_GB": round(pi["hbm_bytes"] / 1e9, 2), "part_build_s": round(tb, 1),
+                                                     "hits_share": round(hits / max(hits_whole, 1), 4)}
+                    torch.cuda.empty_cache()
+            except Exception as ex:
+                proxy = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            legs["table_sharded_proxy"] = proxy
+            log("table_sharded_proxy:", json.dumps(proxy))
+
+        def other_layout(name, steps=5):
+            """The same workload (same seeds: the same table images and reads) on another resident layout, in a process of its OWN: a
+            table allocated in this process right behind a freed one of 60-120 GB ran the same kernel 9 % slower (profiles/r05d_*).
+            Rows are compared by their digest."""
+            import subprocess
+            t0 = time.time()
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--layout", name, "--steps", str(steps), "--warmup", "2", "--no-cpu",
+                   "--no-pipeline", "--no-e2e", "--no-parts-proxy", "--no-two-strand", "--reads", str(n_reads), "--read-len", str(args.read_len),
+                   "--time-budget", "100000"]
+            if args.pitch_layout:
+                cmd.append("--pitch-layout")
+            r = subprocess.run(cmd, capture_output=True, text=True, env={k_: v for k_, v in os.environ.items() if k_ != "MIC_LAYOUT"})
+            dl = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) if r.returncode == 0 else None
+            if dl is None:
+                return {"error": (r.stderr or r.stdout)[-300:]}
+            return {"layout": dl["config"]["table"]["layout"], "value": dl["value"], "unit": "Mreads/s", "ms_per_step": dl["ms_per_step"],
+                    "kernel_ms": dl["roofline"]["kernel_ms"], "kernel": dl["roofline"]["kernel"], "roofline_frac": dl["roofline"]["frac"],
+                    "hbm_GB": dl["config"]["table"]["hbm_GB"], "table_build_s": dl["config"]["setup_s"]["table_build"],
+                    "table_build_stages": dl["config"]["setup_s"]["table_build_stages"],
+                    "flagged_reads_dense_path": dl["config"]["flagged_reads_dense_path"],
+                    "results_equal_headline_table": dl["config"]["results_sha256_16"] == results_digest,
+                    "measured_in": f"a process of its own (bench.py --layout {name}, same seeds)", "leg_s": round(time.time() - t0, 1)}
+        if info["layout"] == 3 and not os.environ.get("MIC_LAYOUT") and not args.no_default_layout and k >= 24 and \
+                leg_allowed("two_strand_table", 70 if full_scale else 25):
+            # `value` is quoted on the table the command line builds (one strand).  The two-strand table (twice the memory, 2 s more
+            # build, no reverse complement in the query kernel) on the same reads, for whoever has the memory and the reads to repay it
+            current_leg[0] = "two_strand_table"
+            try:
+                legs["two_strand_table"] = other_layout("super2")
+            except Exception as ex:
+                legs["two_strand_table"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            log("two_strand_table:", json.dumps(legs["two_strand_table"]))
+            torch.cuda.empty_cache()
+        if args.cross_layouts:
+            cross = {}
+            for name in [x for x in args.cross_layouts.split(",") if x]:
+                if not leg_allowed("cross_layouts." + name, 90 if full_scale else 25):
+                    continue
+                current_leg[0] = "cross_layouts." + name
+                try:
+                    cross[name] = other_layout(name, steps=2)
+                except Exception as ex:
+                    cross[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+                log("cross_layouts", name + ":", json.dumps(cross[name]))
+            cross["all_equal"] = all(v.get("results_equal_headline_table") is True for v in cross.values()) if cross else None
+            legs["cross_layouts"] = cross
+        if not args.no_e2e and leg_allowed("end_to_end", 150 if full_scale else 40):
+            current_leg[0] = "end_to_end"
+            try:
+                del d_res, d_cont, d_rp
+                images = [d_sizes, d_keys, d_labels]
+                del d_sizes, d_keys, d_labels
+                torch.cuda.empty_cache()
+                legs["end_to_end"] = end_to_end_leg(L, spec, w, images, n_el, n_reads, read_len, res, truth, args.e2e_threads, paired=paired,
+                                                    reps=args.e2e_reps, multi=not args.no_multi_engine, multi_reads=args.multi_engine_reads,
+                                                    multi_only=[x for x in args.multi_engine_runs.split(",") if x] or None,
+                                                    leg_allowed=leg_allowed, partial=legs, current_leg=current_leg)
+            except Exception as ex:
+                legs["end_to_end"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            log("end_to_end:", json.dumps(legs["end_to_end"]))
+        current_leg[0] = None
+        if budget_timer:
+            budget_timer.cancel()
 
     # ---- N > 1, read mode: the reference's own multi-GPU layout as a second, separate measurement --------------------
     # (BASELINE.json configs[3]): the table is re-built as this rank's bucket range, every rank probes the SAME reads,

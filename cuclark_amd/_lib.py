@@ -43,7 +43,8 @@ class MicDbInfo(C.Structure):
 
 class MicSynthSpec(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("htsize", C.c_uint64), ("genome_nt", C.c_uint64), ("n_targets", C.c_uint32),
-                ("n_genomes", C.c_uint32), ("k", C.c_int32), ("key_bytes", C.c_int32), ("keep_ppm", C.c_uint32), ("run_len", C.c_uint32)]
+                ("n_genomes", C.c_uint32), ("k", C.c_int32), ("key_bytes", C.c_int32), ("keep_ppm", C.c_uint32), ("run_len", C.c_uint32),
+                ("repeat_ppm", C.c_uint32), ("mosaic_ppm", C.c_uint32)]
 
 
 class MicIngestResult(C.Structure):

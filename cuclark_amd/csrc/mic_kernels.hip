@@ -1953,7 +1953,10 @@ hipError_t mic_launch_query(const MicQueryArgs& a_in, int slot_class, int n_cu, 
     // Small launches (a CLI batch): a wave pays two dependent loads before its first read, so do not shrink below ~8
     // reads per wave unless that would leave resident block slots empty.
     const unsigned fill = (unsigned)n_cu * 8u;                       // one generation of resident blocks
-    const unsigned by_work = (unsigned)((a.n_reads + 31) / 32);      // 8 reads per wave
+    static const bool grid_dbg = getenv("MIC_GRID_DEBUG") != nullptr;   // measuring runs (tools/small_launch_probe.py): reads per wave from the environment, per call
+    unsigned rpw = 8;
+    if (grid_dbg) if (const char* e = getenv("MIC_READS_PER_WAVE")) { const int v = atoi(e); if (v > 0) rpw = (unsigned)v; }
+    const unsigned by_work = (unsigned)((a.n_reads + 4 * rpw - 1) / (4 * rpw));      // 8 reads per wave
     unsigned want = by_work > fill ? by_work : fill;
     if (blocks > want) blocks = want;
   }

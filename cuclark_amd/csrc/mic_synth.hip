@@ -27,15 +27,93 @@ __host__ __device__ inline uint64_t genome_word(uint64_t seed, uint64_t g, uint6
   return mix64(mix64(seed ^ (g * 0x9E3779B97F4A7C15ULL)) + b * 0xD1B54A32D192ED03ULL);
 }
 
-__host__ __device__ inline uint32_t genome_nt(uint64_t seed, uint64_t g, uint64_t p) {
+// ---- genomes that are not uniformly random (mic_synth_spec.repeat_ppm / mosaic_ppm) ------------------------------------------
+// Still pure functions of (seed, genome, position).  A genome is cut into segments of 2048 nucleotides:
+//   * TANDEM REPEATS: a segment holds a tract with probability repeat_ppm x 2048 / 768 / 1e6 - 256 .. 1279 nucleotides somewhere in
+//     its first 1792, a unit of 2 .. 50 nucleotides repeated.  Units of up to 6 nucleotides come from a pool of 64 per length SHARED
+//     by all genomes (microsatellites: the same unit at hundreds of loci - what makes a minimizer crowded); longer units are the
+//     locus's own.  In the DATABASE a k-mer that lies wholly inside a tract of a shared unit is absent (common to many targets:
+//     HashTableStorage_hh.hh:241-292 removes it; what stays are the k-mers across the tract's ends, each locus's own), and inside a
+//     tract of a private unit only its first occurrence is stored (the reference's table holds a k-mer once);
+//   * MOSAIC segments (probability mosaic_ppm / 1e6): the sequence is the genome's, but the LABEL of the k-mer starting at position
+//     p is a function of (segment, p / run), run 1, 2, 4 or 8 - a stretch where ownership changes every few k-mers, as between
+//     close relatives after the removal of what they share: reads from there hit many targets with small equal counts (ties,
+//     rows of more than 15 / 64 targets).
+struct SynthMods { uint32_t tract_ppm, mosaic_ppm, n_targets; };
+struct SegInfo { bool tract, shared, mosaic; uint32_t t_start, t_len, u, mrun; uint64_t useed, mseed; };
+
+__host__ __device__ inline SegInfo seg_info(uint64_t seed, uint64_t g, uint64_t s, const SynthMods& md) {
+  SegInfo si;
+  const uint64_t h = mix64(mix64(seed ^ 0x7A11D3B5ull) + g * 0x9E3779B97F4A7C15ULL + s * 0xD6E8FEB86659FD93ULL);
+  si.tract = md.tract_ppm && (uint32_t)(h % 1000000ull) < md.tract_ppm;
+  si.t_start = (uint32_t)((h >> 20) & 511u);
+  si.t_len = 256u + (uint32_t)((h >> 29) & 1023u);
+  si.u = 2u + (uint32_t)((h >> 39) % 49u);
+  si.shared = si.u <= 6u;
+  si.useed = si.shared ? mix64(seed ^ (0xC0FFEEull + si.u * 0x100ull + ((h >> 48) & 63u))) : mix64(h ^ 0x51A7ull);
+  const uint64_t h2 = mix64(h + 0x2545F4914F6CDD1Dull);
+  si.mosaic = md.mosaic_ppm && (uint32_t)(h2 % 1000000ull) < md.mosaic_ppm;
+  si.mrun = 1u << ((h2 >> 20) & 3u);
+  si.mseed = mix64(h2 ^ 0x77ull);
+  return si;
+}
+
+__host__ __device__ inline uint32_t unit_nt(uint64_t useed, uint32_t j) {      // nucleotide j of a tract's unit
+  return (uint32_t)(mix64(useed + (j >> 5)) >> (2 * (31 - (j & 31)))) & 3u;
+}
+
+__host__ __device__ inline uint32_t genome_nt_plain(uint64_t seed, uint64_t g, uint64_t p) {
   return (uint32_t)(genome_word(seed, g, p >> 5) >> (2 * (31 - (p & 31)))) & 3u;
 }
 
-__device__ inline uint64_t genome_kmer(uint64_t seed, uint64_t g, uint64_t p, int k) {
+__host__ __device__ inline uint32_t genome_nt(uint64_t seed, uint64_t g, uint64_t p, const SynthMods& md) {
+  if (md.tract_ppm) {
+    const SegInfo si = seg_info(seed, g, p >> 11, md);
+    const uint32_t o = (uint32_t)(p & 2047u);
+    if (si.tract && o - si.t_start < si.t_len) return unit_nt(si.useed, (o - si.t_start) % si.u);
+  }
+  return genome_nt_plain(seed, g, p);
+}
+
+// the k-mer starting at p; *stored = false when the database does not hold it (see above)
+__device__ inline uint64_t genome_kmer(uint64_t seed, uint64_t g, uint64_t p, int k, const SynthMods& md, bool* stored) {
+  *stored = true;
+  if (md.tract_ppm) {
+    const uint64_t s0 = p >> 11, s1 = (p + (uint64_t)k - 1) >> 11;
+    const SegInfo a = seg_info(seed, g, s0, md);
+    const bool t1 = s1 != s0 && seg_info(seed, g, s1, md).tract;
+    if (a.tract || t1) {
+      const uint32_t o = (uint32_t)(p & 2047u);
+      if (a.tract && o >= a.t_start && o + (uint32_t)k <= a.t_start + a.t_len) {      // wholly inside the tract
+        if (a.shared || o - a.t_start >= a.u) *stored = false;
+      }
+      uint64_t x = 0;
+      for (int i = 0; i < k; ++i) x = (x << 2) | genome_nt(seed, g, p + (uint64_t)i, md);
+      return x;
+    }
+  }
   uint64_t w0 = genome_word(seed, g, p >> 5), w1 = genome_word(seed, g, (p >> 5) + 1);
   int s = 2 * (int)(p & 31);
   uint64_t x = s ? ((w0 << s) | (w1 >> (64 - s))) : w0;
   return x >> (64 - 2 * k);
+}
+
+// label of the k-mer starting at p of genome g
+__host__ __device__ inline uint32_t genome_label(uint64_t seed, uint64_t g, uint64_t p, const SynthMods& md) {
+  if (md.mosaic_ppm) {
+    const SegInfo si = seg_info(seed, g, p >> 11, md);
+    if (si.mosaic) return (uint32_t)(mix64(si.mseed + (p & 2047u) / si.mrun) % md.n_targets);
+  }
+  return (uint32_t)(g % md.n_targets);
+}
+
+__host__ inline SynthMods make_mods(const mic_synth_spec* spec) {
+  SynthMods md;
+  const uint64_t q = (uint64_t)spec->repeat_ppm * 2048ull / 768ull;
+  md.tract_ppm = (uint32_t)(q > 1000000ull ? 1000000ull : q);
+  md.mosaic_ppm = spec->mosaic_ppm > 1000000u ? 1000000u : spec->mosaic_ppm;
+  md.n_targets = spec->n_targets;
+  return md;
 }
 
 __device__ inline uint64_t revcomp_bits(uint64_t x, int k) {
@@ -50,6 +128,7 @@ struct SynthDev {
   int k;
   MicDiv div;
   uint32_t keep_ppm, run_len;      // fragmented database: see kept_position
+  SynthMods md;
 };
 
 // A database of DISCRIMINATIVE k-mers holds stretches of a genome's k-mers and lacks others (CLARK removes every k-mer two targets
@@ -68,12 +147,14 @@ __host__ __device__ inline bool kept_position(uint64_t seed, uint64_t g, uint64_
 __device__ inline bool kmer_at(const SynthDev& sp, uint64_t idx, uint64_t& rem, uint64_t& quot, uint32_t& label) {
   uint64_t g = idx / sp.kmers_per_genome, p = idx - g * sp.kmers_per_genome;
   if (!kept_position(sp.seed, g, p, sp.keep_ppm, sp.run_len)) return false;
-  uint64_t km = genome_kmer(sp.seed, g, p, sp.k);
+  bool stored;
+  uint64_t km = genome_kmer(sp.seed, g, p, sp.k, sp.md, &stored);
+  if (!stored) return false;
   uint64_t rc = revcomp_bits(km, sp.k);
   uint64_t c = km < rc ? km : rc;
   quot = mic_div(c, sp.div);
   rem = c - quot * sp.div.d;
-  label = (uint32_t)(g % sp.n_targets);
+  label = genome_label(sp.seed, g, p, sp.md);
   return true;
 }
 
@@ -159,6 +240,7 @@ struct ReadGen {
   int k;
   uint32_t random_thr, sub_thr, n_thr;  // thresholds on a 32-bit uniform
   uint32_t keep_ppm, run_len;           // fragmented database (kept_position): the expected hits count kept windows only
+  SynthMods md;
 };
 
 // One read (or the two reads of a pair), nucleotide by nucleotide; shared by the packed and the text generators so that
@@ -189,7 +271,7 @@ __device__ inline int draw_nt(const ReadGen& rg, const ReadDraw& d, int mate, ui
   else {
     const uint64_t fwd = d.p0 + i, bwd = d.p0 + d.span - 1 - i;
     const bool rc = mate > 0 ? !d.rev : d.rev;
-    nt = genome_nt(rg.seed, d.g, (mate > 0) != d.rev ? bwd : fwd);
+    nt = genome_nt(rg.seed, d.g, (mate > 0) != d.rev ? bwd : fwd, rg.md);
     if (rc) nt = 3u - nt;
     sub = (uint32_t)(hb >> 32) < rg.sub_thr;
     if (sub) nt = (nt + 1 + (uint32_t)((hb >> 8) % 3)) & 3u;
@@ -243,7 +325,16 @@ __global__ void reads_kernel(ReadGen rg, size_t n_reads, int paired, uint32_t* _
     }
   }
   if (w < rg.pitch) out[w] = 0;  // terminator
-  if (truth) { truth[2 * r] = d.rnd ? 0 : (uint32_t)(d.g % rg.n_targets) + 1; truth[2 * r + 1] = expect; }
+  if (truth) {
+    // (no claim about a read that touches a segment with a tandem repeat or with mosaic labels: truth[1] = 0)
+    if (!d.rnd && (rg.md.tract_ppm || rg.md.mosaic_ppm)) {
+      for (uint64_t sg = d.p0 >> 11; sg <= (d.p0 + d.span - 1) >> 11; ++sg) {
+        const SegInfo si = seg_info(rg.seed, d.g, sg, rg.md);
+        if (si.tract || si.mosaic) expect = 0;
+      }
+    }
+    truth[2 * r] = d.rnd ? 0 : (uint32_t)(d.g % rg.n_targets) + 1; truth[2 * r + 1] = expect;
+  }
 }
 
 // The same reads as FASTQ / FASTA text, one record of fixed size per read: "@r<9 digits>\n" SEQ "\n+\n" QUAL "\n"
@@ -303,6 +394,7 @@ int mic_synth_db_device(const mic_synth_spec* spec, uint8_t* d_sizes, void* d_ke
   sp.n_kmers = sp.kmers_per_genome * spec->n_genomes;
   sp.n_genomes = spec->n_genomes; sp.n_targets = spec->n_targets; sp.k = spec->k;
   sp.keep_ppm = spec->keep_ppm; sp.run_len = spec->run_len ? spec->run_len : 8;
+  sp.md = make_mods(spec);
   sp.div = mic_make_div(spec->htsize);
   const uint64_t H = spec->htsize;
   const unsigned n_tiles = (unsigned)((H + STILE - 1) / STILE);
@@ -366,6 +458,7 @@ int mic_synth_reads_device2(const mic_synth_spec* spec, uint64_t read_seed, size
   if (rg.genome_len < (paired ? 2ull : 1ull) * read_len) return MIC_E_INVALID;
   rg.n_genomes = spec->n_genomes; rg.n_targets = spec->n_targets; rg.read_len = read_len; rg.k = spec->k;
   rg.keep_ppm = spec->keep_ppm; rg.run_len = spec->run_len ? spec->run_len : 8;
+  rg.md = make_mods(spec);
   rg.pitch = mic_synth_read_pitch(paired ? 2 * read_len + 1 : read_len, spec->k);
   if ((uint64_t)n_reads * rg.pitch > containers_cap || (uint64_t)n_reads * rg.pitch > 0xFFFFFFF0ull) return MIC_E_NOMEM;
   auto thr = [](double p) { double v = p * 4294967296.0; return v <= 0 ? 0u : (v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v); };
@@ -386,6 +479,7 @@ int mic_synth_reads_text_device(const mic_synth_spec* spec, uint64_t read_seed, 
   if (rg.genome_len < 2ull * read_len) return MIC_E_INVALID;
   rg.n_genomes = spec->n_genomes; rg.n_targets = spec->n_targets; rg.read_len = read_len; rg.k = spec->k;
   rg.keep_ppm = spec->keep_ppm; rg.run_len = spec->run_len ? spec->run_len : 8;
+  rg.md = make_mods(spec);
   rg.pitch = 0;
   if ((uint64_t)n_reads * mic_synth_text_record_bytes(read_len, fasta) > text_cap) return MIC_E_NOMEM;
   auto thr = [](double p) { double v = p * 4294967296.0; return v <= 0 ? 0u : (v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v); };

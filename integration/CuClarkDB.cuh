@@ -121,6 +121,13 @@ template <typename HKMERr> class CuClarkDB {
     }
     return true;
   }
+  // CuClarkDB.cuh:148 - declared by the reference, never defined or called there (results reach the caller through the buffers
+  // malloc lent out): here, for completeness, a copy of the batch's final rows once the batch is done
+  bool getFinalResult(size_t b, RESULTS* finalResult) {
+    if (!finalResult || !waitForBatch(b)) return false;
+    memcpy(finalResult, final_ + index_[b] * finalRowSize_, nreads_[b] * finalRowSize_ * sizeof(RESULTS));
+    return true;
+  }
   bool checkBatch(size_t b) { int d = 1; for (size_t i = 0; i < e_.size() && d; ++i) ck(mic_batch_check(e_[i], b, &d)); return d; }
   void freeBatchMemory() { for (size_t d = 0; d < e_.size(); ++d) mic_batches_free(e_[d]); free(final_); free(full_); final_ = full_ = nullptr; }
 };

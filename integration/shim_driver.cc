@@ -41,6 +41,10 @@ int main(int argc, char** argv) {
   db.queryBatch(0, extended);
   db.waitForBatch(0);
   if (!db.checkBatch(0)) return 4;
+  {  // getFinalResult (CuClarkDB.cuh:148): the same rows as the lent buffer holds
+    std::vector<RESULTS> copy(numReads * finalRowSize);
+    if (!db.getFinalResult(0, copy.data()) || memcmp(copy.data(), fin, copy.size() * sizeof(RESULTS)) != 0) return 5;
+  }
   for (size_t t = 0; t < numReads; ++t)
     printf("%u %u %u %u %u\n", fin[t * finalRowSize], fin[t * finalRowSize + 1], fin[t * finalRowSize + 2],
            fin[t * finalRowSize + 3], fin[t * finalRowSize + 4]);

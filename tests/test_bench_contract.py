@@ -44,6 +44,9 @@ def test_bench_tiny_json_contract():
     assert "error" not in e2e, e2e
     assert e2e["csv_lines_equal_kernel_rows"] is True and e2e["objects"] == d["config"]["reads_per_gpu"]
     assert e2e["ingest"]["batches_through_host_path"] == 0
+    # the headline is the table the command line builds (one strand); the two-strand table is a side leg with equal rows
+    assert "both strands" not in d["config"]["table"]["layout"] and d["two_strand_table"]["results_equal_headline_table"] is True
+    assert d["skipped_legs"] == [] and d["cut_off_legs"] == [] and d["wall_s"] < d["time_budget_s"]
 
 
 def _bench(*args, timeout=1500):
@@ -82,7 +85,7 @@ def test_bench_full_config3():
     assert me["reads"] == 2_000_000 and me["all_csv_equal"] is True, me
     r4 = me["runs"]["db_sharded_2"]
     assert r4["csv_equals_one_engine_run"] is True and r4["ingest"]["batches_through_host_path"] == 0
-    assert "query_kernel_r<31, 20, false, true," in r4["kernel"] and "2 part(s) x 1 read group(s)" in r4["layout"]
+    assert "query_kernel_r<31, 20, false, true>" in r4["kernel"] and "2 part(s) x 1 read group(s)" in r4["layout"]
     assert r4["per_batch"]["exchange_MB"] > 0 and r4["per_batch"]["fanout_MB"] > 0 and r4["per_batch"]["kernel_ms_slowest_engine"] > 0
 
 
@@ -138,7 +141,7 @@ def test_bench_light27_config2_proper():
     for name, run in me["runs"].items():
         assert "error" not in run and run["csv_equals_one_engine_run"] is True, (name, run)
         if name.startswith("db_sharded"):
-            assert run["ingest"]["batches_through_host_path"] == 0 and "query_kernel_r<27, 20, false, true," in run["kernel"], (name, run)
+            assert run["ingest"]["batches_through_host_path"] == 0 and "query_kernel_r<27, 20, false, true>" in run["kernel"], (name, run)
             assert run["per_batch"]["exchange_MB"] > 0, (name, run)
     assert me["runs"]["paired_gzip_read_sharded_2"]["inflated_on"] == "device"
     t = d["config"]["table"]
@@ -281,4 +284,39 @@ def test_bench_fragmented_database_known_answer():
     ka = d["known_answer"]
     assert ka["label_and_count_ok"] == 1.0 and ka["random_reads_no_hit"] == 1.0
     assert 0.3 < d["config"]["table"]["kmers"] / 1_500_000 < 0.7
-    assert d["default_layout"]["results_equal_headline_table"] is True
+    assert d["two_strand_table"]["results_equal_headline_table"] is True
+
+
+@pytest.mark.gpu
+def test_bench_time_budget_skips_legs_and_names_them():
+    """--time-budget: extra legs that would start past it are skipped and named in the line; every headline field is there."""
+    d = _bench("--workload", "tiny", "--steps", "2", "--warmup", "1", "--time-budget", "1")
+    for key in ("metric", "value", "roofline", "cpu_baseline", "known_answer"):
+        assert key in d, key
+    assert d["cpu_baseline"]["parity_with_gpu_on_sample"] is True
+    assert {"pipeline", "table_sharded_proxy", "two_strand_table", "end_to_end"} <= set(d["skipped_legs"]), d["skipped_legs"]
+    assert "pipeline" not in d and "end_to_end" not in d
+
+
+@pytest.mark.gpu
+def test_bench_tandem_repeats_workload():
+    """Genomes with 5 % tandem repeats, the short units shared by all genomes (mic_synth_spec.repeat_ppm): crowded minimizers in a
+    side table, reads through crowd_finish_kernel; oracle parity on the sample, known answer on the reads that touch no repeat,
+    one-strand, two-strand and direct tables equal on every read."""
+    d = _bench("--workload", "tiny_repeats", "--steps", "2", "--warmup", "1", "--no-e2e", "--no-pipeline", "--no-parts-proxy", "--cross-layouts", "direct")
+    assert d["cpu_baseline"]["parity_with_gpu_on_sample"] is True
+    ka = d["known_answer"]
+    assert ka["label_and_count_ok"] == 1.0 and ka["random_reads_no_hit"] == 1.0
+    assert d["config"]["crowded"]["side_table_kmers"] > 0 and d["config"]["crowded"]["reads_with_crowded_runs"] > 0, d["config"]["crowded"]
+    assert d["two_strand_table"]["results_equal_headline_table"] is True and d["cross_layouts"]["all_equal"] is True
+
+
+@pytest.mark.gpu
+def test_bench_mosaic_labels_workload_ties_and_dense_rows():
+    """15 % of every genome in segments whose k-mers' labels change every 1 / 2 / 4 / 8 positions (mic_synth_spec.mosaic_ppm): ties
+    between best and second (lower target wins, CuClarkDB.cu:1445-1457), reads with more than 64 targets (the exact dense recount);
+    oracle parity on the sample, all layouts equal on every read."""
+    d = _bench("--workload", "tiny_homolog", "--steps", "2", "--warmup", "1", "--no-e2e", "--no-pipeline", "--no-parts-proxy", "--cross-layouts", "direct,minimizer")
+    assert d["cpu_baseline"]["parity_with_gpu_on_sample"] is True
+    assert d["known_answer"]["tie_rate"] > 0.01 and d["config"]["flagged_reads_dense_path"] > 0, (d["known_answer"], d["config"]["flagged_reads_dense_path"])
+    assert d["two_strand_table"]["results_equal_headline_table"] is True and d["cross_layouts"]["all_equal"] is True

@@ -300,7 +300,7 @@ def test_db_sharded_cli_matches_golden(tmp_path, engines, parts):
         assert f"on {engines} device(s)" in r.stderr and f"table-sharded: {parts} part(s) x {engines // parts} read group(s)" in r.stderr, r.stderr
         assert "peer access: 1" in r.stderr
         # the per-run kernel's PART instantiation (k = 27, m = 20, one strand, slot-range part)
-        assert "[timing] query kernel: query_kernel_r<27, 20, false, true," in r.stderr, r.stderr
+        assert "[timing] query kernel: query_kernel_r<27, 20, false, true>" in r.stderr, r.stderr
         assert open(out + ".csv", "rb").read() == open(os.path.join(gu.GOLDEN, exp), "rb").read(), exp
         if "--extended" not in flag:      # the streaming path, nothing handed back to the host
             assert re.search(r"device ingest: \d+ batches .* 0 through the host path", r.stderr), r.stderr
