@@ -47,7 +47,7 @@ void Classifier::run_segments(SegmentSource& src, const std::string& results_bas
     for (size_t t = 0; t < names_.size(); ++t) { nm[t] = names_[t].c_str(); cap += names_[t].size() + 2; }
     std::vector<char> hb(cap);
     int w = mic_csv_header(hb.data(), hb.size(), opt_.extended ? 1 : 0, nm.data(), (uint32_t)names_.size());
-    if (w > 0) fwrite(hb.data(), 1, (size_t)w, fout);
+    if (w > 0 && fwrite(hb.data(), 1, (size_t)w, fout) != (size_t)w) { fclose(fout); die("cannot write " + csv + " (disk full?)"); }
   }
   // double buffering: segment i+1 is produced on a side thread while segment i is classified
   Segment cur, nxt;
@@ -68,7 +68,9 @@ void Classifier::run_segments(SegmentSource& src, const std::string& results_bas
     nxt = Segment();
     have = have_next;
   }
-  fclose(fout);
+  // a full disk shows here at the latest (the command line leaves through _exit: nothing later would flush or report it)
+  const bool write_failed = ferror(fout) != 0;
+  if (fclose(fout) != 0 || write_failed) { if (err.empty()) err = "cannot write " + csv + " (disk full?)"; }
   release_batches();
   if (!err.empty()) die(err);
   gettimeofday(&t1, nullptr);
@@ -228,7 +230,7 @@ size_t Classifier::process_segment(const uint8_t* map, size_t nb, bool paired, F
     ready[b] = 1;
     while (next_write < nb_total && ready[next_write]) {
       if (sink_) sink_->append(out[next_write]);
-      else fwrite(out[next_write].data(), 1, out[next_write].size(), fout);
+      else if (fwrite(out[next_write].data(), 1, out[next_write].size(), fout) != out[next_write].size() && err.empty()) err = "short write to the result file (disk full?)";
       std::string().swap(out[next_write]);
       ++next_write;
     }

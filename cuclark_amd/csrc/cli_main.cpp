@@ -274,7 +274,14 @@ int main(int argc, char** argv) {
   // the driver takes everything back at once.  MIC_CLI_ORDERLY_EXIT=1 keeps the orderly teardown (the sanitizer builds run with it).
   std::cout.flush(); std::cerr.flush();
   fflush(nullptr);
-  if (!getenv("MIC_CLI_ORDERLY_EXIT")) _exit(0);
+  // (under a profiler or a coverage / trace tool - rocprofv3 preloads its library and flushes its output from an exit handler - the
+  // orderly road is taken without being asked: a fast exit would lose the tool's output)
+  auto tooled = [] {
+    for (const char* v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "LLVM_PROFILE_FILE"}) if (getenv(v)) return true;
+    const char* pre = getenv("LD_PRELOAD");
+    return pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "asan") || strstr(pre, "tsan"));
+  };
+  if (!getenv("MIC_CLI_ORDERLY_EXIT") && !tooled()) _exit(0);
   delete classifier;
   return 0;
 }

@@ -22,6 +22,9 @@
 #ifndef MIC_FUNNEL64
 #define MIC_FUNNEL64 1
 #endif
+#ifndef MIC_X
+#define MIC_X 0          /* measuring builds (tools/ablate_r6.sh): 1 no marker test, 2 no hand-over of crowded runs, 4 no spill of their reads' rows - 7: what the crowded path costs every read */
+#endif
 
 namespace {
 
@@ -211,16 +214,21 @@ __device__ __forceinline__ void finish_read(const RowAcc& acc, uint32_t n_ent, u
                                             uint32_t r, const ARGS& a, int lane) {
   // (count, label + 1) pairs compared as 32-bit scalars: a 64-bit key has no scalar compare and went through the vector unit
   uint32_t bc = 0, bl = 0, sc = 0, sl = 0;       // best and second: count, label + 1 (0 = none)
-  // (the first entry is the best so far without a comparison - its count is at least 1: most reads have one entry, and the
-  // comparisons are scalar work the kernel is short of)
-  if (n_ent) { bl = __builtin_amdgcn_readlane(acc.label1, 0); bc = __builtin_amdgcn_readlane(acc.count, 0); }
-  for (uint32_t i = 1; i < n_ent; ++i) {
-    const uint32_t l1 = __builtin_amdgcn_readlane(acc.label1, i);
-    const uint32_t c = __builtin_amdgcn_readlane(acc.count, i);
-    const bool over_best = c > bc || (c == bc && l1 < bl);
-    const bool over_second = c > sc || (c == sc && l1 < sl);
-    if (over_best) { sc = bc; sl = bl; bc = c; bl = l1; }
-    else if (over_second) { sc = c; sl = l1; }
+  // A row of at most one entry (most reads): the row is written by lane 0, and lane 0 HOLDS entry 0 (or zeros) - best label and
+  // count go into the result row straight from its registers, no v_readlane into scalars and v_mov back (round 6: -4 VALU per read)
+  uint32_t vbl = acc.label1, vbc = acc.count;
+  if (n_ent > 1) {
+    // (the first entry is the best so far without a comparison - its count is at least 1 - and the comparisons are scalar work)
+    bl = __builtin_amdgcn_readlane(acc.label1, 0); bc = __builtin_amdgcn_readlane(acc.count, 0);
+    for (uint32_t i = 1; i < n_ent; ++i) {
+      const uint32_t l1 = __builtin_amdgcn_readlane(acc.label1, i);
+      const uint32_t c = __builtin_amdgcn_readlane(acc.count, i);
+      const bool over_best = c > bc || (c == bc && l1 < bl);
+      const bool over_second = c > sc || (c == sc && l1 < sl);
+      if (over_best) { sc = bc; sl = bl; bc = c; bl = l1; }
+      else if (over_second) { sc = c; sl = l1; }
+    }
+    vbl = bl; vbc = bc;
   }
   uint32_t flags = 0;
   if (a.rows) {
@@ -245,8 +253,8 @@ __device__ __forceinline__ void finish_read(const RowAcc& acc, uint32_t n_ent, u
   if (lane == 0) {
     uint4 lo, hi;
     lo.x = total;
-    lo.y = bl;   // label+1
-    lo.z = bc;
+    lo.y = vbl;   // label+1
+    lo.z = vbc;
     lo.w = sl;
     hi.x = sc;
     hi.y = n_ent; hi.z = flags; hi.w = 0;
@@ -1135,7 +1143,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_s
 __device__ __forceinline__ uint64_t wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 static_assert(MIC_RMAX <= 32, "tally_counts sums the first two rows of lanes");
-#define MIC_R_CROWDED (-(1 << 24))     /* `remaining` of a run that met the marker of a crowded minimizer */
+#define MIC_R_CROWDED (-16)     /* `remaining` of a run that met the marker of a crowded minimizer: negative (a count never is), an inline constant */
 __device__ __forceinline__ void tally_counts(uint32_t lab1, uint32_t cnt, RowAcc& acc, uint32_t& n_ent, uint32_t& overflow,
                                              uint32_t& total, int lane) {
   uint64_t mm = wballot(lab1 != 0);
@@ -1206,6 +1214,8 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const uint32_t*)pb + lane),
                                        (__attribute__((address_space(3))) void*)(entry + 12), 4, 0, 0);
   };
+  // (the pointers through the scalar cache instead - one s_load_dwordx2 two reads ahead, no second DMA, no v_readlane - measured in
+  // round 6: -3 VALU, +6 SALU per read, 1 % slower on the two-strand table, 0.5 % faster on the one-strand one: not kept)
   auto ahead_take = [&](const uint32_t* entry, uint32_t pp_w, uint32_t& hdr, uint32_t& npp, uint32_t& npe) {
     const uint32_t raw = entry[lane];
     npp = __builtin_amdgcn_readlane(raw, 12); npe = __builtin_amdgcn_readlane(raw, 13);
@@ -1353,6 +1363,12 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     __builtin_amdgcn_wave_barrier();
     if (ln < MIC_RMAX) ((uint32_t*)stage)[lane] = cur;
     __builtin_amdgcn_wave_barrier();
+    // (the DMA destinations from an opaque copy of the area's address: as loop invariants the three group offsets are three scalar
+    // registers kept across the kernel - one s_add into m0 each does the same work as the s_mov they replace)
+    // (an LDS byte offset, taken and used as one: a generic pointer rebuilt from its low word would read as NULL for the wave whose
+    // area starts at offset 0 of the block's LDS)
+    uint32_t so = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)stage;
+    asm volatile("" : "+s"(so));
 #pragma unroll
     for (int i = 0; i < MIC_RMAX / 8; ++i) sidx[i] = ((const uint32_t*)stage)[8 * i + (lane >> 3)];
 #pragma unroll
@@ -1360,7 +1376,7 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
       if (8u * i >= nrun) break;
       if (sidx[i] != 0xFFFFFFFFu)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slots + (uint64_t)sidx[i] * 8 + (lane & 7)),
-                                         (__attribute__((address_space(3))) void*)(stage + (64 + MIC_R_SKEW) * i), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(uintptr_t)(so + 16u * (64 + MIC_R_SKEW) * (uint32_t)i), 16, 0, 0);
     }
   };
   // wait for the slots, entries against regions, tally; continuation slots; crowded runs are handed to the follow-up kernel
@@ -1409,7 +1425,9 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
         const uint32_t hits = (same && mineq) ? (uint32_t)__popc((pl >> 16) & range) : 0u;
         // the marker of a crowded minimizer (presence mask 0): nothing of this minimizer is in the chains, the lane's walk ends
         // (kept in `remaining`, as a value no count reaches: a lane mask of its own would cost the loop a scalar register pair)
+#if !(MIC_X & 1)
         remaining = (same && mineq && (pl >> 16) == 0) ? MIC_R_CROWDED : remaining;
+#endif
         // The run's hits are tallied ONCE per round: a lane keeps (label, count) of its run; a second entry with ANOTHER
         // label (the same minimizer in two targets' genomes, both contexts matching parts of the run) is tallied on the
         // spot - a wave-uniform branch that is virtually never taken.
@@ -1425,14 +1443,14 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
       cur = 0xFFFFFFFFu;
       if (wballot(nx)) { if (nx && q[5] <= key) cur = q[31]; }
     } while (wballot(cur != 0xFFFFFFFFu));
-    if (__builtin_expect(wballot(remaining < MIC_R_CROWDED / 2) != 0, 0)) {
+    if (!(MIC_X & 2) && __builtin_expect(wballot(remaining < 0) != 0, 0)) {
       // Rare (a database with microsatellites, a read that overlaps one): the crowded runs of this round become items of the
       // follow-up's work list - the region as the table orients it and the run's range of minimizer positions; the k-mer with
       // its minimizer at position j is the region's nucleotides [ctx - j, ctx - j + k).  One reservation per round.
       // Everything here is kept in VECTOR registers on purpose (the kernarg pointer made opaque, so that the loads from it are
       // vector loads): the entry loop's temporaries are dead at this point, while the scalar file is full - what this block
       // would take of it, the common path would spill and reload per read.
-      const bool crowded = remaining < MIC_R_CROWDED / 2;
+      const bool crowded = remaining < 0;
       const uint32_t n_c = (uint32_t)__popcll(wballot(crowded));
       uint64_t kpv = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+v"(kpv));
@@ -1458,36 +1476,42 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
     }
   };
   // end of a read: best / second and the result row - or, for a read with crowded runs, its row so far into the work area
+  // (ONE scalar test on the common path; everything about the work area behind it, in vector registers as in the block above)
   auto finish = [&](const RowAcc& acc, uint32_t n_ent, uint32_t total, uint32_t overflow, uint32_t r, const uint32_t cg) __attribute__((always_inline)) {
-    uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
-    if (__builtin_expect(cg != MIC_CG_NONE, 0)) {
-      if (cg != MIC_CG_DENSE) {          // (vector registers throughout, as in the block above)
-        uint64_t kpv = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+v"(kpv));
-        const MicQueryArgs* kv = (const MicQueryArgs*)kpv;
-        uint32_t* cw = kv->crowd;
-        uint32_t* pool = kv->crowd_pool;
-        const uint32_t pcap = kv->crowd_pend_cap, wcap = kv->crowd_pool_cap;
-        uint32_t p = 0, off = 0;
+    uint32_t spilled = 0;
+    if (!(MIC_X & 4) && __builtin_expect(cg != MIC_CG_NONE, 0)) {
+      uint64_t kpv = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+v"(kpv));
+      const MicQueryArgs* kv = (const MicQueryArgs*)kpv;
+      uint32_t* cw = kv->crowd;
+      uint32_t* pool = kv->crowd_pool;
+      const uint32_t pcap = kv->crowd_pend_cap, wcap = kv->crowd_pool_cap;
+      uint32_t p = 0xFFFFFFFFu, off = 0;
+      if (cg != MIC_CG_DENSE) {
         if (lane == 0) { p = atomicAdd(&cw[0], 1u); off = atomicAdd(&cw[2], 2u * n_ent); }
         p = __builtin_amdgcn_readfirstlane(p); off = __builtin_amdgcn_readfirstlane(off);
-        asm volatile("" : "+v"(p), "+v"(off));
-        const bool room = off <= wcap && 2u * n_ent <= wcap - off;
-        if (p < pcap) {
-          uint32_t* pd = cw + MIC_CROWD_HDR + 8 * (size_t)p;
-          if (lane == 0) { pd[0] = r; pd[1] = total; pd[2] = room ? (n_ent | (overflow << 8)) : 0xFFFFFFFFu; pd[3] = off; pd[4] = cg; }
-          if (room && (uint32_t)lane < n_ent) { uint32_t* pe_ = pool + (size_t)off + 2 * lane; pe_[0] = acc.label1; pe_[1] = acc.count; }
-        }
-        if (__builtin_amdgcn_readfirstlane((p < pcap && room) ? 1u : 0u)) return;
-        if (lane == 0) atomicAdd(&cw[3], 1u);
       }
-      overflow = 1;                        // -> flagged: the dense path recounts the read, side table and all
+      asm volatile("" : "+v"(p), "+v"(off));
+      const bool room = off <= wcap && 2u * n_ent <= wcap - off;
+      if (p < pcap) {
+        uint32_t* pd = cw + MIC_CROWD_HDR + 8 * (size_t)p;
+        if (lane == 0) { pd[0] = r; pd[1] = total; pd[2] = room ? (n_ent | (overflow << 8)) : 0xFFFFFFFFu; pd[3] = off; pd[4] = cg; }
+        if (room && (uint32_t)lane < n_ent) { uint32_t* pe_ = pool + (size_t)off + 2 * lane; pe_[0] = acc.label1; pe_[1] = acc.count; }
+      }
+      spilled = __builtin_amdgcn_readfirstlane((p < pcap && room) ? 1u : 0u);
+      if (!spilled) {                      // no room (or none wanted): flagged - the dense path recounts the read, side table and all
+        if (lane == 0 && cw != nullptr && cg != MIC_CG_DENSE) atomicAdd(&cw[3], 1u);
+        overflow = 1;
+      }
     }
-    struct { uint32_t* results; uint32_t* rows; uint32_t* flagged; uint32_t row_words, flagged_cap; } fa;
-    fa.results = kc->results; fa.rows = kc->rows; fa.flagged = kc->flagged; fa.row_words = kc->row_words; fa.flagged_cap = kc->flagged_cap;
-    finish_read(acc, n_ent, total, overflow, r, fa, lane);
+    if (!spilled) {
+      uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));
+      const __attribute__((address_space(4))) MicQueryArgs* kc = (const __attribute__((address_space(4))) MicQueryArgs*)kp;
+      struct { uint32_t* results; uint32_t* rows; uint32_t* flagged; uint32_t row_words, flagged_cap; } fa;
+      fa.results = kc->results; fa.rows = kc->rows; fa.flagged = kc->flagged; fa.row_words = kc->row_words; fa.flagged_cap = kc->flagged_cap;
+      finish_read(acc, n_ent, total, overflow, r, fa, lane);
+    }
   };
 
   // One step = one read taken up (N) and the read before it finished (P: its slots are on their way).  The loop below calls it
