@@ -673,7 +673,10 @@ __global__ void __launch_bounds__(TILE) s_expand_kernel(MBuildArgs a, uint32_t t
           const uint32_t lb = s_lb[j];
           int n_c = 0;
           auto put = [&](uint64_t K, int p, uint64_t x) {
-            const unsigned long long g = x * 0x9E3779B97F4A7C15ull;              // the sketch's own hash of x
+            // the sketch's own hash of x: two multiply-xorshift rounds (register index = its top bits, rank = the bits below: from ONE
+            // product both are functions of the same carries, and structured sets - the m-mers of tandem repeats - skew the estimate)
+            unsigned long long g = x * 0x9E3779B97F4A7C15ull;
+            g ^= g >> 32; g *= 0xD6E8FEB86659FD93ull; g ^= g >> 32;
             const uint32_t rank = (uint32_t)__builtin_clzll((g << S_HLL_BITS) | (1ull << (S_HLL_BITS - 1))) + 1u;
             atomicMax(&s_hll[(uint32_t)(g >> (64 - S_HLL_BITS))], rank);
             if (!EMIT) return;
@@ -1351,8 +1354,16 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     ex_cap = (uint32_t)std::min<uint64_t>(tot_elems / 16 + (1u << 20), 0x7FFFFF00ull);
     if (const char* env = getenv("MIC_S_EXTRA_CAP")) { const long v = atol(env); if (v > 0) ex_cap = (uint32_t)v; }   // test hook: a list that runs over
     if (want_sorted) {
-      hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp_bytes, (const SKey*)nullptr, (SKey*)nullptr, (const SVal*)nullptr, (SVal*)nullptr,
-                                         (int)chunk_max, 16, 32, s);
+      // scratch of the sort: the largest any chunk asks for (the library picks its algorithm - and its scratch layout - by the number
+      // of items: the need is not promised to grow with it)
+      sort_tmp_bytes = 0;
+      for (size_t c = 0; c + 1 < cut.size(); ++c) {
+        const uint64_t e0 = h_a[cut[c]].elems, e1 = cut[c + 1] < n_tiles ? h_a[cut[c + 1]].elems : tot_elems;
+        if (e1 == e0) continue;
+        size_t tb = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const SKey*)nullptr, (SKey*)nullptr, (const SVal*)nullptr, (SVal*)nullptr, (int)(e1 - e0), 16, 32, s);
+        if (tb > sort_tmp_bytes) sort_tmp_bytes = tb;
+      }
       size_t free_b = 0, total_b = 0;
       HIPCK(hipMemGetInfo(&free_b, &total_b));
       double avail = (double)free_b - 1.5e9 - (double)mic_build_reserved_hbm;
@@ -1384,6 +1395,7 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
     else s_expand_kernel<uint16_t, EMIT><<<g_, TILE, 0, s>>>(a, T0, T1, E0, d_th, d_tv, d_xh, d_xv, ex_cap, d_ctr, d_hll); } while (0)
     a.n_mslots = 0;
     if (want_sorted) {
+      bool sort_failed = false;
       for (size_t c = 0; c + 1 < cut.size(); ++c) {
         const uint32_t t0 = cut[c], t1 = cut[c + 1];
         const uint64_t e0 = h_a[t0].elems, e1 = t1 < n_tiles ? h_a[t1].elems : tot_elems;
@@ -1395,12 +1407,19 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
           HIPCK(hipMemcpyAsync(d_sh + e0, d_th, (e1 - e0) * sizeof(SKey), hipMemcpyDeviceToDevice, s));
           HIPCK(hipMemcpyAsync(d_sv + e0, d_tv, (e1 - e0) * sizeof(SVal), hipMemcpyDeviceToDevice, s));
         } else
-        HIPCK(hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, tb, (const SKey*)d_th, d_sh + e0, (const SVal*)d_tv, d_sv + e0, (int)(e1 - e0), 16, 32, s));
+        if (hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, tb, (const SKey*)d_th, d_sh + e0, (const SVal*)d_tv, d_sv + e0, (int)(e1 - e0), 16, 32, s) != hipSuccess) {
+          (void)hipGetLastError();
+          sort_failed = true;            // (a sort that refuses its scratch or its launch: the classic road builds the same table)
+          break;
+        }
       }
       unsigned long long h_ctr[3] = {0, 0, 0};
       HIPCK(hipMemcpyAsync(h_ctr, d_ctr, 24, hipMemcpyDeviceToHost, s));
       HIPCK(hipStreamSynchronize(s));
-      if (h_ctr[2]) {          // more tied candidates than the extras' list holds (a database of low complexity): the classic road
+      if (sort_failed) {
+        want_sorted = false;
+        if (timing) fprintf(stderr, "[load]   sorted build given up: the radix sort of a chunk failed\n");
+      } else if (h_ctr[2]) {   // more tied candidates than the extras' list holds (a database of low complexity): the classic road
         want_sorted = false;
         if (timing) fprintf(stderr, "[load]   sorted build given up: %llu extra candidates beyond the list of %u\n", h_ctr[2], ex_cap);
       } else { sorted = true; n_extra = h_ctr[1]; h_scal[0] = h_ctr[0]; }

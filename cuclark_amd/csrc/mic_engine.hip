@@ -161,10 +161,13 @@ struct UploadStage {
   static constexpr size_t CH = 256u << 20;
   void* buf[2] = {nullptr, nullptr};
   bool get(int near_device) {
-    if (buf[0]) return true;
+    if (buf[0] && buf[1]) return true;
     mic_bind_thread_near_device(near_device, 1);
     // (HIP has one context per process: pinned host memory is reachable from every device, whatever device was current)
-    const bool ok = hipHostMalloc(&buf[0], CH, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&buf[1], CH, hipHostMallocDefault) == hipSuccess;
+    bool ok = true;
+    for (void*& b : buf) if (!b && ok) { ok = hipHostMalloc(&b, CH, hipHostMallocDefault) == hipSuccess; if (!ok) b = nullptr; }
+    // both or none: a stage shared by the three files of a load must never hand out one buffer and a null
+    if (!ok) for (void*& b : buf) if (b) { hipHostFree(b); b = nullptr; }
     mic_bind_thread_near_device(near_device, 0);
     return ok;
   }

@@ -320,7 +320,8 @@ int mic_ingest_fetch_group_rows(mic_engine* owner, size_t slot, size_t part, uin
  * packed-read fan-out (owner -> the other engines), its ms summed over the helpers and over the batches, the same with the
  * slowest helper of each batch only, query-kernel ms summed over engines and batches, slowest engine of each batch only, bytes of
  * the row exchange (rows of a read range from the other engines + the results to the owner), its ms summed, slowest engine only.
- * Returns the number of fields; zeros without MIC_GROUP_TIMING.  (The reference times nothing per device; its exchange is
+ * Returns the number of fields (> 0: the one entry point that does not return MIC_OK on success) or a negative code; zeros
+ * without MIC_GROUP_TIMING.  (The reference times nothing per device; its exchange is
  * CuClarkDB.cu:954-974.) */
 #define MIC_GROUP_STATS_FIELDS 10
 int mic_ingest_group_stats(mic_engine* owner, double* out, size_t cap);

@@ -23,6 +23,7 @@ template <typename HKMERr> class CuClarkDB {
   std::vector<mic_engine*> e_; size_t nb_; uint8_t k_; bool ext_ = false; uint32_t rw_ = 16, nt_ = 0;   // rw_: u32 words per sparse row
   uint32_t *res32_ = nullptr, *rows32_ = nullptr; RESULTS *final_ = nullptr, *full_ = nullptr;
   std::vector<ITYPE> index_; std::vector<size_t> nreads_, ncont_; size_t rowSize_ = 0, finalRowSize_ = 5;
+  std::vector<char> waited_;      // batch b's results are merged and converted (until its next queryBatch)
   std::vector<std::vector<uint32_t*> > rp_; std::vector<std::vector<uint16_t*> > ct_;   // [engine][batch]
   static void ck(int rc) { if (rc) { std::cerr << mic_last_error() << std::endl; exit(1); } }   // CUERR behaviour
  public:
@@ -76,6 +77,8 @@ template <typename HKMERr> class CuClarkDB {
     return true;
   }
   bool queryBatch(size_t b, bool isExtended, bool isFollowup = false) {                     // CuClarkDB.cu:878-1033
+    if (waited_.size() <= b) waited_.resize(b + 1, 0);
+    waited_[b] = 0;
     // every device sees all reads (:886-890): ONE upload into the first engine, the packed reads fanned out device to device
     if (e_.size() > 1) ck(mic_batch_query_group(e_.data(), e_.size(), b, 1));
     else ck(mic_batch_query(e_[0], b, isExtended, isFollowup));
@@ -104,6 +107,9 @@ template <typename HKMERr> class CuClarkDB {
     if (ext_) full_[r * rowSize_] = (RESULTS)n;
   }
   bool waitForBatch(size_t b) {                                                             // CuClarkDB.cu:440-445
+    if (waited_.size() > b && waited_[b]) return true;            // (the reference's wait is an event wait: calling it again is harmless)
+    if (waited_.size() <= b) waited_.resize(b + 1, 0);
+    waited_[b] = 1;
     if (e_.size() > 1) ck(mic_batch_merge_shards(e_.data(), e_.size(), b));                 // peer copies + mergeKernel + resultKernel, :954-1024
     else ck(mic_batch_wait(e_[0], b));
     for (size_t r = index_[b]; r < index_[b] + nreads_[b]; ++r) {      // u32 -> RESULTS, the layout CuCLARK_hh.hh reads

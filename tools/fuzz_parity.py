@@ -171,6 +171,8 @@ class OracleProcess:
 
     def __init__(self, seed0):
         env = {k: v for k, v in os.environ.items() if k not in ("MIC_LIB_PATH",)}
+        if "guardalloc" in env.get("LD_PRELOAD", ""):      # (tools/guard_soak.sh watches the PRODUCT side's heap; the oracle has its own rig)
+            del env["LD_PRELOAD"]
         self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-side"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
         self.next_seed = seed0
         for _ in range(self.AHEAD):
