@@ -1190,7 +1190,10 @@ def main():
             dl = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) if r.returncode == 0 else None
             if dl is None:
                 return {"error": (r.stderr or r.stdout)[-300:]}
-            return {"layout": dl["config"]["table"]["layout"], "value": dl["value"], "unit": "Mreads/s", "ms_per_step": dl["ms_per_step"],
+            wanted = {"super2": "both strands", "direct": "direct", "minimizer": "minimizer-keyed", "super": "super-k-mer"}.get(name, "")
+            return {"layout": dl["config"]["table"]["layout"],
+                    "built_the_layout_asked_for": wanted in dl["config"]["table"]["layout"] and (name != "super" or "both strands" not in dl["config"]["table"]["layout"]),
+                    "value": dl["value"], "unit": "Mreads/s", "ms_per_step": dl["ms_per_step"],
                     "kernel_ms": dl["roofline"]["kernel_ms"], "kernel": dl["roofline"]["kernel"], "roofline_frac": dl["roofline"]["frac"],
                     "hbm_GB": dl["config"]["table"]["hbm_GB"], "table_build_s": dl["config"]["setup_s"]["table_build"],
                     "table_build_stages": dl["config"]["setup_s"]["table_build_stages"],

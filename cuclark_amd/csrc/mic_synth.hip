@@ -30,7 +30,7 @@ __host__ __device__ inline uint64_t genome_word(uint64_t seed, uint64_t g, uint6
 // ---- genomes that are not uniformly random (mic_synth_spec.repeat_ppm / mosaic_ppm) ------------------------------------------
 // Still pure functions of (seed, genome, position).  A genome is cut into segments of 2048 nucleotides:
 //   * TANDEM REPEATS: a segment holds a tract with probability repeat_ppm x 2048 / 768 / 1e6 - 256 .. 1279 nucleotides somewhere in
-//     its first 1792, a unit of 2 .. 50 nucleotides repeated.  Units of up to 6 nucleotides come from a pool of 64 per length SHARED
+//     its first 1792, a unit of 4 .. 50 nucleotides repeated.  Units of up to 6 nucleotides come from a pool of 64 per length SHARED
 //     by all genomes (microsatellites: the same unit at hundreds of loci - what makes a minimizer crowded); longer units are the
 //     locus's own.  In the DATABASE a k-mer that lies wholly inside a tract of a shared unit is absent (common to many targets:
 //     HashTableStorage_hh.hh:241-292 removes it; what stays are the k-mers across the tract's ends, each locus's own), and inside a
@@ -48,12 +48,13 @@ __host__ __device__ inline SegInfo seg_info(uint64_t seed, uint64_t g, uint64_t 
   si.tract = md.tract_ppm && (uint32_t)(h % 1000000ull) < md.tract_ppm;
   si.t_start = (uint32_t)((h >> 20) & 511u);
   si.t_len = 256u + (uint32_t)((h >> 29) & 1023u);
-  si.u = 2u + (uint32_t)((h >> 39) % 49u);
+  si.u = 4u + (uint32_t)((h >> 39) % 47u);      // (4 .. 50: units of 2 or 3 nucleotides are 16 / 64 in all - at the headline's scale the
+                                                   // same end-of-tract k-mer would sit in hundreds of genomes and overflow a bucket of 255)
   si.shared = si.u <= 6u;
   si.useed = si.shared ? mix64(seed ^ (0xC0FFEEull + si.u * 0x100ull + ((h >> 48) & 63u))) : mix64(h ^ 0x51A7ull);
   const uint64_t h2 = mix64(h + 0x2545F4914F6CDD1Dull);
   si.mosaic = md.mosaic_ppm && (uint32_t)(h2 % 1000000ull) < md.mosaic_ppm;
-  si.mrun = 1u << ((h2 >> 20) & 3u);
+  { const uint32_t v = (uint32_t)(h2 >> 20) & 31u; si.mrun = v == 0 ? 1u : v <= 10 ? 2u : v <= 20 ? 4u : 8u; }    // (1: one segment in 32)
   si.mseed = mix64(h2 ^ 0x77ull);
   return si;
 }

@@ -456,7 +456,7 @@ typedef struct mic_synth_spec {
                              are kept with probability keep_ppm / 1e6                                                         */
   uint32_t run_len;       /* mean segment length in k-mer positions (0: 8)                                                    */
   uint32_t repeat_ppm;    /* 0: uniformly random genomes.  Otherwise this fraction (x 1e-6) of every genome is TANDEM REPEATS: tracts of
-                             256 .. 1279 nucleotides, units of 2 .. 50; units of up to 6 nucleotides come from a pool shared by all
+                             256 .. 1279 nucleotides, units of 4 .. 50; units of up to 6 nucleotides come from a pool shared by all
                              genomes (microsatellites).  The database holds what the reference's builder would keep of them: nothing that
                              lies wholly inside a shared unit's tract (common to many targets), a private unit's k-mers once          */
   uint32_t mosaic_ppm;    /* this fraction (x 1e-6) of the 2048-nucleotide segments of every genome carries MOSAIC labels: the label of

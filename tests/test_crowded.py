@@ -204,3 +204,44 @@ def test_crowded_runs_go_through_the_follow_up_kernel(layout, monkeypatch):
                     assert st["reads"] > 150 and st["runs"] >= st["reads"] and st["reads_to_dense_path"] == 0 and dense == 0, (name, st, dense)
                     if name == "long":
                         assert st["runs"] > 3 * st["reads"], st
+
+
+@pytest.mark.parametrize("layout", ["super", "super2"])
+def test_crowded_runs_through_the_streaming_ingest_and_a_group_of_parts(layout, monkeypatch):
+    """The same hand-over inside the command line's paths: mic_ingest_classify (FASTA bytes in, CSV out: the slot's own work area) and
+    mic_ingest_classify_group (three parts of the table on three engines: every helper engine has a work area of its own, a crowded
+    run belongs to the part that holds its slot) - results equal to the oracle, CSVs equal to each other."""
+    from cuclark_amd import MiClarkDB, host
+    monkeypatch.setenv("MIC_LAYOUT", layout)
+    rng = np.random.default_rng(47)
+    k, T, htsize = 31, 12, 1 << 18
+    seqs, sizes, keys, labels = _microsatellite_db(rng, k, htsize, T)
+    odb = gu.oracle().db_from_arrays(sizes, keys, labels)
+    data = _reads(rng, seqs, 2500) + b"".join(b">f%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 150)) + b"\n" for i in range(20000))
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    n = rp.size - 1
+    counts, expect = _oracle_results(odb, k, rp, cont, T)
+    names = [f"T{i}" for i in range(T)]
+    with MiClarkDB(k, T) as whole:
+        whole.read_arrays(sizes, keys, labels)
+        assert whole.info()["side_kmers"] > 500
+        whole.ingest_alloc(1, 8 << 20, names, want_results=True)
+        r_w = whole.ingest_classify(0, data)
+        whole.ingest_free()
+    assert r_w["status"] == 0 and r_w["n_reads"] == n and (r_w["results"][:, :5] == expect).all()
+    group = [MiClarkDB(k, T) for _ in range(3)]
+    try:
+        side = 0
+        for p, e in enumerate(group):
+            e.set_part(p, 3)
+            e.read_arrays(sizes, keys, labels)
+            side += e.info()["side_kmers"]
+        assert side > 500
+        group[1].ingest_alloc(1, 8 << 20, names, want_results=True)
+        r = MiClarkDB.ingest_classify_group(group, 1, 0, data)
+        assert r["status"] == 0 and r["n_reads"] == n
+        assert (r["results"][:, :5] == expect).all() and r["csv"] == r_w["csv"]
+    finally:
+        for e in group:
+            e.close()
