@@ -795,11 +795,33 @@ __device__ inline bool s_less(unsigned long long Ka, uint32_t ma, unsigned long 
 struct SWriter {   // where the entries of one slot go: the main slot, then its contiguous continuation slots
   uint32_t* slots; uint64_t main, chain; uint32_t n_total, n_out;
   uint64_t cur, n_slots; uint32_t n_here, pool_cap; uint32_t* pool; bool full;     // one-pass form
-  uint32_t* main_q;      // where the MAIN slot's 32 words are put together: its row of the block's LDS staging (written out coalesced
-                         // by the whole block), or the slot itself
-  __device__ uint32_t* at(uint64_t slot) const { return slot == main ? main_q : slots + slot * 32; }
-  __device__ uint32_t* slot_of(uint32_t idx) const {
-    return idx < MIC_S_CAP ? main_q : slots + (chain + (idx - MIC_S_CAP) / MIC_S_CAP) * 32;
+  // The MAIN slot's 32 words are put together in REGISTERS (round 6; every index below is a constant after unrolling) and written by
+  // their thread as eight 16-byte stores.  Until round 5 they were a row of the block's LDS (written out coalesced by the whole
+  // block): 16.9 of the block's 41 KB - the kernel runs a long chain of dependent instructions per wavefront (28 000 of them), and
+  // LDS capacity held it at 1.5 wavefronts per SIMD; without the rows twice as many are resident.
+  uint32_t row[32];
+  // (spelled out, no loops: the array is promoted to registers only if every index is a constant when the promotion pass first runs)
+  __device__ __forceinline__ void row_init() {
+    row[0] = row[1] = row[2] = row[3] = row[4] = row[5] = 0xFFFFFFFFu;
+    row[6] = row[7] = row[8] = row[9] = row[10] = row[11] = row[12] = row[13] = row[14] = row[15] = row[16] = row[17] = row[18] = 0;
+    row[19] = row[20] = row[21] = row[22] = row[23] = row[24] = row[25] = row[26] = row[27] = row[28] = row[29] = row[30] = row[31] = 0;
+  }
+  // (selects, not branches: a chain of `if (e == 0) row[0] = .. else if (e == 1) row[1] = ..` is folded back into row[e] = .. - a dynamic index,
+  // and the array goes to scratch memory)
+#define S_ROW_PUT(ee) { const bool h_ = e == ee; row[ee] = h_ ? key : row[ee]; row[6 + 3 * ee] = h_ ? a : row[6 + 3 * ee]; row[7 + 3 * ee] = h_ ? b : row[7 + 3 * ee]; \
+                        row[8 + 3 * ee] = h_ ? c : row[8 + 3 * ee]; row[24 + ee] = h_ ? pl : row[24 + ee]; }
+  __device__ __forceinline__ void put_main(uint32_t e, uint32_t key, uint32_t a, uint32_t b, uint32_t c, uint32_t pl) {
+    static_assert(MIC_S_CAP == 6, "one S_ROW_PUT per entry of a slot");
+    S_ROW_PUT(0) S_ROW_PUT(1) S_ROW_PUT(2) S_ROW_PUT(3) S_ROW_PUT(4) S_ROW_PUT(5)
+  }
+#undef S_ROW_PUT
+  // entry e of slot `slot` (the main slot: registers; a continuation slot: the table)
+  __device__ __forceinline__ void put(uint64_t slot, uint32_t e, uint32_t key, uint32_t a, uint32_t b, uint32_t c, uint32_t pl) {
+    if (slot == main) put_main(e, key, a, b, c, pl);
+    else { uint32_t* q = slots + slot * 32; q[e] = key; q[6 + 3 * e] = a; q[7 + 3 * e] = b; q[8 + 3 * e] = c; q[24 + e] = pl; }
+  }
+  __device__ __forceinline__ void set_hdr(uint64_t slot, uint32_t w30, uint32_t w31) {
+    if (slot == main) { row[30] = w30; row[31] = w31; } else { uint32_t* q = slots + slot * 32; q[30] = w30; q[31] = w31; }
   }
 };
 
@@ -813,35 +835,26 @@ __device__ inline void s_slot_init(uint32_t* q) {
 }
 // MODE 0: count the entries, 1: write them (entry counts and chain bases known), 2: write them in one pass (pool)
 template <int MODE>
-__device__ inline void s_emit(const SOpen& o, uint64_t x, int L, SWriter& wr) {
+__device__ __forceinline__ void s_emit(const SOpen& o, uint64_t x, int L, SWriter& wr) {
+  const u128 v = o.S << (96 - 2 * L);
+  const uint32_t v0 = (uint32_t)(v >> 64), v1 = (uint32_t)(v >> 32), v2 = (uint32_t)v, pl = (o.pmask << 16) | o.label;
   if (MODE == 2) {
     if (wr.n_here == MIC_S_CAP && !wr.full) {
       const uint32_t idx = atomicAdd(wr.pool, 1u);
       if (idx >= wr.pool_cap) { wr.full = true; atomicMax(wr.pool + 1, 1u); }
       else {
-        uint32_t* q = wr.at(wr.cur);
         const uint64_t nxt = wr.n_slots + idx;
-        q[30] = MIC_S_CAP | MIC_S_NEXT; q[31] = (uint32_t)nxt;
+        wr.set_hdr(wr.cur, MIC_S_CAP | MIC_S_NEXT, (uint32_t)nxt);
         s_slot_init(wr.slots + nxt * 32);
         wr.cur = nxt; wr.n_here = 0;
       }
     }
-    if (!wr.full) {
-      uint32_t* q = wr.at(wr.cur);
-      const uint32_t e = wr.n_here++;
-      const u128 v = o.S << (96 - 2 * L);
-      q[e] = (uint32_t)x;
-      q[6 + 3 * e] = (uint32_t)(v >> 64); q[7 + 3 * e] = (uint32_t)(v >> 32); q[8 + 3 * e] = (uint32_t)v;
-      q[24 + e] = (o.pmask << 16) | o.label;
-    }
+    if (!wr.full) wr.put(wr.cur, wr.n_here++, (uint32_t)x, v0, v1, v2, pl);
   }
   if (MODE == 1) {
-    uint32_t* q = wr.slot_of(wr.n_out);
-    const uint32_t e = wr.n_out % MIC_S_CAP;
-    const u128 v = o.S << (96 - 2 * L);
-    q[e] = (uint32_t)x;
-    q[6 + 3 * e] = (uint32_t)(v >> 64); q[7 + 3 * e] = (uint32_t)(v >> 32); q[8 + 3 * e] = (uint32_t)v;
-    q[24 + e] = (o.pmask << 16) | o.label;
+    const uint32_t idx = wr.n_out, e = idx % MIC_S_CAP;
+    if (idx < MIC_S_CAP) wr.put_main(e, (uint32_t)x, v0, v1, v2, pl);
+    else { uint32_t* q = wr.slots + (wr.chain + (idx - MIC_S_CAP) / MIC_S_CAP) * 32; q[e] = (uint32_t)x; q[6 + 3 * e] = v0; q[7 + 3 * e] = v1; q[8 + 3 * e] = v2; q[24 + e] = pl; }
   }
   ++wr.n_out;
 }
@@ -850,9 +863,9 @@ __device__ inline void s_emit(const SOpen& o, uint64_t x, int L, SWriter& wr) {
 // One thread per slot: sort the slot's staged candidates, merge them into entries, put the slot together.  The block works
 // out of LDS (round 4): the candidates of its S_TPB consecutive slots are one contiguous piece of the staging area - loaded
 // cooperatively (coalesced), sorted and merged by their threads at LDS latency instead of one dependent global access per
-// comparison - and the S_TPB main slots are put together in LDS rows and written out as ONE contiguous piece of the table
-// (coalesced; one thread writing its 128-byte row word by word before).  A block whose slots hold more candidates than the LDS
-// piece (crowded minimizers) works on the staging area directly, as before; continuation slots are written directly (rare).
+// comparison.  The main slot is put together in its thread's registers and written as eight 16-byte stores (round 6: SWriter).
+// A block whose slots hold more candidates than the LDS piece (crowded minimizers) works on the staging area directly, as before;
+// continuation slots are written directly (rare).
 #define S_TPB 128
 #define S_LDS_CAND 2048
 template <int MODE>
@@ -866,7 +879,6 @@ __global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long
   constexpr bool WRITE = MODE == 1;
   __shared__ unsigned long long s_k[S_LDS_CAND];
   __shared__ uint32_t s_m[S_LDS_CAND];
-  __shared__ uint32_t s_row[MODE != 0 ? S_TPB : 1][33];
   const uint64_t s_first = slot_lo + (uint64_t)blockIdx.x * S_TPB;
   const uint64_t s_end = s_first + S_TPB < slot_hi ? s_first + S_TPB : slot_hi;     // (the grid covers [slot_lo, slot_hi): s_first < slot_hi)
   const uint64_t s = s_first + threadIdx.x;
@@ -902,26 +914,25 @@ __global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long
   };
   const uint32_t n = live ? cnt[s] : 0;
   const unsigned long long my = live ? off[s] - base : c0;
-  unsigned long long* K = in_lds ? s_k + (my - c0) : cand_k + my;
-  uint32_t* M = in_lds ? s_m + (my - c0) : cand_m + my;
   const int w = k - m + 1, L = k + w - 1;
   SWriter wr; wr.slots = slots; wr.main = s; wr.chain = 0; wr.n_total = 0; wr.n_out = 0;
   wr.cur = s; wr.n_slots = n_slots; wr.n_here = 0; wr.pool_cap = pool_cap; wr.pool = pool; wr.full = false;
-  wr.main_q = MODE != 0 ? s_row[MODE != 0 ? threadIdx.x : 0] : nullptr;
-  if (MODE == 2 && live) s_slot_init(wr.main_q);
+  wr.row_init();
   if (WRITE && live) {
     wr.n_total = n_ent[s];
     const uint32_t n_chain = wr.n_total > MIC_S_CAP ? (wr.n_total - 1) / MIC_S_CAP : 0;
     wr.chain = n_slots + chain_off[s];
     for (uint32_t c = 0; c <= n_chain; ++c) {               // headers and empty entries of every slot of this bucket
-      uint32_t* q = c == 0 ? wr.main_q : slots + (wr.chain + c - 1) * 32;
-      for (int e = 0; e < 6; ++e) q[e] = 0xFFFFFFFFu;
-      for (int e = 6; e < 30; ++e) q[e] = 0;
       const uint32_t here = wr.n_total - c * MIC_S_CAP > MIC_S_CAP ? MIC_S_CAP : wr.n_total - c * MIC_S_CAP;
-      q[30] = (wr.n_total ? here : 0) | (c < n_chain ? MIC_S_NEXT : 0);
-      q[31] = c < n_chain ? (uint32_t)(wr.chain + c) : 0;
+      const uint32_t w30 = (wr.n_total ? here : 0) | (c < n_chain ? MIC_S_NEXT : 0), w31 = c < n_chain ? (uint32_t)(wr.chain + c) : 0;
+      if (c == 0) { wr.row[30] = w30; wr.row[31] = w31; }
+      else { uint32_t* q = slots + (wr.chain + c - 1) * 32; s_slot_init(q); q[30] = w30; q[31] = w31; }
     }
   }
+  // Sort and merge, instantiated TWICE - on the block's LDS piece and on the staging area in HBM (blocks that do not fit) - so that the
+  // LDS road is ds_read / ds_write: through ONE pointer that may be either, every access was a FLAT instruction (1 100 per wavefront,
+  // each through the texture path with its aperture check: several times an LDS round trip in a chain of dependent accesses) - round 6.
+  auto sort_and_merge = [&](auto* K, auto* M) __attribute__((always_inline)) {
   if (sort_now) {
     // shell sort of the staged candidates (in place; a second run over the same staging area finds them sorted)
     constexpr uint32_t gaps[8] = {701, 301, 132, 57, 23, 10, 4, 1};
@@ -977,8 +988,11 @@ __global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long
   }
 #pragma unroll
   for (int o = 0; o < S_MAXOPEN; ++o) if (o < n_open) s_emit<MODE>(open[o], cur_x, L, wr);
+  };
+  if (in_lds) sort_and_merge(&s_k[my - c0], &s_m[my - c0]);
+  else sort_and_merge(cand_k + my, cand_m + my);
   if (MODE != 1 && live) { n_ent[s] = wr.n_out; if (wr.n_out > MIC_S_CAP) atomicMax(max_ent, wr.n_out); }
-  if (MODE == 2 && live && !wr.full) { uint32_t* q = wr.at(wr.cur); q[30] = wr.n_here; q[31] = 0; }
+  if (MODE == 2 && live && !wr.full) wr.set_hdr(wr.cur, wr.n_here, 0u);
   __syncthreads();
   // the counting pass of the two-pass form leaves the candidates sorted for the writing pass (one range: it does not sort again)
   if (MODE == 0 && sort_now && in_lds)
@@ -987,11 +1001,12 @@ __global__ void __launch_bounds__(S_TPB) s_merge_kernel(const unsigned long long
       if (packed) { uint32_t j, lb; uint64_t x; unpack(kv, mv, kv, j, lb, x); mv = j | (lb << 8); }
       cand_k[c0 + i] = kv; cand_m[c0 + i] = mv;
     }
-  // the block's main slots: one contiguous piece of the table
-  if (MODE != 0) {
-    const uint32_t words = (uint32_t)(s_end - s_first) * 32u;
-    uint32_t* out = slots + s_first * 32;
-    for (uint32_t i = threadIdx.x; i < words; i += S_TPB) out[i] = s_row[MODE != 0 ? i >> 5 : 0][i & 31u];
+  // the main slot: 128 bytes from its thread's registers
+  if (MODE != 0 && live) {
+    uint4* out = (uint4*)(slots + s * 32);
+#define S_ROW_OUT(i) out[i] = make_uint4(wr.row[4 * i], wr.row[4 * i + 1], wr.row[4 * i + 2], wr.row[4 * i + 3]);
+    S_ROW_OUT(0) S_ROW_OUT(1) S_ROW_OUT(2) S_ROW_OUT(3) S_ROW_OUT(4) S_ROW_OUT(5) S_ROW_OUT(6) S_ROW_OUT(7)
+#undef S_ROW_OUT
   }
 }
 
