@@ -279,7 +279,7 @@ int main(int argc, char** argv) {
   auto tooled = [] {
     for (const char* v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "LLVM_PROFILE_FILE"}) if (getenv(v)) return true;
     const char* pre = getenv("LD_PRELOAD");
-    return pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "asan") || strstr(pre, "tsan") || strstr(pre, "guardalloc"));
+    return pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "guardalloc"));      // (sanitizer runs ask with the variable)
   };
   if (!getenv("MIC_CLI_ORDERLY_EXIT") && !tooled()) _exit(0);
   delete classifier;

@@ -509,6 +509,11 @@ struct GroupStats {
 struct Ingest {
   mic_engine* eng = nullptr; int device = 0;
   size_t max_bytes = 0, max_lines = 0, max_reads = 0, max_tiles = 0, cont_cap = 0, csv_cap = 0;
+  // reads the work area of the crowded runs' follow-up is sized for (mic_internal.h: mic_crowd_dims), 0: none - the engine's table has no
+  // side table (a slot holds max_bytes / 32 reads at most and ~max_bytes / 160 in practice: a quarter of the bound; what does not fit
+  // takes the dense path).  Sized by the bound it was 100 MB per slot and per helper engine of a group - 13 GB of allocations in
+  // front of the first batches of an 8-part run.
+  size_t crowd_reads = 0;
   char* d_tnames = nullptr; uint32_t* d_tname_off = nullptr; uint32_t n_targets = 0;
   int want_results = 0;
   std::vector<Slot> slots;
@@ -577,7 +582,7 @@ void carve_slot(Ingest* g, Slot& s, Arena& dv, Arena& hs, size_t tmp) {
   dv.take(&s.d_cont, g->cont_cap + 192);
   dv.take(&s.d_results, (g->max_reads + 1) * 8);
   dv.take(&s.d_flagged, (size_t)kFlaggedCapI + 1);
-  dv.take(&s.d_crowd, mic_crowd_dims(g->max_reads).words);
+  if (g->crowd_reads) dv.take(&s.d_crowd, mic_crowd_dims(g->max_reads / 4 + 64).words);
   dv.take(&s.d_line_len, g->max_reads + 1);
   dv.take(&s.d_line_off, g->max_reads + 1);
   dv.take(&s.d_csv, g->csv_cap);
@@ -726,7 +731,7 @@ int setup_peers(Ingest* g, Slot& s, mic_engine* const* group, size_t P, size_t o
         a.take(&q.d_cont, g->cont_cap + 192);
         a.take(&q.d_res, (g->max_reads + 1) * 8);
         a.take(&q.d_flagged, (size_t)kFlaggedCapI + 1);
-        a.take(&q.d_crowd, mic_crowd_dims(g->max_reads).words);
+        if (t.side) a.take(&q.d_crowd, mic_crowd_dims(g->max_reads / 4 + 64).words);      // (a helper whose PART has a side table, whatever the owner's has)
       }
       if (!pass) {
         hipError_t e = hipMalloc(&q.block, a.off + 256);
@@ -780,7 +785,7 @@ int group_query_issue(mic_engine* const* group, size_t P, size_t owner, Ingest* 
     MicQueryArgs qa;
     qa.t = t; qa.reads_ptr = q.d_rp; qa.cont = q.d_cont; qa.n_reads = n; qa.row_words = (uint32_t)rw; qa.results = q.d_res;
     qa.rows = q.d_rows; qa.flagged = q.d_flagged; qa.flagged_cap = kFlaggedCapI;
-    mic_crowd_attach(qa, q.d_crowd, g->max_reads);
+    mic_crowd_attach(qa, q.d_crowd, g->max_reads / 4 + 64);
     ITRY(mic_launch_query(qa, sc, ncu, q.stream));
     ITRY(hipEventRecord(q.ev_q, q.stream));
     if (timed) ITRY(hipEventRecord(q.tv[2], q.stream));
@@ -919,6 +924,7 @@ int mic_ingest_alloc(mic_engine* e, size_t n_slots, size_t max_bytes, const char
   // sum of the per-read reservations of record_kernel: nbytes / 8 + 2 (nbytes / (k + 1) + 1) + 8 containers per read
   g->cont_cap = g->max_bytes / 8 + 2 * (g->max_bytes / (size_t)(k + 1)) + 10 * g->max_reads + 64;
   g->csv_cap = g->max_bytes;
+  g->crowd_reads = (t.slots && !t.side) ? 0 : g->max_reads / 4 + 64;      // (no table yet: one may come with a side table)
   g->want_results = want_results;
   g->n_targets = n_targets;
   *mic_engine_ingest_slot(e) = g;
@@ -1044,7 +1050,7 @@ int mic_ingest_classify_group(mic_engine* const* group, size_t n_group, size_t o
     MicQueryArgs qa;
     qa.t = t; qa.reads_ptr = s.d_rp; qa.cont = s.d_cont; qa.n_reads = n_reads; qa.row_words = 0; qa.results = s.d_results;
     qa.rows = nullptr; qa.flagged = s.d_flagged; qa.flagged_cap = kFlaggedCapI;
-    mic_crowd_attach(qa, s.d_crowd, g->max_reads);
+    mic_crowd_attach(qa, s.d_crowd, g->max_reads / 4 + 64);
     ITRY(mic_launch_query(qa, sc, ncu, st));
   } else {
     // table-sharded: all engines of the group probe the batch against their parts, the rows are summed read-range owned
