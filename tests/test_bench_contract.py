@@ -129,7 +129,8 @@ def test_bench_table_sharded_mode_under_rccl_on_one_gpu():
 def test_bench_light27_config2_proper():
     """SURVEY.md 8d config 2 as cuCLARK-l builds it: HTSIZE 57 777 779, k = 27, u32 keys, ~90 M k-mers, 10 M reads."""
     d = _bench("--workload", "light27", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000", "--no-parts-proxy", "--no-default-layout",
-               "--multi-engine-reads", "2000000")
+               "--multi-engine-reads", "2000000",
+               "--multi-engine-runs", "db_sharded_2,db_sharded_4,db_sharded_8,db_sharded_4_parts_2,read_sharded_2,paired_gzip_read_sharded_2")
     _check_config(d, 10_000_000, random_hits_possible=True)
     # end_to_end: the median of three runs of the command, every run's CSV the same, the stages' busy shares and a named bound
     e2e = d["end_to_end"]
