@@ -46,6 +46,65 @@ def random_reads(rng, canon, k, n_reads, read_len, kmer_to_ascii, hit_frac=0.6, 
     return "".join(recs).encode()
 
 
+def microsatellite_db(rng, o, htsize, k, key_bytes, T):
+    """A database of tandem repeats between random flanks (round 6): the flanks of one unit at many sites are hundreds of contexts of
+    ONE minimizer - crowded minimizers, a side table, reads handed to crowd_finish_kernel; plus plain random sequence.  Every k-mer is
+    labelled by the first site it occurs in.  Returns what random_db returns and the sites (the reads are cut from them)."""
+    code = {"A": 3, "C": 2, "G": 1, "T": 0}
+    units = ["AC", "AG", "AAT", "ACG", "AAAC", "ACAG", "A", "AGC", "".join(rng.choice(list("ACGT"), int(rng.integers(2, 9))))]
+    sites = []
+    for i in range(int(rng.integers(60, 260))):
+        u = units[int(rng.integers(0, len(units)))]
+        rep_ = (u * 60)[: int(rng.integers(k, 2 * k + 20))]
+        fl = "".join(rng.choice(list("ACGT"), 2 * k + 8))
+        sites.append(fl[: k + 4] + rep_ + fl[k + 4:])
+    for i in range(20):
+        sites.append("".join(rng.choice(list("ACGT"), int(rng.integers(k, 6 * k)))))
+    mask = (1 << (2 * k)) - 1
+    first = {}
+    for i, sq in enumerate(sites):
+        v = 0
+        for p, ch in enumerate(sq):
+            v = ((v << 2) | code[ch]) & mask
+            if p >= k - 1:
+                first.setdefault(o.canonical(v, k), i % T)
+    canon = sorted(first, key=lambda c: (c % htsize, c // htsize))
+    sizes = np.zeros(htsize, np.int64)
+    keep = []
+    for c in canon:
+        if sizes[c % htsize] < 255 and (c // htsize) < (1 << (8 * key_bytes)):
+            sizes[c % htsize] += 1
+            keep.append(c)
+    import golden_util as gu
+    keys = np.array([c // htsize for c in keep], dtype=np.uint64).astype(gu.KEY_DTYPE[key_bytes])
+    labels = np.array([first[c] for c in keep], dtype=np.uint16)
+    return sizes.astype(np.uint8), keys, labels, np.array(keep, dtype=np.uint64), sites
+
+
+def site_reads(rng, sites, n_reads, read_len, n_rate=0.01):
+    """reads cut out of the sites (either strand, a few substitutions and N) and random ones"""
+    comp = str.maketrans("ACGT", "TGCA")
+    recs = []
+    for i in range(n_reads):
+        if rng.random() < 0.15:
+            sq = "".join(rng.choice(list("ACGT"), int(rng.integers(1, read_len + 1))))
+        else:
+            src = sites[int(rng.integers(0, len(sites)))]
+            a = int(rng.integers(0, max(1, len(src) - 20)))
+            sq = src[a:a + int(rng.integers(max(1, read_len // 2), read_len + 1))]
+            while len(sq) < read_len // 2 and rng.random() < 0.7:      # long reads: several sites end to end
+                sq += sites[int(rng.integers(0, len(sites)))]
+            sq = list(sq[:read_len])
+            for p in range(len(sq)):
+                if rng.random() < n_rate:
+                    sq[p] = "ACGTN"[int(rng.integers(0, 5))]
+            sq = "".join(sq)
+            if i % 2:
+                sq = sq[::-1].translate(comp)
+        recs.append(f">r{i}\n{sq}\n")
+    return "".join(recs).encode()
+
+
 def make_case(seed, pack):
     """ORACLE SIDE: configuration `seed` - the database, the reads, and the answer the oracle gives.  pack(data, k) -> (rp, cont):
     the product's host packer in the one-process form (as before), the oracle's own in the split form."""
@@ -60,10 +119,17 @@ def make_case(seed, pack):
         n_elems = min(n_elems, (1 << (2 * k)) // 3)
     n_elems = min(n_elems, htsize * 200)
     T = int(rng.choice([1, 2, 7, 40, 64, 65, 300, 4096]))
-    sizes, keys, labels, canon = gu.random_db(rng, htsize, n_elems, k, key_bytes, T)
-    odb = o.db_from_arrays(sizes, keys, labels)
     L = int(rng.choice([k, k + 1, 40, 100, 150, 151, 250, 400, 1000]))
-    data = random_reads(rng, canon, k, int(rng.integers(50, 400)), max(L, k), gu.kmer_to_ascii)
+    if seed % 5 == 3 and k >= 20 and htsize >= 1009:
+        # every fifth configuration: tandem repeats - crowded minimizers in the super-k-mer layouts (same answers from every layout)
+        sizes, keys, labels, canon, sites = microsatellite_db(rng, o, htsize, k, key_bytes, T)
+        n_elems = int(keys.size)
+        odb = o.db_from_arrays(sizes, keys, labels)
+        data = site_reads(rng, sites, int(rng.integers(50, 400)), max(L, k))
+    else:
+        sizes, keys, labels, canon = gu.random_db(rng, htsize, n_elems, k, key_bytes, T)
+        odb = o.db_from_arrays(sizes, keys, labels)
+        data = random_reads(rng, canon, k, int(rng.integers(50, 400)), max(L, k), gu.kmer_to_ascii)
     rp, cont = pack(data, k)
     counts, bad = odb.query_batch(k, rp, cont, T)
     assert bad == 0
