@@ -221,3 +221,42 @@ def test_the_librarys_host_code_under_asan_against_a_mock_hip_runtime(tmp_path):
     for name in ("mic_db_load_host", "mic_batches_alloc", "mic_batch_query", "mic_batch_merge_shards", "mic_ingest_classify", "mic_ingest_classify_group"):
         n, bad = calls[name]
         assert n > 20 and bad < n // 2, (name, n, bad)
+
+
+def test_guard_page_allocator_catches_overruns_at_the_store(tmp_path):
+    """tools/sanitize/guardalloc.c (LD_PRELOAD; tools/guard_soak.sh runs the command line and the fuzzer's product side under it): a
+    block ends at an inaccessible page - a store 16 bytes past a 5000-byte block faults AT THE STORE with the arena named, a one-byte
+    overrun into the alignment slack is reported at the free, a use after free faults, clean code runs clean."""
+    import subprocess
+    so = tmp_path / "guardalloc.so"
+    r = subprocess.run(["gcc", "-O2", "-g", "-fPIC", "-shared", "-o", str(so), os.path.join(gu.ROOT, "tools", "sanitize", "guardalloc.c"), "-ldl", "-lpthread"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = tmp_path / "t.c"
+    src.write_text(r'''
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+int main(int argc, char** argv) {
+  int mode = atoi(argv[1]);
+  char* p = malloc(1000); memset(p, 1, 1000);
+  char* q = realloc(p, 5000); memset(q, 2, 5000);
+  char* c = calloc(100, 7); for (int i = 0; i < 700; ++i) if (c[i]) return 3;
+  void* a; if (posix_memalign(&a, 256, 3000)) return 4; memset(a, 3, 3000); free(a);
+  if (mode == 1) q[5000] = 9;
+  if (mode == 2) q[5000 + 16] = 9;
+  if (mode == 3) { free(q); q[10] = 1; }
+  free(q); free(c);
+  printf("ok\n");
+  return 0;
+}''')
+    exe = tmp_path / "t"
+    assert subprocess.run(["gcc", "-O0", "-g", "-o", str(exe), str(src)]).returncode == 0
+    env = dict(os.environ, LD_PRELOAD=str(so), GUARD_REPORT="1")
+    r = subprocess.run([str(exe), "0"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout and "[guardalloc] guarded " in r.stderr and "canary failures 0" in r.stderr, r.stderr
+    r = subprocess.run([str(exe), "1"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "overrun by 1 byte" in r.stderr, r.stderr
+    for mode in ("2", "3"):
+        r = subprocess.run([str(exe), mode], capture_output=True, text=True, env=env)
+        assert r.returncode != 0 and "inside the guarded arena" in r.stderr and "ok" not in r.stdout, (mode, r.stderr)

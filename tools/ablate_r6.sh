@@ -1,11 +1,14 @@
 #!/bin/bash
 # Round-6 ablations of query_kernel_r (MIC_X bits, mic_kernels.hip), each a variant library built ON the GPU box (obj_var does not travel),
-# one PMC pass per variant:   tools/ablate_r6.sh "0 1 3 7 8 24" [bench args, e.g. --layout super2]
+# one PMC pass per variant:   tools/ablate_r6.sh "0 7 rc0=-DMIC_T_RCWIN=0" [bench args, e.g. --layout super2]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 VARS=$1; shift
 mkdir -p $R/gpurun_out/abl
-for x in $VARS; do
-  make -C $R/cuclark_amd/csrc variant VARIANT_FLAGS="-DMIC_X=$x" > $R/gpurun_out/abl/build_$x.log 2>&1 || { echo "build $x failed"; tail -5 $R/gpurun_out/abl/build_$x.log; continue; }
+for item in $VARS; do
+  # an item is a MIC_X value, or name=flags (e.g. rc0=-DMIC_T_RCWIN=0)
+  if [[ "$item" == *=* ]]; then x=${item%%=*}; FL=${item#*=}; else x=$item; FL="-DMIC_X=$item"; fi
+  rm -rf $R/gpurun_out/abl/p_$x
+  make -C $R/cuclark_amd/csrc variant VARIANT_FLAGS="$FL" > $R/gpurun_out/abl/build_$x.log 2>&1 || { echo "build $x failed"; tail -5 $R/gpurun_out/abl/build_$x.log; continue; }
   cp $R/cuclark_amd/csrc/obj_var/libmi_clark_var.so $R/gpurun_out/abl/lib_$x.so
   ( cd /tmp && export TMPDIR=/tmp MIC_LIB_PATH=$R/gpurun_out/abl/lib_$x.so
     echo "variant $x: counters" >> $R/gpurun_out/abl/progress.txt
