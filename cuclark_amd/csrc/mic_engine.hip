@@ -1307,6 +1307,18 @@ int mic_last_crowd_stats(mic_engine* e, uint32_t out[4]) {
   return MIC_OK;
 }
 
+int mic_debug_fetch_crowd(mic_engine* e, uint32_t* out, size_t words, uint32_t caps[3]) {
+  if (!e || !out || !caps) return fail(MIC_E_INVALID, "null argument");
+  if (!e->d_crowd || !e->timed) return fail(MIC_E_STATE, "no work area");
+  int rc = set_device(e);
+  if (rc) return rc;
+  const MicCrowdDims d = mic_crowd_dims(e->crowd_reads);
+  caps[0] = d.pend_cap; caps[1] = d.item_cap; caps[2] = d.pool_cap;
+  HIPTRY(hipEventSynchronize(e->ev1));
+  HIPTRY(hipMemcpy(out, e->d_crowd, (words < d.words ? words : d.words) * 4, hipMemcpyDeviceToHost));
+  return MIC_OK;
+}
+
 int mic_resolve_flagged_device(mic_engine* e, const uint32_t* d_rp, const uint16_t* d_cont, uint32_t* d_results,
                                uint32_t* d_rows, void* stream, size_t* n_resolved) {
   if (!e || !d_rp || !d_cont || !d_results) return fail(MIC_E_INVALID, "null argument");

@@ -1443,14 +1443,14 @@ __global__ void __launch_bounds__(64 * MIC_M_WPB, 32 / MIC_M_WPB) query_kernel_r
       cur = 0xFFFFFFFFu;
       if (wballot(nx)) { if (nx && q[5] <= key) cur = q[31]; }
     } while (wballot(cur != 0xFFFFFFFFu));
-    if (!(MIC_X & 2) && __builtin_expect(wballot(remaining < 0) != 0, 0)) {
+    if (!(MIC_X & 2) && __builtin_expect(wballot(remaining <= MIC_R_CROWDED) != 0, 0)) {
       // Rare (a database with microsatellites, a read that overlaps one): the crowded runs of this round become items of the
       // follow-up's work list - the region as the table orients it and the run's range of minimizer positions; the k-mer with
       // its minimizer at position j is the region's nucleotides [ctx - j, ctx - j + k).  One reservation per round.
       // Everything here is kept in VECTOR registers on purpose (the kernarg pointer made opaque, so that the loads from it are
       // vector loads): the entry loop's temporaries are dead at this point, while the scalar file is full - what this block
       // would take of it, the common path would spill and reload per read.
-      const bool crowded = remaining < 0;
+      const bool crowded = remaining <= MIC_R_CROWDED;
       const uint32_t n_c = (uint32_t)__popcll(wballot(crowded));
       uint64_t kpv = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+v"(kpv));

@@ -250,6 +250,9 @@ int mic_last_query_ms(mic_engine* e, float* ms);
  * follow-up kernel, crowded runs handed to it, words of spilled rows, reads sent to the dense path for lack of room in
  * the work area}.  All zero for any other table.  Synchronous. */
 int mic_last_crowd_stats(mic_engine* e, uint32_t out[4]);
+/* test hook: the first `words` 32-bit words of the work area of the last mic_query_device launch (mic_internal.h: header, pending reads,
+ * items, pool) and its capacities {pending reads, items, pool words}; MIC_E_STATE when the engine has none.  Synchronous. */
+int mic_debug_fetch_crowd(mic_engine* e, uint32_t* out, size_t words, uint32_t caps[3]);
 
 /* ---- device-side ingest: raw FASTA / FASTQ bytes in, result-CSV text out ----------------------------------------
  * The reference does the read indexing (CuCLARK_hh.hh:1339-1534), the 2-bit packing with its N-splitting

@@ -51,7 +51,7 @@ def microsatellite_db(rng, o, htsize, k, key_bytes, T):
     ONE minimizer - crowded minimizers, a side table, reads handed to crowd_finish_kernel; plus plain random sequence.  Every k-mer is
     labelled by the first site it occurs in.  Returns what random_db returns and the sites (the reads are cut from them)."""
     code = {"A": 3, "C": 2, "G": 1, "T": 0}
-    units = ["AC", "AG", "AAT", "ACG", "AAAC", "ACAG", "A", "AGC", "".join(rng.choice(list("ACGT"), int(rng.integers(2, 9))))]
+    units = ["AC", "AG", "AAT", "ACG", "AAAC", "ACAG", "A", "AGC", "GC", "AT", "ACGT", "".join(rng.choice(list("ACGT"), int(rng.integers(2, 9))))]
     sites = []
     for i in range(int(rng.integers(60, 260))):
         u = units[int(rng.integers(0, len(units)))]

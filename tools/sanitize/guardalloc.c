@@ -96,6 +96,17 @@ static void on_fault(int sig, siginfo_t* si, void* ctx) {
     void* bt[64];
     const int nb = backtrace(bt, 64);
     backtrace_symbols_fd(bt, nb, 2);
+  } else if (!t_inside) {
+    /* a fault somewhere else (a wild pointer, a library's own bug): the native stack all the same - Python's faulthandler, which
+       runs next, only knows the interpreter's */
+    t_inside = 1;
+    char msg[160];
+    const int n = snprintf(msg, sizeof msg, "\n[guardalloc] signal %d at address %p (outside the guarded arena); native stack:\n", sig, addr);
+    if (write(2, msg, n) < 0) {}
+    void* bt[64];
+    const int nb = backtrace(bt, 64);
+    backtrace_symbols_fd(bt, nb, 2);
+    t_inside = 0;
   }
   struct sigaction* prev = sig == SIGBUS ? &prev_bus : &prev_segv;
   if (prev->sa_flags & SA_SIGINFO) { if (prev->sa_sigaction) { prev->sa_sigaction(sig, si, ctx); return; } }
