@@ -19,6 +19,7 @@
 #include <atomic>
 #include <thread>
 #include <unistd.h>
+#include <utility>
 #include <vector>
 
 int mic_bind_thread_near_device(int device, int on);   // below: host memory near the device
@@ -39,6 +40,72 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace
 thread_local uint64_t mic_build_reserved_hbm = 0;
+
+// ---- streams and events: pooled for the life of the process, never destroyed -------------------------------------------------------
+// The one native fault this library's soaks ever produced (three sightings in ~100 hours of fuzzing since round 3, "heap corruption,
+// cause unknown") was caught in round 6 under the guard-page allocator with its native stack: the HIP runtime's completion-signal
+// handler (a thread of libhsa-runtime64 calling into libamdhip64: `lock sub [queue + 0x98]`, `xchg [queue + 0x378]`) running for the
+// last command of a stream AFTER hipDeviceSynchronize had returned on the thread that then destroyed that stream - the handler
+// decrements a counter in the freed queue object: a write into whatever the heap put there next.  Twice in two soaks of ~750
+// engine lifetimes each, both inside mic_destroy.  Nothing the caller can order (the wait had returned) - so the objects whose
+// destruction races are not destroyed: an engine's streams and events go back to a pool (drained first), the next engine on that
+// device takes them.  The pool is bounded by the most that were ever live at once.  Creating a stream costs ~2 ms (a hardware queue):
+// a process that builds engines repeatedly also saves that.
+namespace {
+struct StreamPool {
+  std::mutex mu;
+  std::vector<std::pair<int, hipStream_t>> free_streams, all_streams;          // (device, stream)
+  std::vector<std::pair<int, hipEvent_t>> free_events, all_events;             // (device * 2 + timing, event)
+};
+StreamPool& pool() { static StreamPool* p = new StreamPool; return *p; }       // (never destructed: handles outlive every static)
+}  // namespace
+
+hipError_t mic_stream_get(hipStream_t* s) {
+  int dev = 0;
+  hipError_t he = hipGetDevice(&dev);
+  if (he != hipSuccess) return he;
+  StreamPool& P = pool();
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (size_t i = 0; i < P.free_streams.size(); ++i)
+      if (P.free_streams[i].first == dev) { *s = P.free_streams[i].second; P.free_streams.erase(P.free_streams.begin() + (ptrdiff_t)i); return hipSuccess; }
+  }
+  he = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  if (he == hipSuccess) { std::lock_guard<std::mutex> lk(P.mu); P.all_streams.emplace_back(dev, *s); }
+  return he;
+}
+
+void mic_stream_put(hipStream_t s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s);
+  StreamPool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  for (const auto& a : P.all_streams) if (a.second == s) { P.free_streams.push_back(a); return; }
+}
+
+hipError_t mic_event_get(hipEvent_t* ev, bool timing) {
+  int dev = 0;
+  hipError_t he = hipGetDevice(&dev);
+  if (he != hipSuccess) return he;
+  const int key = dev * 2 + (timing ? 1 : 0);
+  StreamPool& P = pool();
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (size_t i = 0; i < P.free_events.size(); ++i)
+      if (P.free_events[i].first == key) { *ev = P.free_events[i].second; P.free_events.erase(P.free_events.begin() + (ptrdiff_t)i); return hipSuccess; }
+  }
+  he = timing ? hipEventCreate(ev) : hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  if (he == hipSuccess) { std::lock_guard<std::mutex> lk(P.mu); P.all_events.emplace_back(key, *ev); }
+  return he;
+}
+
+void mic_event_put(hipEvent_t ev) {
+  if (!ev) return;
+  (void)hipEventSynchronize(ev);             // (recorded work done - or never recorded: returns at once)
+  StreamPool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  for (const auto& a : P.all_events) if (a.second == ev) { P.free_events.push_back(a); return; }
+}
 namespace {
 std::mutex g_report_mu;
 std::string g_report;     // stage times of the last table build that FINISHED in this process, one "name: seconds" per line
@@ -194,7 +261,7 @@ int upload_file_range_multi(FILE* f, const std::vector<UploadDst>& dsts, const c
   stage[0] = st->buf[0]; stage[1] = st->buf[1];
   mic_bind_thread_near_device(dsts[0].device, 1);
   for (size_t i = 0; i < 2 * nd && rc == MIC_OK; ++i) {
-    if (hipSetDevice(dsts[i % nd].device) != hipSuccess || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
+    if (hipSetDevice(dsts[i % nd].device) != hipSuccess || mic_event_get(&ev[i], false) != hipSuccess)
       rc = fail(MIC_E_HIP, "event create failed");
   }
   uint64_t done = 0; int cur = 0;
@@ -242,7 +309,7 @@ int upload_file_range_multi(FILE* f, const std::vector<UploadDst>& dsts, const c
     cur ^= 1; done += n;
   }
   for (size_t d = 0; d < nd; ++d) { hipSetDevice(dsts[d].device); hipStreamSynchronize(dsts[d].stream); }
-  for (hipEvent_t e : ev) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : ev) if (e) mic_event_put(e);
   mic_bind_thread_near_device(dsts[0].device, 0);
   hipSetDevice(dev_now);
   return rc;
@@ -398,10 +465,10 @@ int build_from_device(mic_engine* e, const uint8_t* d_sizes_shard, uint64_t htsi
 
 void free_batches(mic_engine* e) {
   for (Batch& b : e->batches) {
-    if (b.done) hipEventDestroy(b.done);
-    if (b.ev_up) hipEventDestroy(b.ev_up);
-    if (b.ev_k) hipEventDestroy(b.ev_k);
-    if (b.stream) hipStreamDestroy(b.stream);
+    if (b.done) mic_event_put(b.done);
+    if (b.ev_up) mic_event_put(b.ev_up);
+    if (b.ev_k) mic_event_put(b.ev_k);
+    if (b.stream) mic_stream_put(b.stream);
     if (b.d_peer) hipFree(b.d_peer);
     if (b.d_acc) hipFree(b.d_acc);
   }
@@ -604,11 +671,11 @@ int mic_create(const mic_config* cfg, mic_engine** out) {
   e->n_cu = prop.multiProcessorCount;
   memset(&e->info, 0, sizeof(e->info));
   memset(&e->table, 0, sizeof(e->table));
-  hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-  if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking);
-  if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->down_stream, hipStreamNonBlocking);
-  if (he == hipSuccess) he = hipEventCreate(&e->ev0);
-  if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  hipError_t he = mic_stream_get(&e->stream);
+  if (he == hipSuccess) he = mic_stream_get(&e->up_stream);
+  if (he == hipSuccess) he = mic_stream_get(&e->down_stream);
+  if (he == hipSuccess) he = mic_event_get(&e->ev0, true);
+  if (he == hipSuccess) he = mic_event_get(&e->ev1, true);
   if (he == hipSuccess) he = hipMalloc(&e->d_flagged, (size_t)(kFlaggedCap + 1) * 4);
   if (he != hipSuccess) { mic_destroy(e); return fail(MIC_E_HIP, "engine setup: %s", hipGetErrorString(he)); }
   e->flagged_cap = kFlaggedCap;
@@ -628,11 +695,11 @@ int mic_destroy(mic_engine* e) {
   if (e->d_sizes) hipFree(e->d_sizes);
   if (e->d_flagged) hipFree(e->d_flagged);
   if (e->d_crowd) hipFree(e->d_crowd);
-  if (e->ev0) hipEventDestroy(e->ev0);
-  if (e->ev1) hipEventDestroy(e->ev1);
-  if (e->stream) hipStreamDestroy(e->stream);
-  if (e->up_stream) hipStreamDestroy(e->up_stream);
-  if (e->down_stream) hipStreamDestroy(e->down_stream);
+  if (e->ev0) mic_event_put(e->ev0);
+  if (e->ev1) mic_event_put(e->ev1);
+  if (e->stream) mic_stream_put(e->stream);
+  if (e->up_stream) mic_stream_put(e->up_stream);
+  if (e->down_stream) mic_stream_put(e->down_stream);
   delete e;
   return MIC_OK;
 }
@@ -843,10 +910,10 @@ int mic_batches_alloc(mic_engine* e, size_t num_reads_total, size_t max_reads, s
     if (extended) { B.d_rows = (uint32_t*)dp; dp += sz_rows; }
     B.d_flagged = (uint32_t*)dp; dp += sz_fl;
     B.d_crowd = (uint32_t*)dp; dp += sz_crowd;
-    HIPTRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
-    HIPTRY(hipEventCreateWithFlags(&B.done, hipEventDisableTiming));
-    HIPTRY(hipEventCreateWithFlags(&B.ev_up, hipEventDisableTiming));
-    HIPTRY(hipEventCreateWithFlags(&B.ev_k, hipEventDisableTiming));
+    HIPTRY(mic_stream_get(&B.stream));
+    HIPTRY(mic_event_get(&B.done, false));
+    HIPTRY(mic_event_get(&B.ev_up, false));
+    HIPTRY(mic_event_get(&B.ev_k, false));
     reads_pointer[b] = B.h_rp;
     containers[b] = B.h_cont;
   }

@@ -650,8 +650,8 @@ __device__ void fixed_codes_w(Fast& f, int lane) {
 // WRITE = false: the counting form (units that did not fit their region are counted exactly and decoded again)
 template <bool WRITE>
 __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restrict__ d, uint64_t n, GzUnit* __restrict__ units, uint32_t n_units,
-                                               uint16_t* __restrict__ sym, const uint32_t* __restrict__ which, int all_known) {
-  const uint32_t u = which ? which[blockIdx.x] : blockIdx.x;
+                                               uint16_t* __restrict__ sym, const uint32_t* __restrict__ which, int all_known, uint32_t u_base = 0) {
+  const uint32_t u = which ? which[blockIdx.x] : blockIdx.x + u_base;         // (u_base: a stripe of the units, GzJob::next)
   const int lane = threadIdx.x;
   if (u >= n_units) return;
   GzUnit& U = units[u];
@@ -900,9 +900,9 @@ __device__ __forceinline__ void gz_decode_body(Fast& f, const uint8_t* __restric
 // slow each other down, so the registers the compiler likes to take (158: three wavefronts per SIMD) are left to it.
 template <bool WRITE>
 __global__ void __launch_bounds__(64) gz_decode_kernel(const uint8_t* __restrict__ d, uint64_t n, GzUnit* __restrict__ units, uint32_t n_units,
-                                                      uint16_t* __restrict__ sym, const uint32_t* __restrict__ which, int all_known) {
+                                                      uint16_t* __restrict__ sym, const uint32_t* __restrict__ which, int all_known, uint32_t u_base) {
   __shared__ Fast f;
-  gz_decode_body<WRITE>(f, d, n, units, n_units, sym, which, all_known);
+  gz_decode_body<WRITE>(f, d, n, units, n_units, sym, which, all_known, u_base);
 }
 // Block gzip: thousands of small members, more wavefronts than the chip holds - 128 registers, four wavefronts per SIMD (measured on
 // 2 x 4 842 members: 22-27 ms against 28-32)
@@ -963,13 +963,15 @@ __global__ void __launch_bounds__(1024) gz_compose_kernel(const GzUnit* __restri
   for (int i = tid * 8; i < 32768; i += 8192) *(uint4*)(q + i) = *(const uint4*)(cur + i);
 }
 
-// wg[g] = the 32 KiB in front of group g (bytes); the member starts with an empty (zero) window that nothing refers to.
-__global__ void __launch_bounds__(1024) gz_chain_kernel(const uint16_t* __restrict__ qmap, uint32_t n_groups, uint8_t* __restrict__ wg) {
+// wg[g] = the 32 KiB in front of group g (bytes); the member starts with an empty (zero) window that nothing refers to, a later stripe
+// of it (GzJob::next) with the last `have` bytes of the text so far (init = where they start).
+__global__ void __launch_bounds__(1024) gz_chain_kernel(const uint16_t* __restrict__ qmap, uint32_t n_groups, uint8_t* __restrict__ wg,
+                                                       const uint8_t* __restrict__ init, uint32_t have) {
   __shared__ uint8_t w0[32768];
   __shared__ uint8_t w1[32768];
   uint8_t* cur = w0; uint8_t* nxt = w1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < 32768; i += 1024) cur[i] = 0;
+  for (int i = tid; i < 32768; i += 1024) cur[i] = (uint32_t)i >= 32768u - have ? init[(uint32_t)i - (32768u - have)] : (uint8_t)0;
   uint16_t x[32];
   auto fetch = [&](uint32_t g) {
     const uint16_t* q = qmap + (size_t)g * 32768;
@@ -1320,6 +1322,260 @@ done:
 }
 }  // namespace
 
+// ---- one plain member, in stripes ---------------------------------------------------------------------------------------------------
+// The units of a member (one per found block) are taken through decode -> stitch -> windows -> resolve in STRIPES of consecutive units:
+// when a stripe is done its text is final - the window in front of its first unit is the last 32 KiB of the text so far - and the
+// caller can index and classify it while the next stripe decodes (mic_gz_stream_*, round 6).  One stripe of all
+// units is the whole-member call (mic_gz_inflate_device): the same code.  The decode of a unit is a serial thing of ~6 ms whatever
+// the number of units, up to the ~3 000 wavefronts the chip holds: a stripe is about a thousand units - its wavefronts then do not
+// share a SIMD, and what is left of the chip runs the query kernels of the stripe before.
+struct GzJob {
+  mic_engine* eng = nullptr;
+  const uint8_t* p = nullptr; size_t gz_bytes = 0, n = 0, hdr = 0;
+  uint32_t crc = 0, isize = 0;
+  hipStream_t s = nullptr;
+  uint8_t* d_in = nullptr; unsigned long long* d_start = nullptr; GzUnit* d_units = nullptr; uint16_t* d_sym = nullptr;
+  uint16_t* d_pmap = nullptr; uint16_t* d_qmap = nullptr; uint8_t* d_wg = nullptr; uint8_t* d_out = nullptr; GzUnit* d_chain = nullptr;
+  uint32_t* d_crc = nullptr;
+  uint32_t n_chunks = 0;
+  std::vector<GzUnit> units;
+  unsigned long long sym_total = 0, sym_bound = 0, sym_used = 0;      // regions handed out at the start / the bound / symbols the buffer holds now
+  uint64_t total = 0;                                                 // bytes of text that are final
+  unsigned long long pos = 0; bool final = false;                     // the chain so far: where it ends, whether it met the last block
+  size_t next_unit = 0, per_stripe = 0, chain_len = 0;
+  size_t pmap_units = 0, wg_groups = 0;
+  size_t crc_pieces_done = 0;
+  std::vector<uint32_t> piece;
+  char* arena = nullptr; size_t arena_left = 0;
+  std::vector<void*> owned;
+  bool timing = false;
+  struct timespec tq0;
+
+  hipError_t dev_alloc(void** ptr, size_t bytes) {
+    const size_t b = up256(bytes);
+    if (b <= arena_left) { *ptr = arena; arena += b; arena_left -= b; return hipSuccess; }
+    const hipError_t he = hipMalloc(ptr, bytes);
+    if (he == hipSuccess) owned.push_back(*ptr);
+    return he;
+  }
+  void dev_free(void* ptr) {                      // (memory of the reservation stays where it is)
+    for (size_t i = 0; i < owned.size(); ++i) if (owned[i] == ptr) { hipFree(ptr); owned.erase(owned.begin() + (ptrdiff_t)i); return; }
+  }
+  void lap(const char* what) {
+    if (!timing) return;
+    if (s) hipStreamSynchronize(s);
+    struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+    fprintf(stderr, "[gz] %s: %.3f ms\n", what, (t1.tv_sec - tq0.tv_sec) * 1e3 + (t1.tv_nsec - tq0.tv_nsec) / 1e6);
+    tq0 = t1;
+  }
+  bool done() const { return next_unit >= units.size() || final; }
+
+  // upload, find the blocks, set the units up.  stripes = 0: one stripe (everything at once)
+  int open(mic_engine* e, const void* gz, size_t bytes, uint32_t stripes) {
+    int rc = MIC_OK;
+    eng = e; p = (const uint8_t*)gz; gz_bytes = bytes;
+    hdr = gzip_header(p, gz_bytes);
+    if (!hdr) return mic_set_error(MIC_E_UNSUPPORTED, "not a plain gzip member");
+    n = gz_bytes - 8;                                   // deflate data + nothing else expected in front of the trailer
+    crc = (uint32_t)p[n] | ((uint32_t)p[n + 1] << 8) | ((uint32_t)p[n + 2] << 16) | ((uint32_t)p[n + 3] << 24);
+    isize = (uint32_t)p[n + 4] | ((uint32_t)p[n + 5] << 8) | ((uint32_t)p[n + 6] << 16) | ((uint32_t)p[n + 7] << 24);
+    n_chunks = (uint32_t)((n + GZ_CHUNK - 1) / GZ_CHUNK);
+    std::vector<unsigned long long> h_start(n_chunks);
+    // device memory: out of the reservation made for a file of this size, if there is one (mic_gz_reserve), else allocated here
+    {
+      std::lock_guard<std::mutex> lk(g_res_mu);
+      for (GzReserve& r : g_res)
+        if (r.eng == e && r.gz_bytes == gz_bytes && !r.taken) {
+          r.taken = true; arena = r.scratch; arena_left = r.scratch_bytes;
+          if (r.text && (size_t)isize + 64 <= r.text_bytes) { d_out = r.text; r.text = nullptr; }      // (the text is this call's from here on)
+          break;
+        }
+    }
+    timing = getenv("MIC_GZ_TIMING") != nullptr;
+    clock_gettime(CLOCK_MONOTONIC, &tq0);
+    s = call_stream(e);
+    GZTRY(dev_alloc((void**)&d_in, n + 16));
+    GZTRY(hipMemsetAsync(d_in + n, 0, 16, s));
+    GZTRY(hipMemcpyAsync(d_in, p, n, hipMemcpyHostToDevice, s));
+    lap("upload");
+    GZTRY(dev_alloc((void**)&d_start, (size_t)n_chunks * 8));
+    gz_find_kernel<<<n_chunks, 64, 0, s>>>(d_in, n, (uint64_t)hdr * 8, n_chunks, d_start);
+    GZTRY(hipGetLastError());
+    GZTRY(hipMemcpyAsync(h_start.data(), d_start, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s));
+    // The big buffers are allocated while the upload and the finder run (a fresh gigabyte takes the driver 30-40 ms: as much as the
+    // decode): the symbol buffer by its bound - every unit gets 8 x its compressed span + 16 Ki symbols, there are at most n_chunks
+    // units - and the text by the member's ISIZE, which the decode has to arrive at anyway
+    sym_bound = sym_bound_of(n, n_chunks);
+    GZTRY(dev_alloc((void**)&d_sym, (sym_bound + 8) * 2));
+    if (!d_out && (unsigned long long)isize <= 1100ull * n) GZTRY(hipMalloc(&d_out, (size_t)isize + 64));
+    GZTRY(hipStreamSynchronize(s));
+    lap("find blocks (+ symbol and text buffers allocated)");
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      if (h_start[c] == ~0ull) continue;
+      GzUnit u; memset(&u, 0, sizeof(u));
+      u.start_bit = h_start[c];
+      units.push_back(u);
+    }
+    if (units.empty()) { rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: no block found"); goto done; }
+    {
+      // every unit gets a region of the symbol buffer sized by its compressed span (8 x + 16 Ki symbols: FASTQ inflates 3-6 x);
+      // a unit that needs more is counted exactly by the same pass and decoded again into a region of its own
+      unsigned long long so = 0;
+      for (size_t i = 0; i < units.size(); ++i) {
+        units[i].stop_bit = i + 1 < units.size() ? units[i + 1].start_bit : ~0ull;
+        const unsigned long long span = ((i + 1 < units.size() ? units[i + 1].start_bit : (unsigned long long)n * 8) - units[i].start_bit) / 8 + 1;
+        units[i].sym_off = so; units[i].sym_cap = span * 8 + 16384;
+        so += units[i].sym_cap;
+      }
+      sym_total = so;
+    }
+    if (sym_total > sym_bound) { rc = mic_set_error(MIC_E_HIP, "gzip on the device: symbol regions beyond their bound"); goto done; }
+    sym_used = sym_total + 8;
+    per_stripe = units.size();
+    if (stripes > 1) per_stripe = std::max<size_t>((units.size() + stripes - 1) / stripes, 64);
+    GZTRY(dev_alloc((void**)&d_units, units.size() * sizeof(GzUnit)));
+    GZTRY(hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
+    GZTRY(dev_alloc((void**)&d_chain, per_stripe * sizeof(GzUnit)));
+    {
+      uint32_t group = 1;
+      while ((size_t)group * group < per_stripe) ++group;                        // units per group of the window chain: ~sqrt(units)
+      pmap_units = per_stripe; wg_groups = (per_stripe + group - 1) / group;
+      GZTRY(dev_alloc((void**)&d_pmap, pmap_units * (size_t)65536));
+      GZTRY(dev_alloc((void**)&d_qmap, wg_groups * (size_t)65536));
+      GZTRY(dev_alloc((void**)&d_wg, wg_groups * (size_t)32768));
+    }
+    pos = units[0].start_bit;
+    {
+      static std::once_flag lds_once; static hipError_t lds_rc = hipSuccess;
+      std::call_once(lds_once, [] { lds_rc = hipFuncSetAttribute((const void*)gz_compose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536); });
+      GZTRY(lds_rc);
+    }
+  done:
+    return rc;
+  }
+
+  // the next stripe: on MIC_OK the first `total` bytes of the text are final (the stream has been waited for)
+  int next() {
+    int rc = MIC_OK;
+    if (done()) return MIC_OK;
+    const size_t a = next_unit, b = std::min(units.size(), a + per_stripe);
+    const bool last_stripe = b == units.size();
+    const uint64_t text_from = total;
+    std::vector<GzUnit> chain;
+    std::vector<uint32_t> redo;
+    unsigned long long extra = 0;
+    next_unit = b;
+    gz_decode_kernel<true><<<(unsigned)(b - a), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, nullptr, 0, (uint32_t)a);
+    GZTRY(hipGetLastError());
+    GZTRY(hipMemcpyAsync(units.data() + a, d_units + a, (b - a) * sizeof(GzUnit), hipMemcpyDeviceToHost, s));
+    GZTRY(hipStreamSynchronize(s));
+    lap("decode");
+    if (timing) {
+      unsigned long long mx = 0, sum = 0, mxspan = 0, mxc = 0, sumc = 0;
+      for (size_t i = a; i < b; ++i) { const GzUnit& u = units[i]; if (u.n_sym > mx) mx = u.n_sym; sum += u.n_sym; if (u.end_bit - u.start_bit > mxspan) mxspan = u.end_bit - u.start_bit; if (u.pad > mxc) mxc = u.pad; sumc += u.pad; }
+      fprintf(stderr, "[gz] cycles per unit: mean %llu, max %llu; cycles per output symbol %.1f\n", sumc / (b - a), mxc, (double)sumc / (double)(sum ? sum : 1));
+      fprintf(stderr, "[gz] units: %zu, symbols per unit: mean %llu, max %llu; longest span %llu bytes\n", b - a, sum / (b - a), mx, mxspan / 8);
+    }
+    // the chain: a unit is taken iff the chain so far ends exactly on its start; one that starts inside the chain was a false find
+    for (size_t i = a; i < b && !final; ++i) {
+      GzUnit& u = units[i];
+      if (u.start_bit < pos) continue;
+      if (u.start_bit > pos || u.status > GZ_FINAL) { rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: the units do not stitch (unit %zu, status %u)", i, u.status); goto done; }
+      if (u.n_sym > u.sym_cap) { redo.push_back((uint32_t)i); u.sym_off = sym_used + extra; u.sym_cap = u.n_sym; extra += u.n_sym; }
+      u.out_off = total; total += u.n_sym;
+      // more text than the trailer's 32-bit length: a text of 4 GiB or more (the length wraps), or damage - the CPU inflater's case either way
+      if (d_out && total > (uint64_t)isize) { rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: more text than the trailer's length"); goto done; }
+      chain.push_back(u);
+      pos = u.end_bit;
+      final = u.status == GZ_FINAL;
+    }
+    if (final || last_stripe) {
+      // behind the last block: the trailer, right there (bits up to the next byte are padding)
+      if (!final || (pos + 7) / 8 != n) { rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: more than one member, or data behind the last block"); goto done; }
+      if ((uint32_t)total != isize) { rc = mic_set_error(MIC_E_INVALID, "Failed to uncompress input objects."); goto done; }
+    }
+    if (!redo.empty()) {
+      // (a second symbol buffer behind the first would need the first one's copy: the units that overflowed get room behind the
+      // symbols there are, addressed through the same base pointer - offsets are relative to d_sym, so the buffer grows as ONE)
+      uint16_t* bigger = nullptr;
+      GZTRY(dev_alloc((void**)&bigger, (sym_used + extra + 8) * 2));
+      GZTRY(hipMemcpyAsync(bigger, d_sym, sym_used * 2, hipMemcpyDeviceToDevice, s));
+      GZTRY(hipStreamSynchronize(s));
+      dev_free(d_sym); d_sym = bigger; sym_used += extra;
+      uint32_t* d_which = nullptr;
+      GZTRY(dev_alloc((void**)&d_which, redo.size() * 4));
+      hipError_t e1 = hipMemcpyAsync(d_which, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, s);
+      if (e1 == hipSuccess) e1 = hipMemcpyAsync(d_units + a, units.data() + a, (b - a) * sizeof(GzUnit), hipMemcpyHostToDevice, s);
+      if (e1 == hipSuccess) { gz_decode_kernel<true><<<(unsigned)redo.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, d_which, 0, 0); e1 = hipGetLastError(); }
+      std::vector<GzUnit> back(b - a);
+      if (e1 == hipSuccess) e1 = hipMemcpyAsync(back.data(), d_units + a, (b - a) * sizeof(GzUnit), hipMemcpyDeviceToHost, s);
+      if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
+      dev_free(d_which);
+      GZTRY(e1);
+      for (uint32_t i : redo)
+        if (back[i - a].status != units[i].status || back[i - a].end_bit != units[i].end_bit || back[i - a].n_sym != units[i].n_sym) {
+          rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: the second decode of unit %u differs", i); goto done;
+        }
+      for (GzUnit& c : chain) for (uint32_t i : redo) if (c.start_bit == units[i].start_bit) { c.sym_off = units[i].sym_off; c.sym_cap = units[i].sym_cap; }
+      lap("decode again (units that overflowed their region)");
+    }
+    if (!d_out) {                    // (a trailer that promises more than 1100 x the file: the text is allocated once its length is known)
+      if (!done()) { rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: no text buffer for a member in stripes"); goto done; }
+      GZTRY(hipMalloc(&d_out, total + 64));
+    }
+    if (!chain.empty()) {
+      uint32_t group = 1;
+      while ((size_t)group * group < chain.size()) ++group;
+      const uint32_t n_groups = (uint32_t)((chain.size() + group - 1) / group);
+      if (chain.size() > pmap_units || n_groups > wg_groups) { rc = mic_set_error(MIC_E_HIP, "gzip on the device: a stripe beyond its window maps"); goto done; }
+      GZTRY(hipMemcpyAsync(d_chain, chain.data(), chain.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
+      gz_compose_kernel<<<n_groups, 1024, 2 * 65536, s>>>(d_chain, (uint32_t)chain.size(), group, d_sym, d_pmap, d_qmap);
+      GZTRY(hipGetLastError());
+      // the window in front of the stripe: the end of the text so far (nothing in front of the member's first byte)
+      const uint32_t have = text_from >= 32768 ? 32768u : (uint32_t)text_from;
+      gz_chain_kernel<<<1, 1024, 0, s>>>(d_qmap, n_groups, d_wg, d_out + text_from - have, have);
+      GZTRY(hipGetLastError());
+      lap("windows");
+      gz_resolve2_kernel<<<(unsigned)chain.size() * 8u, 256, 0, s>>>(d_chain, (uint32_t)chain.size(), group, d_sym, d_pmap, d_wg, d_out, 8);
+      GZTRY(hipGetLastError());
+      chain_len += chain.size();
+    }
+    {
+      // CRC-32 of the whole 4-KiB pieces that became final (the last stripe: and of the rest)
+      const size_t n_pieces = done() ? (size_t)((total + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE) : (size_t)(total / GZ_CRC_PIECE);
+      if (!d_crc) { GZTRY(dev_alloc((void**)&d_crc, ((size_t)isize / GZ_CRC_PIECE + 2) * 4)); piece = take_hostbuf((size_t)isize / GZ_CRC_PIECE + 2); }
+      if (n_pieces > crc_pieces_done) {
+        const size_t from = crc_pieces_done, cnt = n_pieces - from;
+        const uint64_t upto = done() ? total : (uint64_t)n_pieces * GZ_CRC_PIECE;
+        gz_crc_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, s>>>(d_out + (uint64_t)from * GZ_CRC_PIECE, upto - (uint64_t)from * GZ_CRC_PIECE, d_crc + from);
+        GZTRY(hipGetLastError());
+        GZTRY(hipMemcpyAsync(piece.data() + from, d_crc + from, cnt * 4, hipMemcpyDeviceToHost, s));
+        crc_pieces_done = n_pieces;
+      }
+      GZTRY(hipStreamSynchronize(s));
+      lap("resolve + CRC-32 of the pieces");
+      if (done()) {
+        piece.resize(crc_pieces_done);
+        if (crc_of_pieces(piece, total) != crc) { rc = mic_set_error(MIC_E_INVALID, "Failed to uncompress input objects."); goto done; }   // (gunzip: "crc error")
+        if (timing) fprintf(stderr, "[gz] %zu bytes -> %llu bytes, %u chunks, %zu units found, %zu in the chain\n", gz_bytes, (unsigned long long)total, n_chunks, units.size(), chain_len);
+      }
+    }
+  done:
+    return rc;
+  }
+
+  // everything but the text; the text too unless the caller took it (take_text)
+  uint8_t* take_text() { uint8_t* t = d_out; d_out = nullptr; return t; }
+  void close() {
+    if (s) { hipStreamSynchronize(s); s = nullptr; }
+    for (void* q : owned) hipFree(q);
+    owned.clear();
+    if (d_out) { hipFree(d_out); d_out = nullptr; }
+    keep_hostbuf(piece);
+    lap("buffers freed");
+  }
+};
+
 extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_bytes, void** d_text, size_t* n_text, uint32_t* crc32_expected) {
   if (!e || !gz || !d_text || !n_text) return mic_set_error(MIC_E_INVALID, "null argument");
   *d_text = nullptr; *n_text = 0;
@@ -1332,193 +1588,55 @@ extern "C" int mic_gz_inflate_device(mic_engine* e, const void* gz, size_t gz_by
     if (crc32_expected) *crc32_expected = 0;                                                               // (checked per member, inside)
     return inflate_bgzf(e, p, gz_bytes, d_text, n_text);
   }
-  const size_t hdr = gzip_header(p, gz_bytes);
-  if (!hdr) return mic_set_error(MIC_E_UNSUPPORTED, "not a plain gzip member");
-  const size_t n = gz_bytes - 8;                                   // deflate data + nothing else expected in front of the trailer
-  const uint32_t crc = (uint32_t)p[n] | ((uint32_t)p[n + 1] << 8) | ((uint32_t)p[n + 2] << 16) | ((uint32_t)p[n + 3] << 24);
-  const uint32_t isize = (uint32_t)p[n + 4] | ((uint32_t)p[n + 5] << 8) | ((uint32_t)p[n + 6] << 16) | ((uint32_t)p[n + 7] << 24);
-  if (crc32_expected) *crc32_expected = crc;
-  uint8_t* d_in = nullptr; unsigned long long* d_start = nullptr; GzUnit* d_units = nullptr; uint16_t* d_sym = nullptr;
-  uint16_t* d_pmap = nullptr; uint16_t* d_qmap = nullptr; uint8_t* d_wg = nullptr; uint8_t* d_out = nullptr;
-  uint32_t group = 1, n_groups = 0;
-  const uint32_t n_chunks = (uint32_t)((n + GZ_CHUNK - 1) / GZ_CHUNK);
-  std::vector<unsigned long long> h_start(n_chunks);
-  std::vector<GzUnit> units, chain;
-  std::vector<uint32_t> chain_idx;
-  uint64_t total = 0;
-  unsigned long long sym_total = 0, sym_bound = 0;
-  GzUnit* d_chain = nullptr;
-  hipStream_t s = nullptr;         // (call_stream: one of the engine's copy streams)
-  // device memory: out of the reservation made for a file of this size, if there is one (mic_gz_reserve), else allocated here
-  char* arena = nullptr; size_t arena_left = 0;
-  std::vector<void*> owned;
-  {
-    std::lock_guard<std::mutex> lk(g_res_mu);
-    for (GzReserve& r : g_res)
-      if (r.eng == e && r.gz_bytes == gz_bytes && !r.taken) {
-        r.taken = true; arena = r.scratch; arena_left = r.scratch_bytes;
-        if (r.text && (size_t)isize + 64 <= r.text_bytes) { d_out = r.text; r.text = nullptr; }      // (the text is this call's from here on)
-        break;
-      }
-  }
-  auto dev_alloc = [&](void** ptr, size_t bytes) -> hipError_t {
-    const size_t b = up256(bytes);
-    if (b <= arena_left) { *ptr = arena; arena += b; arena_left -= b; return hipSuccess; }
-    const hipError_t he = hipMalloc(ptr, bytes);
-    if (he == hipSuccess) owned.push_back(*ptr);
-    return he;
-  };
-  auto dev_free = [&](void* ptr) {               // (memory of the reservation stays where it is)
-    for (size_t i = 0; i < owned.size(); ++i) if (owned[i] == ptr) { hipFree(ptr); owned.erase(owned.begin() + (ptrdiff_t)i); return; }
-  };
-  const bool timing = getenv("MIC_GZ_TIMING") != nullptr;
-  struct timespec tq0; clock_gettime(CLOCK_MONOTONIC, &tq0);
-  auto lap = [&](const char* what) {
-    if (!timing) return;
-    if (s) hipStreamSynchronize(s);
-    struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-    fprintf(stderr, "[gz] %s: %.3f ms\n", what, (t1.tv_sec - tq0.tv_sec) * 1e3 + (t1.tv_nsec - tq0.tv_nsec) / 1e6);
-    tq0 = t1;
-  };
-  s = call_stream(e);
-  GZTRY(dev_alloc((void**)&d_in, n + 16));
-  GZTRY(hipMemsetAsync(d_in + n, 0, 16, s));
-  GZTRY(hipMemcpyAsync(d_in, p, n, hipMemcpyHostToDevice, s));
-  lap("upload");
-  GZTRY(dev_alloc((void**)&d_start, (size_t)n_chunks * 8));
-  gz_find_kernel<<<n_chunks, 64, 0, s>>>(d_in, n, (uint64_t)hdr * 8, n_chunks, d_start);
-  GZTRY(hipGetLastError());
-  GZTRY(hipMemcpyAsync(h_start.data(), d_start, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s));
-  // The big buffers are allocated while the upload and the finder run (a fresh gigabyte takes the driver 30-40 ms: as much as the
-  // decode): the symbol buffer by its bound - every unit gets 8 x its compressed span + 16 Ki symbols, there are at most n_chunks
-  // units - and the text by the member's ISIZE, which the decode has to arrive at anyway
-  sym_bound = sym_bound_of(n, n_chunks);
-  GZTRY(dev_alloc((void**)&d_sym, (sym_bound + 8) * 2));
-  if (!d_out && (unsigned long long)isize <= 1100ull * n) GZTRY(hipMalloc(&d_out, (size_t)isize + 64));
-  GZTRY(hipStreamSynchronize(s));
-  lap("find blocks (+ symbol and text buffers allocated)");
-  for (uint32_t c = 0; c < n_chunks; ++c) {
-    if (h_start[c] == ~0ull) continue;
-    GzUnit u; memset(&u, 0, sizeof(u));
-    u.start_bit = h_start[c];
-    units.push_back(u);
-  }
-  {
-    // every unit gets a region of the symbol buffer sized by its compressed span (8 x + 16 Ki symbols: FASTQ inflates 3-6 x);
-    // a unit that needs more is counted exactly by the same pass and decoded again into a region of its own
-    unsigned long long so = 0;
-    for (size_t i = 0; i < units.size(); ++i) {
-      units[i].stop_bit = i + 1 < units.size() ? units[i + 1].start_bit : ~0ull;
-      const unsigned long long span = ((i + 1 < units.size() ? units[i + 1].start_bit : (unsigned long long)n * 8) - units[i].start_bit) / 8 + 1;
-      units[i].sym_off = so; units[i].sym_cap = span * 8 + 16384;
-      so += units[i].sym_cap;
-    }
-    sym_total = so;
-  }
-  if (sym_total > sym_bound) { rc = mic_set_error(MIC_E_HIP, "gzip on the device: symbol regions beyond their bound"); goto done; }
-  GZTRY(dev_alloc((void**)&d_units, units.size() * sizeof(GzUnit)));
-  GZTRY(hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
-  gz_decode_kernel<true><<<(unsigned)units.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, nullptr, 0);
-  GZTRY(hipGetLastError());
-  GZTRY(hipMemcpyAsync(units.data(), d_units, units.size() * sizeof(GzUnit), hipMemcpyDeviceToHost, s));
-  GZTRY(dev_alloc((void**)&d_chain, units.size() * sizeof(GzUnit)));           // (while the decode runs)
-  while ((size_t)group * group < units.size()) ++group;                          // units per group of the window chain: ~sqrt(units)
-  n_groups = (uint32_t)((units.size() + group - 1) / group);
-  GZTRY(dev_alloc((void**)&d_pmap, units.size() * (size_t)65536));
-  GZTRY(dev_alloc((void**)&d_qmap, (size_t)n_groups * 65536));
-  GZTRY(dev_alloc((void**)&d_wg, (size_t)n_groups * 32768));
-  GZTRY(hipStreamSynchronize(s));
-  lap("decode");
-  if (timing) {
-    unsigned long long mx = 0, sum = 0, mxspan = 0;
-    unsigned long long mxc = 0, sumc = 0;
-    for (const GzUnit& u : units) { if (u.n_sym > mx) mx = u.n_sym; sum += u.n_sym; if (u.end_bit - u.start_bit > mxspan) mxspan = u.end_bit - u.start_bit; if (u.pad > mxc) mxc = u.pad; sumc += u.pad; }
-    fprintf(stderr, "[gz] cycles per unit: mean %llu, max %llu; cycles per output symbol %.1f\n", sumc / units.size(), mxc, (double)sumc / (double)(sum ? sum : 1));
-    fprintf(stderr, "[gz] units: %zu, symbols per unit: mean %llu, max %llu; longest span %llu bytes\n", units.size(), sum / units.size(), mx, mxspan / 8);
-  }
-  // the chain: a unit is taken iff the chain so far ends exactly on its start; one that starts inside the chain was a false find
-  {
-    unsigned long long pos = units[0].start_bit;
-    bool final = false;
-    std::vector<uint32_t> redo;
-    unsigned long long extra = 0;
-    for (size_t i = 0; i < units.size() && !final; ++i) {
-      GzUnit& u = units[i];
-      if (u.start_bit < pos) continue;
-      if (u.start_bit > pos || u.status > GZ_FINAL) { rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: the units do not stitch (unit %zu, status %u)", i, u.status); goto done; }
-      if (u.n_sym > u.sym_cap) { redo.push_back((uint32_t)i); u.sym_off = sym_total + 8 + extra; u.sym_cap = u.n_sym; extra += u.n_sym; }
-      chain_idx.push_back((uint32_t)i);
-      pos = u.end_bit;
-      final = u.status == GZ_FINAL;
-    }
-    // behind the last block: the trailer, right there (bits up to the next byte are padding)
-    if (!final || (pos + 7) / 8 != n) { rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: more than one member, or data behind the last block"); goto done; }
-    for (uint32_t i : chain_idx) { units[i].out_off = total; total += units[i].n_sym; }
-    if ((uint32_t)total != isize) { rc = mic_set_error(MIC_E_INVALID, "Failed to uncompress input objects."); goto done; }
-    if (!redo.empty()) {
-      // (a second symbol buffer behind the first would need the first one's copy: the units that overflowed get a buffer of their own,
-      // addressed through the same base pointer - offsets are relative to d_sym, so the extra buffer is allocated as ONE with it)
-      uint16_t* bigger = nullptr;
-      GZTRY(dev_alloc((void**)&bigger, (sym_total + 8 + extra + 8) * 2));
-      GZTRY(hipMemcpyAsync(bigger, d_sym, (sym_total + 8) * 2, hipMemcpyDeviceToDevice, s));
-      GZTRY(hipStreamSynchronize(s));
-      dev_free(d_sym); d_sym = bigger;
-      uint32_t* d_which = nullptr;
-      GZTRY(dev_alloc((void**)&d_which, redo.size() * 4));
-      hipError_t e1 = hipMemcpyAsync(d_which, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, s);
-      if (e1 == hipSuccess) e1 = hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s);
-      if (e1 == hipSuccess) { gz_decode_kernel<true><<<(unsigned)redo.size(), 64, 0, s>>>(d_in, n, d_units, (uint32_t)units.size(), d_sym, d_which, 0); e1 = hipGetLastError(); }
-      std::vector<GzUnit> back(units.size());
-      if (e1 == hipSuccess) e1 = hipMemcpyAsync(back.data(), d_units, units.size() * sizeof(GzUnit), hipMemcpyDeviceToHost, s);
-      if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
-      dev_free(d_which);
-      GZTRY(e1);
-      for (uint32_t i : redo)
-        if (back[i].status != units[i].status || back[i].end_bit != units[i].end_bit || back[i].n_sym != units[i].n_sym) {
-          rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: the second decode of unit %u differs", i); goto done;
-        }
-      lap("decode again (units that overflowed their region)");
-    }
-  }
-  for (uint32_t i : chain_idx) chain.push_back(units[i]);
-  GZTRY(hipMemcpyAsync(d_chain, chain.data(), chain.size() * sizeof(GzUnit), hipMemcpyHostToDevice, s));
-  if (!d_out) GZTRY(hipMalloc(&d_out, total + 64));
-  n_groups = (uint32_t)((chain.size() + group - 1) / group);
-  {
-    static std::once_flag lds_once; static hipError_t lds_rc = hipSuccess;
-    std::call_once(lds_once, [] { lds_rc = hipFuncSetAttribute((const void*)gz_compose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536); });
-    GZTRY(lds_rc);
-  }
-  gz_compose_kernel<<<n_groups, 1024, 2 * 65536, s>>>(d_chain, (uint32_t)chain.size(), group, d_sym, d_pmap, d_qmap);
-  GZTRY(hipGetLastError());
-  gz_chain_kernel<<<1, 1024, 0, s>>>(d_qmap, n_groups, d_wg);
-  GZTRY(hipGetLastError());
-  lap("windows");
-  gz_resolve2_kernel<<<(unsigned)chain.size() * 8u, 256, 0, s>>>(d_chain, (uint32_t)chain.size(), group, d_sym, d_pmap, d_wg, d_out, 8);
-  GZTRY(hipGetLastError());
-  {
-    const size_t n_pieces = (size_t)((total + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE);
-    std::vector<uint32_t> piece = take_hostbuf(n_pieces);
-    struct Keep { std::vector<uint32_t>& v; ~Keep() { keep_hostbuf(v); } } keep{piece};
-    if (n_pieces) {
-      uint32_t* d_crc = nullptr;
-      GZTRY(dev_alloc((void**)&d_crc, n_pieces * 4));
-      gz_crc_kernel<<<(unsigned)((n_pieces + 255) / 256), 256, 0, s>>>(d_out, total, d_crc);
-      GZTRY(hipGetLastError());
-      GZTRY(hipMemcpyAsync(piece.data(), d_crc, n_pieces * 4, hipMemcpyDeviceToHost, s));
-    }
-    GZTRY(hipStreamSynchronize(s));
-    lap("resolve + CRC-32 of the pieces");
-    if (crc_of_pieces(piece, total) != crc) { rc = mic_set_error(MIC_E_INVALID, "Failed to uncompress input objects."); goto done; }   // (gunzip: "crc error")
-  }
-  if (timing) fprintf(stderr, "[gz] %zu bytes -> %llu bytes, %u chunks, %zu units found, %zu in the chain\n", gz_bytes, (unsigned long long)total, n_chunks, units.size(), chain.size());
-  *d_text = d_out; d_out = nullptr; *n_text = total;
-done:
-  if (s) { hipStreamSynchronize(s); s = nullptr; }
-  for (void* q : owned) hipFree(q);
-  if (d_out) hipFree(d_out);
-  lap("buffers freed");
+  GzJob job;
+  rc = job.open(e, gz, gz_bytes, 0);
+  if (crc32_expected) *crc32_expected = job.crc;
+  while (rc == MIC_OK && !job.done()) rc = job.next();
+  if (rc == MIC_OK) { *n_text = (size_t)job.total; *d_text = job.take_text(); }
+  job.close();
   return rc;
+}
+
+// The same in stripes: open uploads, finds the blocks and hands the (whole) text buffer out; every next() makes a further piece of it
+// final.  A failure in a later stripe (MIC_E_UNSUPPORTED: units that do not stitch, a second member) comes after text was handed
+// out: the caller that has used it starts over on its CPU inflater.
+struct mic_gz_stream { GzJob job; int device = 0; bool text_taken = false; };
+
+extern "C" int mic_gz_stream_open(mic_engine* e, const void* gz, size_t gz_bytes, uint32_t stripes, mic_gz_stream** out, void** d_text, size_t* n_text) {
+  if (!e || !gz || !out || !d_text || !n_text) return mic_set_error(MIC_E_INVALID, "null argument");
+  *out = nullptr; *d_text = nullptr; *n_text = 0;
+  MicTable t_; int sc_, ncu_, dev_, k_; uint32_t nt_;
+  int rc = mic_engine_table(e, &t_, &sc_, &ncu_, &dev_, &k_, &nt_);
+  if (rc) return rc;
+  if (hipSetDevice(dev_) != hipSuccess) return mic_set_error(MIC_E_HIP, "hipSetDevice failed");
+  const uint8_t* p = (const uint8_t*)gz;
+  if (gz_bytes >= 18 && p[0] == 0x1f && p[1] == 0x8b && (p[3] & 4) && p[12] == 'B' && p[13] == 'C')
+    return mic_set_error(MIC_E_UNSUPPORTED, "block gzip is inflated in one piece (mic_gz_inflate_device)");
+  mic_gz_stream* h = new mic_gz_stream;
+  h->device = dev_;
+  rc = h->job.open(e, gz, gz_bytes, stripes ? stripes : 1);
+  if (rc == MIC_OK && !h->job.d_out) rc = mic_set_error(MIC_E_UNSUPPORTED, "gzip on the device: a trailer that promises more than 1100 x the file");
+  if (rc != MIC_OK) { h->job.close(); delete h; return rc; }
+  *out = h; *d_text = h->job.d_out; *n_text = (size_t)h->job.isize;
+  return MIC_OK;
+}
+
+extern "C" int mic_gz_stream_next(mic_gz_stream* h, size_t* n_final, int* done) {
+  if (!h || !n_final || !done) return mic_set_error(MIC_E_INVALID, "null argument");
+  if (hipSetDevice(h->device) != hipSuccess) return mic_set_error(MIC_E_HIP, "hipSetDevice failed");
+  const int rc = h->job.next();
+  *n_final = rc == MIC_OK ? (size_t)h->job.total : 0;
+  *done = h->job.done() ? 1 : 0;
+  return rc;
+}
+
+extern "C" int mic_gz_stream_close(mic_gz_stream* h, int keep_text) {
+  if (!h) return MIC_OK;
+  (void)hipSetDevice(h->device);
+  if (keep_text) (void)h->job.take_text();       // (the caller's from here on: mic_gz_free_text)
+  h->job.close();
+  delete h;
+  return MIC_OK;
 }
 
 extern "C" int mic_gz_reserve(mic_engine* e, size_t gz_bytes, uint32_t isize) {

@@ -608,10 +608,10 @@ int alloc_slot(Ingest* g, Slot& s, size_t tmp, int device) {
   Arena dv2, hs2;
   dv2.base = (char*)d; hs2.base = (char*)h;
   carve_slot(g, s, dv2, hs2, tmp);
-  if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)) != hipSuccess ||
-      (e = hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming)) != hipSuccess ||
-      (e = hipEventCreateWithFlags(&s.ev_k, hipEventDisableTiming)) != hipSuccess ||
+  if ((e = mic_stream_get(&s.stream)) != hipSuccess ||
+      (e = mic_event_get(&s.ev, false)) != hipSuccess ||
+      (e = mic_event_get(&s.ev_up, false)) != hipSuccess ||
+      (e = mic_event_get(&s.ev_k, false)) != hipSuccess ||
       // the query kernel's read-ahead looks past the last read of a batch: no stale length slots there
       (e = hipMemsetAsync(s.d_cont, 0, (g->cont_cap + 192) * 2, s.stream)) != hipSuccess ||
       (e = hipStreamSynchronize(s.stream)) != hipSuccess)
@@ -625,14 +625,14 @@ void free_ingest(Ingest* g) {
   for (Slot& s : g->slots) {
     if (s.stream) hipStreamSynchronize(s.stream);
     free_peers(s);
-    if (s.ev_pack) hipEventDestroy(s.ev_pack);
+    if (s.ev_pack) mic_event_put(s.ev_pack);
     hipSetDevice(g->device);
     for (void* p : s.dev_allocs) hipFree(p);
     for (void* p : s.host_allocs) hipHostFree(p);
-    if (s.ev) hipEventDestroy(s.ev);
-    if (s.ev_up) hipEventDestroy(s.ev_up);
-    if (s.ev_k) hipEventDestroy(s.ev_k);
-    if (s.stream) hipStreamDestroy(s.stream);
+    if (s.ev) mic_event_put(s.ev);
+    if (s.ev_up) mic_event_put(s.ev_up);
+    if (s.ev_k) mic_event_put(s.ev_k);
+    if (s.stream) mic_stream_put(s.stream);
   }
   if (g->d_tnames) hipFree(g->d_tnames);
   if (g->d_tname_off) hipFree(g->d_tname_off);
@@ -654,10 +654,10 @@ __global__ void __launch_bounds__(256) group_overflow_kernel(const uint32_t* __r
 void free_peers(Slot& s) {
   for (Slot::Peer& p : s.peers) {
     hipSetDevice(p.device);
-    if (p.stream && p.stream != s.stream) { hipStreamSynchronize(p.stream); hipStreamDestroy(p.stream); }
-    if (p.ev_q) hipEventDestroy(p.ev_q);
-    if (p.ev_done) hipEventDestroy(p.ev_done);
-    for (hipEvent_t e : p.tv) if (e) hipEventDestroy(e);
+    if (p.stream && p.stream != s.stream) { hipStreamSynchronize(p.stream); mic_stream_put(p.stream); }
+    if (p.ev_q) mic_event_put(p.ev_q);
+    if (p.ev_done) mic_event_put(p.ev_done);
+    for (hipEvent_t e : p.tv) if (e) mic_event_put(e);
     if (p.block) hipFree(p.block);
   }
   s.peers.clear();
@@ -738,18 +738,18 @@ int setup_peers(Ingest* g, Slot& s, mic_engine* const* group, size_t P, size_t o
         if (e != hipSuccess) return mic_set_error(MIC_E_NOMEM, "table-sharded ingest slot: %zu bytes on device %d: %s", a.off, dev, hipGetErrorString(e));
       }
     }
-    ITRY(hipEventCreateWithFlags(&q.ev_q, hipEventDisableTiming));
-    ITRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
-    if (s.timed) for (hipEvent_t& e : q.tv) ITRY(hipEventCreate(&e));
+    ITRY(mic_event_get(&q.ev_q, false));
+    ITRY(mic_event_get(&q.ev_done, false));
+    if (s.timed) for (hipEvent_t& e : q.tv) ITRY(mic_event_get(&e, true));
     if (own) { q.d_rp = s.d_rp; q.d_cont = s.d_cont; q.d_res = s.d_results; q.d_flagged = s.d_flagged; q.d_crowd = s.d_crowd; q.stream = s.stream; }
     else {
-      ITRY(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+      ITRY(mic_stream_get(&q.stream));
       ITRY(hipMemsetAsync(q.d_cont, 0, (g->cont_cap + 192) * 2, q.stream));     // (the query kernel's read-ahead looks past the last read)
       ITRY(hipStreamSynchronize(q.stream));
     }
   }
   ITRY(hipSetDevice(s.peers[owner].device));
-  if (!s.ev_pack) ITRY(hipEventCreateWithFlags(&s.ev_pack, hipEventDisableTiming));
+  if (!s.ev_pack) ITRY(mic_event_get(&s.ev_pack, false));
   mic_peer_enable_engines(group, P);
   return MIC_OK;
 }

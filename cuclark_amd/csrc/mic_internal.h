@@ -208,4 +208,10 @@ int mic_build_stable(const uint8_t* d_sizes, uint64_t n_buckets, uint64_t bucket
 // sums over d_sizes[0..n): total elements and non-empty buckets
 int mic_reduce_sizes(const uint8_t* d_sizes, uint64_t n, uint64_t* total, uint64_t* nonzero, hipStream_t s);
 
+// Streams and events come from a process-wide pool and go back to it; none is ever destroyed (mic_engine.hip: why).
+hipError_t mic_stream_get(hipStream_t* s);                 // a non-blocking stream of the current device
+void mic_stream_put(hipStream_t s);                        // drained first; nullptr is fine
+hipError_t mic_event_get(hipEvent_t* ev, bool timing);     // an event of the current device
+void mic_event_put(hipEvent_t ev);
+
 #endif

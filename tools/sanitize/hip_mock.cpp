@@ -188,6 +188,9 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
   return hipSuccess;
 }
 hipError_t hipStreamDestroy(hipStream_t s) {
+  // the library pools its streams and events for the life of the process (mic_engine.hip: mic_stream_put - the runtime's completion
+  // handler races their destruction): a destroy is a regression
+  if (!getenv("MOCK_HIP_ALLOW_DESTROY")) { fprintf(stderr, "hip_mock: hipStreamDestroy called - streams are pooled, never destroyed\n"); abort(); }
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   Stream* st = (Stream*)s;
   run(st, nullptr);
@@ -203,6 +206,7 @@ hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0);
 static std::vector<Event*>& g_graveyard = *new std::vector<Event*>();       // (a destroyed event may still be waited for by a queued operation: the real
                                                                             // runtime keeps it alive too; never freed, and reachable for the leak check)
 hipError_t hipEventDestroy(hipEvent_t e) {
+  if (!getenv("MOCK_HIP_ALLOW_DESTROY")) { fprintf(stderr, "hip_mock: hipEventDestroy called - events are pooled, never destroyed\n"); abort(); }
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   g_graveyard.push_back((Event*)e);
   return hipSuccess;
