@@ -115,6 +115,10 @@ SYMBOLS = [
     ("mic_pairs_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),
     ("mic_pairs_free", C.c_int, [_VP, _VP]),
     ("mic_text_index_device", C.c_int, [_VP, _VP, _SZ, C.POINTER(_VP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    ("mic_text_index_front_device", C.c_int, [_VP, _VP, _SZ, C.POINTER(_VP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    ("mic_gz_stream_open", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_SZ)]),
+    ("mic_gz_stream_next", C.c_int, [_VP, C.POINTER(_SZ), C.POINTER(C.c_int)]),
+    ("mic_gz_stream_close", C.c_int, [_VP, C.c_int]),
     ("mic_text_offsets", C.c_int, [_VP, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(_SZ), C.POINTER(C.c_uint32)]),
     ("mic_text_to_slot", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _SZ, C.POINTER(_SZ)]),
     ("mic_text_copy", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _VP, _SZ, C.POINTER(_SZ)]),

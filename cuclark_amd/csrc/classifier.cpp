@@ -304,17 +304,28 @@ void Classifier::run(const std::string& objects, const std::string& results) {
         std::cerr << "Note: the compressed input is inflated on the host (no peer access between the devices in use)." << std::endl;
       if (gz_on_device_ && !getenv("MIC_GZ_HOST")) {
         // inflated on the device, its FASTQ records handed to the ingest slots there (MIC_GZ_HOST=1: on the host, below)
-        DeviceGzFeeder feed(engines_[0], obj, "");
-        if (feed.ok()) {
-          gettimeofday(&tb, nullptr);
-          prelude_s_ = (tb.tv_sec - ta.tv_sec) + (tb.tv_usec - ta.tv_usec) / 1e6;
-          run_stream(feed, res, false, (size_t)feed.text_bytes());
-          prelude_s_ = 0;
-          mic_gz_release(engines_[0]);
-          return;
+        // MIC_GZ_STRIPES=n: the member in n stripes of its deflate blocks, a stripe indexed and classified while the later ones decode
+        // (mic_gz_stream_*; round 6).  Built, measured, not the default: the decode holds every wavefront slot of the chip for two rounds of
+        // ~10 ms (14 KB of LDS a wavefront: 11 a CU), the first stripe's text is there when nearly all of them are, and the windows kernel
+        // of a stripe (128 KB of LDS a block) waits for a CU the decodes have left - 4 M reads: 57-60 ms either way.
+        unsigned stripes = 1;
+        if (const char* env = getenv("MIC_GZ_STRIPES")) { const long v = atol(env); if (v >= 1 && v <= 64) stripes = (unsigned)v; }
+        bool again = false;
+        {
+          DeviceGzFeeder feed(engines_[0], obj, "", stripes);
+          if (feed.ok()) {
+            gettimeofday(&tb, nullptr);
+            prelude_s_ = (tb.tv_sec - ta.tv_sec) + (tb.tv_usec - ta.tv_usec) / 1e6;
+            // a later stripe that does not stitch, holds a second member or fails its checks: the feeder gives up, run_stream removes what it
+            // wrote, and everything starts again on the CPU inflater - which takes such files, or reports them the reference's way
+            again = !run_stream(feed, res, false, (size_t)feed.text_bytes());
+            if (again) std::cerr << "Note: the device inflater gave the file back after its first stripes (" << feed.gave_up_why() << "); inflating on the host." << std::endl;
+            prelude_s_ = 0;
+            if (!again) { mic_gz_release(engines_[0]); return; }
+          } else if (getenv("MIC_CLI_TIMING")) std::cerr << "[timing] device inflate: not used (" << feed.why() << ")" << std::endl;
         }
-        if (getenv("MIC_CLI_TIMING")) std::cerr << "[timing] device inflate: not used (" << feed.why() << ")" << std::endl;
         mic_gz_release(engines_[0]);
+        if (again) gettimeofday(&ta, nullptr);
       }
       InflatedFile inf;
       const int rc = inf.inflate(obj, inflate_threads(opt_.threads, 1));

@@ -4,6 +4,11 @@
 #define MIC_CLASSIFIER_FEEDERS_HPP
 #include "classifier_internal.hpp"
 
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
 namespace mic {
 namespace detail {
 
@@ -757,32 +762,47 @@ class PairedFileFeeder : public Classifier::Feeder {
 // inflates on the host as before.  Ranges count RECORDS: off = first, len = number.
 class DeviceGzFeeder : public Classifier::Feeder {
  public:
-  DeviceGzFeeder(mic_engine* e, const std::string& f1, const std::string& f2) : e_(e), paired_(!f2.empty()) {
+  // stripes > 1 (one file only): the member is inflated a stripe at a time on a thread of its own and its records are handed out as they
+  // become final (mic_gz_stream_*) - the classifier works on stripe i while stripe i + 1 decodes.  A failure after records were
+  // handed out makes assign() throw and gave_up() true: the caller starts over on the CPU inflater.
+  DeviceGzFeeder(mic_engine* e, const std::string& f1, const std::string& f2, unsigned stripes = 1) : e_(e), paired_(!f2.empty()) {
     const bool timing = getenv("MIC_CLI_TIMING") != nullptr;
     struct timeval t0, t1, t2;
     gettimeofday(&t0, nullptr);
     const std::string* names[2] = {&f1, &f2};
     int rc[2] = {MIC_E_UNSUPPORTED, paired_ ? MIC_E_UNSUPPORTED : MIC_OK};
-    auto inflate = [&](int i) {
+    auto map_file = [&](int i) -> bool {
       const int fd = open(names[i]->c_str(), O_RDONLY);
       struct stat st;
-      if (fd == -1) return;
+      if (fd == -1) return false;
+      bool ok = false;
       if (fstat(fd, &st) == 0 && st.st_size > 18) {
         void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m != MAP_FAILED) {
-          uint32_t crc = 0;
-          rc[i] = mic_gz_inflate_device(e_, m, (size_t)st.st_size, &text_[i], &n_[i], &crc);
-          // The mapping stays until the feeder goes: the runtime pins the pages it uploads from, and unmapping pinned pages makes the
-          // driver take the process's queues off the device and put them back - the next kernel then starts 4 ms late (measured).
-          map_[i] = m; map_n_[i] = (size_t)st.st_size;
-        }
+        // The mapping stays until the feeder goes: the runtime pins the pages it uploads from, and unmapping pinned pages makes the
+        // driver take the process's queues off the device and put them back - the next kernel then starts 4 ms late (measured).
+        if (m != MAP_FAILED) { map_[i] = m; map_n_[i] = (size_t)st.st_size; ok = true; }
       }
       close(fd);
+      return ok;
     };
-    std::thread other;
-    if (paired_) other = std::thread([&] { inflate(1); });
-    inflate(0);
-    if (other.joinable()) other.join();
+    auto inflate = [&](int i) {
+      if (!map_file(i)) return;
+      uint32_t crc = 0;
+      rc[i] = mic_gz_inflate_device(e_, map_[i], map_n_[i], &text_[i], &n_[i], &crc);
+    };
+    if (!paired_ && stripes > 1) {
+      if (!map_file(0)) return;
+      const int st = open_stream(stripes, timing, t0);
+      if (st > 0) return;                                    // in stripes: the inflater thread is on its way
+      if (st < 0) return;                                    // (began and failed, nothing handed out: the host path takes the file)
+      // not a text for stripes: the whole of it is there (FASTA), or the member is taken in one piece (block gzip)
+      if (!text_[0]) { uint32_t crc = 0; rc[0] = mic_gz_inflate_device(e_, map_[0], map_n_[0], &text_[0], &n_[0], &crc); } else rc[0] = MIC_OK;
+    } else {
+      std::thread other;
+      if (paired_) other = std::thread([&] { inflate(1); });
+      inflate(0);
+      if (other.joinable()) other.join();
+    }
     gettimeofday(&t1, nullptr);
     if (rc[0] != MIC_OK || rc[1] != MIC_OK) { why_ = "the device inflater does not take this file"; return; }
     uint32_t status = 0;
@@ -810,6 +830,9 @@ class DeviceGzFeeder : public Classifier::Feeder {
     ok_ = true;
   }
   ~DeviceGzFeeder() override {
+    if (inflater_.joinable()) inflater_.join();
+    if (gs_) mic_gz_stream_close(gs_, 1);                   // (the text is freed below)
+    for (Piece& pc : pieces_) if (pc.t) mic_text_free(e_, pc.t);
     for (int i = 0; i < 2; ++i) if (map_[i]) munmap(map_[i], map_n_[i]);
     if (pairs_) mic_pairs_free(e_, pairs_);
     if (single_) mic_text_free(e_, single_);
@@ -817,13 +840,17 @@ class DeviceGzFeeder : public Classifier::Feeder {
   }
   bool ok() const { return ok_; }
   const char* why() const { return why_; }
-  uint64_t text_bytes() const { return off_.empty() ? 0 : off_.back(); }
+  bool gave_up() const override { return gave_up_.load(); }   // the striped inflate failed: the file is the CPU inflater's (run_stream returns false)
+  std::string gave_up_why() { std::lock_guard<std::mutex> lk(mu_); return gave_up_why_; }
+  bool striped() const { return striped_; }
+  uint64_t text_bytes() const { return striped_ ? isize_ : off_.empty() ? 0 : off_.back(); }
   bool fastq() const override { return false; }          // (nothing for the loaders to strip: the slots are filled on the device)
   bool resident() const override { return true; }
   int resident_flags() const override { return paired_ || fasta_ ? MIC_INGEST_RESIDENT : MIC_INGEST_RESIDENT_FASTQ; }
-  uint64_t remaining() const override { return off_.back() - off_[cur_]; }
+  uint64_t remaining() const override { return striped_ ? (isize_ > handed_ ? isize_ - handed_ : 0) : off_.back() - off_[cur_]; }
 
   bool assign(size_t want, size_t cap, Classifier::Range& r) override {
+    if (striped_) return assign_striped(want, cap, r);
     if (rec_of(cur_) >= n_rec_) return false;
     const uint64_t limit = std::min<uint64_t>(want, cap - cap / 16);
     // the last boundary whose text still fits (at least one stride: a stride that does not fit is handed to the host path)
@@ -838,7 +865,7 @@ class DeviceGzFeeder : public Classifier::Feeder {
   size_t fill_resident(const Classifier::Range& r, mic_engine* e, size_t slot) override {
     size_t n = 0;
     // (e: the engine the slot belongs to - on another device than the text it reads / copies over peer access)
-    const int rc = paired_ ? mic_pairs_merge_to_slot(e, pairs_, r.off, r.off + r.len, slot, &n) : mic_text_to_slot(e, single_, r.off, r.off + r.len, slot, &n);
+    const int rc = paired_ ? mic_pairs_merge_to_slot(e, pairs_, r.off, r.off + r.len, slot, &n) : mic_text_to_slot(e, text_of(r), r.off, r.off + r.len, slot, &n);
     return rc == MIC_OK ? n : (size_t)-1;
   }
   size_t fill(const Classifier::Range& r, uint8_t* dst, size_t cap) override {
@@ -846,18 +873,139 @@ class DeviceGzFeeder : public Classifier::Feeder {
     return to_host(r, dst, cap, n) == MIC_OK ? n : (size_t)-1;
   }
   void text(const Classifier::Range& r, std::string& out) override {
-    const uint64_t a = r.off / stride_, b = r.off + r.len >= n_rec_ ? off_.size() - 1 : (r.off + r.len) / stride_;
-    out.resize((size_t)(off_[b] - off_[a]));
+    uint64_t bytes;
+    if (striped_) {
+      std::lock_guard<std::mutex> lk(mu_);
+      const Piece& pc = pieces_[(size_t)r.off2];
+      const uint64_t a = r.off / pc.stride, b = r.off + r.len >= pc.n_rec ? pc.off.size() - 1 : (r.off + r.len) / pc.stride;
+      bytes = pc.off[b] - pc.off[a];
+    } else {
+      const uint64_t a = r.off / stride_, b = r.off + r.len >= n_rec_ ? off_.size() - 1 : (r.off + r.len) / stride_;
+      bytes = off_[b] - off_[a];
+    }
+    out.resize((size_t)bytes);
     size_t n = 0;
     if (!out.empty()) check(to_host(r, &out[0], out.size(), n), "text of a batch");
     out.resize(n);
   }
 
  private:
+  // one stripe's (or several stripes') whole records: a text handle of its own, records numbered from 0
+  struct Piece { mic_text* t = nullptr; uint64_t n_rec = 0; uint32_t stride = 64; std::vector<uint64_t> off; size_t cur = 0; };
+
+  mic_text* text_of(const Classifier::Range& r) {
+    if (!striped_) return single_;
+    std::lock_guard<std::mutex> lk(mu_);
+    return pieces_[(size_t)r.off2].t;
+  }
   int to_host(const Classifier::Range& r, void* dst, size_t cap, size_t& n) {
-    return paired_ ? mic_pairs_text(e_, pairs_, r.off, r.off + r.len, dst, cap, &n) : mic_text_copy(e_, single_, r.off, r.off + r.len, dst, cap, &n);
+    return paired_ ? mic_pairs_text(e_, pairs_, r.off, r.off + r.len, dst, cap, &n) : mic_text_copy(e_, text_of(r), r.off, r.off + r.len, dst, cap, &n);
   }
   uint64_t rec_of(size_t i) const { return std::min<uint64_t>((uint64_t)i * stride_, n_rec_); }
+
+  // ---- the striped form
+  void give_up(const std::string& why) {
+    std::lock_guard<std::mutex> lk(mu_);
+    gave_up_ = true; gave_up_why_ = why; inflating_ = false;
+    cv_.notify_all();
+  }
+  // the text [carry_, n_final) has become final: its whole records (last: all of it) become a piece
+  bool index_upto(size_t n_final, bool last) {
+    if (n_final <= carry_) { if (last && pieces_.empty()) { give_up("no records"); return false; } return true; }
+    mic_text* t = nullptr; uint64_t n_rec = 0, used = 0; uint32_t status = 0;
+    const uint8_t* from = (const uint8_t*)text_[0] + carry_;
+    const int rc = last ? mic_text_index_device(e_, from, n_final - carry_, &t, &n_rec, &status)
+                        : mic_text_index_front_device(e_, from, n_final - carry_, &t, &n_rec, &used, &status);
+    if (rc != MIC_OK || status || (last && (!t || mic_text_format(t) != '@'))) {
+      if (t) mic_text_free(e_, t);
+      give_up("not FASTQ records of four lines");
+      return false;
+    }
+    if (last) used = n_final - carry_;
+    if (t) {
+      Piece pc;
+      pc.t = t; pc.n_rec = n_rec;
+      const uint64_t* s = nullptr; size_t ns = 0;
+      if (mic_text_offsets(t, &s, &ns, &pc.stride) != MIC_OK || ns < 2) { mic_text_free(e_, t); give_up("no record offsets"); return false; }
+      pc.off.assign(s, s + ns);
+      std::lock_guard<std::mutex> lk(mu_);
+      pieces_.push_back(std::move(pc));
+      n_rec_ += n_rec;
+      cv_.notify_all();
+    }
+    carry_ += used;
+    return true;
+  }
+  // 1: in stripes; 0: not in stripes - text_[0] null (take the member whole) or all of it inflated (n_[0] bytes); -1: the host path's
+  int open_stream(unsigned stripes, bool timing, const struct timeval& t0) {
+    size_t isize = 0;
+    if (mic_gz_stream_open(e_, map_[0], map_n_[0], stripes, &gs_, &text_[0], &isize) != MIC_OK) { gs_ = nullptr; text_[0] = nullptr; return 0; }
+    isize_ = isize;
+    size_t n_final = 0; int done = 0;
+    if (mic_gz_stream_next(gs_, &n_final, &done) != MIC_OK) { why_ = "the device inflater does not take this file"; return -1; }
+    char first = 0;
+    if (n_final == 0 || mic_gz_copy_text(e_, text_[0], 0, 1, &first) != MIC_OK) { why_ = "the device inflater does not take this file"; return -1; }
+    if (first != '@') {
+      // FASTA (or something the index will turn down): its records are not cut by counting lines - all stripes now, then as one text
+      while (!done) if (mic_gz_stream_next(gs_, &n_final, &done) != MIC_OK) { why_ = "the device inflater does not take this file"; return -1; }
+      n_[0] = n_final;
+      mic_gz_stream_close(gs_, 1); gs_ = nullptr;
+      return 0;
+    }
+    striped_ = true;
+    if (!index_upto(n_final, done != 0)) { striped_ = false; why_ = "not FASTQ records of four lines"; return -1; }
+    struct timeval t1;
+    gettimeofday(&t1, nullptr);
+    if (timing)
+      std::cerr << "[timing] device inflate in stripes: the first " << n_final / 1e6 << " MB of " << isize_ / 1e6 << " MB of text after "
+                << ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_usec - t0.tv_usec) / 1e3) << " ms, " << n_rec_ << " records indexed" << std::endl;
+    inflating_ = done == 0;
+    if (inflating_)
+      inflater_ = std::thread([this, timing, t0] {
+        for (;;) {
+          size_t nf = 0; int dn = 0;
+          if (mic_gz_stream_next(gs_, &nf, &dn) != MIC_OK) { give_up(mic_last_error()); return; }
+          if (!index_upto(nf, dn != 0)) return;
+          if (dn) break;
+        }
+        struct timeval t2;
+        gettimeofday(&t2, nullptr);
+        if (timing)
+          std::cerr << "[timing] device inflate in stripes: all " << isize_ / 1e6 << " MB of text after "
+                    << ((t2.tv_sec - t0.tv_sec) * 1e3 + (t2.tv_usec - t0.tv_usec) / 1e3) << " ms" << std::endl;
+        std::lock_guard<std::mutex> lk(mu_);
+        inflating_ = false;
+        cv_.notify_all();
+      });
+    ok_ = true;
+    return 1;
+  }
+  bool assign_striped(size_t want, size_t cap, Classifier::Range& r) {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      if (gave_up_) throw std::runtime_error("the device inflater gave the file back: " + gave_up_why_);
+      if (piece_cur_ < pieces_.size()) {
+        Piece& pc = pieces_[piece_cur_];
+        const uint64_t rec_cur = std::min<uint64_t>((uint64_t)pc.cur * pc.stride, pc.n_rec);
+        if (rec_cur < pc.n_rec) {
+          const uint64_t limit = std::min<uint64_t>(want, cap - cap / 16);
+          size_t hi = (size_t)(std::upper_bound(pc.off.begin() + (ptrdiff_t)pc.cur, pc.off.end(), pc.off[pc.cur] + limit) - pc.off.begin()) - 1;
+          if (hi <= pc.cur) hi = pc.cur + 1;
+          auto rec_at = [&](size_t i) { return std::min<uint64_t>((uint64_t)i * pc.stride, pc.n_rec); };
+          while (hi + 1 < pc.off.size() && rec_at(hi) == rec_cur) ++hi;
+          r.off = rec_cur; r.len = (size_t)(rec_at(hi) - rec_cur); r.off2 = piece_cur_; r.len2 = 0; r.mem = nullptr; r.keep.reset();
+          handed_ += pc.off[std::min(hi, pc.off.size() - 1)] - pc.off[pc.cur];
+          pc.cur = hi;
+          if (r.len != 0) return true;
+        }
+        ++piece_cur_;
+        continue;
+      }
+      if (!inflating_) return false;
+      cv_.wait(lk);
+    }
+  }
+
   mic_engine* e_;
   bool paired_, fasta_ = false;
   void* text_[2] = {nullptr, nullptr};
@@ -872,6 +1020,19 @@ class DeviceGzFeeder : public Classifier::Feeder {
   size_t cur_ = 0;
   bool ok_ = false;
   const char* why_ = "";
+  // striped
+  mic_gz_stream* gs_ = nullptr;
+  bool striped_ = false;
+  std::deque<Piece> pieces_;
+  size_t piece_cur_ = 0;
+  uint64_t isize_ = 0, handed_ = 0;
+  size_t carry_ = 0;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool inflating_ = false;
+  std::atomic<bool> gave_up_{false};
+  std::string gave_up_why_;
+  std::thread inflater_;
 };
 
 

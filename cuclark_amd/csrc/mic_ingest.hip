@@ -50,8 +50,9 @@ __device__ __forceinline__ uint32_t newline_mask(uint32_t x) {       // 0x80 in 
 }
 
 // newline flags of the 16 bytes at byte offset `pos` (16-byte aligned): bit i = byte i is '\n' and lies below nb
-__device__ __forceinline__ uint32_t tile_flags(const uint8_t* __restrict__ raw, uint32_t pos, uint32_t nb) {
-  if (pos >= nb) return 0;
+// (from: bytes below it are not the text's - the front of an aligned-down buffer, mic_text_index_front_device)
+__device__ __forceinline__ uint32_t tile_flags(const uint8_t* __restrict__ raw, uint32_t pos, uint32_t nb, uint32_t from = 0) {
+  if (pos >= nb || pos + 16 <= from) return 0;
   const uint4 v = *(const uint4*)(raw + pos);
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};
   uint32_t f = 0;
@@ -62,13 +63,14 @@ __device__ __forceinline__ uint32_t tile_flags(const uint8_t* __restrict__ raw, 
   }
   const uint32_t left = nb - pos;
   if (left < 16) f &= (1u << left) - 1u;
+  if (pos < from) f &= ~((1u << (from - pos)) - 1u);
   return f;
 }
 
-__global__ void __launch_bounds__(256) line_count_kernel(const uint8_t* __restrict__ raw, uint32_t nb, uint32_t* __restrict__ tile_cnt) {
+__global__ void __launch_bounds__(256) line_count_kernel(const uint8_t* __restrict__ raw, uint32_t nb, uint32_t* __restrict__ tile_cnt, uint32_t from = 0) {
   __shared__ uint32_t s_w[4];
   const uint32_t pos = blockIdx.x * ING_TILE + threadIdx.x * 16;
-  uint32_t c = __popc(tile_flags(raw, pos, nb));
+  uint32_t c = __popc(tile_flags(raw, pos, nb, from));
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -77,10 +79,10 @@ __global__ void __launch_bounds__(256) line_count_kernel(const uint8_t* __restri
 
 // line_start[L] = offset of the first byte of line L (line 0 starts at 0; a '\n' at p starts the next line at p + 1)
 __global__ void __launch_bounds__(256) line_start_kernel(const uint8_t* __restrict__ raw, uint32_t nb, const uint32_t* __restrict__ tile_off,
-                                                         uint32_t* __restrict__ line_start, uint32_t cap) {
+                                                         uint32_t* __restrict__ line_start, uint32_t cap, uint32_t from = 0) {
   __shared__ uint32_t s_w[4];
   const uint32_t pos = blockIdx.x * ING_TILE + threadIdx.x * 16;
-  uint32_t f = tile_flags(raw, pos, nb);
+  uint32_t f = tile_flags(raw, pos, nb, from);
   const uint32_t c = __popc(f);
   uint32_t inc = c;                               // inclusive scan inside the wave
   const int lane = threadIdx.x & 63;
@@ -90,7 +92,7 @@ __global__ void __launch_bounds__(256) line_start_kernel(const uint8_t* __restri
   uint32_t base = tile_off[blockIdx.x];
   for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_w[w];
   uint32_t rank = base + inc - c;                 // newlines before this thread's bytes
-  if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = from;
   while (f) {
     const int b = __ffs((int)f) - 1;
     f &= f - 1;
@@ -434,8 +436,8 @@ __global__ void ingest_warm_kernel(uint32_t* p) { if (p && threadIdx.x == 1000) 
 // what the host wants to know about a text once its line ends are counted, gathered for ONE small copy (a copy into pageable host
 // memory costs about a millisecond whatever its size): out[0] = line ends, out[1] = last byte, out[2] = first byte
 __global__ void text_facts_kernel(const uint8_t* __restrict__ raw, uint32_t nb, const uint32_t* __restrict__ tile_off, uint32_t n_tiles,
-                                  uint32_t* __restrict__ out) {
-  out[0] = tile_off[n_tiles]; out[1] = raw[nb - 1]; out[2] = raw[0]; out[3] = 0;
+                                  uint32_t* __restrict__ out, uint32_t from = 0) {
+  out[0] = tile_off[n_tiles]; out[1] = raw[nb - 1]; out[2] = raw[from]; out[3] = 0;
 }
 
 // one wavefront per record: ">id\n" seq1 "N" seq2 "\n" at off[r] - off[r0]
@@ -1269,16 +1271,34 @@ int mic_text_free(mic_engine* e, mic_text* p) {
   return MIC_OK;
 }
 
+// partial: the text is the front of a longer one (a stripe of a member still being inflated, mic_gz_stream_next) - FASTQ only, the
+// whole records of it are indexed (lines that end in '\n', four to a record), *n_used = where the first record that is not whole
+// starts; no whole record yet: MIC_OK, *out = nullptr, *n_used = 0
+static int text_index(mic_engine* e, const void* d_text, size_t n, bool partial, mic_text** out, uint64_t* n_records, uint64_t* n_used, uint32_t* status);
+
 int mic_text_index_device(mic_engine* e, const void* d_text, size_t n, mic_text** out, uint64_t* n_records, uint32_t* status) {
+  uint64_t used = 0;
+  return text_index(e, d_text, n, false, out, n_records, &used, status);
+}
+
+int mic_text_index_front_device(mic_engine* e, const void* d_text, size_t n, mic_text** out, uint64_t* n_records, uint64_t* n_used, uint32_t* status) {
+  if (!n_used) return mic_set_error(MIC_E_INVALID, "null argument");
+  return text_index(e, d_text, n, true, out, n_records, n_used, status);
+}
+
+static int text_index(mic_engine* e, const void* d_text, size_t n, bool partial, mic_text** out, uint64_t* n_records, uint64_t* n_used, uint32_t* status) {
   if (!e || !d_text || !out || !n_records || !status) return mic_set_error(MIC_E_INVALID, "null argument");
-  *out = nullptr; *n_records = 0; *status = 0;
+  *out = nullptr; *n_records = 0; *status = 0; *n_used = 0;
   if (n == 0 || n >= 0xFFFFFF00ull) { *status = PS_BIG; return MIC_OK; }
   MicTable t; int sc, ncu, dev, k; uint32_t nt;
   int rc = mic_engine_table(e, &t, &sc, &ncu, &dev, &k, &nt);
   if (rc) return rc;
   if (hipSetDevice(dev) != hipSuccess) return mic_set_error(MIC_E_HIP, "hipSetDevice failed");
   mic_text* p = new mic_text;
-  p->device = dev; p->t = (const uint8_t*)d_text; p->nb = (uint32_t)n;
+  // the kernels read 16 aligned bytes a thread: the text counts from the 4-KiB boundary in front of it, `from` bytes are not its own
+  const uint32_t from = (uint32_t)((uintptr_t)d_text & 4095u);
+  if (n + from >= 0xFFFFFF00ull) { delete p; *status = PS_BIG; return MIC_OK; }
+  p->device = dev; p->t = (const uint8_t*)d_text - from; p->nb = (uint32_t)(n + from);
   const uint8_t* raw = p->t;
   const uint32_t nb = p->nb, n_tiles = (nb + ING_TILE - 1) / ING_TILE;
   uint32_t nl = 0; uint8_t first = 0, last = 0;
@@ -1296,18 +1316,24 @@ int mic_text_index_device(mic_engine* e, const void* d_text, size_t n, mic_text*
     char* q = (char*)p->d_scratch;
     d_tile = (uint32_t*)q; q += a0; d_tile_off = (uint32_t*)q; q += a0; d_facts = (uint32_t*)q; q += 256; d_tmp = q;
   }
-  line_count_kernel<<<n_tiles, 256, 0, st>>>(raw, nb, d_tile);
+  line_count_kernel<<<n_tiles, 256, 0, st>>>(raw, nb, d_tile, from);
   PTRY(hipMemsetAsync(d_tile + n_tiles, 0, 4, st));
   {
     size_t tb = tmp_bytes;
     PTRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_tile, d_tile_off, (int)(n_tiles + 1), st));
   }
-  text_facts_kernel<<<1, 1, 0, st>>>(raw, nb, d_tile_off, n_tiles, d_facts);
+  text_facts_kernel<<<1, 1, 0, st>>>(raw, nb, d_tile_off, n_tiles, d_facts, from);
   PTRY(hipGetLastError());
   PTRY(hipMemcpyAsync(facts, d_facts, 16, hipMemcpyDeviceToHost, st));
   PTRY(hipStreamSynchronize(st));
   nl = facts[0]; last = (uint8_t)facts[1]; first = (uint8_t)facts[2];
   n_lines = (uint64_t)nl + (last != '\n' ? 1 : 0);
+  if (partial) {
+    if (first != '@') { *status = PS_HEADER; goto done; }
+    n_lines = (uint64_t)nl / 4 * 4;              // whole records of whole lines; what follows is the next call's
+    last = '\n';
+    if (n_lines == 0) { mic_text_free(e, p); return MIC_OK; }
+  }
   if (first == '>') {
     // FASTA: a record is a '>' line and what follows it up to the next one (sequences over several lines)
     p->fasta = true;
@@ -1323,7 +1349,7 @@ int mic_text_index_device(mic_engine* e, const void* d_text, size_t n, mic_text*
     uint32_t* d_rec = (uint32_t*)((char*)p->d_block + b_ls + b_fl);
     unsigned long long* d_samples = (unsigned long long*)((char*)p->d_block + b_ls + 2 * b_fl);
     void* d_tmp2 = (char*)p->d_block + b_ls + 2 * b_fl + b_smp;
-    line_start_kernel<<<n_tiles, 256, 0, st>>>(raw, nb, d_tile_off, p->d_ls, (uint32_t)(n_lines + 2));
+    line_start_kernel<<<n_tiles, 256, 0, st>>>(raw, nb, d_tile_off, p->d_ls, (uint32_t)(n_lines + 2), from);
     PTRY(hipGetLastError());
     if (last != '\n') { nl = nb + 1; PTRY(hipMemcpyAsync(p->d_ls + n_lines, &nl, 4, hipMemcpyHostToDevice, st)); }
     const unsigned gl = (unsigned)((n_lines + 1 + 255) / 256);
@@ -1352,7 +1378,7 @@ int mic_text_index_device(mic_engine* e, const void* d_text, size_t n, mic_text*
     PTRY(hipMalloc(&p->d_block, b_ls + b_smp));
     p->d_ls = (uint32_t*)p->d_block;
     unsigned long long* d_samples = (unsigned long long*)((char*)p->d_block + b_ls);
-    line_start_kernel<<<n_tiles, 256, 0, st>>>(raw, nb, d_tile_off, p->d_ls, (uint32_t)std::min<uint64_t>(n_lines + 2, 0xFFFFFFFFull));
+    line_start_kernel<<<n_tiles, 256, 0, st>>>(raw, nb, d_tile_off, p->d_ls, (uint32_t)std::min<uint64_t>(n_lines + 2, 0xFFFFFFFFull), from);
     PTRY(hipGetLastError());
     if (last != '\n') { nl = nb + 1; PTRY(hipMemcpyAsync(p->d_ls + n_lines, &nl, 4, hipMemcpyHostToDevice, st)); }
     p->samples.resize(n_samples);
@@ -1360,6 +1386,7 @@ int mic_text_index_device(mic_engine* e, const void* d_text, size_t n, mic_text*
     PTRY(hipGetLastError());
     PTRY(hipMemcpyAsync(p->samples.data(), d_samples, n_samples * 8, hipMemcpyDeviceToHost, st));
     PTRY(hipStreamSynchronize(st));
+    *n_used = p->samples.back() - from;
   }
 done:
   if (st) hipStreamSynchronize(st);

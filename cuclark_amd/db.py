@@ -199,6 +199,39 @@ class MiClarkDB:
     def free_text(self, d_text):
         self.L.mic_gz_free_text(self.h, d_text)
 
+    def gunzip_stripes(self, gz_bytes, stripes, on_stripe=None):
+        """The same member in stripes (mic_gz_stream_*): yields nothing, calls on_stripe(d_text, n_final, done) after every stripe and
+        returns (text bytes, [n_final of every stripe]).  Raises like gunzip - possibly after some stripes went through."""
+        buf = np.frombuffer(gz_bytes, np.uint8)
+        h, d_text, n = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+        rc = self.L.mic_gz_stream_open(self.h, buf.ctypes.data, buf.size, int(stripes), C.byref(h), C.byref(d_text), C.byref(n))
+        if rc == -7:
+            raise MiClarkUnsupported(self.L.mic_last_error().decode())
+        check(rc)
+        finals = []
+        try:
+            done, nf = C.c_int(0), C.c_size_t(0)
+            while not done.value:
+                rc = self.L.mic_gz_stream_next(h, C.byref(nf), C.byref(done))
+                if rc == -7:
+                    raise MiClarkUnsupported(self.L.mic_last_error().decode())
+                check(rc)
+                finals.append(int(nf.value))
+                if on_stripe:
+                    on_stripe(d_text.value, int(nf.value), bool(done.value))
+            out = np.empty(finals[-1], np.uint8)
+            if out.size:
+                check(self.L.mic_gz_copy_text(self.h, d_text, 0, out.size, out.ctypes.data))
+            return out.tobytes(), finals
+        finally:
+            self.L.mic_gz_stream_close(h, 0)
+
+    def text_index_front(self, d_text, n):
+        """Whole FASTQ records at the front of a text that is still growing: (handle or None, records, bytes used, status)."""
+        h, nr, used, st = C.c_void_p(), C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        check(self.L.mic_text_index_front_device(self.h, d_text, n, C.byref(h), C.byref(nr), C.byref(used), C.byref(st)))
+        return h.value, int(nr.value), int(used.value), int(st.value)
+
     # -- paired-end FASTQ texts on the device: the reference's merge (file.cc:205-268) without the host (mic_pairs_*)
     def pairs_index(self, d_text1, n1, d_text2, n2):
         """Returns (handle, n_records, offsets, stride), or (None, status, None, None) when the texts need the host reader."""

@@ -350,6 +350,21 @@ int mic_gz_free_text(mic_engine* e, void* d_text);
 int mic_gz_reserve(mic_engine* e, size_t gz_bytes, uint32_t isize);
 uint64_t mic_gz_reserve_bytes(size_t gz_bytes, uint32_t isize);
 int mic_gz_release(mic_engine* e);
+/* One plain member in STRIPES (round 6; BASELINE config 5, "gzip FASTQ ingest overlapped"): the units of the member - one per deflate
+ * block - go through decode, stitching, windows and resolve a stripe of consecutive units at a time, and when a stripe is done its
+ * text is final: the caller indexes and classifies it (mic_text_index_front_device, mic_text_to_slot) while the next stripe decodes.
+ * mic_gz_stream_open   uploads the file, finds its blocks, hands out the text buffer of *n_text bytes (the trailer's ISIZE), nothing
+ *                      of it final yet; `stripes` = how many pieces to cut the units into (>= 1).  Block gzip: MIC_E_UNSUPPORTED
+ *                      (mic_gz_inflate_device takes it whole).
+ * mic_gz_stream_next   the next stripe, synchronously: on MIC_OK the first *n_final bytes of the text are final; *done = 1 with the last
+ *                      stripe, after length and CRC-32 were checked against the trailer.  MIC_E_UNSUPPORTED / MIC_E_INVALID as for
+ *                      mic_gz_inflate_device - but possibly after text was handed out: a caller that used it starts over on its CPU
+ *                      inflater (exe/cuCLARK does, classifier.cpp).
+ * mic_gz_stream_close  frees everything; keep_text != 0: but the text, the caller's from then on (mic_gz_free_text). */
+typedef struct mic_gz_stream mic_gz_stream;
+int mic_gz_stream_open(mic_engine* e, const void* gz, size_t gz_bytes, uint32_t stripes, mic_gz_stream** out, void** d_text, size_t* n_text);
+int mic_gz_stream_next(mic_gz_stream* s, size_t* n_final, int* done);
+int mic_gz_stream_close(mic_gz_stream* s, int keep_text);
 
 /* ---- paired-end FASTQ texts that are on the device already (inflated there): the reference's merge, on the device ----
  * file.cc:205-268 (mergePairedFiles) writes ">id\nseq1Nseq2\n" per pair of records, id = the header's first field between
@@ -390,6 +405,11 @@ int mic_pairs_free(mic_engine* e, mic_pairs* p);
  *                        reproduce come back as MIC_INGEST_FALLBACK as always, and mic_text_copy gives their bytes to the host. */
 typedef struct mic_text mic_text;
 int mic_text_index_device(mic_engine* e, const void* d_text, size_t n, mic_text** out, uint64_t* n_records, uint32_t* status);
+/* the FRONT of a FASTQ text that is still growing (mic_gz_stream_next): its whole records - lines that end in a newline, four to a
+ * record - are indexed, *n_used = where the first record that is not whole begins (the next call's text starts there).  No whole
+ * record yet: MIC_OK, *out = NULL, *n_used = 0.  *status = MIC_PAIRS_HEADER when the text does not begin with '@'.  The rest of the
+ * text, once it is all there: mic_text_index_device from where the last front ended (d_text need not be aligned for either). */
+int mic_text_index_front_device(mic_engine* e, const void* d_text, size_t n, mic_text** out, uint64_t* n_records, uint64_t* n_used, uint32_t* status);
 int mic_text_format(const mic_text* p);
 int mic_text_offsets(const mic_text* p, const uint64_t** samples, size_t* n_samples, uint32_t* stride);
 int mic_text_to_slot(mic_engine* e, mic_text* p, uint64_t r0, uint64_t r1, size_t slot, size_t* n_bytes);

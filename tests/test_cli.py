@@ -640,3 +640,44 @@ def test_compressed_mates_inflated_and_merged_on_the_device_equal_the_host_path(
         r = _run([EXE_L, "-T", t, "-D", d, "-P", p1, p2, "-R", os.path.join(tmp, "bad"), "-n", "3"], env=dict(os.environ, MIC_CLI_TIMING="1"))
         assert r.returncode != 0 and "read id does not match between files" in (r.stderr + r.stdout)
         assert "device inflate: not used" in r.stderr
+
+
+@pytest.mark.gpu
+def test_one_gzip_member_in_stripes_and_a_file_given_back_midway(tmp_path):
+    """MIC_GZ_STRIPES (mic_gz_stream_*, DeviceGzFeeder): the member inflated a stripe of deflate blocks at a time on a thread of its
+    own, its FASTQ records handed to the ingest slots as they become final.  Same CSV as the plain file.  Two members in one file: the
+    first stripes go through, the stripe that meets the end of the first member gives the file back, the run starts over on the CPU
+    inflater - same CSV again, and a note on stderr."""
+    import gzip
+    tmp = str(tmp_path)
+    d = _db_dir(tmp, "light_k27_u32", light=True)
+    t = _targets_file(tmp)
+    one = open(os.path.join(gu.GOLDEN, "reads_k27.fq"), "rb").read()
+    data = one * 700                                                # ~13 MB of text: ~50 deflate blocks at level 1
+    plain = os.path.join(tmp, "many.fq")
+    open(plain, "wb").write(data)
+    gz1 = os.path.join(tmp, "many.fq.gz")
+    open(gz1, "wb").write(gzip.compress(data, 1))
+    cut = data.index(b"\n@fq0/1", len(data) // 2) + 1
+    gz2 = os.path.join(tmp, "many_mm.fq.gz")
+    open(gz2, "wb").write(gzip.compress(data[:cut], 1) + gzip.compress(data[cut:], 1))
+    r = _run([EXE_L, "-T", t, "-D", d, "-O", plain, "-R", os.path.join(tmp, "plain"), "-n", "4"])
+    assert r.returncode == 0, r.stderr
+    expect = open(os.path.join(tmp, "plain.csv"), "rb").read()
+    assert expect.count(b"\n") == 1 + 700 * (open(os.path.join(gu.GOLDEN, "expected_k27_fq.csv"), "rb").read().count(b"\n") - 1)
+    env = dict(os.environ, MIC_GZ_STRIPES="3", MIC_GZ_STRIPE_UNITS="16", MIC_CLI_TIMING="1")
+    r = _run([EXE_L, "-T", t, "-D", d, "-O", gz1, "-R", os.path.join(tmp, "s1"), "-n", "4"], env=env)
+    assert r.returncode == 0, r.stderr
+    assert "device inflate in stripes: all" in r.stderr and "gave the file back" not in r.stderr, r.stderr
+    assert open(os.path.join(tmp, "s1.csv"), "rb").read() == expect
+    r = _run([EXE_L, "-T", t, "-D", d, "-O", gz2, "-R", os.path.join(tmp, "s2"), "-n", "4"], env=env)
+    assert r.returncode == 0, r.stderr
+    assert "device inflate in stripes: the first" in r.stderr and "gave the file back" in r.stderr, r.stderr
+    assert open(os.path.join(tmp, "s2.csv"), "rb").read() == expect
+    # damage in a later stripe: reported the reference's way by the inflater the run falls back to, nothing classified
+    broken = bytearray(open(gz1, "rb").read())
+    broken[len(broken) * 3 // 4] ^= 0x5A
+    bad = os.path.join(tmp, "broken.fq.gz")
+    open(bad, "wb").write(bytes(broken))
+    r = _run([EXE_L, "-T", t, "-D", d, "-O", bad, "-R", os.path.join(tmp, "s3"), "-n", "4"], env=env)
+    assert r.returncode != 0 and "uncompress" in (r.stderr + r.stdout)

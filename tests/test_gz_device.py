@@ -291,3 +291,62 @@ def test_random_streams_against_zlib(engine, seed):
             block = int(rng.choice([300, 4096, 0xFF00, 65536]))
             assert engine.gunzip(_bgzf(data, block, level if level else 1))[0] == data, (trial, "bgzf", block)
     assert took >= 30, took                      # (unsupported is for what the finder cannot stitch: the rare exception, not the rule)
+
+
+@pytest.mark.parametrize("stripes", [2, 3, 5])
+def test_a_member_in_stripes(engine, stripes):
+    """mic_gz_stream_*: the units of the member decoded, stitched and resolved a stripe at a time, the window in front of a stripe
+    the end of the text so far.  After every stripe the text up to n_final is final (compared right then), and its whole FASTQ
+    records are what mic_text_index_front_device finds from where the last front ended."""
+    rng = np.random.default_rng(100 + stripes)
+    data = _fastq(rng, 220000)                      # ~73 MB of text: ~280 deflate blocks at level 1, stripes of >= 64 units
+    gz = _gz(data, 1)
+    seen = {"carry": 0, "records": 0}
+
+    def on_stripe(d_text, n_final, done):
+        part = np.empty(n_final - seen["carry"], np.uint8)
+        gu_lib = engine.L
+        assert gu_lib.mic_gz_copy_text(engine.h, d_text, seen["carry"], part.size, part.ctypes.data) == 0
+        assert part.tobytes() == data[seen["carry"]:n_final]
+        if not done:
+            h, n_rec, used, st = engine.text_index_front(d_text + seen["carry"], n_final - seen["carry"])
+            chunk = data[seen["carry"]:n_final]
+            whole_lines = chunk.count(b"\n") // 4 * 4
+            end = 0
+            for _ in range(whole_lines):
+                end = chunk.index(b"\n", end) + 1
+            assert st == 0 and n_rec == whole_lines // 4 and used == end, (n_rec, used, whole_lines, end)
+            if h:
+                gu_lib.mic_text_free(engine.h, h)
+            seen["records"] += n_rec
+            seen["carry"] += used
+
+    text, finals = engine.gunzip_stripes(gz, stripes, on_stripe)
+    assert text == data
+    assert len(finals) >= 2 and finals == sorted(finals) and finals[-1] == len(data)
+    assert seen["records"] > 0 and data[seen["carry"]:].count(b"\n") % 4 == 0
+
+
+def test_stripes_meet_what_the_whole_inflate_refuses(engine):
+    """a second member behind the first, a damaged block in a later stripe, a wrong CRC: the stripes in front of it go through (their
+    text is right), then the call says so - the caller starts over on its CPU inflater (tests/test_cli.py)"""
+    from cuclark_amd.db import MiClarkUnsupported
+    from cuclark_amd._lib import MicError as MiClarkError
+    rng = np.random.default_rng(7)
+    data = _fastq(rng, 200000)
+    gz = _gz(data, 1)
+    got = []
+    with pytest.raises(MiClarkUnsupported):
+        engine.gunzip_stripes(gz + _gz(b"@x\nACGT\n+\nFFFF\n", 1), 3, lambda d, n, done: got.append(n))
+    bad = bytearray(gz)
+    bad[-8] ^= 1                                                   # the trailer's CRC-32
+    got2 = []
+    with pytest.raises(MiClarkError):
+        engine.gunzip_stripes(bytes(bad), 3, lambda d, n, done: got2.append(n))
+    assert len(got2) >= 1                                          # (the stripes in front of the last went through)
+    bad = bytearray(gz)
+    for o in range(len(gz) * 3 // 4, len(gz) * 3 // 4 + 64):       # a later stripe's data
+        bad[o] ^= 0x5A
+    with pytest.raises((MiClarkUnsupported, MiClarkError)):
+        engine.gunzip_stripes(bytes(bad), 3)
+    assert engine.gunzip(gz)[0] == data                            # (and the engine is fine afterwards)
