@@ -9,8 +9,10 @@ D=$(grep -o "files kept in .*" $OUT/bench.err | awk '{print $4}')
 CMD="$R/exe/cuCLARK -k 31 --htsize 1610612741 -T $D/targets.txt -D $D/DB -O $D/reads_1.fq -R $D/out_p -n 12"
 for MB in ${@:-64 128}; do
   for rep in 1 2; do
-    /usr/bin/time -f "wall %e s" env MIC_INGEST_MB=$MB MIC_CLI_TIMING=1 timeout -k 10 120 $CMD > $OUT/run_${MB}_$rep.out 2> $OUT/run_${MB}_$rep.err
-    echo "MB=$MB rep=$rep: $(grep -o 'Assignment time: [0-9.]* s' $OUT/run_${MB}_$rep.out) $(grep -o 'wall [0-9.]* s' $OUT/run_${MB}_$rep.err) $(grep -o 'device ingest: [0-9]* batches of <= [0-9]* KB on [0-9]* slot' $OUT/run_${MB}_$rep.err)"
+    t0=$(date +%s.%N)
+    MIC_INGEST_MB=$MB MIC_CLI_TIMING=1 timeout -k 10 120 $CMD > $OUT/run_${MB}_$rep.out 2> $OUT/run_${MB}_$rep.err
+    t1=$(date +%s.%N)
+    echo "MB=$MB rep=$rep: $(grep -o 'Assignment time: [0-9.]* s' $OUT/run_${MB}_$rep.out) wall $(python3 -c "print(round($t1 - $t0, 2))") s $(grep -o 'device ingest: [0-9]* batches of <= [0-9]* KB on [0-9]* slot' $OUT/run_${MB}_$rep.err)"
   done
   ( cd /tmp && export TMPDIR=/tmp MIC_INGEST_MB=$MB MIC_CLI_ORDERLY_EXIT=1
     timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$MB -- $CMD > $OUT/kt_$MB.out 2> $OUT/kt_$MB.err )
