@@ -93,7 +93,10 @@ typedef struct mic_db_info {
   uint64_t side_bytes;     /* HBM of that side table (part of hbm_bytes)                            */
 } mic_db_info;
 
-/* ---- engine lifetime: CuClarkDB ctor/dtor (CuClarkDB.cu:85-253) ----------------------------- */
+/* ---- engine lifetime: CuClarkDB ctor/dtor (CuClarkDB.cu:85-253) -----------------------------
+ * mic_destroy waits for the device and frees the engine's memory; its HIP streams and events go back to a pool of the process
+ * for the next engine on that device and are never destroyed (the runtime's completion handler races a stream's destruction:
+ * DESIGN.md 7). */
 int mic_create(const mic_config* cfg, mic_engine** out);
 int mic_destroy(mic_engine* e);
 const char* mic_last_error(void);

@@ -121,6 +121,11 @@ CASES = [
     ("gzip_one_member", ["-O", "r1.fq.gz"], "single", {"MIC_INGEST_KB": "96"}),
     ("gzip_one_member_host", ["-O", "r1.fq.gz"], "single", {"MIC_INGEST_MB": "2", "MIC_GZ_HOST": "1"}),
     ("fasta_gzip", ["-O", "r.fa.gz"], "single", {"MIC_INGEST_MB": "2"}),
+    # the member in stripes (MIC_GZ_STRIPES): the feeder's inflater thread hands records out as they become final; FASTA is not cut in
+    # stripes (all of it, then one text); two members: the first stripe goes out, the next gives the file back, the run starts over
+    ("gzip_stripes", ["-O", "r1.fq.gz"], "single", {"MIC_INGEST_KB": "96", "MIC_GZ_STRIPES": "5"}),
+    ("gzip_stripes_fasta", ["-O", "r.fa.gz"], "single", {"MIC_INGEST_KB": "96", "MIC_GZ_STRIPES": "3"}),
+    ("gzip_stripes_given_back", ["-O", "r.fq.gz"], "single", {"MIC_INGEST_KB": "96", "MIC_GZ_STRIPES": "3"}),
     ("bgzf_host", ["-O", "r.bgzf.fq.gz"], "single", {"MIC_INGEST_MB": "2", "MIC_GZ_HOST": "1"}),
     # several engines (MIC_SHARD_ENGINES: two / three mock engines): the slots - and the batches - are dealt over the engines, the
     # "device" text of a compressed input fills slots of every engine; read-sharded (default) and table-sharded (--db-sharded:
@@ -142,7 +147,7 @@ def test_host_pipeline_under_sanitizers(flavour, rig):
     jobs = []
     # TSan (5-15 x slower) runs the cases that differ in which threads exist and what they share; ASan + UBSan all of them
     tsan_cases = {"fastq", "fastq_tiny_slots", "gzip_two_members", "pairs_parallel_merge", "pairs_serial_reader", "pairs_gzip",
-                  "pairs_gzip_small_slots", "pairs_gzip_host", "gzip_one_member", "fasta_gzip", "fastq_two_engines", "pairs_gzip_two_engines",
+                  "pairs_gzip_small_slots", "pairs_gzip_host", "gzip_one_member", "fasta_gzip", "gzip_stripes", "gzip_stripes_given_back", "fastq_two_engines", "pairs_gzip_two_engines",
                   "gzip_three_engines", "fastq_table_sharded_2x2", "pairs_gzip_table_sharded_3"}
     assert tsan_cases <= {c[0] for c in CASES}
     for i, (name, objects, want, env, *more) in enumerate(CASES):

@@ -143,6 +143,53 @@ int mic_gz_inflate_device(mic_engine*, const void* gz, size_t gz_bytes, void** d
   *d_text = t; *n_text = out.size();
   return MIC_OK;
 }
+// the member in stripes: everything is inflated at open, the text is handed out a part at a time.  Several ordinary members: the
+// first part goes out, the next call gives the file back (what the device does when a later stripe meets the end of the first member)
+struct mic_gz_stream { uint8_t* text = nullptr; size_t n = 0, given = 0; uint32_t stripes = 1, at = 0; bool give_back = false; };
+int mic_gz_stream_open(mic_engine* e, const void* gz, size_t gz_bytes, uint32_t stripes, mic_gz_stream** out, void** d_text, size_t* n_text) {
+  const uint8_t* p = (const uint8_t*)gz;
+  *out = nullptr; *d_text = nullptr; *n_text = 0;
+  if (gz_bytes >= 18 && (p[3] & 4) && p[12] == 'B' && p[13] == 'C') return MIC_E_UNSUPPORTED;
+  void* t = nullptr; size_t n = 0; uint32_t crc = 0;
+  bool give_back = false;
+  int rc = mic_gz_inflate_device(e, gz, gz_bytes, &t, &n, &crc);
+  if (rc == MIC_E_UNSUPPORTED && gz_bytes >= 18 && p[0] == 0x1f && p[1] == 0x8b) {
+    // (several members: the first member's text for the stripes in front of the give-back)
+    z_stream z; memset(&z, 0, sizeof(z));
+    if (inflateInit2(&z, 31) != Z_OK) return MIC_E_HIP;
+    std::string o; std::vector<uint8_t> buf(1 << 16);
+    z.next_in = (Bytef*)p; z.avail_in = (uInt)gz_bytes;
+    for (;;) {
+      z.next_out = buf.data(); z.avail_out = (uInt)buf.size();
+      const int r = inflate(&z, Z_NO_FLUSH);
+      o.append((const char*)buf.data(), buf.size() - z.avail_out);
+      if (r == Z_STREAM_END) break;
+      if (r != Z_OK) { inflateEnd(&z); return MIC_E_INVALID; }
+    }
+    inflateEnd(&z);
+    t = malloc(o.size() ? o.size() : 1); memcpy(t, o.data(), o.size()); n = o.size();
+    give_back = true; rc = MIC_OK;
+  }
+  if (rc != MIC_OK) return rc;
+  mic_gz_stream* h = new mic_gz_stream;
+  h->text = (uint8_t*)t; h->n = n; h->stripes = stripes ? stripes : 1; h->give_back = give_back;
+  *out = h; *d_text = t; *n_text = n;
+  return MIC_OK;
+}
+int mic_gz_stream_next(mic_gz_stream* h, size_t* n_final, int* done) {
+  *n_final = 0; *done = 0;
+  if (h->give_back && h->at >= 1) return MIC_E_UNSUPPORTED;
+  ++h->at;
+  h->given = h->at >= h->stripes && !h->give_back ? h->n : h->n / (h->stripes + 1) * h->at;
+  *n_final = h->given; *done = h->given == h->n && !h->give_back;
+  return MIC_OK;
+}
+int mic_gz_stream_close(mic_gz_stream* h, int keep_text) {
+  if (!h) return MIC_OK;
+  if (!keep_text) free(h->text);
+  delete h;
+  return MIC_OK;
+}
 int mic_gz_free_text(mic_engine*, void* t) { free(t); return MIC_OK; }
 int mic_gz_copy_text(mic_engine*, const void* t, size_t off, size_t n, void* dst) { memcpy(dst, (const uint8_t*)t + off, n); return MIC_OK; }
 int mic_gz_reserve(mic_engine*, size_t, uint32_t) { return MIC_OK; }
@@ -245,6 +292,24 @@ int mic_text_index_device(mic_engine*, const void* t, size_t n, mic_text** out, 
   p->rec.push_back(n);
   for (uint64_t i = 0; i < p->n_rec / p->stride + 2; ++i) p->samples.push_back(p->rec[std::min<uint64_t>(i * p->stride, p->n_rec)]);
   *out = p; *n_records = p->n_rec;
+  return MIC_OK;
+}
+int mic_text_index_front_device(mic_engine*, const void* t, size_t n, mic_text** out, uint64_t* n_records, uint64_t* n_used, uint32_t* status) {
+  *out = nullptr; *n_records = 0; *n_used = 0; *status = 0;
+  if (!n) return MIC_OK;
+  const uint8_t* q = (const uint8_t*)t;
+  if (q[0] != '@') { *status = MIC_PAIRS_HEADER; return MIC_OK; }
+  std::vector<size_t> ls(1, 0);
+  for (size_t i = 0; i < n; ++i) if (q[i] == '\n') ls.push_back(i + 1);
+  const size_t whole = (ls.size() - 1) / 4;
+  if (!whole) return MIC_OK;
+  mic_text* p = new mic_text;
+  p->t = q; p->n = ls[4 * whole];
+  for (size_t r = 0; r < whole; ++r) p->rec.push_back(ls[4 * r]);
+  p->n_rec = whole;
+  p->rec.push_back(p->n);
+  for (uint64_t i = 0; i < p->n_rec / p->stride + 2; ++i) p->samples.push_back(p->rec[std::min<uint64_t>(i * p->stride, p->n_rec)]);
+  *out = p; *n_records = whole; *n_used = p->n;
   return MIC_OK;
 }
 int mic_text_format(const mic_text* p) { return p ? (p->fasta ? '>' : '@') : 0; }
