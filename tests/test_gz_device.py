@@ -350,3 +350,29 @@ def test_stripes_meet_what_the_whole_inflate_refuses(engine):
     with pytest.raises((MiClarkUnsupported, MiClarkError)):
         engine.gunzip_stripes(bytes(bad), 3)
     assert engine.gunzip(gz)[0] == data                            # (and the engine is fine afterwards)
+
+
+def test_a_text_of_four_gib_and_more_goes_back_to_the_caller(engine):
+    """ISIZE is the length mod 2^32: a member of 2^32 + 1000 bytes says 1000.  Until round 6 the text buffer was sized by that field
+    and the stitched length compared with it as 32-bit numbers - equal - so the resolve pass would have written 4 GiB into a buffer of
+    1 KiB.  Now more text than the trailer's length is MIC_E_UNSUPPORTED the moment the chain gets there, and the caller's CPU
+    inflater (which streams) takes the file."""
+    import struct
+    from cuclark_amd.db import MiClarkUnsupported
+    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+    zeros = bytes(1 << 26)
+    body = [c.compress(zeros) for _ in range(64)] + [c.compress(bytes(1000)), c.flush()]
+    n = (1 << 32) + 1000
+    crc = 0
+    for _ in range(64):
+        crc = zlib.crc32(zeros, crc)
+    crc = zlib.crc32(bytes(1000), crc)
+    gz = b"\x1f\x8b\x08\0\0\0\0\0\0\xff" + b"".join(body) + struct.pack("<II", crc, n & 0xFFFFFFFF)
+    assert zlib.decompressobj(31).decompress(gz, 100) == bytes(100)            # (a valid member)
+    with pytest.raises(MiClarkUnsupported):
+        engine.gunzip(gz)
+    with pytest.raises(MiClarkUnsupported):
+        engine.gunzip_stripes(gz, 2)
+    rng = np.random.default_rng(5)
+    data = _fastq(rng, 2000)
+    assert engine.gunzip(_gz(data, 6))[0] == data
