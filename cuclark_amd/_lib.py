@@ -96,6 +96,7 @@ SYMBOLS = [
     ("mic_last_query_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
     ("mic_last_crowd_stats", C.c_int, [_VP, C.POINTER(C.c_uint32)]),
     ("mic_debug_fetch_crowd", C.c_int, [_VP, _VP, _SZ, C.POINTER(C.c_uint32)]),
+    ("mic_debug_stream_pool", C.c_int, [C.POINTER(C.c_uint32)]),
     ("mic_ingest_alloc", C.c_int, [_VP, _SZ, _SZ, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.POINTER(_VP)]),
     ("mic_ingest_classify", C.c_int, [_VP, _SZ, _SZ, C.c_int, C.POINTER(MicIngestResult)]),
     ("mic_ingest_classify_group", C.c_int, [C.POINTER(C.c_void_p), _SZ, _SZ, _SZ, _SZ, C.c_int, C.POINTER(MicIngestResult)]),

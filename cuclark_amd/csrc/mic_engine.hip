@@ -99,6 +99,15 @@ hipError_t mic_event_get(hipEvent_t* ev, bool timing) {
   return he;
 }
 
+extern "C" int mic_debug_stream_pool(uint32_t out[4]) {
+  if (!out) return MIC_E_INVALID;
+  StreamPool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  out[0] = (uint32_t)P.all_streams.size(); out[1] = (uint32_t)P.free_streams.size();
+  out[2] = (uint32_t)P.all_events.size(); out[3] = (uint32_t)P.free_events.size();
+  return MIC_OK;
+}
+
 void mic_event_put(hipEvent_t ev) {
   if (!ev) return;
   (void)hipEventSynchronize(ev);             // (recorded work done - or never recorded: returns at once)

@@ -99,6 +99,8 @@ typedef struct mic_db_info {
  * DESIGN.md 7). */
 int mic_create(const mic_config* cfg, mic_engine** out);
 int mic_destroy(mic_engine* e);
+/* test hook: {streams ever created, streams in the pool now, events ever created, events in the pool now} of this process */
+int mic_debug_stream_pool(uint32_t out[4]);
 const char* mic_last_error(void);
 /* Number of usable devices (reference: cudaGetDeviceCount loop, CuClarkDB.cu:104-181). */
 int mic_device_count(int* count);

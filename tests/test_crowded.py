@@ -279,3 +279,37 @@ def test_palindromic_repeats_at_even_k(k, n_sites, monkeypatch):
         assert bad.size == 0, (layout, k, bad[:5], res[bad[:3], :5], expect[bad[:3]])
         if layout == "super" and n_sites >= 400:
             assert info["side_kmers"] > 0
+
+
+def test_engines_come_and_go_on_the_same_streams():
+    """mic_destroy gives the engine's streams and events back to a pool of the process and never destroys them (the HIP runtime's
+    completion handler races a stream's destruction - the native fault of the fuzzer): engine after engine, with batch
+    buffers and ingest slots, the numbers of streams and events ever created stay where the first engines put them."""
+    import ctypes as C
+    from cuclark_amd import MiClarkDB, host
+    rng = np.random.default_rng(3)
+    k, T, htsize = 21, 5, 1 << 12
+    seqs, sizes, keys, labels = _microsatellite_db(rng, k, htsize, T, n_sites=40)
+    data = _reads(rng, seqs, 200)
+    idx = host.index_reads(data)
+    rp, cont = host.pack_reads(data, idx["seq_s"], idx["seq_e"], idx["length"], k)
+    counts, first = None, None
+    for i in range(40):
+        with MiClarkDB(k, T, num_batches=1 + i % 3) as e:
+            e.read_arrays(sizes, keys, labels)
+            if e.num_batches == 1:
+                res = e.classify_packed(rp, cont)
+                first = res if first is None else first
+                assert (res == first).all()
+            else:                                               # (batch buffers: a stream and three events per batch)
+                n = rp.size - 1
+                e.malloc(n, n, max(cont.size, 1), np.linspace(0, n, e.num_batches + 1).astype(np.uint32))
+                e.freeBatchMemory()
+            out = (C.c_uint32 * 4)()
+            assert e.L.mic_debug_stream_pool(out) == 0
+            if i == 5:
+                counts = (out[0], out[2])
+            if i > 5:
+                assert (out[0], out[2]) == counts, (i, list(out), counts)
+    out = (C.c_uint32 * 4)()
+    assert first is not None and e.L.mic_debug_stream_pool(out) == 0 and out[0] == out[1] and out[2] == out[3]     # all back in the pool
