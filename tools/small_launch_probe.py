@@ -45,13 +45,15 @@ d_res = torch.zeros((n_max, 8), dtype=torch.int32, device=dev)
 out = {}
 for n in (30_000, 70_000, 137_000, 300_000, 600_000, 2_000_000):
     row = {}
-    for rpw in (4, 8, 12, 16, 24, 32, 48):
+    # (besides the fixed values: exactly one / two / three generations of the 8 192 resident wavefronts)
+    gens = sorted({max(1, -(-n // (8192 * g))) for g in (1, 2, 3)})
+    for rpw in sorted(set((4, 8, 12, 16, 24, 32, 48)) | set(gens)):
         os.environ["MIC_READS_PER_WAVE"] = str(rpw)
         ms = []
         for it in range(8):
             eng.query_device(d_rp.data_ptr(), d_cont.data_ptr(), n, d_res.data_ptr())
             ms.append(eng.last_query_ms())
         row[rpw] = round(float(np.median(ms[2:])) * 1e3, 1)
-    out[n] = {"us": row, "best_rpw": min(row, key=row.get), "Mreads_s_at_8": round(n / row[8], 1), "Mreads_s_best": round(n / min(row.values()), 1)}
+    out[n] = {"us": row, "generations_1_2_3_rpw": gens[::-1], "best_rpw": min(row, key=row.get), "Mreads_s_at_8": round(n / row[8], 1), "Mreads_s_best": round(n / min(row.values()), 1)}
     print(n, json.dumps(out[n]), file=sys.stderr, flush=True)
 print(json.dumps({"what": "query kernel time (us) of small launches by reads per wave", "layout": args.layout, "parts": args.parts, "launches": out}))
