@@ -1423,8 +1423,9 @@ struct GzJob {
     GZTRY(dev_alloc((void**)&d_in, n + 16));
     GZTRY(dev_alloc((void**)&d_start, (size_t)n_chunks * 8));
     GZTRY(hipMemsetAsync(d_in + n, 0, 16, s));
-    // (tried in round 6: the file up in 32-MiB pieces on the other copy stream, the finder following piece by piece - 16.1 ms instead of
-    // 5.0 + 8.7: an upload from pageable memory pins as it goes and holds the host for every piece)
+    // (tried in round 6: the file up in 16 / 32-MiB pieces on the other copy stream, the finder following piece by piece - 16.1 ms from
+    // pageable memory, 15.0 ms from a pinned copy of the file, against 4.3-5.0 + 8.7 one after the other: the finder's 29 039 chunk
+    // wavefronts pack the chip for 14 rounds when launched at once; a launch per piece is a round of its own with its own tail)
     GZTRY(hipMemcpyAsync(d_in, p, n, hipMemcpyHostToDevice, s));
     lap("upload");
     gz_find_kernel<<<n_chunks, 64, 0, s>>>(d_in, n, (uint64_t)hdr * 8, n_chunks, d_start);
